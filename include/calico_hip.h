@@ -1,0 +1,261 @@
+/*
+ * calico_hip.h — C ABI of libcalico_hip.so, the MI355X (gfx950) drop-in for the
+ * hot path of yangjames/Calico:  BatchOptimizer::Optimize
+ * (reference calico/batch_optimizer.cpp:53-81).
+ *
+ * The reference builds a ceres::Problem (parameter blocks + one residual block
+ * per measurement), calls ceres::Solve, then re-evaluates every residual
+ * block.  This header is what a maintainer binds instead of Ceres for that
+ * path: every entry point names the reference interface it replaces.  The ABI
+ * is plain C: opaque handle, caller-owned host buffers, int32 status codes
+ * (absl::StatusCode numbering, as the reference's absl::Status uses), no
+ * exceptions, no C++/torch types.
+ *
+ * Conventions
+ *  - all floating point is IEEE-754 double (the reference path is double only);
+ *  - quaternion blocks are stored x,y,z,w (Eigen::Quaterniond::coeffs(),
+ *    reference optimization_utils.h:51-60);
+ *  - host buffers are only read during the call that receives them;
+ *  - one handle = one HIP device + one stream; a handle is not thread-safe.
+ */
+#ifndef CALICO_HIP_H_
+#define CALICO_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: absl::StatusCode numbering ------------------------- */
+#define CALICO_OK 0
+#define CALICO_INVALID_ARGUMENT 3
+#define CALICO_FAILED_PRECONDITION 9
+#define CALICO_UNIMPLEMENTED 12
+#define CALICO_INTERNAL 13
+
+/* ---- enums: integer values identical to the reference ----------------- */
+/* ceres manifold kinds used by the reference (optimization_utils.h:51-60) */
+#define CALICO_MANIFOLD_EUCLIDEAN 0
+#define CALICO_MANIFOLD_EIGEN_QUATERNION 1
+/* sensors::CameraIntrinsicsModel (camera_models.h:16-33) */
+#define CALICO_CAMERA_NONE 0
+#define CALICO_CAMERA_OPENCV5 1
+#define CALICO_CAMERA_OPENCV8 2
+#define CALICO_CAMERA_KANNALA_BRANDT 3
+#define CALICO_CAMERA_DOUBLE_SPHERE 4
+#define CALICO_CAMERA_FIELD_OF_VIEW 5
+#define CALICO_CAMERA_UNIFIED 6
+#define CALICO_CAMERA_EXTENDED_UNIFIED 7
+/* sensors::{Gyroscope,Accelerometer}IntrinsicsModel (gyroscope_models.h:16-25) */
+#define CALICO_IMU_NONE 0
+#define CALICO_IMU_SCALE_ONLY 1
+#define CALICO_IMU_SCALE_AND_BIAS 2
+#define CALICO_IMU_VECTOR_NAV 3
+/* utils::LossFunctionType (optimization_utils.h:15-22) */
+#define CALICO_LOSS_NONE 0
+#define CALICO_LOSS_HUBER 1
+#define CALICO_LOSS_CAUCHY 2
+/* ceres::TerminationType */
+#define CALICO_CONVERGENCE 0
+#define CALICO_NO_CONVERGENCE 1
+#define CALICO_FAILURE 2
+/* sensor kinds of this ABI */
+#define CALICO_SENSOR_CAMERA 0
+#define CALICO_SENSOR_GYROSCOPE 1
+#define CALICO_SENSOR_ACCELEROMETER 2
+
+typedef struct calico_problem calico_problem;
+
+/* Mirrors the fields of ceres::Solver::Options the reference sets or exposes
+ * (batch_optimizer.cpp:10-17, calico.cpp:378-394) plus the Ceres trust-region
+ * defaults the path depends on.  calico_default_solver_options() fills it the
+ * way DefaultSolverOptions() + Ceres defaults do. */
+typedef struct calico_solver_options {
+  int32_t max_num_iterations;                /* 50 */
+  int32_t num_threads;                       /* 1; honoured by CPU code only */
+  int32_t minimizer_progress_to_stdout;      /* reference default: 1 */
+  int32_t jacobi_scaling;                    /* 1 */
+  int32_t max_num_consecutive_invalid_steps; /* 5 */
+  int32_t sync_every; /* HIP: LM iterations enqueued between host syncs (>=1) */
+  double function_tolerance;                 /* 1e-8  (batch_optimizer.cpp:14) */
+  double gradient_tolerance;                 /* 1e-10 */
+  double parameter_tolerance;                /* 1e-10 (batch_optimizer.cpp:15) */
+  double initial_trust_region_radius;        /* 1e4 */
+  double max_trust_region_radius;            /* 1e16 */
+  double min_trust_region_radius;            /* 1e-32 */
+  double min_relative_decrease;              /* 1e-3 */
+  double min_lm_diagonal;                    /* 1e-6 */
+  double max_lm_diagonal;                    /* 1e32 */
+} calico_solver_options;
+
+/* The fields of ceres::Solver::Summary the reference reads or binds
+ * (calico.cpp:356-375, batch_optimizer_test.cpp:186-187). */
+typedef struct calico_summary {
+  int32_t termination_type;
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  int32_t num_iterations; /* LM iterations run, iteration 0 excluded */
+  int32_t num_jacobian_evaluations;
+  int32_t num_cost_evaluations;
+  int32_t num_residual_blocks;
+  int32_t num_residuals;
+  int32_t num_parameter_blocks;
+  int32_t num_parameters;
+  int32_t num_effective_parameters;
+  int32_t num_residual_blocks_reduced;
+  int32_t num_residuals_reduced;
+  int32_t num_parameter_blocks_reduced;
+  int32_t num_parameters_reduced;
+  int32_t num_effective_parameters_reduced;
+  double initial_cost;
+  double final_cost;
+  double total_time_in_seconds;
+  double solve_time_in_seconds; /* LM loop only (device-timed on HIP) */
+  char message[256];
+} calico_summary;
+
+/* One row of Ceres' per-iteration progress table. */
+typedef struct calico_iteration {
+  int32_t iteration;
+  int32_t step_is_valid;
+  int32_t step_is_successful;
+  int32_t reserved;
+  double cost;
+  double cost_change;
+  double gradient_max_norm;
+  double step_norm;
+  double relative_decrease;
+  double trust_region_radius;
+} calico_iteration;
+
+/* ---- lifetime --------------------------------------------------------- */
+/* Replaces `ceres::Problem problem;` (batch_optimizer.cpp:57).  device = HIP
+ * device ordinal. Fails with CALICO_INTERNAL when no GPU is usable: there is
+ * no CPU fallback behind this ABI. */
+int32_t calico_problem_create(calico_problem** out, int32_t device);
+void calico_problem_destroy(calico_problem* p);
+/* Message of the last non-OK status on this handle ("" if none). */
+const char* calico_last_error(const calico_problem* p);
+void calico_default_solver_options(calico_solver_options* o);
+
+/* ---- parameters ------------------------------------------------------- */
+/* Replaces ceres::Problem::AddParameterBlock (+ SetParameterBlockConstant,
+ * + EigenQuaternionManifold) as used by world_model.cpp:40-77,
+ * bspline.hpp:10-17, camera.cpp:92-113, gyroscope.cpp:10-31,
+ * accelerometer.cpp:10-33, optimization_utils.h:51-68.  size must be 4 for
+ * the quaternion manifold. */
+int32_t calico_problem_add_param_block(calico_problem* p, const double* values,
+                                       int32_t size, int32_t manifold,
+                                       int32_t is_constant,
+                                       int32_t* block_id_out);
+/* Read / overwrite the current value of a block (the reference hands Ceres
+ * pointers into the user's objects and reads them back in place). */
+int32_t calico_get_param_block(calico_problem* p, int32_t block_id,
+                               double* out);
+int32_t calico_set_param_block(calico_problem* p, int32_t block_id,
+                               const double* values);
+
+/* Replaces Trajectory::AddParametersToProblem + GetEvaluationParams
+ * (trajectory.cpp:51-79, bspline.hpp:138-161): the uniform knot vector
+ * (n_knots entries), the per-segment basis matrices (n_segments × order ×
+ * order, row-major, n_segments = n_knots - 2*(order-1) - 1) and the block ids
+ * of the n_knots - order control points (6-vectors [axis-angle; position]). */
+int32_t calico_problem_set_spline(calico_problem* p, int32_t order,
+                                  int32_t n_knots, const double* knots,
+                                  const double* basis,
+                                  const int32_t* ctrl_block_ids);
+
+/* Rigid body (calibration chart) pose blocks, world_model.h:54-69. */
+int32_t calico_problem_add_rigid_body(calico_problem* p, int32_t q_block,
+                                      int32_t t_block, int32_t* body_id_out);
+
+/* ---- sensors ---------------------------------------------------------- */
+/* One call per Sensor object: what AddParametersToProblem registered plus the
+ * per-sensor state AddResidualsToProblem reads (model, sigma -> information
+ * 1/sigma, loss type + scale).  kind/model per the enums above.
+ * gravity_block is used by accelerometers only (pass -1 otherwise). */
+int32_t calico_problem_add_sensor(calico_problem* p, int32_t kind,
+                                  int32_t model, int32_t intrinsics_block,
+                                  int32_t q_block, int32_t t_block,
+                                  int32_t latency_block, int32_t gravity_block,
+                                  double sigma, int32_t loss,
+                                  double loss_scale, int32_t* sensor_id_out);
+
+/* Replaces Camera::AddResidualsToProblem (camera.cpp:115-153) for the
+ * non-outlier measurements of one camera: pixels n×2, stamps n, the rigid
+ * body and the model-point parameter block of every observation. */
+int32_t calico_problem_add_camera_residuals(calico_problem* p,
+                                            int32_t sensor_id, int64_t n,
+                                            const double* pixels,
+                                            const double* stamps,
+                                            const int32_t* body_ids,
+                                            const int32_t* point_blocks);
+/* Replaces Gyroscope/Accelerometer::AddResidualsToProblem
+ * (gyroscope.cpp:33-54, accelerometer.cpp:35-56): measurements n×3. */
+int32_t calico_problem_add_imu_residuals(calico_problem* p, int32_t sensor_id,
+                                         int64_t n, const double* measurements,
+                                         const double* stamps);
+
+/* ---- solve ------------------------------------------------------------ */
+/* Replaces ceres::Solve (batch_optimizer.cpp:72-73): Levenberg–Marquardt
+ * trust region on the flattened problem, entirely on the device. */
+int32_t calico_solve(calico_problem* p, const calico_solver_options* options,
+                     calico_summary* summary);
+/* Per-iteration table of the last solve; returns rows written via *n_out. */
+int32_t calico_get_iterations(calico_problem* p, calico_iteration* out,
+                              int32_t max_rows, int32_t* n_out);
+
+/* Replaces Sensor::UpdateResiduals (camera.cpp:70-80, gyroscope.cpp:171-182,
+ * accelerometer.cpp:58-69): sigma-weighted residuals WITHOUT the loss
+ * function, in the order the residuals were added. out is n×dim (dim 2 for a
+ * camera, 3 for an IMU sensor); valid[i]=0 where the projection failed
+ * (the reference returns kInternal in that case; so does this call, after
+ * filling both arrays). */
+int32_t calico_get_residuals(calico_problem* p, int32_t sensor_id, double* out,
+                             uint8_t* valid);
+/* The outlier-tagging step that follows the path in the reference's demos
+ * (kalibr_multicam_demo.ipynb:666-674 -> Camera::MarkOutliersById):
+ * mask[i] = 1 iff the residual is valid and ||r_i|| <= threshold. */
+int32_t calico_get_inlier_mask(calico_problem* p, int32_t sensor_id,
+                               double threshold, uint8_t* mask);
+
+/* ---- evaluation entry points (parity tests, benchmarks) --------------- */
+/* Number of tangent columns of the reduced problem and their order:
+ * [control points (6 each, spline order) | remaining free, used blocks in
+ * block-id order]. */
+int32_t calico_num_effective_parameters(calico_problem* p, int32_t* n_out);
+/* One residual+Jacobian evaluation at the current parameters, as Ceres'
+ * Evaluator would do for the LM loop (loss corrected, manifold projected):
+ * cost, gradient (n), and the Gauss-Newton matrix JᵀJ expanded to dense
+ * row-major n×n.  Any output pointer may be NULL. */
+int32_t calico_evaluate(calico_problem* p, double* cost, double* gradient,
+                        double* jtj_dense);
+
+/* ---- multi-GPU -------------------------------------------------------- */
+/* Observations shard across ranks; the only exchange is the sum of the
+ * packed normal-equation buffer (and of the candidate cost).  The host owns
+ * the communicator: it registers a callback that must all-reduce (sum)
+ * n doubles in place at device address buf, ordered on HIP stream `stream`
+ * (e.g. torch.distributed.all_reduce over RCCL). Without a callback the
+ * handle is single-rank. */
+typedef int32_t (*calico_allreduce_fn)(void* ctx, void* buf, int64_t n,
+                                       void* stream);
+int32_t calico_problem_set_allreduce(calico_problem* p, calico_allreduce_fn fn,
+                                     void* ctx);
+/* Use an externally owned HIP stream (hipStream_t) for all work of this
+ * handle, e.g. torch's current stream so the callback above is ordered. */
+int32_t calico_problem_set_stream(calico_problem* p, void* stream);
+
+/* ---- timing ----------------------------------------------------------- */
+/* HIP-event timings of the last solve, milliseconds summed over launches,
+ * and launch counts, for the named phase: 0 jacobian evaluation (residual +
+ * Jacobian + JᵀJ partials), 1 reduction of partials, 2 linear solve,
+ * 3 cost-only evaluation, 4 LM control + update. */
+int32_t calico_get_phase_time(calico_problem* p, int32_t phase, double* ms,
+                              int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CALICO_HIP_H_ */
