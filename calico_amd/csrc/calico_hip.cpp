@@ -1,0 +1,893 @@
+// calico_hip.cpp — host side of libcalico_hip.so: the C ABI of
+// include/calico_hip.h, problem flattening, and the LM driver loop.
+//
+// What the reference does per Optimize() call (batch_optimizer.cpp:53-81) —
+// build a ceres::Problem from the sensors / world model / trajectory, run
+// ceres::Solve, re-evaluate the residual blocks — maps here to:
+//   add_* calls  -> host-side block / observation tables,
+//   finalize()   -> cells, work items, gather lists, device upload,
+//   calico_solve -> device-resident LM (kernels in eval_kernels.hip and
+//                   solve_kernels.hip; this file only enqueues them and reads
+//                   back one small state struct per iteration),
+//   calico_get_residuals -> cost-only kernel without the loss function.
+// There is no CPU compute path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/calico_hip.h"
+#include "problem_dev.hpp"
+
+namespace cal {
+
+// ---- kernels (eval_kernels.hip / solve_kernels.hip) -------------------------
+void launch_eval(const EvalArgs& a, bool jac, hipStream_t stream);
+hipError_t configure_eval_kernels(size_t max_lds_bytes);
+
+void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
+                   int n_thin, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
+                   const LmState* st, int need_flag, hipStream_t s);
+void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
+                      IterLog* log, int log_cap, int first, int jacobi, hipStream_t s);
+size_t band_cholesky_lds_bytes(const SolveArgs& a);
+size_t dense_cholesky_lds_bytes(const SolveArgs& a);
+hipError_t configure_solve_kernels(size_t band_lds, size_t dense_lds, size_t back_lds);
+void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, double* x_cand, const BlockDev* blocks,
+                  int n_blocks, bool dense_in_lds, hipStream_t s);
+void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const LmState* st, hipStream_t s);
+void launch_control(LmState* st, const LmOptionsDev& o, const double* R2, double* x, const double* x_cand, int n_amb,
+                    IterLog* log, int log_cap, hipStream_t s);
+void launch_init_state(LmState* st, double radius, double x_norm, hipStream_t s);
+
+}  // namespace cal
+
+using namespace cal;
+
+namespace {
+
+constexpr size_t kMaxLds = 160 * 1024;
+constexpr int kLogCap = 4096;
+constexpr int kNumPhases = 5;
+
+struct HBlock {
+  std::vector<double> v;
+  int size = 0, manifold = 0;
+  bool constant = false, used = false;
+  int amb_off = 0;
+  int tan = -1;      // solver tangent index (6·cp for control points, 6·n_cp + c for calibration blocks)
+  int eff = -1;      // tangent index in the reduced-problem order exported by calico_evaluate
+  int tangent_size() const { return manifold == CALICO_MANIFOLD_EIGEN_QUATERNION ? 3 : size; }
+};
+struct HBody { int q, t; };
+struct HSensor {
+  int kind, model, K;
+  int intr, q, t, lat, grav;
+  double sigma, info;
+  int loss; double loss_scale;
+  std::vector<double> meas, stamps;
+  std::vector<int> body, point, seg;
+  std::vector<int64_t> sorted_pos;  // original observation -> position in the sorted device arrays
+  int dim() const { return kind == CALICO_SENSOR_CAMERA ? 2 : 3; }
+  int64_t n() const { return int64_t(stamps.size()); }
+};
+
+template <class T> struct DevBuf {
+  T* p = nullptr; size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  hipError_t alloc(size_t count) {
+    if (count == n && p) return hipSuccess;
+    release();
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  hipError_t upload(const std::vector<T>& h, hipStream_t s) {
+    hipError_t e = alloc(h.size());
+    if (e != hipSuccess || h.empty()) return e;
+    return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
+  }
+};
+
+struct PhaseTimer {
+  std::vector<hipEvent_t> pool;
+  struct Rec { int phase; hipEvent_t a, b; };
+  std::vector<Rec> pending;
+  size_t next = 0;
+  double ms[kNumPhases] = {0, 0, 0, 0, 0};
+  int64_t count[kNumPhases] = {0, 0, 0, 0, 0};
+  hipEvent_t get() {
+    if (next == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
+    return pool[next++];
+  }
+  void begin(int phase, hipStream_t s) { Rec r; r.phase = phase; r.a = get(); r.b = nullptr; (void)hipEventRecord(r.a, s); pending.push_back(r); }
+  void end(hipStream_t s) { Rec& r = pending.back(); r.b = get(); (void)hipEventRecord(r.b, s); }
+  void resolve() {  // call after a stream sync
+    for (const Rec& r : pending) {
+      float t = 0; if (r.b && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.phase] += t; count[r.phase]++; }
+    }
+    pending.clear(); next = 0;
+  }
+  void reset() { for (int i = 0; i < kNumPhases; ++i) { ms[i] = 0; count[i] = 0; } }
+  ~PhaseTimer() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); }
+};
+
+}  // namespace
+
+struct calico_problem {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string error;
+  std::vector<HBlock> blocks;
+  std::vector<HBody> bodies;
+  std::vector<HSensor> sensors;
+  int order = 0;
+  std::vector<double> knots, valid_knots, basis;
+  std::vector<int> ctrl;
+  bool dirty = true;
+  calico_allreduce_fn allreduce = nullptr;
+  void* allreduce_ctx = nullptr;
+
+  // flattened problem
+  int n_cp = 0, m = 0, n_amb = 0, n_eff = 0, n_items = 0, lds_cols = 0;
+  int64_t n_obs = 0;
+  size_t partial_doubles = 0;
+  std::vector<int> eff_to_tan;
+  std::vector<BlockDev> h_blocks;
+  std::vector<ItemDev> h_items;
+  std::vector<double> h_x;
+  int n_thin = 0, n_fat = 0;
+  bool dense_in_lds = true;
+
+  DevBuf<double> d_x, d_xc, d_knots, d_basis, d_m0, d_m1, d_m2, d_stamp, d_partials, d_R, d_R2, d_Lw, d_Y, d_S, d_y,
+      d_dadd, d_scale, d_res;
+  DevBuf<int> d_ctrl_off, d_point_off, d_out_thin, d_idx_thin, d_out_fat, d_idx_fat;
+  DevBuf<int64_t> d_ptr_thin, d_ptr_fat;
+  DevBuf<uint8_t> d_cp_active, d_valid;
+  DevBuf<SensorDev> d_sensors;
+  DevBuf<LayoutDev> d_layouts;
+  DevBuf<ItemDev> d_items;
+  DevBuf<BlockDev> d_blocks;
+  DevBuf<LmState> d_state;
+  DevBuf<IterLog> d_log;
+  LmState* h_state = nullptr;  // pinned
+  std::vector<calico_iteration> iterations;
+  PhaseTimer timer;
+
+  int set_error(int code, const std::string& msg) { error = msg; return code; }
+  int hip_error(hipError_t e, const char* what) {
+    return set_error(CALICO_INTERNAL, std::string(what) + ": " + hipGetErrorString(e));
+  }
+};
+
+#define HIP_TRY(p, expr)                                    \
+  do {                                                      \
+    hipError_t _e = (expr);                                 \
+    if (_e != hipSuccess) return (p)->hip_error(_e, #expr); \
+  } while (0)
+
+namespace {
+
+// bspline.hpp:138-150
+int spline_index(const calico_problem* p, double t) {
+  const std::vector<double>& vk = p->valid_knots;
+  if (t == vk.back()) return int(vk.size()) - 2;
+  if (t < vk.back()) return int(std::upper_bound(vk.begin(), vk.end(), t) - vk.begin()) - 1;
+  return -1;
+}
+int camera_num_params(int model) {
+  switch (model) { case 1: return 8; case 2: return 11; case 3: return 7; case 4: return 5; case 5: return 4; case 6: return 4;
+    case 7: return 5; default: return -1; }
+}
+int imu_num_params(int model) { return model == 1 ? 1 : (model == 2 ? 4 : (model == 3 ? 12 : -1)); }
+
+SolveArgs make_solve_args(calico_problem* p) {
+  SolveArgs a;
+  a.R = p->d_R.p; a.Lw = p->d_Lw.p; a.Y = p->d_Y.p; a.S = p->d_S.p; a.y = p->d_y.p; a.dadd = p->d_dadd.p;
+  a.scale = p->d_scale.p; a.cp_active = p->d_cp_active.p; a.st = p->d_state.p; a.n_cp = p->n_cp; a.k = p->order; a.m = p->m;
+  return a;
+}
+
+EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool want_res) {
+  EvalArgs a;
+  a.x = x; a.sensors = p->d_sensors.p; a.layouts = p->d_layouts.p; a.items = p->d_items.p;
+  a.knots = p->d_knots.p; a.basis = p->d_basis.p; a.ctrl_off = p->d_ctrl_off.p;
+  a.m0 = p->d_m0.p; a.m1 = p->d_m1.p; a.m2 = p->d_m2.p; a.stamp = p->d_stamp.p; a.point_off = p->d_point_off.p;
+  a.partials = p->d_partials.p; a.item_cost = p->d_partials.p + p->partial_doubles;
+  a.res_out = want_res ? p->d_res.p : nullptr; a.valid_out = want_res ? p->d_valid.p : nullptr;
+  a.order = p->order; a.n_items = p->n_items; a.lds_cols = p->lds_cols; a.apply_loss = apply_loss;
+  return a;
+}
+
+// Flatten the host tables into cells / work items / gather lists and upload.
+int finalize(calico_problem* p) {
+  if (!p->dirty) return CALICO_OK;
+  if (p->order <= 0) return p->set_error(CALICO_FAILED_PRECONDITION, "spline not set");
+  const int k = p->order;
+  if (k > 8) return p->set_error(CALICO_UNIMPLEMENTED, "spline order > 8 is not supported by the HIP kernels");
+  HIP_TRY(p, hipSetDevice(p->device));
+  const int n_cp = int(p->ctrl.size());
+  p->n_cp = n_cp;
+  // ---- ambient offsets, used flags ----
+  int off = 0;
+  for (HBlock& b : p->blocks) { b.amb_off = off; off += b.size; b.used = false; b.tan = -1; b.eff = -1; }
+  p->n_amb = off;
+  std::vector<char> is_ctrl(p->blocks.size(), 0);
+  for (int id : p->ctrl) is_ctrl[id] = 1;
+  std::vector<uint8_t> cp_active(n_cp, 0);
+  for (HSensor& s : p->sensors) {
+    if (s.n() == 0) continue;
+    p->blocks[s.intr].used = p->blocks[s.q].used = p->blocks[s.t].used = p->blocks[s.lat].used = true;
+    if (s.kind == CALICO_SENSOR_ACCELEROMETER) p->blocks[s.grav].used = true;
+    for (int64_t i = 0; i < s.n(); ++i) {
+      for (int j = 0; j < k; ++j) cp_active[s.seg[i] + j] = 1;
+      if (s.kind == CALICO_SENSOR_CAMERA) {
+        p->blocks[s.point[i]].used = true;
+        p->blocks[p->bodies[s.body[i]].q].used = p->blocks[p->bodies[s.body[i]].t].used = true;
+      }
+    }
+  }
+  for (int i = 0; i < n_cp; ++i) {
+    HBlock& b = p->blocks[p->ctrl[i]];
+    b.used = cp_active[i] != 0;
+    if (b.constant && b.used) return p->set_error(CALICO_UNIMPLEMENTED, "constant control points are not supported");
+    b.tan = 6 * i;
+  }
+  // ---- tangent order ----
+  p->h_blocks.clear(); p->eff_to_tan.clear();
+  int eff = 0;
+  for (int i = 0; i < n_cp; ++i) {
+    if (!cp_active[i]) continue;
+    HBlock& b = p->blocks[p->ctrl[i]];
+    b.eff = eff; eff += 6;
+    for (int c = 0; c < 6; ++c) p->eff_to_tan.push_back(6 * i + c);
+    p->h_blocks.push_back({b.amb_off, 6, 0, 6 * i});
+  }
+  int m = 0;
+  for (size_t id = 0; id < p->blocks.size(); ++id) {
+    HBlock& b = p->blocks[id];
+    if (is_ctrl[id] || b.constant || !b.used) continue;
+    b.tan = 6 * n_cp + m; b.eff = eff;
+    for (int c = 0; c < b.tangent_size(); ++c) p->eff_to_tan.push_back(b.tan + c);
+    p->h_blocks.push_back({b.amb_off, b.size, b.manifold, b.tan});
+    m += b.tangent_size(); eff += b.tangent_size();
+  }
+  p->m = m; p->n_eff = eff;
+  const int NS = 6 * n_cp;
+  // ---- layouts ----
+  std::vector<SensorDev> sd(p->sensors.size());
+  std::vector<LayoutDev> layouts;
+  std::vector<std::vector<int>> layout_gmap;             // local calibration column -> solver tangent index
+  std::map<std::pair<int, int>, int> layout_of;          // (sensor, body) -> layout id
+  auto is_free = [&](int id) { return id >= 0 && !p->blocks[id].constant; };
+  for (size_t si = 0; si < p->sensors.size(); ++si) {
+    const HSensor& s = p->sensors[si];
+    SensorDev& d = sd[si];
+    d.kind = s.kind; d.model = s.model; d.K = s.K; d.loss = s.loss;
+    d.intr_off = p->blocks[s.intr].amb_off; d.q_off = p->blocks[s.q].amb_off; d.t_off = p->blocks[s.t].amb_off;
+    d.lat_off = p->blocks[s.lat].amb_off; d.grav_off = s.grav >= 0 ? p->blocks[s.grav].amb_off : 0; d.pad0 = 0;
+    d.info = s.info; d.loss_scale = s.loss_scale;
+    for (int64_t i = 0; i < s.n(); ++i) {
+      const int body = s.kind == CALICO_SENSOR_CAMERA ? s.body[i] : -1;
+      if (s.kind == CALICO_SENSOR_CAMERA && !p->blocks[s.point[i]].constant)
+        return p->set_error(CALICO_UNIMPLEMENTED, "free model points (model_definition_is_constant=false) are not supported yet");
+      if (layout_of.count({int(si), body})) continue;
+      LayoutDev L;
+      L.sensor = int(si); L.pad0 = 0;
+      std::vector<int> gmap;
+      int c = 6 * k;
+      auto add = [&](int id, int* slot) {
+        if (is_free(id)) { *slot = c; for (int q = 0; q < p->blocks[id].tangent_size(); ++q) gmap.push_back(p->blocks[id].tan + q); c += p->blocks[id].tangent_size(); }
+        else *slot = -1;
+      };
+      add(s.intr, &L.c_intr); add(s.q, &L.c_q);
+      if (s.kind == CALICO_SENSOR_GYROSCOPE) L.c_t = -1; else add(s.t, &L.c_t);
+      add(s.lat, &L.c_lat);
+      L.c_bq = L.c_bt = L.c_grav = -1; L.bq_off = L.bt_off = 0;
+      if (s.kind == CALICO_SENSOR_CAMERA) {
+        add(p->bodies[body].q, &L.c_bq); add(p->bodies[body].t, &L.c_bt);
+        L.bq_off = p->blocks[p->bodies[body].q].amb_off; L.bt_off = p->blocks[p->bodies[body].t].amb_off;
+      } else if (s.kind == CALICO_SENSOR_ACCELEROMETER) {
+        add(s.grav, &L.c_grav);
+      }
+      L.ncols = c;
+      layout_of[{int(si), body}] = int(layouts.size());
+      layouts.push_back(L); layout_gmap.push_back(gmap);
+    }
+  }
+  // ---- sort observations by (layout, segment) and cut work items ----
+  struct Key { int layout, seg, sensor; int64_t idx; };
+  std::vector<Key> keys;
+  int64_t n_obs = 0;
+  for (const HSensor& s : p->sensors) n_obs += s.n();
+  keys.reserve(size_t(n_obs));
+  for (size_t si = 0; si < p->sensors.size(); ++si) {
+    HSensor& s = p->sensors[si];
+    s.sorted_pos.assign(size_t(s.n()), 0);
+    for (int64_t i = 0; i < s.n(); ++i) {
+      const int body = s.kind == CALICO_SENSOR_CAMERA ? s.body[i] : -1;
+      keys.push_back({layout_of[{int(si), body}], s.seg[i], int(si), i});
+    }
+  }
+  std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
+    return a.layout != b.layout ? a.layout < b.layout : a.seg < b.seg; });
+  p->n_obs = n_obs;
+  std::vector<double> m0(n_obs), m1(n_obs), m2(n_obs), st(n_obs);
+  std::vector<int> point_off(n_obs, 0);
+  p->h_items.clear();
+  size_t poff = 0;
+  int max_cols = 0;
+  for (int64_t q = 0; q < n_obs;) {
+    int64_t e = q;
+    while (e < n_obs && keys[e].layout == keys[q].layout && keys[e].seg == keys[q].seg) ++e;
+    const LayoutDev& L = layouts[keys[q].layout];
+    const int dim = p->sensors[L.sensor].dim();
+    const int chunk = kRowsPerItem / dim;
+    max_cols = std::max(max_cols, L.ncols + 1);
+    for (int64_t b = q; b < e; b += chunk) {
+      ItemDev it;
+      it.layout = keys[q].layout; it.seg = keys[q].seg; it.obs_begin = int(b); it.obs_count = int(std::min<int64_t>(chunk, e - b));
+      it.partial_off = int64_t(poff);
+      poff += size_t(L.ncols + 1) * (L.ncols + 1);
+      p->h_items.push_back(it);
+    }
+    q = e;
+  }
+  for (int64_t q = 0; q < n_obs; ++q) {
+    HSensor& s = p->sensors[keys[q].sensor];
+    const int64_t i = keys[q].idx;
+    s.sorted_pos[size_t(i)] = q;
+    const int dim = s.dim();
+    m0[q] = s.meas[i * dim]; m1[q] = s.meas[i * dim + 1]; m2[q] = dim == 3 ? s.meas[i * dim + 2] : 0.0;
+    st[q] = s.stamps[i];
+    if (s.kind == CALICO_SENSOR_CAMERA) point_off[q] = p->blocks[s.point[i]].amb_off;
+  }
+  p->n_items = int(p->h_items.size());
+  p->partial_doubles = poff;
+  if (poff + 2 * size_t(p->n_items) >= size_t(0x7fffffff))
+    return p->set_error(CALICO_UNIMPLEMENTED, "problem too large for 32-bit gather indices");
+  p->lds_cols = (max_cols + 3) & ~3;
+  if (size_t(p->lds_cols) * kRowPad * sizeof(double) > kMaxLds)
+    return p->set_error(CALICO_UNIMPLEMENTED, "too many Jacobian columns per residual block for the LDS staging area");
+  // ---- gather lists ----
+  SolveArgs sa; sa.n_cp = n_cp; sa.k = k; sa.m = m;
+  const size_t r_size = sa.r_size();
+  if (r_size >= size_t(0x7fffffff)) return p->set_error(CALICO_UNIMPLEMENTED, "normal-equation buffer too large");
+  struct Pair { int dst, src; };
+  std::vector<Pair> pairs;
+  pairs.reserve(poff / 2 + 4 * size_t(p->n_items));
+  for (int itn = 0; itn < p->n_items; ++itn) {
+    const ItemDev& it = p->h_items[size_t(itn)];
+    const LayoutDev& L = layouts[it.layout];
+    const std::vector<int>& gmap = layout_gmap[it.layout];
+    const int nc = L.ncols, n1 = nc + 1;
+    auto tan_of = [&](int c) { return c < 6 * k ? 6 * (it.seg + c / 6) + c % 6 : gmap[size_t(c - 6 * k)]; };
+    for (int i = 0; i < nc; ++i) {
+      const int ti = tan_of(i);
+      pairs.push_back({int(sa.off_g()) + ti, int(it.partial_off) + i * n1 + nc});
+      for (int j = i; j < nc; ++j) {
+        const int tj = tan_of(j);
+        const int src = int(it.partial_off) + i * n1 + j;
+        if (ti < NS && tj < NS) {
+          const int a = ti / 6, b = tj / 6;  // a <= b
+          pairs.push_back({int(sa.off_B()) + (a * k + (b - a)) * 36 + (ti % 6) * 6 + (tj % 6), src});
+          if (a == b && ti != tj) pairs.push_back({int(sa.off_B()) + (a * k) * 36 + (tj % 6) * 6 + (ti % 6), src});
+        } else if (ti < NS) {
+          pairs.push_back({int(sa.off_E() + size_t(ti) * m + (tj - NS)), src});
+        } else {
+          const int a = ti - NS, b = tj - NS;
+          pairs.push_back({int(sa.off_C() + size_t(a) * m + b), src});
+          if (a != b) pairs.push_back({int(sa.off_C() + size_t(b) * m + a), src});
+        }
+      }
+    }
+    pairs.push_back({0, int(poff) + 2 * itn});
+    pairs.push_back({1, int(poff) + 2 * itn + 1});
+  }
+  std::stable_sort(pairs.begin(), pairs.end(), [](const Pair& a, const Pair& b) { return a.dst < b.dst; });
+  std::vector<int> out_thin, idx_thin, out_fat, idx_fat;
+  std::vector<int64_t> ptr_thin(1, 0), ptr_fat(1, 0);
+  for (size_t q = 0; q < pairs.size();) {
+    size_t e = q;
+    while (e < pairs.size() && pairs[e].dst == pairs[q].dst) ++e;
+    const bool fat = (e - q) > 48;
+    std::vector<int>& out = fat ? out_fat : out_thin;
+    std::vector<int>& idx = fat ? idx_fat : idx_thin;
+    std::vector<int64_t>& ptr = fat ? ptr_fat : ptr_thin;
+    out.push_back(pairs[q].dst);
+    for (size_t r = q; r < e; ++r) idx.push_back(pairs[r].src);
+    ptr.push_back(int64_t(idx.size()));
+    q = e;
+  }
+  p->n_thin = int(out_thin.size()); p->n_fat = int(out_fat.size());
+  // ---- upload ----
+  hipStream_t s = p->stream;
+  p->h_x.assign(size_t(p->n_amb), 0.0);
+  for (const HBlock& b : p->blocks) std::copy(b.v.begin(), b.v.end(), p->h_x.begin() + b.amb_off);
+  std::vector<int> ctrl_off(n_cp);
+  for (int i = 0; i < n_cp; ++i) ctrl_off[i] = p->blocks[p->ctrl[i]].amb_off;
+  HIP_TRY(p, p->d_x.upload(p->h_x, s)); HIP_TRY(p, p->d_xc.upload(p->h_x, s));
+  HIP_TRY(p, p->d_knots.upload(p->knots, s)); HIP_TRY(p, p->d_basis.upload(p->basis, s));
+  HIP_TRY(p, p->d_ctrl_off.upload(ctrl_off, s));
+  HIP_TRY(p, p->d_m0.upload(m0, s)); HIP_TRY(p, p->d_m1.upload(m1, s)); HIP_TRY(p, p->d_m2.upload(m2, s));
+  HIP_TRY(p, p->d_stamp.upload(st, s)); HIP_TRY(p, p->d_point_off.upload(point_off, s));
+  HIP_TRY(p, p->d_sensors.upload(sd, s)); HIP_TRY(p, p->d_layouts.upload(layouts, s));
+  HIP_TRY(p, p->d_items.upload(p->h_items, s)); HIP_TRY(p, p->d_blocks.upload(p->h_blocks, s));
+  HIP_TRY(p, p->d_cp_active.upload(cp_active, s));
+  HIP_TRY(p, p->d_out_thin.upload(out_thin, s)); HIP_TRY(p, p->d_idx_thin.upload(idx_thin, s));
+  HIP_TRY(p, p->d_ptr_thin.upload(ptr_thin, s));
+  HIP_TRY(p, p->d_out_fat.upload(out_fat, s)); HIP_TRY(p, p->d_idx_fat.upload(idx_fat, s));
+  HIP_TRY(p, p->d_ptr_fat.upload(ptr_fat, s));
+  HIP_TRY(p, p->d_partials.alloc(poff + 2 * size_t(p->n_items)));
+  HIP_TRY(p, p->d_R.alloc(r_size)); HIP_TRY(p, hipMemsetAsync(p->d_R.p, 0, r_size * sizeof(double), s));
+  HIP_TRY(p, p->d_R2.alloc(2));
+  const int NT = 6 * n_cp + m;
+  HIP_TRY(p, p->d_Lw.alloc(size_t(NS) * 6 * k)); HIP_TRY(p, p->d_Y.alloc(size_t(NS) * (m + 1)));
+  HIP_TRY(p, p->d_S.alloc(size_t(m + 1) * (m + 1)));
+  HIP_TRY(p, p->d_y.alloc(NT)); HIP_TRY(p, p->d_dadd.alloc(NT)); HIP_TRY(p, p->d_scale.alloc(NT));
+  HIP_TRY(p, p->d_res.alloc(size_t(n_obs) * 3)); HIP_TRY(p, p->d_valid.alloc(size_t(n_obs)));
+  HIP_TRY(p, p->d_state.alloc(1)); HIP_TRY(p, p->d_log.alloc(kLogCap));
+  if (!p->h_state) HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LmState)));
+  // kernel attributes
+  HIP_TRY(p, configure_eval_kernels(size_t(p->lds_cols) * kRowPad * sizeof(double)));
+  sa = make_solve_args(p);
+  const size_t band_lds = band_cholesky_lds_bytes(sa);
+  if (band_lds > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "calibration block too wide for the banded factorisation window");
+  const size_t dense_lds = dense_cholesky_lds_bytes(sa);
+  p->dense_in_lds = dense_lds <= kMaxLds - 1024;
+  const size_t back_lds = size_t(NS + 6 * k) * sizeof(double);
+  if (back_lds > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "trajectory too long for the back-substitution window");
+  HIP_TRY(p, configure_solve_kernels(band_lds, p->dense_in_lds ? dense_lds : 0, back_lds));
+  HIP_TRY(p, hipStreamSynchronize(s));
+  p->dirty = false;
+  return CALICO_OK;
+}
+
+int upload_x(calico_problem* p) {
+  for (const HBlock& b : p->blocks) std::copy(b.v.begin(), b.v.end(), p->h_x.begin() + b.amb_off);
+  HIP_TRY(p, hipMemcpyAsync(p->d_x.p, p->h_x.data(), p->h_x.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(p, hipMemcpyAsync(p->d_xc.p, p->h_x.data(), p->h_x.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  return CALICO_OK;
+}
+
+int do_allreduce(calico_problem* p, double* buf, int64_t n) {
+  if (!p->allreduce) return CALICO_OK;
+  const int st = p->allreduce(p->allreduce_ctx, buf, n, p->stream);
+  if (st != 0) return p->set_error(CALICO_INTERNAL, "all-reduce callback failed");
+  return CALICO_OK;
+}
+
+// residual + Jacobian evaluation at d_x into the reduce buffer R.
+int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag) {
+  // The evaluation kernels carry no early-exit of their own: skipping is decided by the host (see solve loop).
+  (void)need_flag;
+  p->timer.begin(0, p->stream);
+  launch_eval(make_eval_args(p, p->d_x.p, 1, false), true, p->stream);
+  p->timer.end(p->stream);
+  p->timer.begin(1, p->stream);
+  launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->d_out_fat.p,
+                p->d_ptr_fat.p, p->d_idx_fat.p, p->n_fat, st, 0, p->stream);
+  p->timer.end(p->stream);
+  SolveArgs sa = make_solve_args(p);
+  return do_allreduce(p, p->d_R.p, int64_t(sa.r_size()));
+}
+
+int read_state(calico_problem* p) {
+  HIP_TRY(p, hipMemcpyAsync(p->h_state, p->d_state.p, sizeof(LmState), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(p, hipStreamSynchronize(p->stream));
+  p->timer.resolve();
+  return CALICO_OK;
+}
+
+void fill_counts(calico_problem* p, calico_summary* sm) {
+  int nrb = 0, nr = 0;
+  for (const HSensor& s : p->sensors) { nrb += int(s.n()); nr += int(s.n()) * s.dim(); }
+  sm->num_residual_blocks = nrb; sm->num_residuals = nr;
+  sm->num_residual_blocks_reduced = nrb; sm->num_residuals_reduced = nr;
+  sm->num_parameter_blocks = int(p->blocks.size());
+  int np = 0, ne = 0, npr = 0;
+  for (const HBlock& b : p->blocks) { np += b.size; ne += b.tangent_size(); }
+  sm->num_parameters = np; sm->num_effective_parameters = ne;
+  sm->num_parameter_blocks_reduced = int(p->h_blocks.size());
+  for (const BlockDev& b : p->h_blocks) npr += b.size;
+  sm->num_parameters_reduced = npr;
+  sm->num_effective_parameters_reduced = p->n_eff;
+}
+
+const char* reason_message(int reason) {
+  switch (reason) {
+    case 1: return "Maximum number of iterations reached.";
+    case 2: return "Gradient tolerance reached.";
+    case 3: return "Minimum trust region radius reached.";
+    case 4: return "Parameter tolerance reached.";
+    case 5: return "Function tolerance reached.";
+    case 10: return "Initial residual and Jacobian evaluation failed.";
+    case 11: return "Residual and Jacobian evaluation failed.";
+    case 12: return "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps.";
+    default: return "";
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t calico_problem_create(calico_problem** out, int32_t device) {
+  if (!out) return CALICO_INVALID_ARGUMENT;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return CALICO_INTERNAL;
+  if (hipSetDevice(device) != hipSuccess) return CALICO_INTERNAL;
+  calico_problem* p = new calico_problem();
+  p->device = device;
+  if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) { delete p; return CALICO_INTERNAL; }
+  p->own_stream = true;
+  *out = p;
+  return CALICO_OK;
+}
+
+void calico_problem_destroy(calico_problem* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  if (p->h_state) (void)hipHostFree(p->h_state);
+  if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+}
+
+const char* calico_last_error(const calico_problem* p) { return p ? p->error.c_str() : "null problem"; }
+
+void calico_default_solver_options(calico_solver_options* o) {
+  // DefaultSolverOptions() (batch_optimizer.cpp:10-17) over Ceres' Solver::Options defaults.
+  o->max_num_iterations = 50; o->num_threads = 1; o->minimizer_progress_to_stdout = 1; o->jacobi_scaling = 1;
+  o->max_num_consecutive_invalid_steps = 5; o->sync_every = 1;
+  o->function_tolerance = 1e-8; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-10;
+  o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
+}
+
+int32_t calico_problem_add_param_block(calico_problem* p, const double* values, int32_t size, int32_t manifold,
+                                       int32_t is_constant, int32_t* block_id_out) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  if (size <= 0 || !values) return p->set_error(CALICO_INVALID_ARGUMENT, "bad parameter block");
+  if (manifold == CALICO_MANIFOLD_EIGEN_QUATERNION && size != 4)
+    return p->set_error(CALICO_INVALID_ARGUMENT, "quaternion manifold needs size 4");
+  if (manifold != CALICO_MANIFOLD_EUCLIDEAN && manifold != CALICO_MANIFOLD_EIGEN_QUATERNION)
+    return p->set_error(CALICO_INVALID_ARGUMENT, "unknown manifold");
+  HBlock b; b.v.assign(values, values + size); b.size = size; b.manifold = manifold; b.constant = is_constant != 0;
+  p->blocks.push_back(b);
+  p->dirty = true;
+  if (block_id_out) *block_id_out = int32_t(p->blocks.size()) - 1;
+  return CALICO_OK;
+}
+
+int32_t calico_get_param_block(calico_problem* p, int32_t id, double* out) {
+  if (!p || id < 0 || id >= int(p->blocks.size()) || !out) return p ? p->set_error(CALICO_INVALID_ARGUMENT, "bad block id") : CALICO_INVALID_ARGUMENT;
+  std::copy(p->blocks[id].v.begin(), p->blocks[id].v.end(), out);
+  return CALICO_OK;
+}
+
+int32_t calico_set_param_block(calico_problem* p, int32_t id, const double* v) {
+  if (!p || id < 0 || id >= int(p->blocks.size()) || !v) return p ? p->set_error(CALICO_INVALID_ARGUMENT, "bad block id") : CALICO_INVALID_ARGUMENT;
+  std::copy(v, v + p->blocks[id].size, p->blocks[id].v.begin());
+  return CALICO_OK;
+}
+
+int32_t calico_problem_set_spline(calico_problem* p, int32_t order, int32_t n_knots, const double* knots,
+                                  const double* basis, const int32_t* ctrl) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  if (order < 2 || order > 16 || n_knots < 2 * order || !knots || !basis || !ctrl)
+    return p->set_error(CALICO_INVALID_ARGUMENT, "bad spline");
+  const int deg = order - 1;
+  for (int i = 0; i < n_knots - order; ++i)
+    if (ctrl[i] < 0 || ctrl[i] >= int(p->blocks.size()) || p->blocks[ctrl[i]].size != 6)
+      return p->set_error(CALICO_INVALID_ARGUMENT, "control point blocks must be 6-vectors");
+  p->order = order;
+  p->knots.assign(knots, knots + n_knots);
+  p->valid_knots.assign(knots + deg, knots + n_knots - deg);
+  const int nseg = int(p->valid_knots.size()) - 1;
+  p->basis.assign(basis, basis + size_t(nseg) * order * order);
+  p->ctrl.assign(ctrl, ctrl + (n_knots - order));
+  p->dirty = true;
+  return CALICO_OK;
+}
+
+int32_t calico_problem_add_rigid_body(calico_problem* p, int32_t q, int32_t t, int32_t* id_out) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  const int nb = int(p->blocks.size());
+  if (q < 0 || q >= nb || t < 0 || t >= nb || p->blocks[q].size != 4 || p->blocks[t].size != 3)
+    return p->set_error(CALICO_INVALID_ARGUMENT, "rigid body pose blocks must be a quaternion and a 3-vector");
+  p->bodies.push_back({q, t});
+  p->dirty = true;
+  if (id_out) *id_out = int32_t(p->bodies.size()) - 1;
+  return CALICO_OK;
+}
+
+int32_t calico_problem_add_sensor(calico_problem* p, int32_t kind, int32_t model, int32_t intr, int32_t q, int32_t t,
+                                  int32_t lat, int32_t grav, double sigma, int32_t loss, double loss_scale,
+                                  int32_t* id_out) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  if (kind < 0 || kind > 2) return p->set_error(CALICO_INVALID_ARGUMENT, "unknown sensor kind");
+  const int K = kind == CALICO_SENSOR_CAMERA ? camera_num_params(model) : imu_num_params(model);
+  // camera.cpp:94-97 / gyroscope.cpp:12-15: model not set -> FailedPrecondition
+  if (K < 0) return p->set_error(CALICO_FAILED_PRECONDITION, "Cannot add sensor parameters. Sensor model is not yet defined.");
+  const int nb = int(p->blocks.size());
+  auto ok = [&](int id, int size) { return id >= 0 && id < nb && p->blocks[id].size == size; };
+  if (!ok(intr, K)) return p->set_error(CALICO_INVALID_ARGUMENT, "intrinsics block size does not match the model");
+  if (!ok(q, 4) || !ok(t, 3) || !ok(lat, 1)) return p->set_error(CALICO_INVALID_ARGUMENT, "bad extrinsics / latency blocks");
+  if (kind == CALICO_SENSOR_ACCELEROMETER && !ok(grav, 3)) return p->set_error(CALICO_INVALID_ARGUMENT, "bad gravity block");
+  if (loss < 0 || loss > 2) return p->set_error(CALICO_INVALID_ARGUMENT, "unknown loss function");
+  HSensor s; s.kind = kind; s.model = model; s.K = K; s.intr = intr; s.q = q; s.t = t; s.lat = lat;
+  s.grav = kind == CALICO_SENSOR_ACCELEROMETER ? grav : -1;
+  s.sigma = sigma; s.info = sigma > 0.0 ? 1.0 / sigma : 1.0;  // camera_cost_functor.cpp:15 (Q9)
+  s.loss = loss; s.loss_scale = loss_scale;
+  p->sensors.push_back(s);
+  p->dirty = true;
+  if (id_out) *id_out = int32_t(p->sensors.size()) - 1;
+  return CALICO_OK;
+}
+
+static int32_t add_obs(calico_problem* p, int32_t sid, int64_t n, const double* meas, const double* stamps,
+                       const int32_t* body, const int32_t* point) {
+  if (sid < 0 || sid >= int(p->sensors.size())) return p->set_error(CALICO_INVALID_ARGUMENT, "bad sensor id");
+  if (p->order <= 0) return p->set_error(CALICO_FAILED_PRECONDITION, "spline must be set before residuals");
+  if (n < 0 || (n > 0 && (!meas || !stamps))) return p->set_error(CALICO_INVALID_ARGUMENT, "bad observation arrays");
+  HSensor& s = p->sensors[sid];
+  const int dim = s.dim();
+  // validate first so a failing call adds nothing
+  for (int64_t i = 0; i < n; ++i) {
+    if (spline_index(p, stamps[i]) < 0)
+      return p->set_error(CALICO_INVALID_ARGUMENT, "measurement stamp is outside the spline's valid knots");
+    if (body) {
+      // camera.cpp:126-131
+      if (body[i] < 0 || body[i] >= int(p->bodies.size()))
+        return p->set_error(CALICO_FAILED_PRECONDITION,
+                            "Attempted to create cost function from an observation for a rigidbody that does not exist in the world model.");
+      if (point[i] < 0 || point[i] >= int(p->blocks.size()) || p->blocks[point[i]].size != 3)
+        return p->set_error(CALICO_INVALID_ARGUMENT, "model point block must be a 3-vector");
+    }
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    s.seg.push_back(spline_index(p, stamps[i]));
+    s.stamps.push_back(stamps[i]);
+    if (body) { s.body.push_back(body[i]); s.point.push_back(point[i]); }
+    for (int c = 0; c < dim; ++c) s.meas.push_back(meas[i * dim + c]);
+  }
+  p->dirty = true;
+  return CALICO_OK;
+}
+
+int32_t calico_problem_add_camera_residuals(calico_problem* p, int32_t sid, int64_t n, const double* px, const double* st,
+                                            const int32_t* body, const int32_t* point) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  if (sid >= 0 && sid < int(p->sensors.size()) && p->sensors[sid].kind != CALICO_SENSOR_CAMERA)
+    return p->set_error(CALICO_INVALID_ARGUMENT, "sensor is not a camera");
+  if (n > 0 && (!body || !point)) return p->set_error(CALICO_INVALID_ARGUMENT, "bad observation arrays");
+  return add_obs(p, sid, n, px, st, body, point);
+}
+
+int32_t calico_problem_add_imu_residuals(calico_problem* p, int32_t sid, int64_t n, const double* m, const double* st) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  if (sid >= 0 && sid < int(p->sensors.size()) && p->sensors[sid].kind == CALICO_SENSOR_CAMERA)
+    return p->set_error(CALICO_INVALID_ARGUMENT, "sensor is not an IMU sensor");
+  return add_obs(p, sid, n, m, st, nullptr, nullptr);
+}
+
+int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico_summary* sm) {
+  if (!p || !opt || !sm) return CALICO_INVALID_ARGUMENT;
+  const auto t_start = std::chrono::steady_clock::now();
+  std::memset(sm, 0, sizeof(*sm));
+  int rc = finalize(p);
+  if (rc != CALICO_OK) return rc;
+  HIP_TRY(p, hipSetDevice(p->device));
+  rc = upload_x(p);
+  if (rc != CALICO_OK) return rc;
+  fill_counts(p, sm);
+  p->iterations.clear();
+  p->timer.reset();
+  LmOptionsDev o;
+  o.max_num_iterations = opt->max_num_iterations; o.max_num_consecutive_invalid_steps = opt->max_num_consecutive_invalid_steps;
+  o.function_tolerance = opt->function_tolerance; o.gradient_tolerance = opt->gradient_tolerance;
+  o.parameter_tolerance = opt->parameter_tolerance; o.max_radius = opt->max_trust_region_radius;
+  o.min_radius = opt->min_trust_region_radius; o.min_relative_decrease = opt->min_relative_decrease;
+  o.min_lm_diagonal = opt->min_lm_diagonal; o.max_lm_diagonal = opt->max_lm_diagonal;
+  double xn = 0.0;
+  for (const BlockDev& b : p->h_blocks) for (int i = 0; i < b.size; ++i) xn += p->h_x[b.amb_off + i] * p->h_x[b.amb_off + i];
+  hipStream_t s = p->stream;
+  const auto t_loop = std::chrono::steady_clock::now();
+  launch_init_state(p->d_state.p, opt->initial_trust_region_radius, std::sqrt(xn), s);
+  SolveArgs sa = make_solve_args(p);
+  // iteration 0
+  rc = enqueue_jacobian_eval(p, nullptr, 0);
+  if (rc != CALICO_OK) return rc;
+  p->timer.begin(4, s);
+  launch_post_eval(sa, p->d_x.p, p->d_blocks.p, int(p->h_blocks.size()), o, p->d_log.p, kLogCap, 1, opt->jacobi_scaling, s);
+  p->timer.end(s);
+  rc = read_state(p);
+  if (rc != CALICO_OK) return rc;
+  sm->num_jacobian_evaluations = 1;
+  while (!p->h_state->terminated) {
+    p->timer.begin(2, s);
+    launch_solve(sa, o, p->d_x.p, p->d_xc.p, p->d_blocks.p, int(p->h_blocks.size()), p->dense_in_lds, s);
+    p->timer.end(s);
+    p->timer.begin(3, s);
+    launch_eval(make_eval_args(p, p->d_xc.p, 1, false), false, s);
+    launch_cost_reduce(p->d_partials.p + p->partial_doubles, p->n_items, p->d_R2.p, p->d_state.p, s);
+    p->timer.end(s);
+    rc = do_allreduce(p, p->d_R2.p, 2);
+    if (rc != CALICO_OK) return rc;
+    p->timer.begin(4, s);
+    launch_control(p->d_state.p, o, p->d_R2.p, p->d_x.p, p->d_xc.p, p->n_amb, p->d_log.p, kLogCap, s);
+    p->timer.end(s);
+    rc = read_state(p);
+    if (rc != CALICO_OK) return rc;
+    sm->num_cost_evaluations++;
+    if (p->h_state->terminated) break;
+    if (p->h_state->need_jacobian) {
+      rc = enqueue_jacobian_eval(p, nullptr, 0);
+      if (rc != CALICO_OK) return rc;
+      p->timer.begin(4, s);
+      launch_post_eval(sa, p->d_x.p, p->d_blocks.p, int(p->h_blocks.size()), o, p->d_log.p, kLogCap, 0, opt->jacobi_scaling, s);
+      p->timer.end(s);
+      rc = read_state(p);
+      if (rc != CALICO_OK) return rc;
+      sm->num_jacobian_evaluations++;
+    }
+  }
+  const double t_solve = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
+  // results
+  const LmState st = *p->h_state;
+  std::vector<IterLog> log(size_t(std::max(0, std::min(st.n_log, kLogCap))));
+  if (!log.empty()) HIP_TRY(p, hipMemcpyAsync(log.data(), p->d_log.p, log.size() * sizeof(IterLog), hipMemcpyDeviceToHost, s));
+  HIP_TRY(p, hipMemcpyAsync(p->h_x.data(), p->d_x.p, p->h_x.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(p, hipStreamSynchronize(s));
+  for (HBlock& b : p->blocks) std::copy(p->h_x.begin() + b.amb_off, p->h_x.begin() + b.amb_off + b.size, b.v.begin());
+  for (const IterLog& r : log) {
+    calico_iteration it;
+    it.iteration = r.iteration; it.step_is_valid = r.step_is_valid; it.step_is_successful = r.step_is_successful; it.reserved = 0;
+    it.cost = r.cost; it.cost_change = r.cost_change; it.gradient_max_norm = r.gradient_max_norm; it.step_norm = r.step_norm;
+    it.relative_decrease = r.relative_decrease; it.trust_region_radius = r.trust_region_radius;
+    p->iterations.push_back(it);
+    if (opt->minimizer_progress_to_stdout) {
+      if (r.iteration == 0) std::printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n");
+      std::printf("%4d % 8e   % 3.2e   % 3.2e  % 3.2e  % 3.2e % 3.2e\n", r.iteration, r.cost, r.cost_change, r.gradient_max_norm,
+                  r.step_norm, r.relative_decrease, r.trust_region_radius);
+    }
+  }
+  sm->termination_type = st.termination_type;
+  sm->num_successful_steps = st.num_successful; sm->num_unsuccessful_steps = st.num_unsuccessful;
+  sm->num_iterations = log.empty() ? 0 : log.back().iteration;
+  sm->initial_cost = st.initial_cost;
+  sm->final_cost = st.termination_type == CALICO_FAILURE ? 0.0 : std::min(st.initial_cost, st.min_cost);
+  std::snprintf(sm->message, sizeof(sm->message), "%s", reason_message(st.termination_reason));
+  sm->solve_time_in_seconds = t_solve;
+  sm->total_time_in_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  return CALICO_OK;
+}
+
+int32_t calico_get_iterations(calico_problem* p, calico_iteration* out, int32_t max_rows, int32_t* n_out) {
+  if (!p || !out || !n_out) return CALICO_INVALID_ARGUMENT;
+  const int n = std::min<int>(max_rows, int(p->iterations.size()));
+  for (int i = 0; i < n; ++i) out[i] = p->iterations[size_t(i)];
+  *n_out = n;
+  return CALICO_OK;
+}
+
+int32_t calico_get_residuals(calico_problem* p, int32_t sid, double* out, uint8_t* valid) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  if (sid < 0 || sid >= int(p->sensors.size()) || !out) return p->set_error(CALICO_INVALID_ARGUMENT, "bad sensor id");
+  int rc = finalize(p);
+  if (rc != CALICO_OK) return rc;
+  HIP_TRY(p, hipSetDevice(p->device));
+  rc = upload_x(p);
+  if (rc != CALICO_OK) return rc;
+  launch_eval(make_eval_args(p, p->d_x.p, 0, true), false, p->stream);
+  std::vector<double> r(size_t(p->n_obs) * 3);
+  std::vector<uint8_t> v(size_t(p->n_obs));
+  HIP_TRY(p, hipMemcpyAsync(r.data(), p->d_res.p, r.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(p, hipMemcpyAsync(v.data(), p->d_valid.p, v.size(), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(p, hipStreamSynchronize(p->stream));
+  const HSensor& s = p->sensors[sid];
+  const int dim = s.dim();
+  bool all = true;
+  for (int64_t i = 0; i < s.n(); ++i) {
+    const int64_t q = s.sorted_pos[size_t(i)];
+    for (int c = 0; c < dim; ++c) out[i * dim + c] = v[size_t(q)] ? r[size_t(q) * 3 + c] : 0.0;
+    if (valid) valid[i] = v[size_t(q)];
+    if (!v[size_t(q)]) all = false;
+  }
+  // camera.cpp:73-76: a failing block makes UpdateResiduals return kInternal
+  return all ? CALICO_OK : p->set_error(CALICO_INTERNAL, "Failed to update residual");
+}
+
+int32_t calico_get_inlier_mask(calico_problem* p, int32_t sid, double threshold, uint8_t* mask) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  if (sid < 0 || sid >= int(p->sensors.size()) || !mask) return p->set_error(CALICO_INVALID_ARGUMENT, "bad sensor id");
+  const HSensor& s = p->sensors[sid];
+  const int dim = s.dim();
+  std::vector<double> r(size_t(s.n()) * dim);
+  std::vector<uint8_t> v(size_t(s.n()));
+  const int rc = calico_get_residuals(p, sid, r.data(), v.data());
+  if (rc != CALICO_OK && rc != CALICO_INTERNAL) return rc;
+  for (int64_t i = 0; i < s.n(); ++i) {
+    double sq = 0;
+    for (int c = 0; c < dim; ++c) sq += r[i * dim + c] * r[i * dim + c];
+    mask[i] = (v[size_t(i)] && std::sqrt(sq) <= threshold) ? 1 : 0;
+  }
+  return CALICO_OK;
+}
+
+int32_t calico_num_effective_parameters(calico_problem* p, int32_t* n_out) {
+  if (!p || !n_out) return CALICO_INVALID_ARGUMENT;
+  const int rc = finalize(p);
+  if (rc != CALICO_OK) return rc;
+  *n_out = p->n_eff;
+  return CALICO_OK;
+}
+
+int32_t calico_evaluate(calico_problem* p, double* cost, double* gradient, double* jtj) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  int rc = finalize(p);
+  if (rc != CALICO_OK) return rc;
+  HIP_TRY(p, hipSetDevice(p->device));
+  rc = upload_x(p);
+  if (rc != CALICO_OK) return rc;
+  rc = enqueue_jacobian_eval(p, nullptr, 0);
+  if (rc != CALICO_OK) return rc;
+  SolveArgs sa = make_solve_args(p);
+  std::vector<double> R(sa.r_size());
+  HIP_TRY(p, hipMemcpyAsync(R.data(), p->d_R.p, R.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(p, hipStreamSynchronize(p->stream));
+  p->timer.resolve();
+  if (R[1] > 0.0) return p->set_error(CALICO_INTERNAL, "residual evaluation failed");
+  if (cost) *cost = R[0];
+  const int n = p->n_eff, NS = 6 * p->n_cp, m = p->m, k = p->order;
+  auto H = [&](int ta, int tb) -> double {  // solver tangent indices
+    if (ta > tb) std::swap(ta, tb);
+    if (tb < NS) {
+      const int a = ta / 6, b = tb / 6;
+      if (b - a >= k) return 0.0;
+      return R[sa.off_B() + (size_t(a) * k + (b - a)) * 36 + (ta % 6) * 6 + (tb % 6)];
+    }
+    if (ta < NS) return R[sa.off_E() + size_t(ta) * m + (tb - NS)];
+    return R[sa.off_C() + size_t(ta - NS) * m + (tb - NS)];
+  };
+  if (gradient) for (int i = 0; i < n; ++i) gradient[i] = R[sa.off_g() + p->eff_to_tan[size_t(i)]];
+  if (jtj)
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) jtj[size_t(i) * n + j] = H(p->eff_to_tan[size_t(i)], p->eff_to_tan[size_t(j)]);
+  return CALICO_OK;
+}
+
+int32_t calico_problem_set_allreduce(calico_problem* p, calico_allreduce_fn fn, void* ctx) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  p->allreduce = fn; p->allreduce_ctx = ctx;
+  return CALICO_OK;
+}
+
+int32_t calico_problem_set_stream(calico_problem* p, void* stream) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+  p->stream = reinterpret_cast<hipStream_t>(stream);
+  p->own_stream = false;
+  return CALICO_OK;
+}
+
+int32_t calico_get_phase_time(calico_problem* p, int32_t phase, double* ms, int64_t* launches) {
+  if (!p || phase < 0 || phase >= kNumPhases) return CALICO_INVALID_ARGUMENT;
+  if (ms) *ms = p->timer.ms[phase];
+  if (launches) *launches = p->timer.count[phase];
+  return CALICO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,617 @@
+// eval_kernels.hip — residual / Jacobian / normal-equation partials on gfx950.
+//
+// One wave (64 lanes) per work item: a run of residual blocks that share one
+// cell = (sensor, rigid body, spline segment). Stage A: one residual block per
+// lane — the lane evaluates the reference's cost functor and its analytic
+// Jacobian in FP64 registers (wave-uniform parameter blocks come in through
+// scalar loads), applies the robust loss, and stages its Jacobian rows
+// transposed in LDS (column-major, padded stride, conflict-free 16-byte
+// writes). Stage B: the wave forms the item's dense JᵀJ | Jᵀr block from LDS
+// with 4×4 register tiles and writes it once, coalesced. The per-observation
+// Jacobian never touches HBM.
+//
+// Reference arithmetic reproduced here:
+//   camera_cost_functor.h:71-147, gyroscope_cost_functor.h:58-118,
+//   accelerometer_cost_functor.h:62-147, bspline.hpp:39-72, geometry.h:137-222.
+#include <hip/hip_runtime.h>
+
+#include "device_math.hpp"
+#include "problem_dev.hpp"
+
+namespace cal {
+
+// Wave-uniform context of a work item.
+struct ItemCtx {
+  const SensorDev* s;
+  const LayoutDev* L;
+  int k;
+  double knot0, knot1;
+  const double* M;        // k×k basis of the segment
+  const int* ctrl_off;    // ambient offsets of the segment's k control points
+  const double* x;
+};
+
+// Evaluate spline value / derivatives at t: out[d][6] = sum_i W[d][i] * ctrl_i.
+template <int ND>
+DEV void spline_eval(const ItemCtx& c, double t, double W[ND][kMaxOrder], double out[ND][6]) {
+  spline_weights<ND>(c.k, c.knot0, c.knot1, c.M, t, W);
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+#pragma unroll
+    for (int a = 0; a < 6; ++a) out[d][a] = 0.0;
+  for (int i = 0; i < c.k; ++i) {
+    const double* cp = c.x + c.ctrl_off[i];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double v = cp[a];
+#pragma unroll
+      for (int d = 0; d < ND; ++d) out[d][a] += W[d][i] * v;
+    }
+  }
+}
+
+struct RowSink {
+  double* J;  // LDS, column-major [col][kRowPad]
+  int row0;
+  DEV void put(int col, int r, double v) const { J[col * kRowPad + row0 + r] = v; }
+};
+
+// ---------------------------------------------------------------------------
+// Camera: residual (2) and Jacobian rows. Returns false on invalid projection.
+// ---------------------------------------------------------------------------
+template <int MODEL, bool JAC>
+DEV bool camera_block(const ItemCtx& c, double px, double py, double stamp, const double* xm, double res[2],
+                      const RowSink& sink, double* cost, int apply_loss) {
+  const SensorDev& S = *c.s;
+  const LayoutDev& L = *c.L;
+  const double* intr = c.x + S.intr_off;
+  const double* qp = c.x + S.q_off;
+  const double* tp = c.x + S.t_off;
+  const double lat = c.x[S.lat_off];
+  const double* bq = c.x + L.bq_off;
+  const double* bt = c.x + L.bt_off;
+  Q4 q_rc; q_rc.x = qp[0]; q_rc.y = qp[1]; q_rc.z = qp[2]; q_rc.w = qp[3];
+  Q4 q_wm; q_wm.x = bq[0]; q_wm.y = bq[1]; q_wm.z = bq[2]; q_wm.w = bq[3];
+  const M3 R_rc = rotmat(normalized(q_rc));
+  const M3 R_wm = rotmat(normalized(q_wm));
+  const V3 t_rc = mk(tp[0], tp[1], tp[2]);
+  const V3 t_wm = mk(bt[0], bt[1], bt[2]);
+  constexpr int ND = JAC ? 2 : 1;
+  double W[ND][kMaxOrder], P[ND][6];
+  spline_eval<ND>(c, stamp - lat, W, P);
+  const V3 phi = mk(-P[0][0], -P[0][1], -P[0][2]);
+  const V3 t_wr = mk(P[0][3], P[0][4], P[0][5]);
+  const M3 R_rw = rotmat(angle_axis_to_quat(phi));
+  const V3 Rx = mul(R_wm, mk(xm[0], xm[1], xm[2]));
+  const V3 v = (Rx + t_wm) - t_wr;
+  const V3 y = mul(R_rw, v);
+  const V3 z = y - t_rc;
+  const V3 xc = mulT(R_rc, z);
+  double pix[2], D[2][3], dK[2][kMaxIntr];
+  if (!project<MODEL, JAC>(intr, xc, pix, D, dK)) return false;
+  double r0 = (px - pix[0]) * S.info, r1 = (py - pix[1]) * S.info;
+  const double sq = r0 * r0 + r1 * r1;
+  double ls = 1.0, rho = sq;
+  if (apply_loss) rho = loss_eval(S.loss, S.loss_scale, sq, &ls);
+  *cost = 0.5 * rho;
+  res[0] = r0 * ls; res[1] = r1 * ls;
+  if constexpr (JAC) {
+    const double fac = -S.info * ls;
+    // DRt = D·R_rcᵀ, DG = DRt·R_rw  (2×3)
+    double DRt[2][3], DG[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) DRt[r][j] = D[r][0] * R_rc.m[j][0] + D[r][1] * R_rc.m[j][1] + D[r][2] * R_rc.m[j][2];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) DG[r][j] = DRt[r][0] * R_rw.m[0][j] + DRt[r][1] * R_rw.m[1][j] + DRt[r][2] * R_rw.m[2][j];
+    }
+    // A = dr/dp (2×6): rotation part fac·DRt·[y]×·J_l(phi); translation part -fac·DG
+    const Rodrigues<double> rod = rodrigues<double>(phi.x, phi.y, phi.z, false);
+    const M3 Jl = rod_J_matrix(rod);
+    const M3 Sy = skew(y);
+    double A[2][6];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      double T1[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) T1[j] = DRt[r][0] * Sy.m[0][j] + DRt[r][1] * Sy.m[1][j] + DRt[r][2] * Sy.m[2][j];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) A[r][j] = fac * (T1[0] * Jl.m[0][j] + T1[1] * Jl.m[1][j] + T1[2] * Jl.m[2][j]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) A[r][3 + j] = -fac * DG[r][j];
+    }
+    // spline columns: w_i · A
+    for (int i = 0; i < c.k; ++i) {
+      const double w = W[0][i];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) { sink.put(6 * i + a, 0, w * A[0][a]); sink.put(6 * i + a, 1, w * A[1][a]); }
+    }
+    if (L.c_intr >= 0) {
+      constexpr int K = CamK<MODEL>::K;
+#pragma unroll
+      for (int j = 0; j < K; ++j) { sink.put(L.c_intr + j, 0, fac * dK[0][j]); sink.put(L.c_intr + j, 1, fac * dK[1][j]); }
+    }
+    if (L.c_q >= 0) {  // d xc / d delta = 2 R_rcᵀ [z]×
+      const M3 Sz = skew(z);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          sink.put(L.c_q + j, r, 2.0 * fac * (DRt[r][0] * Sz.m[0][j] + DRt[r][1] * Sz.m[1][j] + DRt[r][2] * Sz.m[2][j]));
+    }
+    if (L.c_t >= 0) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) sink.put(L.c_t + j, r, -fac * DRt[r][j]);
+    }
+    if (L.c_lat >= 0) {  // dp/dlat = -pdot
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) s += A[r][a] * P[ND - 1][a];
+        sink.put(L.c_lat, r, -s);
+      }
+    }
+    if (L.c_bq >= 0) {  // d xc / d delta_wm = -2 G [R_wm x_m]×
+      const M3 Sx = skew(Rx);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          sink.put(L.c_bq + j, r, -2.0 * fac * (DG[r][0] * Sx.m[0][j] + DG[r][1] * Sx.m[1][j] + DG[r][2] * Sx.m[2][j]));
+    }
+    if (L.c_bt >= 0) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) sink.put(L.c_bt + j, r, fac * DG[r][j]);
+    }
+  }
+  return true;
+}
+
+template <bool JAC>
+DEV bool camera_dispatch(const ItemCtx& c, double px, double py, double stamp, const double* xm, double res[2],
+                         const RowSink& sink, double* cost, int apply_loss) {
+  switch (c.s->model) {
+    case 1: return camera_block<1, JAC>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
+    case 2: return camera_block<2, JAC>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
+    case 3: return camera_block<3, JAC>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
+    case 4: return camera_block<4, JAC>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
+    case 5: return camera_block<5, JAC>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
+    case 6: return camera_block<6, JAC>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
+    default: return camera_block<7, JAC>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// IMU kinematics shared by the gyroscope and accelerometer blocks.
+// ---------------------------------------------------------------------------
+// omega = J(phi)·phid and W = d omega / d phi (via D3 over phi).
+DEV void omega_and_dphi(V3 phi, V3 phid, V3* omega, double Wm[3][3]) {
+  D3 px = mkd(phi.x), py = mkd(phi.y), pz = mkd(phi.z);
+  px.d0 = 1.0; py.d1 = 1.0; pz.d2 = 1.0;
+  const Rodrigues<D3> R = rodrigues<D3>(px, py, pz, false);
+  D3 ox, oy, oz;
+  rod_J_apply<D3>(R, mkd(phid.x), mkd(phid.y), mkd(phid.z), &ox, &oy, &oz);
+  *omega = mk(ox.v, oy.v, oz.v);
+  Wm[0][0] = ox.d0; Wm[0][1] = ox.d1; Wm[0][2] = ox.d2;
+  Wm[1][0] = oy.d0; Wm[1][1] = oy.d1; Wm[1][2] = oy.d2;
+  Wm[2][0] = oz.d0; Wm[2][1] = oz.d1; Wm[2][2] = oz.d2;
+}
+
+template <bool JAC>
+DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], const RowSink& sink, double* cost,
+                    int apply_loss) {
+  const SensorDev& S = *c.s;
+  const LayoutDev& L = *c.L;
+  const double* intr = c.x + S.intr_off;
+  const double* qp = c.x + S.q_off;
+  const double lat = c.x[S.lat_off];
+  Q4 q; q.x = qp[0]; q.y = qp[1]; q.z = qp[2]; q.w = qp[3];
+  const M3 R_rg = rotmat(normalized(q));
+  constexpr int ND = JAC ? 3 : 2;
+  double W[ND][kMaxOrder], P[ND][6];
+  spline_eval<ND>(c, stamp - lat, W, P);
+  const V3 phi = mk(-P[0][0], -P[0][1], -P[0][2]);
+  const V3 phid = mk(-P[1][0], -P[1][1], -P[1][2]);
+  V3 omega;
+  double Wm[3][3];
+  M3 Jl;
+  if constexpr (JAC) {
+    omega_and_dphi(phi, phid, &omega, Wm);
+    Jl = rod_J_matrix(rodrigues<double>(phi.x, phi.y, phi.z, false));
+  } else {
+    const Rodrigues<double> R = rodrigues<double>(phi.x, phi.y, phi.z, false);
+    rod_J_apply<double>(R, phid.x, phid.y, phid.z, &omega.x, &omega.y, &omega.z);
+  }
+  const V3 og = -mulT(R_rg, omega);
+  double f[3], Mw[3][3], dK[3][kMaxIntr];
+  imu_project<JAC>(S.model, intr, og, f, Mw, dK);
+  double r[3] = {(meas.x - f[0]) * S.info, (meas.y - f[1]) * S.info, (meas.z - f[2]) * S.info};
+  const double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  double ls = 1.0, rho = sq;
+  if (apply_loss) rho = loss_eval(S.loss, S.loss_scale, sq, &ls);
+  *cost = 0.5 * rho;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) res[i] = r[i] * ls;
+  if constexpr (JAC) {
+    const double fac = -S.info * ls;
+    // B = fac · Mw · (-R_rgᵀ)  : dr/d omega_rw
+    double B[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) B[i][j] = -fac * (Mw[i][0] * R_rg.m[j][0] + Mw[i][1] * R_rg.m[j][1] + Mw[i][2] * R_rg.m[j][2]);
+    // A0 = dr/dp_r = B·W·(-1); A1 = dr/dpdot_r = B·J·(-1)
+    double A0[3][3], A1[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        A0[i][j] = -(B[i][0] * Wm[0][j] + B[i][1] * Wm[1][j] + B[i][2] * Wm[2][j]);
+        A1[i][j] = -(B[i][0] * Jl.m[0][j] + B[i][1] * Jl.m[1][j] + B[i][2] * Jl.m[2][j]);
+      }
+    for (int i = 0; i < c.k; ++i) {
+      const double w0 = W[0][i], w1 = W[1][i];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          sink.put(6 * i + a, rr, w0 * A0[rr][a] + w1 * A1[rr][a]);
+          sink.put(6 * i + 3 + a, rr, 0.0);
+        }
+    }
+    if (L.c_intr >= 0) {
+      const int K = imu_num_params(S.model);
+      for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) sink.put(L.c_intr + j, rr, fac * dK[rr][j]);
+    }
+    if (L.c_q >= 0) {  // d og / d delta = -2 R_rgᵀ [omega]×
+      const M3 So = skew(omega);
+      double RtS[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) RtS[i][j] = R_rg.m[0][i] * So.m[0][j] + R_rg.m[1][i] * So.m[1][j] + R_rg.m[2][i] * So.m[2][j];
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          sink.put(L.c_q + j, rr, -2.0 * fac * (Mw[rr][0] * RtS[0][j] + Mw[rr][1] * RtS[1][j] + Mw[rr][2] * RtS[2][j]));
+    }
+    if (L.c_t >= 0) {  // the translation extrinsic has zero derivative (gyroscope_cost_functor.h:94-114)
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) sink.put(L.c_t + j, rr, 0.0);
+    }
+    if (L.c_lat >= 0) {
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) s += A0[rr][a] * P[1][a] + A1[rr][a] * P[ND - 1][a];
+        sink.put(L.c_lat, rr, -s);
+      }
+    }
+  }
+  return true;
+}
+
+template <bool JAC>
+DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], const RowSink& sink, double* cost,
+                     int apply_loss) {
+  const SensorDev& S = *c.s;
+  const LayoutDev& L = *c.L;
+  const double* intr = c.x + S.intr_off;
+  const double* qp = c.x + S.q_off;
+  const double* tp = c.x + S.t_off;
+  const double* gp = c.x + S.grav_off;
+  const double lat = c.x[S.lat_off];
+  Q4 q; q.x = qp[0]; q.y = qp[1]; q.z = qp[2]; q.w = qp[3];
+  const M3 R_ra = rotmat(normalized(q));
+  const V3 t = mk(tp[0], tp[1], tp[2]);
+  const V3 g = mk(gp[0], gp[1], gp[2]);
+  constexpr int ND = JAC ? 4 : 3;
+  double W[ND][kMaxOrder], P[ND][6];
+  spline_eval<ND>(c, stamp - lat, W, P);
+  const V3 phi = mk(-P[0][0], -P[0][1], -P[0][2]);
+  const V3 phid = mk(-P[1][0], -P[1][1], -P[1][2]);
+  const V3 phidd = mk(-P[2][0], -P[2][1], -P[2][2]);
+  const V3 aw = mk(P[2][3], P[2][4], P[2][5]);
+  const M3 R_rw = rotmat(angle_axis_to_quat(phi));
+  V3 omega, alpha;
+  double dw_dphi[3][3], da_dphi[3][3];
+  if constexpr (JAC) {
+    D3 px = mkd(phi.x), py = mkd(phi.y), pz = mkd(phi.z);
+    px.d0 = 1.0; py.d1 = 1.0; pz.d2 = 1.0;
+    const Rodrigues<D3> R = rodrigues<D3>(px, py, pz, true);
+    D3 o[3], jdd[3], Hv[3][3];
+    rod_J_apply<D3>(R, mkd(phid.x), mkd(phid.y), mkd(phid.z), &o[0], &o[1], &o[2]);
+    rod_J_apply<D3>(R, mkd(phidd.x), mkd(phidd.y), mkd(phidd.z), &jdd[0], &jdd[1], &jdd[2]);
+    rod_H_apply<D3>(R, mkd(phid.x), mkd(phid.y), mkd(phid.z), Hv);
+    D3 al[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) al[j] = phid.x * Hv[0][j] + phid.y * Hv[1][j] + phid.z * Hv[2][j] + jdd[j];
+    omega = mk(o[0].v, o[1].v, o[2].v);
+    alpha = mk(al[0].v, al[1].v, al[2].v);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      dw_dphi[j][0] = o[j].d0; dw_dphi[j][1] = o[j].d1; dw_dphi[j][2] = o[j].d2;
+      da_dphi[j][0] = al[j].d0; da_dphi[j][1] = al[j].d1; da_dphi[j][2] = al[j].d2;
+    }
+  } else {
+    const Rodrigues<double> R = rodrigues<double>(phi.x, phi.y, phi.z, true);
+    double jdd[3], Hv[3][3];
+    rod_J_apply<double>(R, phid.x, phid.y, phid.z, &omega.x, &omega.y, &omega.z);
+    rod_J_apply<double>(R, phidd.x, phidd.y, phidd.z, &jdd[0], &jdd[1], &jdd[2]);
+    rod_H_apply<double>(R, phid.x, phid.y, phid.z, Hv);
+    alpha = mk(phid.x * Hv[0][0] + phid.y * Hv[1][0] + phid.z * Hv[2][0] + jdd[0],
+               phid.x * Hv[0][1] + phid.y * Hv[1][1] + phid.z * Hv[2][1] + jdd[1],
+               phid.x * Hv[0][2] + phid.y * Hv[1][2] + phid.z * Hv[2][2] + jdd[2]);
+  }
+  // b = R_rw (a_w - g) + omega×(omega×t) - alpha×t ;  f = R_raᵀ b
+  const V3 rag = mul(R_rw, aw - g);
+  const V3 b = rag + cross(omega, cross(omega, t)) - cross(alpha, t);
+  const V3 fs = mulT(R_ra, b);
+  double f[3], Mw[3][3], dK[3][kMaxIntr];
+  imu_project<JAC>(S.model, intr, fs, f, Mw, dK);
+  double r[3] = {(meas.x - f[0]) * S.info, (meas.y - f[1]) * S.info, (meas.z - f[2]) * S.info};
+  const double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  double ls = 1.0, rho = sq;
+  if (apply_loss) rho = loss_eval(S.loss, S.loss_scale, sq, &ls);
+  *cost = 0.5 * rho;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) res[i] = r[i] * ls;
+  if constexpr (JAC) {
+    const double fac = -S.info * ls;
+    // Bm = fac · Mw · R_raᵀ : dr/db
+    double Bm[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Bm[i][j] = fac * (Mw[i][0] * R_ra.m[j][0] + Mw[i][1] * R_ra.m[j][1] + Mw[i][2] * R_ra.m[j][2]);
+    // db/d omega = (omega·t) I + omega tᵀ - 2 t omegaᵀ ;  db/d alpha = [t]×
+    const double ot = dot(omega, t);
+    double dbdw[3][3];
+    const M3 St = skew(t);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        dbdw[i][j] = (i == j ? ot : 0.0) + comp(omega, i) * comp(t, j) - 2.0 * comp(t, i) * comp(omega, j);
+    // explicit Hessian slices for d alpha / d phid:  H[i][j][l] = (H_i e_l)_j
+    const Rodrigues<double> Rd = rodrigues<double>(phi.x, phi.y, phi.z, true);
+    const M3 Jl = rod_J_matrix(Rd);
+    double Hm[3][3][3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      double Hv[3][3];
+      rod_H_apply<double>(Rd, l == 0 ? 1.0 : 0.0, l == 1 ? 1.0 : 0.0, l == 2 ? 1.0 : 0.0, Hv);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Hm[i][j][l] = Hv[i][j];
+    }
+    double da_dphid[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int l = 0; l < 3; ++l) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s += Hm[i][j][l] * comp(phid, i) + Hm[l][j][i] * comp(phid, i);
+        da_dphid[j][l] = s;
+      }
+    // db/dphi = -[rag]× J_l + dbdw·dw_dphi + St·da_dphi
+    const M3 Sr = skew(rag);
+    double db_dphi[3][3], db_dphid[3][3], db_dphidd[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        double s = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int q2 = 0; q2 < 3; ++q2) {
+          s += -Sr.m[i][q2] * Jl.m[q2][j] + dbdw[i][q2] * dw_dphi[q2][j] + St.m[i][q2] * da_dphi[q2][j];
+          s1 += dbdw[i][q2] * Jl.m[q2][j] + St.m[i][q2] * da_dphid[q2][j];
+          s2 += St.m[i][q2] * Jl.m[q2][j];
+        }
+        db_dphi[i][j] = s; db_dphid[i][j] = s1; db_dphidd[i][j] = s2;
+      }
+    // A0 = dr/dp_r, A1 = dr/dpdot_r, A2r = dr/dpddot_r (phi = -p_r), A2t = dr/dpddot_t = Bm·R_rw
+    double A0[3][3], A1[3][3], A2r[3][3], A2t[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int q2 = 0; q2 < 3; ++q2) {
+          s0 += Bm[i][q2] * db_dphi[q2][j]; s1 += Bm[i][q2] * db_dphid[q2][j];
+          s2 += Bm[i][q2] * db_dphidd[q2][j]; s3 += Bm[i][q2] * R_rw.m[q2][j];
+        }
+        A0[i][j] = -s0; A1[i][j] = -s1; A2r[i][j] = -s2; A2t[i][j] = s3;
+      }
+    for (int i = 0; i < c.k; ++i) {
+      const double w0 = W[0][i], w1 = W[1][i], w2 = W[2][i];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          sink.put(6 * i + a, rr, w0 * A0[rr][a] + w1 * A1[rr][a] + w2 * A2r[rr][a]);
+          sink.put(6 * i + 3 + a, rr, w2 * A2t[rr][a]);
+        }
+    }
+    if (L.c_intr >= 0) {
+      const int K = imu_num_params(S.model);
+      for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) sink.put(L.c_intr + j, rr, fac * dK[rr][j]);
+    }
+    if (L.c_q >= 0) {  // d f / d delta = 2 R_raᵀ [b]×
+      const M3 Sb = skew(b);
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          sink.put(L.c_q + j, rr, 2.0 * (Bm[rr][0] * Sb.m[0][j] + Bm[rr][1] * Sb.m[1][j] + Bm[rr][2] * Sb.m[2][j]));
+    }
+    if (L.c_t >= 0) {  // db/dt = [omega]×[omega]× - [alpha]×
+      const M3 So = skew(omega), Sa = skew(alpha);
+      const M3 So2 = mul(So, So);
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          double s = 0.0;
+#pragma unroll
+          for (int q2 = 0; q2 < 3; ++q2) s += Bm[rr][q2] * (So2.m[q2][j] - Sa.m[q2][j]);
+          sink.put(L.c_t + j, rr, s);
+        }
+    }
+    if (L.c_lat >= 0) {
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+          s += A0[rr][a] * P[1][a] + A1[rr][a] * P[2][a] + A2r[rr][a] * P[ND - 1][a] + A2t[rr][a] * P[ND - 1][3 + a];
+        sink.put(L.c_lat, rr, -s);
+      }
+    }
+    if (L.c_grav >= 0) {  // db/dg = -R_rw
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) sink.put(L.c_grav + j, rr, -A2t[rr][j]);
+    }
+  }
+  return true;
+}
+
+DEV double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// The evaluation kernel. JAC: stage Jacobian rows and form the item's
+// [JᵀJ | Jᵀr] block; !JAC: residuals / cost only.
+// grid = n_items, block = 64 (one wave).
+// ---------------------------------------------------------------------------
+template <bool JAC>
+__global__ __launch_bounds__(64) void eval_items_kernel(EvalArgs a) {
+  extern __shared__ double lds[];
+  const int item_id = blockIdx.x;
+  const int lane = threadIdx.x;
+  const ItemDev it = a.items[item_id];
+  const LayoutDev& L = a.layouts[it.layout];
+  const SensorDev& S = a.sensors[L.sensor];
+  ItemCtx c;
+  c.s = &S; c.L = &L; c.k = a.order; c.x = a.x;
+  const int ki = it.seg + a.order - 1;
+  c.knot0 = a.knots[ki]; c.knot1 = a.knots[ki + 1];
+  c.M = a.basis + size_t(it.seg) * a.order * a.order;
+  c.ctrl_off = a.ctrl_off + it.seg;
+  const int dim = (S.kind == 0) ? 2 : 3;
+  const int ncols = L.ncols;           // Jacobian columns; column ncols holds the residual
+  const int cp4 = (ncols + 1 + 3) & ~3;
+  const int nrows = dim * it.obs_count;
+  if constexpr (JAC) {
+    // zero the staging area (inactive lanes / padding columns contribute 0)
+    for (int i = lane; i < cp4 * kRowPad; i += 64) lds[i] = 0.0;
+    __syncthreads();
+  }
+  const bool active = lane < it.obs_count;
+  const int o = it.obs_begin + lane;
+  double res[3] = {0.0, 0.0, 0.0};
+  double cost = 0.0;
+  bool ok = true;
+  RowSink sink; sink.J = lds; sink.row0 = dim * lane;
+  if (active) {
+    const double st = a.stamp[o];
+    if (S.kind == 0) {
+      ok = camera_dispatch<JAC>(c, a.m0[o], a.m1[o], st, a.x + a.point_off[o], res, sink, &cost, a.apply_loss);
+    } else if (S.kind == 1) {
+      ok = gyro_block<JAC>(c, mk(a.m0[o], a.m1[o], a.m2[o]), st, res, sink, &cost, a.apply_loss);
+    } else {
+      ok = accel_block<JAC>(c, mk(a.m0[o], a.m1[o], a.m2[o]), st, res, sink, &cost, a.apply_loss);
+    }
+    if (!ok) { cost = 0.0; res[0] = res[1] = res[2] = 0.0; }
+    if (a.res_out) {
+      for (int r = 0; r < dim; ++r) a.res_out[size_t(o) * 3 + r] = res[r];
+      a.valid_out[o] = ok ? 1 : 0;
+    }
+  }
+  const double item_cost = wave_sum(cost);
+  const double n_invalid = wave_sum((active && !ok) ? 1.0 : 0.0);
+  if (lane == 0) { a.item_cost[2 * item_id] = item_cost; a.item_cost[2 * item_id + 1] = n_invalid; }
+  if constexpr (JAC) {
+    if (active) {
+      if (!ok) {  // drop the block: zero its rows
+        for (int col = 0; col < ncols; ++col)
+          for (int r = 0; r < dim; ++r) sink.put(col, r, 0.0);
+      }
+      for (int r = 0; r < dim; ++r) sink.put(ncols, r, res[r]);
+    }
+    __syncthreads();
+    // Stage B: P = [J r]ᵀ [J r], upper 4×4 tiles.
+    const int nt = cp4 >> 2;
+    const int ntiles = nt * (nt + 1) / 2;
+    const int n1 = ncols + 1;
+    double* out = a.partials + it.partial_off;
+    for (int tile = lane; tile < ntiles; tile += 64) {
+      // tile index -> (ti <= tj)
+      int ti = 0, rem = tile;
+      while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
+      const int tj = ti + rem;
+      const double* ca = lds + (4 * ti) * kRowPad;
+      const double* cb = lds + (4 * tj) * kRowPad;
+      double acc[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+      for (int r = 0; r < nrows; ++r) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { av[i] = ca[i * kRowPad + r]; bv[i] = cb[i * kRowPad + r]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gi = 4 * ti + i, gj = 4 * tj + j;
+          if (gi < n1 && gj < n1 && gi <= gj) out[size_t(gi) * n1 + gj] = acc[i][j];
+        }
+    }
+  }
+}
+
+void launch_eval(const EvalArgs& a, bool jac, hipStream_t stream) {
+  if (a.n_items == 0) return;
+  if (jac) {
+    const size_t lds = size_t(a.lds_cols) * kRowPad * sizeof(double);
+    hipLaunchKernelGGL(eval_items_kernel<true>, dim3(a.n_items), dim3(64), lds, stream, a);
+  } else {
+    hipLaunchKernelGGL(eval_items_kernel<false>, dim3(a.n_items), dim3(64), 0, stream, a);
+  }
+}
+
+hipError_t configure_eval_kernels(size_t max_lds_bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_items_kernel<true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, int(max_lds_bytes));
+}
+
+}  // namespace cal

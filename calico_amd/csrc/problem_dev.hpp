@@ -1,0 +1,122 @@
+// problem_dev.hpp — device-side problem description shared by host and kernels.
+//
+// Data layout in HBM (all FP64 unless noted):
+//   x[n_amb]            ambient parameter values of every block (current point),
+//   x_cand[n_amb]       candidate point of the LM step,
+//   obs_* SoA arrays    observations sorted by (layout, segment), i.e. by "cell":
+//                       every residual block of a cell touches the same k control
+//                       points and the same calibration blocks, so its Jacobian
+//                       rows share one local column set,
+//   partials            per work item: (c+1)×(c+1) [JᵀJ | Jᵀr] block + cost + flag,
+//   R (reduce buffer)   [cost | invalid | g(NT) | band blocks | border E | corner C],
+//                       the only thing exchanged between GPUs.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace cal {
+
+constexpr int kRowsPerItem = 128;   // LDS rows staged per work item (64 camera obs × 2)
+constexpr int kRowPad = 129;        // row stride (doubles) of a staged Jacobian column
+
+struct SensorDev {
+  int kind, model, K, loss;
+  int intr_off, q_off, t_off, lat_off, grav_off;  // ambient offsets into x
+  int pad0;
+  double info, loss_scale;
+};
+
+// Local column layout of one (sensor, rigid body) pair. Column order:
+// [spline 6k | intrinsics | q | t | latency | body q | body t | gravity];
+// an entry is -1 when that block is constant (no column).
+struct LayoutDev {
+  int sensor, ncols;
+  int c_intr, c_q, c_t, c_lat, c_bq, c_bt, c_grav;
+  int bq_off, bt_off;  // ambient offsets of the rigid body pose (cameras)
+  int pad0;
+};
+
+// One work item = up to kRowsPerItem residual rows of one cell.
+struct ItemDev {
+  int layout, seg, obs_begin, obs_count;
+  int64_t partial_off;  // offset (doubles) of this item's partial block
+};
+
+struct EvalArgs {
+  const double* x;
+  const SensorDev* sensors;
+  const LayoutDev* layouts;
+  const ItemDev* items;
+  const double* knots;
+  const double* basis;    // per segment k×k
+  const int* ctrl_off;    // ambient offset of every control point
+  const double* m0; const double* m1; const double* m2; const double* stamp;
+  const int* point_off;   // ambient offset of the observed model point (cameras)
+  double* partials;
+  double* item_cost;      // per item: [cost, invalid]
+  double* res_out;        // residual write-back (n_obs × 3), or nullptr
+  uint8_t* valid_out;
+  int order, n_items, lds_cols, apply_loss;
+};
+
+// LM state kept on the device; the control kernel is its only writer.
+struct LmState {
+  double radius, decrease_factor;
+  double x_cost, candidate_cost, model_cost_change;
+  double x_norm, cand_norm, step_norm, gradient_max_norm, gradient_norm;
+  double relative_decrease, cost_change;
+  double initial_cost, min_cost;
+  int iteration;
+  int need_jacobian;      // the last step was accepted: re-evaluate J at x
+  int terminated, termination_type, termination_reason;
+  int step_valid, step_successful, chol_failed;
+  int num_consecutive_invalid, num_successful, num_unsuccessful;
+  int invalid_eval;       // candidate evaluation hit an invalid projection
+  int n_log, pad;
+};
+
+struct LmOptionsDev {
+  int max_num_iterations, max_num_consecutive_invalid_steps;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  double max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+};
+
+struct IterLog {  // mirrors calico_iteration
+  int iteration, step_is_valid, step_is_successful, reserved;
+  double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius;
+};
+
+struct BlockDev {  // one reduced (free, used) parameter block
+  int amb_off, size, manifold, tan_off;
+};
+
+#if defined(__HIPCC__)
+#define CAL_HD __host__ __device__
+#else
+#define CAL_HD
+#endif
+
+// Arguments of the linear-solve kernels. The reduce buffer R is laid out as
+// [cost | invalid | g(NT) | band blocks B(n_cp,k,6,6) | border E(6n_cp,m) | corner C(m,m)].
+struct SolveArgs {
+  const double* R;
+  double* Lw;             // [n_s][W]   band factor, column oriented: Lw[c][t] = L(c+t, c)
+  double* Y;              // [n_s][m+1] L^-1 [E | g_s]
+  double* S;              // [m+1][m+1] reduced system; row m carries the right-hand side
+  double* y;              // [NT] solution of the damped system (unscaled): delta = -y
+  double* dadd;           // [NT] damping added to the diagonal
+  double* scale;          // [NT] Jacobi scaling 1/(1+sqrt(H_jj)) from iteration 0
+  const uint8_t* cp_active;  // [n_cp]
+  LmState* st;
+  int n_cp, k, m;
+  CAL_HD int n_s() const { return 6 * n_cp; }
+  CAL_HD int W() const { return 6 * k; }
+  CAL_HD int NT() const { return 6 * n_cp + m; }
+  CAL_HD size_t off_g() const { return 2; }
+  CAL_HD size_t off_B() const { return 2 + size_t(NT()); }
+  CAL_HD size_t off_E() const { return off_B() + size_t(n_cp) * k * 36; }
+  CAL_HD size_t off_C() const { return off_E() + size_t(n_s()) * m; }
+  CAL_HD size_t r_size() const { return off_C() + size_t(m) * m; }
+};
+
+}  // namespace cal
