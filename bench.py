@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: Levenberg-Marquardt iterations per second on the
+4-camera + IMU, ~100k-observation synthetic problem (BASELINE.json configs[3]).
+
+A "step" is one LM iteration of calico_solve (linear solve + candidate cost
+evaluation + accept/reject, and a residual/Jacobian/JtJ evaluation whenever the
+step is accepted) with all observations resident in HBM. The timed region runs
+whole solves from the perturbed initial guess (reference default tolerances)
+until exactly K iterations have been made; each solve's initial evaluation
+(iteration 0) is inside the timed region and not counted as a step.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_jacobian_launch(scene):
+    """SURVEY.md §8(d) per-block figure restricted to what ONE launch of the fused
+    residual/Jacobian/JtJ kernel stands for: read the observation (40 B), write the
+    residual (8d), write the Jacobian (8dc), read both back for assembly (8dc + 8d).
+    d = residual dim, c = active tangent columns of the block."""
+    from calico_amd import _capi
+    total = 0
+    k6 = 6 * scene.order
+    for s in scene.sensors:
+        c = k6
+        if s.enable_intrinsics:
+            c += len(s.intrinsics)
+        if s.enable_extrinsics:
+            c += 3 + (0 if s.kind == _capi.SENSOR_GYROSCOPE else 3)
+        if s.enable_latency:
+            c += 1
+        d = s.dim
+        total += s.n * (40 + 16 * d + 16 * d * c)
+    return total
+
+
+def cpu_baseline(scene, iters=25):
+    """The CPU oracle (restatement of the reference's Ceres path) on the host cores
+    of this box: a bounded sample of the same workload. Reported, never shipped."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    from calico_amd import synthetic as syn
+    api = helpers.oracle_api()
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    built = syn.build_problem(api, scene)
+    o = api.default_options()
+    o.minimizer_progress_to_stdout = 0
+    o.max_num_iterations = iters
+    o.num_threads = threads
+    t = time.time()
+    s = built.problem.solve(o)
+    dt = time.time() - t
+    nit = max(1, s.num_iterations)
+    return {"value": nit / dt, "unit": "LM iterations/s", "cores": threads, "kind": "port",
+            "sample": "%d LM iterations (+ initial evaluation) of the same %d-block problem in %.1f s"
+                      % (nit, scene.num_blocks, dt)}
+
+
+class _DevArray:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (3 = north star)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from calico_amd import _capi, synthetic as syn
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libcalico_hip.so is the only backend")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    api = _capi.load_hip()
+    scene = syn.config_scene(args.config)
+    built = syn.build_problem(api, scene, device=local_rank)
+    P = built.problem
+    keep = []
+    if world > 1:
+        stream = torch.cuda.current_stream().cuda_stream
+        P.set_stream(stream)
+        P.set_shard(rank, world)
+
+        def allreduce(ctx, buf, n, strm):
+            t = torch.as_tensor(_DevArray(buf, n), device="cuda")
+            dist.all_reduce(t)
+            return 0
+        P.set_allreduce(allreduce)
+        keep.append(allreduce)
+
+    # initial values of every free block, to restart solves inside the timed region
+    init = [(int(b), scene.ctrl[i].copy()) for i, b in enumerate(built.ctrl_blocks)]
+    for s, sb in zip(scene.sensors, built.sensor_blocks):
+        init += [(sb["intrinsics"], s.intrinsics.copy()), (sb["t"], s.t.copy()), (sb["q"], s.q.copy()),
+                 (sb["latency"], np.array([s.latency]))]
+
+    def reset():
+        for b, v in init:
+            P.set_param_block(b, v)
+
+    opts = api.default_options()
+    opts.minimizer_progress_to_stdout = 0
+
+    def run_iterations(n):
+        """Exactly n LM iterations, spread over as many full solves as needed."""
+        done = jac = cost = 0
+        solves = 0
+        last = None
+        while done < n:
+            reset()
+            opts.max_num_iterations = min(50, n - done)
+            s = P.solve(opts)
+            if s.num_iterations <= 0:
+                raise RuntimeError("solve made no progress: %s" % s.message.decode())
+            done += s.num_iterations
+            jac += s.num_jacobian_evaluations
+            cost += s.num_cost_evaluations
+            solves += 1
+            last = s
+        return done, jac, cost, solves, last
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_iterations(max(1, args.warmup))
+    phase0 = [P.phase_time(i) for i in range(5)]  # timers reset at every solve; only deltas below matter
+    barrier()
+    t0 = time.perf_counter()
+    # phase timers accumulate per solve: collect them solve by solve
+    done = jac = cost = solves = 0
+    phase_ms = [0.0] * 5
+    phase_n = [0] * 5
+    last = None
+    while done < args.steps:
+        reset()
+        opts.max_num_iterations = min(50, args.steps - done)
+        s = P.solve(opts)
+        if s.num_iterations <= 0:
+            raise RuntimeError("solve made no progress: %s" % s.message.decode())
+        done += s.num_iterations
+        jac += s.num_jacobian_evaluations
+        cost += s.num_cost_evaluations
+        solves += 1
+        last = s
+        for i in range(5):
+            ms, n = P.phase_time(i)
+            phase_ms[i] += ms
+            phase_n[i] += n
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        n_blocks = scene.num_blocks
+        jac_ms = phase_ms[0] / max(1, phase_n[0])
+        alg_bytes = algorithmic_bytes_per_jacobian_launch(scene) / world
+        achieved = alg_bytes / (jac_ms * 1e-3) / 1e9 if jac_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("eval_items_kernel_jac_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "LM iterations/sec on the 4-cam+IMU ~100k-observation problem",
+            "value": done / elapsed,
+            "unit": "LM iterations/s",
+            "n_gpus": world,
+            "steps": done,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / done,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE.json configs[%d]: %d cameras + gyro + accel, %d residual blocks (%d scalar residuals), "
+                            "%d control points, robust kernels %s" % (
+                                args.config, sum(1 for s in scene.sensors if s.kind == 0), n_blocks,
+                                sum(s.n * s.dim for s in scene.sensors), len(scene.ctrl),
+                                "on" if any(s.loss for s in scene.sensors) else "off"),
+                "residual_blocks": n_blocks,
+                "effective_parameters": last.num_effective_parameters_reduced,
+                "solves_in_timed_region": solves,
+                "jacobian_evaluations": jac,
+                "cost_evaluations": cost,
+                "residual_blocks_evaluated_per_s": n_blocks * (jac + cost) / elapsed,
+                "parallelism": "obs-shard x%d + all-reduce(JtJ,Jtr,cost)" % world if world > 1 else "single GPU",
+                "phase_ms_per_launch": {
+                    "jacobian_eval": jac_ms,
+                    "gather": phase_ms[1] / max(1, phase_n[1]),
+                    "linear_solve": phase_ms[2] / max(1, phase_n[2]),
+                    "cost_eval": phase_ms[3] / max(1, phase_n[3]),
+                    "control": phase_ms[4] / max(1, phase_n[4]),
+                },
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "eval_items_kernel<true> (fused residual + Jacobian + JtJ partials)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": jac_ms, "launches": phase_n[0],
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

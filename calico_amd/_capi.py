@@ -118,7 +118,7 @@ ABI_SYMBOLS = [
     "problem_set_spline", "problem_add_rigid_body", "problem_add_sensor",
     "problem_add_camera_residuals", "problem_add_imu_residuals", "solve",
     "get_iterations", "get_residuals", "get_inlier_mask",
-    "num_effective_parameters", "evaluate", "problem_set_allreduce",
+    "num_effective_parameters", "evaluate", "problem_set_allreduce", "problem_set_shard",
     "problem_set_stream", "get_phase_time",
 ]
 
@@ -157,6 +157,7 @@ class CApi:
         g("evaluate", C.c_int32, [P, D, D, D])
         if has_device:
             g("problem_set_allreduce", C.c_int32, [P, ALLREDUCE_FN, C.c_void_p])
+            g("problem_set_shard", C.c_int32, [P, C.c_int32, C.c_int32])
             g("problem_set_stream", C.c_int32, [P, C.c_void_p])
             g("get_phase_time", C.c_int32, [P, C.c_int32, D, C.POINTER(C.c_int64)])
 
@@ -284,6 +285,9 @@ class Problem:
         cb = ALLREDUCE_FN(pyfunc)
         self._keep.append(cb)
         self._check(self.api.problem_set_allreduce(self.h, cb, None))
+
+    def set_shard(self, rank, world_size):
+        self._check(self.api.problem_set_shard(self.h, int(rank), int(world_size)))
 
     def set_stream(self, stream_ptr):
         self._check(self.api.problem_set_stream(self.h, C.c_void_p(stream_ptr)))

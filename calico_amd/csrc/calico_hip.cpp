@@ -24,6 +24,7 @@
 
 #include "../../include/calico_hip.h"
 #include "problem_dev.hpp"
+#include "shard.hpp"
 
 namespace cal {
 
@@ -136,14 +137,15 @@ struct calico_problem {
   bool dirty = true;
   calico_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
+  int rank = 0, world = 1;
 
   // flattened problem
-  int n_cp = 0, m = 0, n_amb = 0, n_eff = 0, n_items = 0, lds_cols = 0;
+  int n_cp = 0, m = 0, n_amb = 0, n_eff = 0, n_items = 0, n_items_all = 0, lds_cols = 0;
   int64_t n_obs = 0;
   size_t partial_doubles = 0;
   std::vector<int> eff_to_tan;
   std::vector<BlockDev> h_blocks;
-  std::vector<ItemDev> h_items;
+  std::vector<ItemDev> h_items, h_items_all;
   std::vector<double> h_x;
   int n_thin = 0, n_fat = 0;
   bool dense_in_lds = true;
@@ -155,7 +157,7 @@ struct calico_problem {
   DevBuf<uint8_t> d_cp_active, d_valid;
   DevBuf<SensorDev> d_sensors;
   DevBuf<LayoutDev> d_layouts;
-  DevBuf<ItemDev> d_items;
+  DevBuf<ItemDev> d_items, d_items_all;
   DevBuf<BlockDev> d_blocks;
   DevBuf<LmState> d_state;
   DevBuf<IterLog> d_log;
@@ -323,8 +325,7 @@ int finalize(calico_problem* p) {
   p->n_obs = n_obs;
   std::vector<double> m0(n_obs), m1(n_obs), m2(n_obs), st(n_obs);
   std::vector<int> point_off(n_obs, 0);
-  p->h_items.clear();
-  size_t poff = 0;
+  p->h_items.clear(); p->h_items_all.clear();
   int max_cols = 0;
   for (int64_t q = 0; q < n_obs;) {
     int64_t e = q;
@@ -336,11 +337,23 @@ int finalize(calico_problem* p) {
     for (int64_t b = q; b < e; b += chunk) {
       ItemDev it;
       it.layout = keys[q].layout; it.seg = keys[q].seg; it.obs_begin = int(b); it.obs_count = int(std::min<int64_t>(chunk, e - b));
-      it.partial_off = int64_t(poff);
-      poff += size_t(L.ncols + 1) * (L.ncols + 1);
-      p->h_items.push_back(it);
+      it.partial_off = 0;
+      p->h_items_all.push_back(it);
     }
     q = e;
+  }
+  // this rank's shard: a contiguous window of spline segments (shard.hpp)
+  const int nseg = int(p->valid_knots.size()) - 1;
+  std::vector<int64_t> per_seg(size_t(nseg), 0);
+  for (const ItemDev& it : p->h_items_all) per_seg[size_t(it.seg)] += it.obs_count;
+  const std::vector<int> win = shard_windows(per_seg, p->world);
+  size_t poff = 0;
+  for (ItemDev it : p->h_items_all) {
+    if (it.seg < win[size_t(p->rank)] || it.seg >= win[size_t(p->rank) + 1]) continue;
+    const LayoutDev& L = layouts[it.layout];
+    it.partial_off = int64_t(poff);
+    poff += size_t(L.ncols + 1) * (L.ncols + 1);
+    p->h_items.push_back(it);
   }
   for (int64_t q = 0; q < n_obs; ++q) {
     HSensor& s = p->sensors[keys[q].sensor];
@@ -352,6 +365,7 @@ int finalize(calico_problem* p) {
     if (s.kind == CALICO_SENSOR_CAMERA) point_off[q] = p->blocks[s.point[i]].amb_off;
   }
   p->n_items = int(p->h_items.size());
+  p->n_items_all = int(p->h_items_all.size());
   p->partial_doubles = poff;
   if (poff + 2 * size_t(p->n_items) >= size_t(0x7fffffff))
     return p->set_error(CALICO_UNIMPLEMENTED, "problem too large for 32-bit gather indices");
@@ -421,13 +435,14 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_m0.upload(m0, s)); HIP_TRY(p, p->d_m1.upload(m1, s)); HIP_TRY(p, p->d_m2.upload(m2, s));
   HIP_TRY(p, p->d_stamp.upload(st, s)); HIP_TRY(p, p->d_point_off.upload(point_off, s));
   HIP_TRY(p, p->d_sensors.upload(sd, s)); HIP_TRY(p, p->d_layouts.upload(layouts, s));
-  HIP_TRY(p, p->d_items.upload(p->h_items, s)); HIP_TRY(p, p->d_blocks.upload(p->h_blocks, s));
+  HIP_TRY(p, p->d_items.upload(p->h_items, s)); HIP_TRY(p, p->d_items_all.upload(p->h_items_all, s));
+  HIP_TRY(p, p->d_blocks.upload(p->h_blocks, s));
   HIP_TRY(p, p->d_cp_active.upload(cp_active, s));
   HIP_TRY(p, p->d_out_thin.upload(out_thin, s)); HIP_TRY(p, p->d_idx_thin.upload(idx_thin, s));
   HIP_TRY(p, p->d_ptr_thin.upload(ptr_thin, s));
   HIP_TRY(p, p->d_out_fat.upload(out_fat, s)); HIP_TRY(p, p->d_idx_fat.upload(idx_fat, s));
   HIP_TRY(p, p->d_ptr_fat.upload(ptr_fat, s));
-  HIP_TRY(p, p->d_partials.alloc(poff + 2 * size_t(p->n_items)));
+  HIP_TRY(p, p->d_partials.alloc(poff + 2 * size_t(std::max(p->n_items, p->n_items_all))));
   HIP_TRY(p, p->d_R.alloc(r_size)); HIP_TRY(p, hipMemsetAsync(p->d_R.p, 0, r_size * sizeof(double), s));
   HIP_TRY(p, p->d_R2.alloc(2));
   const int NT = 6 * n_cp + m;
@@ -790,7 +805,11 @@ int32_t calico_get_residuals(calico_problem* p, int32_t sid, double* out, uint8_
   HIP_TRY(p, hipSetDevice(p->device));
   rc = upload_x(p);
   if (rc != CALICO_OK) return rc;
-  launch_eval(make_eval_args(p, p->d_x.p, 0, true), false, p->stream);
+  {
+    EvalArgs ea = make_eval_args(p, p->d_x.p, 0, true);
+    ea.items = p->d_items_all.p; ea.n_items = p->n_items_all;  // every rank re-evaluates all blocks here
+    launch_eval(ea, false, p->stream);
+  }
   std::vector<double> r(size_t(p->n_obs) * 3);
   std::vector<uint8_t> v(size_t(p->n_obs));
   HIP_TRY(p, hipMemcpyAsync(r.data(), p->d_res.p, r.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
@@ -871,6 +890,13 @@ int32_t calico_evaluate(calico_problem* p, double* cost, double* gradient, doubl
 int32_t calico_problem_set_allreduce(calico_problem* p, calico_allreduce_fn fn, void* ctx) {
   if (!p) return CALICO_INVALID_ARGUMENT;
   p->allreduce = fn; p->allreduce_ctx = ctx;
+  return CALICO_OK;
+}
+
+int32_t calico_problem_set_shard(calico_problem* p, int32_t rank, int32_t world_size) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  if (world_size < 1 || rank < 0 || rank >= world_size) return p->set_error(CALICO_INVALID_ARGUMENT, "bad rank / world size");
+  p->rank = rank; p->world = world_size; p->dirty = true;
   return CALICO_OK;
 }
 

@@ -598,7 +598,7 @@ def make_scene(n_cameras=1, camera_model=1, imu=False, imu_model=2, duration=Non
         else:
             q_true = quat_from_axis_angle(rand_unit() * (2.0 * np.pi / 180.0))
             t_true = 0.05 * rng.uniform(-1, 1, 3)
-            lat_true = 0.01 * ((c % 2) * 2 - 1) * (1 + c // 2) / 2.0
+            lat_true = 0.01 if n_cameras == 2 else 0.0025 * c  # stamps = t + latency must stay inside the knots
         px, valid, st, frame, pidx = project_camera(spl, camera_model, truth, q_true, t_true, lat_true, cam_times,
                                                     points, body_q, body_t)
         px, st, pidx = px[valid], st[valid], pidx[valid]

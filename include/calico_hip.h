@@ -243,6 +243,13 @@ typedef int32_t (*calico_allreduce_fn)(void* ctx, void* buf, int64_t n,
                                        void* stream);
 int32_t calico_problem_set_allreduce(calico_problem* p, calico_allreduce_fn fn,
                                      void* ctx);
+/* Every rank receives the WHOLE problem through the add_* calls above and
+ * keeps only its shard on the device: rank r of world_size evaluates the
+ * residual blocks whose spline segment lies in its time window (contiguous
+ * windows balanced by block count). All ranks solve the same reduced system
+ * after the all-reduce, so their parameter estimates stay identical. */
+int32_t calico_problem_set_shard(calico_problem* p, int32_t rank,
+                                 int32_t world_size);
 /* Use an externally owned HIP stream (hipStream_t) for all work of this
  * handle, e.g. torch's current stream so the callback above is ordered. */
 int32_t calico_problem_set_stream(calico_problem* p, void* stream);
