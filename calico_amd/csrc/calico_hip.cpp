@@ -38,8 +38,9 @@ void launch_gather(double* R, const double* src, const int* out_idx_thin, const 
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s);
 size_t band_cholesky_lds_bytes(const SolveArgs& a);
-size_t dense_cholesky_lds_bytes(const SolveArgs& a);
-hipError_t configure_solve_kernels(size_t band_lds, size_t dense_lds, size_t back_lds);
+size_t reduced_solve_lds_bytes(const SolveArgs& a);
+int schur_slices(const SolveArgs& a);
+hipError_t configure_solve_kernels(size_t band_lds, size_t reduced_lds);
 void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, double* x_cand, const BlockDev* blocks,
                   int n_blocks, bool dense_in_lds, hipStream_t s);
 void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const LmState* st, hipStream_t s);
@@ -150,7 +151,7 @@ struct calico_problem {
   int n_thin = 0, n_fat = 0;
   bool dense_in_lds = true;
 
-  DevBuf<double> d_x, d_xc, d_knots, d_basis, d_m0, d_m1, d_m2, d_stamp, d_partials, d_R, d_R2, d_Lw, d_Y, d_S, d_y,
+  DevBuf<double> d_x, d_xc, d_knots, d_basis, d_m0, d_m1, d_m2, d_stamp, d_partials, d_R, d_R2, d_Lb, d_Linv, d_Y, d_S, d_Spart, d_Swork, d_y,
       d_dadd, d_scale, d_res;
   DevBuf<int> d_ctrl_off, d_point_off, d_out_thin, d_idx_thin, d_out_fat, d_idx_fat;
   DevBuf<int64_t> d_ptr_thin, d_ptr_fat;
@@ -194,7 +195,8 @@ int imu_num_params(int model) { return model == 1 ? 1 : (model == 2 ? 4 : (model
 
 SolveArgs make_solve_args(calico_problem* p) {
   SolveArgs a;
-  a.R = p->d_R.p; a.Lw = p->d_Lw.p; a.Y = p->d_Y.p; a.S = p->d_S.p; a.y = p->d_y.p; a.dadd = p->d_dadd.p;
+  a.R = p->d_R.p; a.Lb = p->d_Lb.p; a.Linv = p->d_Linv.p; a.Y = p->d_Y.p; a.S = p->d_S.p; a.Spart = p->d_Spart.p;
+  a.Swork = p->d_Swork.p; a.y = p->d_y.p; a.dadd = p->d_dadd.p;
   a.scale = p->d_scale.p; a.cp_active = p->d_cp_active.p; a.st = p->d_state.p; a.n_cp = p->n_cp; a.k = p->order; a.m = p->m;
   return a;
 }
@@ -446,7 +448,8 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_R.alloc(r_size)); HIP_TRY(p, hipMemsetAsync(p->d_R.p, 0, r_size * sizeof(double), s));
   HIP_TRY(p, p->d_R2.alloc(2));
   const int NT = 6 * n_cp + m;
-  HIP_TRY(p, p->d_Lw.alloc(size_t(NS) * 6 * k)); HIP_TRY(p, p->d_Y.alloc(size_t(NS) * (m + 1)));
+  HIP_TRY(p, p->d_Lb.alloc(size_t(NS) * 6 * k)); HIP_TRY(p, p->d_Linv.alloc(size_t(n_cp) * 36));
+  HIP_TRY(p, p->d_Y.alloc(size_t(NS) * (m + 1)));
   HIP_TRY(p, p->d_S.alloc(size_t(m + 1) * (m + 1)));
   HIP_TRY(p, p->d_y.alloc(NT)); HIP_TRY(p, p->d_dadd.alloc(NT)); HIP_TRY(p, p->d_scale.alloc(NT));
   HIP_TRY(p, p->d_res.alloc(size_t(n_obs) * 3)); HIP_TRY(p, p->d_valid.alloc(size_t(n_obs)));
@@ -456,12 +459,13 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, configure_eval_kernels(size_t(p->lds_cols) * kRowPad * sizeof(double)));
   sa = make_solve_args(p);
   const size_t band_lds = band_cholesky_lds_bytes(sa);
-  if (band_lds > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "calibration block too wide for the banded factorisation window");
-  const size_t dense_lds = dense_cholesky_lds_bytes(sa);
-  p->dense_in_lds = dense_lds <= kMaxLds - 1024;
-  const size_t back_lds = size_t(NS + 6 * k) * sizeof(double);
-  if (back_lds > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "trajectory too long for the back-substitution window");
-  HIP_TRY(p, configure_solve_kernels(band_lds, p->dense_in_lds ? dense_lds : 0, back_lds));
+  if (band_lds > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "spline order too high for the banded factorisation window");
+  const size_t reduced_lds = reduced_solve_lds_bytes(sa);
+  p->dense_in_lds = reduced_lds <= kMaxLds - 1024;
+  HIP_TRY(p, p->d_Spart.alloc(size_t(schur_slices(sa)) * (m + 1) * (m + 1)));
+  HIP_TRY(p, p->d_Swork.alloc(p->dense_in_lds ? 1 : reduced_lds / sizeof(double) + 8));
+  sa = make_solve_args(p);
+  HIP_TRY(p, configure_solve_kernels(band_lds, p->dense_in_lds ? reduced_lds : 0));
   HIP_TRY(p, hipStreamSynchronize(s));
   p->dirty = false;
   return CALICO_OK;

@@ -100,9 +100,12 @@ struct BlockDev {  // one reduced (free, used) parameter block
 // [cost | invalid | g(NT) | band blocks B(n_cp,k,6,6) | border E(6n_cp,m) | corner C(m,m)].
 struct SolveArgs {
   const double* R;
-  double* Lw;             // [n_s][W]   band factor, column oriented: Lw[c][t] = L(c+t, c)
+  double* Lb;             // [n_cp][6k][6] band factor by block column: Lb[J][r][c] = L(6J+r, 6J+c)
+  double* Linv;           // [n_cp][6][6]  inverse of every 6x6 pivot block
   double* Y;              // [n_s][m+1] L^-1 [E | g_s]
-  double* S;              // [m+1][m+1] reduced system; row m carries the right-hand side
+  double* S;              // [m+1][m+1] C + damping; row/column m carry g_c
+  double* Spart;          // [slices][m+1][m+1] partial products of YtY
+  double* Swork;          // global fallback workspace of the reduced solve
   double* y;              // [NT] solution of the damped system (unscaled): delta = -y
   double* dadd;           // [NT] damping added to the diagonal
   double* scale;          // [NT] Jacobi scaling 1/(1+sqrt(H_jj)) from iteration 0

@@ -138,29 +138,34 @@ __global__ __launch_bounds__(256) void post_eval_kernel(SolveArgs a, const doubl
 
 // ---------------------------------------------------------------------------
 // Build the damped working copies (one thread per entry).
+//   Lb[J][r][c] = H(6J + r, 6J + c), r = 0..6k-1, c = 0..5  (block column J of the band, lower part)
+//   Y[c][j]     = E(c, j) for j < m, g_s(c) for j = m
+//   S[r][c]     = C(r, c) (+ damping), row m / column m carry g_c
 // ---------------------------------------------------------------------------
 __global__ void prepare_kernel(SolveArgs a, LmOptionsDev o) {
   const LmState* st = a.st;
   if (st->terminated) return;
   const int n_s = a.n_s(), W = a.W(), m = a.m, m1 = a.m + 1;
   const double radius = st->radius;
-  const size_t nL = size_t(n_s) * W, nY = size_t(n_s) * m1, nS = size_t(m1) * m1;
+  const size_t nL = size_t(a.n_cp) * W * 6, nY = size_t(n_s) * m1, nS = size_t(m1) * m1;
   const size_t total = nL + nY + nS;
   for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += size_t(gridDim.x) * blockDim.x) {
     if (i < nL) {
-      const int c = int(i / W), t = int(i % W);
-      const bool act = a.cp_active[c / 6] != 0;
+      const int J = int(i / (size_t(W) * 6)), rem = int(i % (size_t(W) * 6));
+      const int r = rem / 6, cc = rem % 6;
+      const int col = 6 * J + cc, row = 6 * J + r;
+      const bool act = a.cp_active[J] != 0;
       double v = 0.0;
-      if (c + t < n_s) v = band_entry(a, c + t, c);
-      if (t == 0) {
-        if (!act) { v = 1.0; a.dadd[c] = 0.0; }
+      if (row < n_s) v = (row >= col) ? band_entry(a, row, col) : band_entry(a, col, row);
+      if (row == col) {
+        if (!act) { v = 1.0; a.dadd[col] = 0.0; }
         else {
-          const double s = a.scale[c];
+          const double s = a.scale[col];
           const double d = fmin(fmax(v * s * s, o.min_lm_diagonal), o.max_lm_diagonal) / (radius * s * s);
-          a.dadd[c] = d; v += d;
+          a.dadd[col] = d; v += d;
         }
-      } else if (!act || (c + t < n_s && !a.cp_active[(c + t) / 6])) v = 0.0;
-      a.Lw[i] = v;
+      } else if (!act || (row < n_s && !a.cp_active[row / 6])) v = 0.0;
+      a.Lb[i] = v;
     } else if (i < nL + nY) {
       const size_t q = i - nL;
       const int c = int(q / m1), j = int(q % m1);
@@ -187,163 +192,321 @@ __global__ void prepare_kernel(SolveArgs a, LmOptionsDev o) {
 }
 
 // ---------------------------------------------------------------------------
-// Bordered banded Cholesky, right-looking, one workgroup. A ring of W+1 rows
-// (band column + border row each) lives in LDS; finished rows stream out and
-// fresh rows stream in while the window advances.
+// Bordered banded Cholesky, blocked by control point (6 columns per step).
+// Workgroup w owns border columns [w·bs, (w+1)·bs) of Y = L⁻¹[E | g_s]; every
+// workgroup re-factors the (cheap) band so no inter-workgroup traffic exists.
+// The k block columns of the active window live in an LDS ring; the next block
+// is prefetched two steps ahead through registers.
+// Per step: (1) every thread factors the 6×6 pivot block redundantly,
+// (2) panel rows x = a·L11⁻ᵀ, (3) rank-6 trailing update. Two barriers per step.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a) {
+DEVI void chol6_and_inverse(const double* A /* [r*6+c], lower */, double L[6][6], double Li[6][6], bool* fail) {
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = A[j * 6 + j];
+#pragma unroll
+    for (int q = 0; q < j; ++q) d -= L[j][q] * L[j][q];
+    if (!(d > 0.0) || !isfinite(d)) { *fail = true; d = 1.0; }
+    const double l = sqrt(d);
+    const double inv = 1.0 / l;
+    L[j][j] = l; Li[j][j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double v = A[i * 6 + j];
+#pragma unroll
+      for (int q = 0; q < j; ++q) v -= L[i][q] * L[j][q];
+      L[i][j] = v * inv;
+    }
+  }
+  // inverse of the lower-triangular factor
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double v = 0.0;
+#pragma unroll
+      for (int q = j; q < i; ++q) v += L[i][q] * Li[q][j];
+      Li[i][j] = -v * Li[i][i];
+    }
+}
+
+__global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs) {
   LmState* st = a.st;
   if (st->terminated) return;
   extern __shared__ double lds[];
-  const int n = a.n_s(), W = a.W(), m1 = a.m + 1;
-  const int RW = W + m1;          // ring row: [band column (W) | border row (m+1)]
-  const int NR = W + 1;           // ring slots
-  const int tid = threadIdx.x, nth = blockDim.x;
-  __shared__ int s_fail;
-  if (tid == 0) s_fail = 0;
-  auto load_row = [&](int c) {
-    double* row = lds + (c % NR) * RW;
-    for (int i = tid; i < RW; i += nth) row[i] = (i < W) ? a.Lw[size_t(c) * W + i] : a.Y[size_t(c) * m1 + (i - W)];
+  const int k = a.k, W = 6 * k, ncp = a.n_cp, m1 = a.m + 1;
+  const int j0 = blockIdx.x * bs;
+  const int nb = max(0, min(bs, m1 - j0));
+  const int SL = W * 6 + bs * 6;  // doubles per ring slot: band block [W][6] + border [bs][6]
+  const int NSL = k + 1;
+  const int tid = threadIdx.x;
+  const int nband = W * 6, nelem = nband + nb * 6;
+  constexpr int NE = 3;  // (48*6 + 16*6) / 256 rounded up
+  auto slot = [&](int J) { return lds + (J % NSL) * SL; };
+  // pair table (r1 <= r2 over rows 6..W-1) after the ring
+  unsigned short* tab = reinterpret_cast<unsigned short*>(lds + NSL * SL);
+  const int nrr = W - 6;
+  const int npairs = nrr * (nrr + 1) / 2;
+  for (int e = tid; e < npairs; e += 256) {
+    int r1 = 0, rem = e;
+    while (rem >= nrr - r1) { rem -= nrr - r1; ++r1; }
+    tab[e] = (unsigned short)(((6 + r1) << 8) | (6 + r1 + rem));
+  }
+  auto gload = [&](int J, double regs[NE]) {
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = tid + 256 * u;
+      double v = 0.0;
+      if (J < ncp && e < nelem) {
+        if (e < nband) v = a.Lb[size_t(J) * nband + e];
+        else { const int q = e - nband; const int c = q / nb, j = q % nb; v = a.Y[(size_t(6 * J + c)) * m1 + j0 + j]; }
+      }
+      regs[u] = v;
+    }
   };
-  for (int c = 0; c < W && c < n; ++c) load_row(c);
+  auto sstore = [&](int J, const double regs[NE]) {
+    double* s = slot(J);
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = tid + 256 * u;
+      if (e < nelem) {
+        if (e < nband) s[e] = regs[u];
+        else { const int q = e - nband; const int c = q / nb, j = q % nb; s[nband + j * 6 + c] = regs[u]; }
+      }
+    }
+  };
+  double regs[NE];
+  for (int J = 0; J < k && J < ncp; ++J) { gload(J, regs); sstore(J, regs); }
+  gload(k, regs);  // block k rides in registers until step 0
+  bool fail = false;
   __syncthreads();
-  for (int c = 0; c < n; ++c) {
-    double* rc = lds + (c % NR) * RW;
-    const double p = rc[0];
-    double l;
-    if (!(p > 0.0) || !isfinite(p)) { if (tid == 0) s_fail = 1; l = 1.0; } else l = sqrt(p);
-    const double inv = 1.0 / l;
-    __syncthreads();  // everyone has read the pivot
-    for (int i = tid; i < RW; i += nth) rc[i] = (i == 0) ? l : rc[i] * inv;
-    if (c + W < n) load_row(c + W);   // free slot (c+W) % (W+1)
+  for (int J = 0; J < ncp; ++J) {
+    double* sj = slot(J);
+    if (J + k < ncp) sstore(J + k, regs);
+    gload(J + k + 1, regs);
+    // (1) pivot block, redundantly in every thread
+    double L[6][6], Li[6][6];
+    chol6_and_inverse(sj, L, Li, &fail);
+    // (2) panel
+    const int nrows = min(W, 6 * (ncp - J));
+    if (tid < W - 6) {
+      const int r = 6 + tid;
+      if (r < nrows) {
+        double av[6], xv[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) av[c] = sj[r * 6 + c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double v = 0.0;
+#pragma unroll
+          for (int q = 0; q <= c; ++q) v += av[q] * Li[c][q];
+          xv[c] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) sj[r * 6 + c] = xv[c];
+        if (blockIdx.x == 0) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) a.Lb[size_t(J) * nband + r * 6 + c] = xv[c];
+        }
+      }
+    } else if (tid >= 64 && tid - 64 < nb) {
+      const int j = tid - 64;
+      double* br = sj + nband + j * 6;
+      double av[6], xv[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) av[c] = br[c];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q <= c; ++q) v += av[q] * Li[c][q];
+        xv[c] = v;
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) { br[c] = xv[c]; a.Y[size_t(6 * J + c) * m1 + j0 + j] = xv[c]; }
+    } else if (blockIdx.x == 0 && tid >= 128 && tid < 128 + 36) {
+      const int r = (tid - 128) / 6, c = (tid - 128) % 6;
+      a.Lb[size_t(J) * nband + r * 6 + c] = (c <= r) ? L[r][c] : 0.0;
+      a.Linv[size_t(J) * 36 + r * 6 + c] = (c <= r) ? Li[r][c] : 0.0;
+    }
     __syncthreads();
-    // trailing update + stream the finished row out
-    const int tmax = min(W - 1, n - 1 - c);
-    const int npairs = W * (W - 1) / 2;
-    for (int q = tid; q < npairs; q += nth) {
-      // q -> (t1, t2), 1 <= t1 <= t2 <= W-1
-      int t1 = 1, rem = q;
-      while (rem >= W - t1) { rem -= W - t1; ++t1; }
-      const int t2 = t1 + rem;
-      if (t2 <= tmax) lds[((c + t1) % NR) * RW + (t2 - t1)] -= rc[t2] * rc[t1];
+    // (3) trailing update of the window
+    for (int e = tid; e < npairs; e += 256) {
+      const int r1 = tab[e] >> 8, r2 = tab[e] & 255;
+      if (r2 < nrows) {
+        double d = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) d += sj[r2 * 6 + c] * sj[r1 * 6 + c];
+        const int b1 = r1 / 6;
+        slot(J + b1)[(r2 - 6 * b1) * 6 + (r1 - 6 * b1)] -= d;
+      }
     }
-    for (int q = tid; q < tmax * m1; q += nth) {
-      const int t = 1 + q / m1, j = q % m1;
-      lds[((c + t) % NR) * RW + W + j] -= rc[t] * rc[W + j];
-    }
-    for (int i = tid; i < RW; i += nth) {
-      if (i < W) a.Lw[size_t(c) * W + i] = rc[i]; else a.Y[size_t(c) * m1 + (i - W)] = rc[i];
+    for (int e = tid; e < nrr * nb; e += 256) {
+      const int r1 = 6 + e / nb, j = e % nb;
+      if (r1 < nrows) {
+        double d = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) d += sj[nband + j * 6 + c] * sj[r1 * 6 + c];
+        const int b1 = r1 / 6;
+        slot(J + b1)[nband + j * 6 + (r1 - 6 * b1)] -= d;
+      }
     }
     __syncthreads();
   }
-  if (tid == 0 && s_fail) st->chol_failed = 1;
+  if (fail && tid == 0) st->chol_failed = 1;
 }
 
-// S -= YᵀY over the band rows (lower triangle incl. the right-hand-side row m).
-__global__ void schur_kernel(SolveArgs a) {
+// Partial products of YᵀY: tile (16×16, lower tiles) × row slice. Spart[ks][r][c].
+__global__ __launch_bounds__(256) void schur_kernel(SolveArgs a, int rows_per_slice) {
   const LmState* st = a.st;
   if (st->terminated) return;
+  __shared__ double sA[32][17], sB[32][17];
   const int m1 = a.m + 1, n = a.n_s();
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= m1 * m1) return;
-  const int r = idx / m1, c = idx % m1;
-  if (c > r || (r == a.m && c == a.m)) return;
-  double s = 0.0;
-  for (int q = 0; q < n; ++q) s += a.Y[size_t(q) * m1 + r] * a.Y[size_t(q) * m1 + c];
-  a.S[size_t(r) * m1 + c] -= s;
+  const int nt = (m1 + 15) / 16;
+  // blockIdx.x -> lower tile (tr >= tc)
+  int tr = 0, rem = blockIdx.x;
+  while (rem > tr) { rem -= tr + 1; ++tr; }
+  const int tc = rem;
+  const int ks = blockIdx.y;
+  const int q0 = ks * rows_per_slice, q1 = min(n, q0 + rows_per_slice);
+  const int ti = threadIdx.x / 16, tj = threadIdx.x % 16;
+  double acc = 0.0;
+  for (int q = q0; q < q1; q += 32) {
+    for (int e = threadIdx.x; e < 32 * 16; e += 256) {
+      const int rr = e / 16, cc = e % 16;
+      const int row = q + rr;
+      const int ca = tr * 16 + cc, cb = tc * 16 + cc;
+      sA[rr][cc] = (row < q1 && ca < m1) ? a.Y[size_t(row) * m1 + ca] : 0.0;
+      sB[rr][cc] = (row < q1 && cb < m1) ? a.Y[size_t(row) * m1 + cb] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int rr = 0; rr < 32; ++rr) acc += sA[rr][ti] * sB[rr][tj];
+    __syncthreads();
+  }
+  const int r = tr * 16 + ti, c = tc * 16 + tj;
+  if (r < m1 && c < m1) a.Spart[(size_t(ks) * m1 + r) * m1 + c] = acc;
+  (void)nt;
 }
 
-// Dense Cholesky of the reduced system (rows 0..m-1) with the right-hand side
-// carried as row m, then the backward substitution: y_c.
-__global__ __launch_bounds__(256) void dense_cholesky_kernel(SolveArgs a, int use_lds) {
+// Reduced system: S = C + D² - YᵀY (sum of the slices in a fixed order), dense
+// Cholesky with the right-hand side carried as row m, back substitution for
+// y_c, then z = L⁻¹g_s - Y·y_c and the blocked backward band sweep for y_s.
+__global__ __launch_bounds__(256) void reduced_solve_kernel(SolveArgs a, int n_slices, int use_lds) {
   LmState* st = a.st;
   if (st->terminated) return;
   extern __shared__ double lds[];
-  const int m = a.m, m1 = a.m + 1;
-  const int tid = threadIdx.x, nth = blockDim.x;
-  double* A = use_lds ? lds : a.S;
+  const int m = a.m, m1 = a.m + 1, n = a.n_s(), W = a.W(), ncp = a.n_cp;
+  const int LD = m1 | 1;  // odd row stride: conflict-free column walks
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* A = use_lds ? lds : a.Swork;
+  double* yv = use_lds ? lds + size_t(m1) * LD : a.Swork + size_t(m1) * LD;   // m1 doubles
+  double* z = yv + m1;                                                        // n + W doubles
   __shared__ int s_fail;
   if (tid == 0) s_fail = 0;
-  if (use_lds) { for (int i = tid; i < m1 * m1; i += nth) A[i] = a.S[i]; }
-  __syncthreads();
-  for (int j = 0; j < m; ++j) {
-    const double p = A[j * m1 + j];
-    double l;
-    if (!(p > 0.0) || !isfinite(p)) { if (tid == 0) s_fail = 1; l = 1.0; } else l = sqrt(p);
-    const double inv = 1.0 / l;
-    __syncthreads();
-    for (int i = j + tid; i <= m; i += nth) A[i * m1 + j] = (i == j) ? l : A[i * m1 + j] * inv;
-    __syncthreads();
-    const int rem = m - j;  // rows j+1..m
-    for (int q = tid; q < rem * rem; q += nth) {
-      const int i = j + 1 + q / rem, c = j + 1 + q % rem;
-      if (c <= i && c < m) A[i * m1 + c] -= A[i * m1 + j] * A[c * m1 + j];
+  for (int e = tid; e < m1 * m1; e += 256) {
+    const int r = e / m1, c = e % m1;
+    if (c <= r) {
+      double v = a.S[size_t(r) * m1 + c];
+      for (int ks = 0; ks < n_slices; ++ks) v -= a.Spart[(size_t(ks) * m1 + r) * m1 + c];
+      A[r * LD + c] = v;
     }
+  }
+  __syncthreads();
+  {
+    const int ti = tid >> 4, tj = tid & 15;
+    double rs_prev = 0.0;
+    for (int j = 0; j < m; ++j) {
+      double p = A[j * LD + j];
+      if (!(p > 0.0) || !isfinite(p)) { if (tid == 0) s_fail = 1; p = 1.0; }
+      if (j > 0) { for (int i = j - 1 + tid; i <= m; i += 256) A[i * LD + (j - 1)] *= rs_prev; }  // lazy scaling of column j-1
+      const double ip = 1.0 / p;
+      for (int i = j + 1 + ti; i <= m; i += 16) {
+        const double aij = A[i * LD + j] * ip;
+        const int cmax = min(i, m - 1);
+        for (int c = j + 1 + tj; c <= cmax; c += 16) A[i * LD + c] -= aij * A[c * LD + j];
+      }
+      rs_prev = 1.0 / sqrt(p);
+      __syncthreads();
+    }
+    if (m > 0) { for (int i = m - 1 + tid; i <= m; i += 256) A[i * LD + (m - 1)] *= rs_prev; }
     __syncthreads();
   }
-  // row m now holds L⁻¹ b. Backward: Lᵀ y = that.
-  for (int j = m - 1; j >= 0; --j) {
-    if (tid == 0) A[m * m1 + j] = A[m * m1 + j] / A[j * m1 + j];
-    __syncthreads();
-    const double yj = A[m * m1 + j];
-    for (int i = tid; i < j; i += nth) A[m * m1 + i] -= A[j * m1 + i] * yj;
-    __syncthreads();
+  // backward substitution Lᵀ y_c = (row m), one wave, dot-product form
+  if (wave == 0) {
+    for (int j = m - 1; j >= 0; --j) {
+      double part = 0.0;
+      for (int i = j + 1 + lane; i < m; i += 64) part += A[i * LD + j] * yv[i];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+      if (lane == 0) yv[j] = (A[m * LD + j] - part) / A[j * LD + j];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
   }
-  for (int i = tid; i < m; i += nth) a.y[a.n_s() + i] = A[m * m1 + i];
-  if (tid == 0 && s_fail) st->chol_failed = 1;
-}
-
-// z = L⁻¹g_s - Y y_c ; then Lᵀ y_s = z by a backward band sweep (one wave).
-__global__ __launch_bounds__(256) void back_substitute_kernel(SolveArgs a) {
-  const LmState* st = a.st;
-  if (st->terminated) return;
-  extern __shared__ double z[];  // n_s + W doubles
-  const int n = a.n_s(), W = a.W(), m = a.m, m1 = a.m + 1;
-  const int tid = threadIdx.x, nth = blockDim.x;
-  const double* yc = a.y + n;
-  for (int c = tid; c < n; c += nth) {
+  __syncthreads();
+  for (int i = tid; i < m; i += 256) a.y[n + i] = yv[i];
+  // z = Y[:, m] - Y[:, :m]·y_c : one wave per row, coalesced
+  for (int c = wave; c < n; c += 4) {
     const double* row = a.Y + size_t(c) * m1;
-    double s = row[m];
-    for (int j = 0; j < m; ++j) s -= row[j] * yc[j];
-    z[c] = s;
+    double part = 0.0;
+    for (int j = lane; j < m; j += 64) part += row[j] * yv[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (lane == 0) z[c] = row[m] - part;
   }
-  for (int c = n + tid; c < n + W; c += nth) z[c] = 0.0;
+  for (int c = n + tid; c < n + W; c += 256) z[c] = 0.0;
   __syncthreads();
-  if (tid < 64) {
-    const int lane = tid;
-    // Lane t-1 (t = 1..W-1 <= 64) multiplies L(c+t, c) with y[c+t]; lane 0 finishes y[c].
-    // The band columns are independent of the recurrence: prefetch them eight columns ahead.
-    constexpr int PF = 8;
-    double lcur[PF], dcur[PF], lnxt[PF], dnxt[PF];
-    auto fetch = [&](int cbase, double* lv, double* dv) {
+  // blocked backward sweep: y_J = L11⁻ᵀ (z_J - Σ_{r>=6} Lb[J][r][:]ᵀ y[6J+r])
+  if (wave == 0) {
+    const int nband = W * 6;
+    double lrow[6], linv = 0.0;
+    auto fetch = [&](int J) {
+      const int r = 6 + lane;
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int c = cbase - u;
-        lv[u] = (c >= 0 && 1 + lane < W) ? a.Lw[size_t(c) * W + 1 + lane] : 0.0;
-        dv[u] = (c >= 0) ? a.Lw[size_t(c) * W] : 1.0;
-      }
+      for (int c = 0; c < 6; ++c) lrow[c] = (J >= 0 && r < W) ? a.Lb[size_t(J) * nband + r * 6 + c] : 0.0;
+      linv = (J >= 0 && lane < 36) ? a.Linv[size_t(J) * 36 + lane] : 0.0;
     };
-    fetch(n - 1, lnxt, dnxt);
-    for (int cbase = n - 1; cbase >= 0; cbase -= PF) {
+    fetch(ncp - 1);
+    for (int J = ncp - 1; J >= 0; --J) {
+      double cur[6];
 #pragma unroll
-      for (int u = 0; u < PF; ++u) { lcur[u] = lnxt[u]; dcur[u] = dnxt[u]; }
-      fetch(cbase - PF, lnxt, dnxt);
+      for (int c = 0; c < 6; ++c) cur[c] = lrow[c];
+      const double curinv = linv;
+      fetch(J - 1);
+      const int r = 6 + lane;
+      const double yr = (r < W) ? z[6 * J + r] : 0.0;
+      double s[6];
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int c = cbase - u;
-        if (c < 0) break;
-        double prod = (1 + lane < W) ? lcur[u] * z[c + 1 + lane] : 0.0;
+      for (int c = 0; c < 6; ++c) {
+        double v = cur[c] * yr;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) prod += __shfl_xor(prod, off, 64);
-        if (lane == 0) z[c] = (z[c] - prod) / dcur[u];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        s[c] = z[6 * J + c] - v;
       }
+      // y_c = Σ_{q >= c} Linv[q][c] s_q ; lane (q*6 + c) holds Linv[q][c]
+      double contrib = 0.0;
+      if (lane < 36) { const int q = lane / 6; contrib = curinv * s[q]; }
+      // sum over q for fixed c: lanes c, c+6, ..., c+30
+      double t = contrib;
+      t += __shfl(contrib, (lane + 6) & 63, 64) * ((lane + 6) < 36 ? 1.0 : 0.0);
+      double acc = contrib;
+#pragma unroll
+      for (int q = 1; q < 6; ++q) {
+        const double other = __shfl(contrib, (lane + 6 * q) & 63, 64);
+        if (lane + 6 * q < 36) acc += other;
+      }
+      (void)t;
+      if (lane < 6) z[6 * J + lane] = acc;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
   }
   __syncthreads();
-  for (int c = tid; c < n; c += nth) a.y[c] = z[c];
+  for (int c = tid; c < n; c += 256) a.y[c] = z[c];
+  if (tid == 0 && s_fail) st->chol_failed = 1;
 }
 
 // delta = -y ; candidate = Plus(x, delta) ; model cost change ; step norms.
@@ -509,31 +672,39 @@ void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* block
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s) {
   hipLaunchKernelGGL(post_eval_kernel, dim3(1), dim3(256), 0, s, a, x, blocks, n_blocks, o, log, log_cap, first, jacobi);
 }
-size_t band_cholesky_lds_bytes(const SolveArgs& a) { return size_t(a.W() + 1) * (a.W() + a.m + 1) * sizeof(double); }
-size_t dense_cholesky_lds_bytes(const SolveArgs& a) { return size_t(a.m + 1) * (a.m + 1) * sizeof(double); }
-hipError_t configure_solve_kernels(size_t band_lds, size_t dense_lds, size_t back_lds) {
+constexpr int kBorderSlice = 16;   // border columns per workgroup of the banded factorisation
+constexpr int kSchurRows = 96;     // band rows per slice of the YᵀY product
+size_t band_cholesky_lds_bytes(const SolveArgs& a) {
+  const int W = a.W();
+  const int nrr = W - 6;
+  return size_t(a.k + 1) * (W * 6 + kBorderSlice * 6) * sizeof(double) + size_t(nrr * (nrr + 1) / 2) * sizeof(unsigned short) + 16;
+}
+size_t reduced_solve_lds_bytes(const SolveArgs& a) {
+  const int m1 = a.m + 1;
+  return (size_t(m1) * (m1 | 1) + m1 + a.n_s() + a.W()) * sizeof(double);
+}
+int schur_slices(const SolveArgs& a) { return (a.n_s() + kSchurRows - 1) / kSchurRows; }
+hipError_t configure_solve_kernels(size_t band_lds, size_t reduced_lds) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&band_cholesky_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(band_lds));
   if (e != hipSuccess) return e;
-  if (dense_lds) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_cholesky_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, int(dense_lds));
-    if (e != hipSuccess) return e;
-  }
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&back_substitute_kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, int(back_lds));
+  if (reduced_lds)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&reduced_solve_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, int(reduced_lds));
+  return e;
 }
 void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, double* x_cand, const BlockDev* blocks,
-                  int n_blocks, bool dense_in_lds, hipStream_t s) {
-  const size_t total = size_t(a.n_s()) * a.W() + size_t(a.n_s()) * (a.m + 1) + size_t(a.m + 1) * (a.m + 1);
+                  int n_blocks, bool reduced_in_lds, hipStream_t s) {
+  const int m1 = a.m + 1;
+  const size_t total = size_t(a.n_cp) * a.W() * 6 + size_t(a.n_s()) * m1 + size_t(m1) * m1;
   const int pb = int((total + 255) / 256);
   hipLaunchKernelGGL(prepare_kernel, dim3(pb < 2048 ? pb : 2048), dim3(256), 0, s, a, o);
-  hipLaunchKernelGGL(band_cholesky_kernel, dim3(1), dim3(256), band_cholesky_lds_bytes(a), s, a);
-  const int m1 = a.m + 1;
-  hipLaunchKernelGGL(schur_kernel, dim3((m1 * m1 + 255) / 256), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(dense_cholesky_kernel, dim3(1), dim3(256), dense_in_lds ? dense_cholesky_lds_bytes(a) : 0, s, a,
-                     dense_in_lds ? 1 : 0);
-  hipLaunchKernelGGL(back_substitute_kernel, dim3(1), dim3(256), size_t(a.n_s() + a.W()) * sizeof(double), s, a);
+  const int nwg = (m1 + kBorderSlice - 1) / kBorderSlice;
+  hipLaunchKernelGGL(band_cholesky_kernel, dim3(nwg), dim3(256), band_cholesky_lds_bytes(a), s, a, kBorderSlice);
+  const int nt = (m1 + 15) / 16;
+  hipLaunchKernelGGL(schur_kernel, dim3(nt * (nt + 1) / 2, schur_slices(a)), dim3(256), 0, s, a, kSchurRows);
+  hipLaunchKernelGGL(reduced_solve_kernel, dim3(1), dim3(256), reduced_in_lds ? reduced_solve_lds_bytes(a) : 0, s, a,
+                     schur_slices(a), reduced_in_lds ? 1 : 0);
   hipLaunchKernelGGL(update_kernel, dim3(1), dim3(256), 0, s, a, x, x_cand, blocks, n_blocks);
 }
 void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const LmState* st, hipStream_t s) {
