@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (3 = north star)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-every", type=int, default=8)
     args = ap.parse_args()
 
     import torch
@@ -125,17 +126,26 @@ def main():
         init += [(sb["intrinsics"], s.intrinsics.copy()), (sb["t"], s.t.copy()), (sb["q"], s.q.copy()),
                  (sb["latency"], np.array([s.latency]))]
 
+    init_ids = np.array([b for b, _ in init], np.int32)
+    init_vals = np.concatenate([np.asarray(v, float).ravel() for _, v in init])
+
     def reset():
-        for b, v in init:
-            P.set_param_block(b, v)
+        P.set_param_blocks(init_ids, init_vals)
 
     opts = api.default_options()
     opts.minimizer_progress_to_stdout = 0
+    opts.sync_every = args.sync_every  # LM iterations enqueued per host round trip (single GPU)
 
-    def run_iterations(n):
-        """Exactly n LM iterations, spread over as many full solves as needed."""
-        done = jac = cost = 0
-        solves = 0
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed_solves(n):
+        """n LM iterations over whole solves; returns counters and the HIP-event phase times."""
+        done = jac = cost = solves = 0
+        phase_ms = [0.0] * 5
+        phase_n = [0] * 5
         last = None
         while done < n:
             reset()
@@ -148,37 +158,20 @@ def main():
             cost += s.num_cost_evaluations
             solves += 1
             last = s
-        return done, jac, cost, solves, last
+            for i in range(5):  # the timers restart at every solve
+                ms, cnt = P.phase_time(i)
+                phase_ms[i] += ms
+                phase_n[i] += cnt
+        return done, jac, cost, solves, last, phase_ms, phase_n
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    run_iterations(max(1, args.warmup))
-    phase0 = [P.phase_time(i) for i in range(5)]  # timers reset at every solve; only deltas below matter
+    # warmup: all phases bracketed by HIP events -> per-phase breakdown (reported, untimed)
+    P.set_phase_timing(0x1f)
+    _, _, _, _, _, wu_ms, wu_n = timed_solves(max(1, args.warmup))
+    # timed region: only the dominant kernel (phase 0) carries events
+    P.set_phase_timing(0x01)
     barrier()
     t0 = time.perf_counter()
-    # phase timers accumulate per solve: collect them solve by solve
-    done = jac = cost = solves = 0
-    phase_ms = [0.0] * 5
-    phase_n = [0] * 5
-    last = None
-    while done < args.steps:
-        reset()
-        opts.max_num_iterations = min(50, args.steps - done)
-        s = P.solve(opts)
-        if s.num_iterations <= 0:
-            raise RuntimeError("solve made no progress: %s" % s.message.decode())
-        done += s.num_iterations
-        jac += s.num_jacobian_evaluations
-        cost += s.num_cost_evaluations
-        solves += 1
-        last = s
-        for i in range(5):
-            ms, n = P.phase_time(i)
-            phase_ms[i] += ms
-            phase_n[i] += n
+    done, jac, cost, solves, last, phase_ms, phase_n = timed_solves(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -188,7 +181,7 @@ def main():
 
     if rank == 0:
         n_blocks = scene.num_blocks
-        jac_ms = phase_ms[0] / max(1, phase_n[0])
+        jac_ms = phase_ms[0] / max(1, jac)  # event time over the evaluations actually made (skipped launches exit at once)
         alg_bytes = algorithmic_bytes_per_jacobian_launch(scene) / world
         achieved = alg_bytes / (jac_ms * 1e-3) / 1e9 if jac_ms > 0 else 0.0
         traffic = None
@@ -224,19 +217,20 @@ def main():
                 "cost_evaluations": cost,
                 "residual_blocks_evaluated_per_s": n_blocks * (jac + cost) / elapsed,
                 "parallelism": "obs-shard x%d + all-reduce(JtJ,Jtr,cost)" % world if world > 1 else "single GPU",
-                "phase_ms_per_launch": {
-                    "jacobian_eval": jac_ms,
-                    "gather": phase_ms[1] / max(1, phase_n[1]),
-                    "linear_solve": phase_ms[2] / max(1, phase_n[2]),
-                    "cost_eval": phase_ms[3] / max(1, phase_n[3]),
-                    "control": phase_ms[4] / max(1, phase_n[4]),
+                "sync_every": args.sync_every if world == 1 else 1,
+                "phase_ms_per_launch_warmup": {
+                    "jacobian_eval": wu_ms[0] / max(1, wu_n[0]),
+                    "gather": wu_ms[1] / max(1, wu_n[1]),
+                    "linear_solve": wu_ms[2] / max(1, wu_n[2]),
+                    "cost_eval": wu_ms[3] / max(1, wu_n[3]),
+                    "control": wu_ms[4] / max(1, wu_n[4]),
                 },
             },
             "roofline": {
                 "bound": "hbm", "kernel": "eval_items_kernel<true> (fused residual + Jacobian + JtJ partials)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": jac_ms, "launches": phase_n[0],
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": jac_ms, "launches": jac,
             },
         }
         if not args.no_cpu_baseline and world == 1:

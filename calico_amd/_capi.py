@@ -114,12 +114,12 @@ def _i32(a):
 # Every symbol include/calico_hip.h declares (without prefix).
 ABI_SYMBOLS = [
     "problem_create", "problem_destroy", "last_error", "default_solver_options",
-    "problem_add_param_block", "get_param_block", "set_param_block",
+    "problem_add_param_block", "get_param_block", "set_param_block", "set_param_blocks",
     "problem_set_spline", "problem_add_rigid_body", "problem_add_sensor",
     "problem_add_camera_residuals", "problem_add_imu_residuals", "solve",
     "get_iterations", "get_residuals", "get_inlier_mask",
     "num_effective_parameters", "evaluate", "problem_set_allreduce", "problem_set_shard",
-    "problem_set_stream", "get_phase_time",
+    "problem_set_stream", "get_phase_time", "set_phase_timing",
 ]
 
 
@@ -142,6 +142,7 @@ class CApi:
         g("problem_add_param_block", C.c_int32, [P, D, C.c_int32, C.c_int32, C.c_int32, I])
         g("get_param_block", C.c_int32, [P, C.c_int32, D])
         g("set_param_block", C.c_int32, [P, C.c_int32, D])
+        g("set_param_blocks", C.c_int32, [P, C.c_int32, I, D])
         g("problem_set_spline", C.c_int32, [P, C.c_int32, C.c_int32, D, D, I])
         g("problem_add_rigid_body", C.c_int32, [P, C.c_int32, C.c_int32, I])
         g("problem_add_sensor", C.c_int32,
@@ -160,6 +161,7 @@ class CApi:
             g("problem_set_shard", C.c_int32, [P, C.c_int32, C.c_int32])
             g("problem_set_stream", C.c_int32, [P, C.c_void_p])
             g("get_phase_time", C.c_int32, [P, C.c_int32, D, C.POINTER(C.c_int64)])
+            g("set_phase_timing", C.c_int32, [P, C.c_int32])
 
     def _get(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)
@@ -217,6 +219,10 @@ class Problem:
     def set_param_block(self, block_id, values):
         v = _f64(values).ravel()
         self._check(self.api.set_param_block(self.h, block_id, _dp(v)))
+
+    def set_param_blocks(self, block_ids, values_concat):
+        ids, v = _i32(block_ids), _f64(values_concat)
+        self._check(self.api.set_param_blocks(self.h, ids.size, _ip(ids), _dp(v)))
 
     def set_spline(self, order, knots, basis, ctrl_block_ids):
         k, b, c = _f64(knots), _f64(basis), _i32(ctrl_block_ids)
@@ -291,6 +297,9 @@ class Problem:
 
     def set_stream(self, stream_ptr):
         self._check(self.api.problem_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def set_phase_timing(self, mask):
+        self._check(self.api.set_phase_timing(self.h, int(mask)))
 
     def phase_time(self, phase):
         ms = C.c_double(0)

@@ -39,8 +39,8 @@ void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* block
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s);
 size_t band_cholesky_lds_bytes(const SolveArgs& a);
 size_t reduced_solve_lds_bytes(const SolveArgs& a);
-int schur_slices(const SolveArgs& a);
-hipError_t configure_solve_kernels(size_t band_lds, size_t reduced_lds);
+size_t band_backsolve_lds_bytes(const SolveArgs& a);
+hipError_t configure_solve_kernels(size_t band_lds, size_t reduced_lds, size_t back_lds);
 void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, double* x_cand, const BlockDev* blocks,
                   int n_blocks, bool dense_in_lds, hipStream_t s);
 void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const LmState* st, hipStream_t s);
@@ -110,8 +110,14 @@ struct PhaseTimer {
     if (next == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
     return pool[next++];
   }
-  void begin(int phase, hipStream_t s) { Rec r; r.phase = phase; r.a = get(); r.b = nullptr; (void)hipEventRecord(r.a, s); pending.push_back(r); }
-  void end(hipStream_t s) { Rec& r = pending.back(); r.b = get(); (void)hipEventRecord(r.b, s); }
+  int mask = 0x1f;
+  bool open_rec = false;
+  void begin(int phase, hipStream_t s) {
+    open_rec = (mask >> phase) & 1;
+    if (!open_rec) return;
+    Rec r; r.phase = phase; r.a = get(); r.b = nullptr; (void)hipEventRecord(r.a, s); pending.push_back(r);
+  }
+  void end(hipStream_t s) { if (!open_rec) return; Rec& r = pending.back(); r.b = get(); (void)hipEventRecord(r.b, s); open_rec = false; }
   void resolve() {  // call after a stream sync
     for (const Rec& r : pending) {
       float t = 0; if (r.b && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.phase] += t; count[r.phase]++; }
@@ -209,6 +215,7 @@ EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool
   a.partials = p->d_partials.p; a.item_cost = p->d_partials.p + p->partial_doubles;
   a.res_out = want_res ? p->d_res.p : nullptr; a.valid_out = want_res ? p->d_valid.p : nullptr;
   a.order = p->order; a.n_items = p->n_items; a.lds_cols = p->lds_cols; a.apply_loss = apply_loss;
+  a.st = nullptr; a.need_flag = 0; a.pad1 = 0;
   return a;
 }
 
@@ -462,10 +469,12 @@ int finalize(calico_problem* p) {
   if (band_lds > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "spline order too high for the banded factorisation window");
   const size_t reduced_lds = reduced_solve_lds_bytes(sa);
   p->dense_in_lds = reduced_lds <= kMaxLds - 1024;
-  HIP_TRY(p, p->d_Spart.alloc(size_t(schur_slices(sa)) * (m + 1) * (m + 1)));
-  HIP_TRY(p, p->d_Swork.alloc(p->dense_in_lds ? 1 : reduced_lds / sizeof(double) + 8));
+  HIP_TRY(p, p->d_Spart.alloc(size_t(m + 1) * (m + 1)));
+  const size_t back_lds = band_backsolve_lds_bytes(sa);
+  if (back_lds > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "trajectory too long for the back-substitution window");
+  HIP_TRY(p, p->d_Swork.alloc(std::max<size_t>(reduced_lds / sizeof(double) + 8, size_t(m + 1) * 16 * 13 + 8)));
   sa = make_solve_args(p);
-  HIP_TRY(p, configure_solve_kernels(band_lds, p->dense_in_lds ? reduced_lds : 0));
+  HIP_TRY(p, configure_solve_kernels(band_lds, p->dense_in_lds ? reduced_lds : 0, back_lds));
   HIP_TRY(p, hipStreamSynchronize(s));
   p->dirty = false;
   return CALICO_OK;
@@ -485,17 +494,20 @@ int do_allreduce(calico_problem* p, double* buf, int64_t n) {
   return CALICO_OK;
 }
 
-// residual + Jacobian evaluation at d_x into the reduce buffer R.
+// residual + Jacobian evaluation at d_x into the reduce buffer R. With st != nullptr the
+// kernels skip themselves on the device when the solve has terminated or (need_flag) when
+// the last step was rejected, so whole iterations can be enqueued without a host round trip.
 int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag) {
-  // The evaluation kernels carry no early-exit of their own: skipping is decided by the host (see solve loop).
-  (void)need_flag;
   p->timer.begin(0, p->stream);
-  launch_eval(make_eval_args(p, p->d_x.p, 1, false), true, p->stream);
+  EvalArgs ea = make_eval_args(p, p->d_x.p, 1, false);
+  ea.st = st; ea.need_flag = need_flag;
+  launch_eval(ea, true, p->stream);
   p->timer.end(p->stream);
   p->timer.begin(1, p->stream);
   launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->d_out_fat.p,
-                p->d_ptr_fat.p, p->d_idx_fat.p, p->n_fat, st, 0, p->stream);
+                p->d_ptr_fat.p, p->d_idx_fat.p, p->n_fat, st, need_flag, p->stream);
   p->timer.end(p->stream);
+  if (need_flag) return CALICO_OK;  // single-rank asynchronous path: no exchange
   SolveArgs sa = make_solve_args(p);
   return do_allreduce(p, p->d_R.p, int64_t(sa.r_size()));
 }
@@ -598,6 +610,18 @@ int32_t calico_get_param_block(calico_problem* p, int32_t id, double* out) {
 int32_t calico_set_param_block(calico_problem* p, int32_t id, const double* v) {
   if (!p || id < 0 || id >= int(p->blocks.size()) || !v) return p ? p->set_error(CALICO_INVALID_ARGUMENT, "bad block id") : CALICO_INVALID_ARGUMENT;
   std::copy(v, v + p->blocks[id].size, p->blocks[id].v.begin());
+  return CALICO_OK;
+}
+
+int32_t calico_set_param_blocks(calico_problem* p, int32_t n, const int32_t* ids, const double* v) {
+  if (!p || n < 0 || (n > 0 && (!ids || !v))) return p ? p->set_error(CALICO_INVALID_ARGUMENT, "bad arguments") : CALICO_INVALID_ARGUMENT;
+  for (int i = 0; i < n; ++i)
+    if (ids[i] < 0 || ids[i] >= int(p->blocks.size())) return p->set_error(CALICO_INVALID_ARGUMENT, "bad block id");
+  for (int i = 0; i < n; ++i) {
+    HBlock& b = p->blocks[ids[i]];
+    std::copy(v, v + b.size, b.v.begin());
+    v += b.size;
+  }
   return CALICO_OK;
 }
 
@@ -733,35 +757,47 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   p->timer.end(s);
   rc = read_state(p);
   if (rc != CALICO_OK) return rc;
-  sm->num_jacobian_evaluations = 1;
+  const int n_blocks = int(p->h_blocks.size());
+  // One LM iteration = linear solve + candidate cost + control (+ Jacobian evaluation if the
+  // step was accepted). Multi-rank runs need the host between the phases (the all-reduce must
+  // not run when the evaluation was skipped); single-rank runs enqueue `sync_every` complete
+  // iterations, every kernel deciding on the device whether it still has work.
+  const bool async = p->allreduce == nullptr;
+  const int batch = async ? std::max(1, opt->sync_every) : 1;
   while (!p->h_state->terminated) {
-    p->timer.begin(2, s);
-    launch_solve(sa, o, p->d_x.p, p->d_xc.p, p->d_blocks.p, int(p->h_blocks.size()), p->dense_in_lds, s);
-    p->timer.end(s);
-    p->timer.begin(3, s);
-    launch_eval(make_eval_args(p, p->d_xc.p, 1, false), false, s);
-    launch_cost_reduce(p->d_partials.p + p->partial_doubles, p->n_items, p->d_R2.p, p->d_state.p, s);
-    p->timer.end(s);
-    rc = do_allreduce(p, p->d_R2.p, 2);
-    if (rc != CALICO_OK) return rc;
-    p->timer.begin(4, s);
-    launch_control(p->d_state.p, o, p->d_R2.p, p->d_x.p, p->d_xc.p, p->n_amb, p->d_log.p, kLogCap, s);
-    p->timer.end(s);
-    rc = read_state(p);
-    if (rc != CALICO_OK) return rc;
-    sm->num_cost_evaluations++;
-    if (p->h_state->terminated) break;
-    if (p->h_state->need_jacobian) {
-      rc = enqueue_jacobian_eval(p, nullptr, 0);
+    for (int b = 0; b < batch; ++b) {
+      p->timer.begin(2, s);
+      launch_solve(sa, o, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, p->dense_in_lds, s);
+      p->timer.end(s);
+      p->timer.begin(3, s);
+      {
+        EvalArgs ea = make_eval_args(p, p->d_xc.p, 1, false);
+        ea.st = p->d_state.p;
+        launch_eval(ea, false, s);
+      }
+      launch_cost_reduce(p->d_partials.p + p->partial_doubles, p->n_items, p->d_R2.p, p->d_state.p, s);
+      p->timer.end(s);
+      rc = do_allreduce(p, p->d_R2.p, 2);
       if (rc != CALICO_OK) return rc;
       p->timer.begin(4, s);
-      launch_post_eval(sa, p->d_x.p, p->d_blocks.p, int(p->h_blocks.size()), o, p->d_log.p, kLogCap, 0, opt->jacobi_scaling, s);
+      launch_control(p->d_state.p, o, p->d_R2.p, p->d_x.p, p->d_xc.p, p->n_amb, p->d_log.p, kLogCap, s);
       p->timer.end(s);
-      rc = read_state(p);
+      if (!async) {
+        rc = read_state(p);
+        if (rc != CALICO_OK) return rc;
+        if (p->h_state->terminated || !p->h_state->need_jacobian) continue;
+      }
+      rc = enqueue_jacobian_eval(p, p->d_state.p, async ? 1 : 0);
       if (rc != CALICO_OK) return rc;
-      sm->num_jacobian_evaluations++;
+      p->timer.begin(4, s);
+      launch_post_eval(sa, p->d_x.p, p->d_blocks.p, n_blocks, o, p->d_log.p, kLogCap, 0, opt->jacobi_scaling, s);
+      p->timer.end(s);
     }
+    rc = read_state(p);
+    if (rc != CALICO_OK) return rc;
   }
+  sm->num_jacobian_evaluations = p->h_state->n_jac_evals;
+  sm->num_cost_evaluations = p->h_state->n_cost_evals;
   const double t_solve = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
   // results
   const LmState st = *p->h_state;
@@ -910,6 +946,12 @@ int32_t calico_problem_set_stream(calico_problem* p, void* stream) {
   if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
   p->stream = reinterpret_cast<hipStream_t>(stream);
   p->own_stream = false;
+  return CALICO_OK;
+}
+
+int32_t calico_set_phase_timing(calico_problem* p, int32_t mask) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  p->timer.mask = mask;
   return CALICO_OK;
 }
 

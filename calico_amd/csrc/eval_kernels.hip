@@ -509,6 +509,7 @@ DEV double wave_sum(double v) {
 template <bool JAC>
 __global__ __launch_bounds__(64) void eval_items_kernel(EvalArgs a) {
   extern __shared__ double lds[];
+  if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
   const int item_id = blockIdx.x;
   const int lane = threadIdx.x;
   const ItemDev it = a.items[item_id];

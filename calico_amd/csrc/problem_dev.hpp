@@ -57,6 +57,8 @@ struct EvalArgs {
   double* res_out;        // residual write-back (n_obs × 3), or nullptr
   uint8_t* valid_out;
   int order, n_items, lds_cols, apply_loss;
+  const struct LmState* st;  // optional: skip when terminated (and, with need_flag, when no Jacobian is due)
+  int need_flag, pad1;
 };
 
 // LM state kept on the device; the control kernel is its only writer.
@@ -72,7 +74,7 @@ struct LmState {
   int step_valid, step_successful, chol_failed;
   int num_consecutive_invalid, num_successful, num_unsuccessful;
   int invalid_eval;       // candidate evaluation hit an invalid projection
-  int n_log, pad;
+  int n_log, n_jac_evals, n_cost_evals, pad;
 };
 
 struct LmOptionsDev {
@@ -104,7 +106,7 @@ struct SolveArgs {
   double* Linv;           // [n_cp][6][6]  inverse of every 6x6 pivot block
   double* Y;              // [n_s][m+1] L^-1 [E | g_s]
   double* S;              // [m+1][m+1] C + damping; row/column m carry g_c
-  double* Spart;          // [slices][m+1][m+1] partial products of YtY
+  double* Spart;          // [m+1][m+1] reduced system S - YtY (lower triangle)
   double* Swork;          // global fallback workspace of the reduced solve
   double* y;              // [NT] solution of the damped system (unscaled): delta = -y
   double* dadd;           // [NT] damping added to the diagonal

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void post_eval_kernel(SolveArgs a, const doubl
   }
   if (tid == 0) {
     st->x_cost = a.R[0];
+    st->n_jac_evals += 1;
     st->gradient_max_norm = s_max[0];
     st->gradient_norm = sqrt(s_sum[0]);
     st->need_jacobian = 0;
@@ -200,6 +201,14 @@ __global__ void prepare_kernel(SolveArgs a, LmOptionsDev o) {
 // Per step: (1) every thread factors the 6×6 pivot block redundantly,
 // (2) panel rows x = a·L11⁻ᵀ, (3) rank-6 trailing update. Two barriers per step.
 // ---------------------------------------------------------------------------
+// 1/sqrt(d) to double precision: hardware estimate + two Newton steps (no division, no sqrt call).
+DEVI double rsqrt_nr(double d) {
+  double r = __builtin_amdgcn_rsq(d);
+  r = r * (1.5 - 0.5 * d * r * r);
+  r = r * (1.5 - 0.5 * d * r * r);
+  return r;
+}
+
 DEVI void chol6_and_inverse(const double* A /* [r*6+c], lower */, double L[6][6], double Li[6][6], bool* fail) {
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -207,9 +216,8 @@ DEVI void chol6_and_inverse(const double* A /* [r*6+c], lower */, double L[6][6]
 #pragma unroll
     for (int q = 0; q < j; ++q) d -= L[j][q] * L[j][q];
     if (!(d > 0.0) || !isfinite(d)) { *fail = true; d = 1.0; }
-    const double l = sqrt(d);
-    const double inv = 1.0 / l;
-    L[j][j] = l; Li[j][j] = inv;
+    const double inv = rsqrt_nr(d);
+    L[j][j] = d * inv; Li[j][j] = inv;
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       double v = A[i * 6 + j];
@@ -238,10 +246,10 @@ __global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs)
   const int j0 = blockIdx.x * bs;
   const int nb = max(0, min(bs, m1 - j0));
   const int SL = W * 6 + bs * 6;  // doubles per ring slot: band block [W][6] + border [bs][6]
-  const int NSL = k + 1;
+  const int NSL = k + 2;          // active window (k) + two blocks in flight
   const int tid = threadIdx.x;
   const int nband = W * 6, nelem = nband + nb * 6;
-  constexpr int NE = 3;  // (48*6 + 16*6) / 256 rounded up
+  constexpr int NE = 2;           // elements per thread: (48*6 + 16*6) / 256
   auto slot = [&](int J) { return lds + (J % NSL) * SL; };
   // pair table (r1 <= r2 over rows 6..W-1) after the ring
   unsigned short* tab = reinterpret_cast<unsigned short*>(lds + NSL * SL);
@@ -252,49 +260,56 @@ __global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs)
     while (rem >= nrr - r1) { rem -= nrr - r1; ++r1; }
     tab[e] = (unsigned short)(((6 + r1) << 8) | (6 + r1 + rem));
   }
+  // per-thread element descriptors (fixed over the sweep)
+  int g_off[NE], l_off[NE];   // global offset within a block column (Lb: e ; Y: c*m1 + j0 + j, flagged), LDS offset
+  bool is_y[NE], has[NE];
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const int e = tid + 256 * u;
+    has[u] = e < nelem; is_y[u] = false; g_off[u] = 0; l_off[u] = 0;
+    if (has[u]) {
+      if (e < nband) { g_off[u] = e; l_off[u] = e; }
+      else { const int q = e - nband; const int c = q / nb, j = q % nb; is_y[u] = true; g_off[u] = c * m1 + j0 + j; l_off[u] = nband + j * 6 + c; }
+    }
+  }
   auto gload = [&](int J, double regs[NE]) {
 #pragma unroll
     for (int u = 0; u < NE; ++u) {
-      const int e = tid + 256 * u;
       double v = 0.0;
-      if (J < ncp && e < nelem) {
-        if (e < nband) v = a.Lb[size_t(J) * nband + e];
-        else { const int q = e - nband; const int c = q / nb, j = q % nb; v = a.Y[(size_t(6 * J + c)) * m1 + j0 + j]; }
-      }
+      if (J < ncp && has[u]) v = is_y[u] ? a.Y[size_t(6 * J) * m1 + g_off[u]] : a.Lb[size_t(J) * nband + g_off[u]];
       regs[u] = v;
     }
   };
   auto sstore = [&](int J, const double regs[NE]) {
     double* s = slot(J);
 #pragma unroll
-    for (int u = 0; u < NE; ++u) {
-      const int e = tid + 256 * u;
-      if (e < nelem) {
-        if (e < nband) s[e] = regs[u];
-        else { const int q = e - nband; const int c = q / nb, j = q % nb; s[nband + j * 6 + c] = regs[u]; }
-      }
-    }
+    for (int u = 0; u < NE; ++u) if (has[u]) s[l_off[u]] = regs[u];
   };
-  double regs[NE];
+  double regs[NE], regs2[NE];
   for (int J = 0; J < k && J < ncp; ++J) { gload(J, regs); sstore(J, regs); }
-  gload(k, regs);  // block k rides in registers until step 0
+  gload(k, regs);       // blocks k and k+1 ride in registers
+  gload(k + 1, regs2);
   bool fail = false;
+  // thread roles in the panel phase
+  const int prow = 6 + tid;                 // band row (tid < W-6)
+  const int bj = tid - 64;                  // border row (64 <= tid < 64+nb)
   __syncthreads();
   for (int J = 0; J < ncp; ++J) {
     double* sj = slot(J);
     if (J + k < ncp) sstore(J + k, regs);
-    gload(J + k + 1, regs);
+#pragma unroll
+    for (int u = 0; u < NE; ++u) regs[u] = regs2[u];
+    gload(J + k + 2, regs2);
     // (1) pivot block, redundantly in every thread
     double L[6][6], Li[6][6];
     chol6_and_inverse(sj, L, Li, &fail);
     // (2) panel
     const int nrows = min(W, 6 * (ncp - J));
     if (tid < W - 6) {
-      const int r = 6 + tid;
-      if (r < nrows) {
+      if (prow < nrows) {
         double av[6], xv[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) av[c] = sj[r * 6 + c];
+        for (int c = 0; c < 6; ++c) av[c] = sj[prow * 6 + c];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           double v = 0.0;
@@ -303,15 +318,14 @@ __global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs)
           xv[c] = v;
         }
 #pragma unroll
-        for (int c = 0; c < 6; ++c) sj[r * 6 + c] = xv[c];
+        for (int c = 0; c < 6; ++c) sj[prow * 6 + c] = xv[c];
         if (blockIdx.x == 0) {
 #pragma unroll
-          for (int c = 0; c < 6; ++c) a.Lb[size_t(J) * nband + r * 6 + c] = xv[c];
+          for (int c = 0; c < 6; ++c) a.Lb[size_t(J) * nband + prow * 6 + c] = xv[c];
         }
       }
-    } else if (tid >= 64 && tid - 64 < nb) {
-      const int j = tid - 64;
-      double* br = sj + nband + j * 6;
+    } else if (bj >= 0 && bj < nb) {
+      double* br = sj + nband + bj * 6;
       double av[6], xv[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) av[c] = br[c];
@@ -323,11 +337,17 @@ __global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs)
         xv[c] = v;
       }
 #pragma unroll
-      for (int c = 0; c < 6; ++c) { br[c] = xv[c]; a.Y[size_t(6 * J + c) * m1 + j0 + j] = xv[c]; }
+      for (int c = 0; c < 6; ++c) { br[c] = xv[c]; a.Y[size_t(6 * J + c) * m1 + j0 + bj] = xv[c]; }
     } else if (blockIdx.x == 0 && tid >= 128 && tid < 128 + 36) {
       const int r = (tid - 128) / 6, c = (tid - 128) % 6;
-      a.Lb[size_t(J) * nband + r * 6 + c] = (c <= r) ? L[r][c] : 0.0;
-      a.Linv[size_t(J) * 36 + r * 6 + c] = (c <= r) ? Li[r][c] : 0.0;
+      // pick L[r][c] / Li[r][c] without dynamic register indexing
+      double lv = 0.0, iv = 0.0;
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+        for (int cc = 0; cc <= rr; ++cc) if (rr == r && cc == c) { lv = L[rr][cc]; iv = Li[rr][cc]; }
+      a.Lb[size_t(J) * nband + r * 6 + c] = lv;
+      a.Linv[size_t(J) * 36 + r * 6 + c] = iv;
     }
     __syncthreads();
     // (3) trailing update of the window
@@ -356,62 +376,57 @@ __global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs)
   if (fail && tid == 0) st->chol_failed = 1;
 }
 
-// Partial products of YᵀY: tile (16×16, lower tiles) × row slice. Spart[ks][r][c].
-__global__ __launch_bounds__(256) void schur_kernel(SolveArgs a, int rows_per_slice) {
+// Sred = S - YᵀY, one 16×16 lower tile per workgroup, 64-row chunks staged in LDS with register prefetch.
+__global__ __launch_bounds__(256) void schur_kernel(SolveArgs a) {
   const LmState* st = a.st;
   if (st->terminated) return;
-  __shared__ double sA[32][17], sB[32][17];
+  __shared__ double sA[64][17], sB[64][17];
   const int m1 = a.m + 1, n = a.n_s();
-  const int nt = (m1 + 15) / 16;
-  // blockIdx.x -> lower tile (tr >= tc)
   int tr = 0, rem = blockIdx.x;
   while (rem > tr) { rem -= tr + 1; ++tr; }
   const int tc = rem;
-  const int ks = blockIdx.y;
-  const int q0 = ks * rows_per_slice, q1 = min(n, q0 + rows_per_slice);
   const int ti = threadIdx.x / 16, tj = threadIdx.x % 16;
-  double acc = 0.0;
-  for (int q = q0; q < q1; q += 32) {
-    for (int e = threadIdx.x; e < 32 * 16; e += 256) {
-      const int rr = e / 16, cc = e % 16;
-      const int row = q + rr;
-      const int ca = tr * 16 + cc, cb = tc * 16 + cc;
-      sA[rr][cc] = (row < q1 && ca < m1) ? a.Y[size_t(row) * m1 + ca] : 0.0;
-      sB[rr][cc] = (row < q1 && cb < m1) ? a.Y[size_t(row) * m1 + cb] : 0.0;
+  // each thread stages 4 rows × (A,B) per chunk: rows ti, ti+16, ti+32, ti+48 ; column tj
+  const int ca = tr * 16 + tj, cb = tc * 16 + tj;
+  double pa[4], pb[4];
+  auto fetch = [&](int q) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = q + ti + 16 * u;
+      pa[u] = (row < n && ca < m1) ? a.Y[size_t(row) * m1 + ca] : 0.0;
+      pb[u] = (row < n && cb < m1) ? a.Y[size_t(row) * m1 + cb] : 0.0;
     }
+  };
+  double acc = 0.0;
+  fetch(0);
+  for (int q = 0; q < n; q += 64) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { sA[ti + 16 * u][tj] = pa[u]; sB[ti + 16 * u][tj] = pb[u]; }
     __syncthreads();
-#pragma unroll 8
-    for (int rr = 0; rr < 32; ++rr) acc += sA[rr][ti] * sB[rr][tj];
+    if (q + 64 < n) fetch(q + 64);
+#pragma unroll 16
+    for (int rr = 0; rr < 64; ++rr) acc += sA[rr][ti] * sB[rr][tj];
     __syncthreads();
   }
   const int r = tr * 16 + ti, c = tc * 16 + tj;
-  if (r < m1 && c < m1) a.Spart[(size_t(ks) * m1 + r) * m1 + c] = acc;
-  (void)nt;
+  if (r < m1 && c < m1 && c <= r) a.Spart[size_t(r) * m1 + c] = a.S[size_t(r) * m1 + c] - acc;
 }
 
-// Reduced system: S = C + D² - YᵀY (sum of the slices in a fixed order), dense
-// Cholesky with the right-hand side carried as row m, back substitution for
-// y_c, then z = L⁻¹g_s - Y·y_c and the blocked backward band sweep for y_s.
-__global__ __launch_bounds__(256) void reduced_solve_kernel(SolveArgs a, int n_slices, int use_lds) {
+// Dense Cholesky of the reduced system (right-hand side carried as row m) and
+// the backward substitution for y_c. One workgroup; one barrier per column.
+__global__ __launch_bounds__(256) void reduced_solve_kernel(SolveArgs a, int use_lds) {
   LmState* st = a.st;
   if (st->terminated) return;
   extern __shared__ double lds[];
-  const int m = a.m, m1 = a.m + 1, n = a.n_s(), W = a.W(), ncp = a.n_cp;
+  const int m = a.m, m1 = a.m + 1, n = a.n_s();
   const int LD = m1 | 1;  // odd row stride: conflict-free column walks
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double* A = use_lds ? lds : a.Swork;
-  double* yv = use_lds ? lds + size_t(m1) * LD : a.Swork + size_t(m1) * LD;   // m1 doubles
-  double* z = yv + m1;                                                        // n + W doubles
+  double* yv = A + size_t(m1) * LD;   // m1 doubles
   __shared__ int s_fail;
   if (tid == 0) s_fail = 0;
-  for (int e = tid; e < m1 * m1; e += 256) {
-    const int r = e / m1, c = e % m1;
-    if (c <= r) {
-      double v = a.S[size_t(r) * m1 + c];
-      for (int ks = 0; ks < n_slices; ++ks) v -= a.Spart[(size_t(ks) * m1 + r) * m1 + c];
-      A[r * LD + c] = v;
-    }
-  }
+  for (int r = wave; r < m1; r += 4)
+    for (int c = lane; c <= r; c += 64) A[r * LD + c] = a.Spart[size_t(r) * m1 + c];
   __syncthreads();
   {
     const int ti = tid >> 4, tj = tid & 15;
@@ -420,13 +435,14 @@ __global__ __launch_bounds__(256) void reduced_solve_kernel(SolveArgs a, int n_s
       double p = A[j * LD + j];
       if (!(p > 0.0) || !isfinite(p)) { if (tid == 0) s_fail = 1; p = 1.0; }
       if (j > 0) { for (int i = j - 1 + tid; i <= m; i += 256) A[i * LD + (j - 1)] *= rs_prev; }  // lazy scaling of column j-1
-      const double ip = 1.0 / p;
+      const double rs = rsqrt_nr(p);
+      const double ip = rs * rs;
       for (int i = j + 1 + ti; i <= m; i += 16) {
         const double aij = A[i * LD + j] * ip;
         const int cmax = min(i, m - 1);
         for (int c = j + 1 + tj; c <= cmax; c += 16) A[i * LD + c] -= aij * A[c * LD + j];
       }
-      rs_prev = 1.0 / sqrt(p);
+      rs_prev = rs;
       __syncthreads();
     }
     if (m > 0) { for (int i = m - 1 + tid; i <= m; i += 256) A[i * LD + (m - 1)] *= rs_prev; }
@@ -447,66 +463,178 @@ __global__ __launch_bounds__(256) void reduced_solve_kernel(SolveArgs a, int n_s
   }
   __syncthreads();
   for (int i = tid; i < m; i += 256) a.y[n + i] = yv[i];
-  // z = Y[:, m] - Y[:, :m]·y_c : one wave per row, coalesced
-  for (int c = wave; c < n; c += 4) {
-    const double* row = a.Y + size_t(c) * m1;
-    double part = 0.0;
-    for (int j = lane; j < m; j += 64) part += row[j] * yv[j];
+  if (tid == 0 && s_fail) st->chol_failed = 1;
+}
+
+// Register-resident variant: thread (ti, tj) of a 16×16 grid owns the entries
+// (ti + 16a, tj + 16b) of the reduced matrix for the whole factorisation; per
+// column only the pivot column is broadcast through a double-buffered LDS
+// vector, so a step costs one barrier, 2·NT LDS reads and NT² register FMAs.
+// The factor is streamed column-major to Lst (LDS or global) for the backward
+// substitution. Valid for m+1 <= 16·NT.
+template <int NT>
+__global__ __launch_bounds__(256) void reduced_solve_reg_kernel(SolveArgs a, int l_in_lds) {
+  LmState* st = a.st;
+  if (st->terminated) return;
+  extern __shared__ double lds[];
+  const int m = a.m, m1 = a.m + 1, n = a.n_s();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ti = tid >> 4, tj = tid & 15;
+  constexpr int NP = 16 * NT;
+  double* colbuf = lds;                 // [2][NP]
+  double* yv = lds + 2 * NP;            // [NP]
+  double* Lst = l_in_lds ? lds + 4 * NP : a.Swork;   // column-major factor: Lst[j*NP + i]
+  __shared__ int s_fail;
+  if (tid == 0) s_fail = 0;
+  double A[NT][NT];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    if (lane == 0) z[c] = row[m] - part;
+  for (int aa = 0; aa < NT; ++aa)
+#pragma unroll
+    for (int bb = 0; bb < NT; ++bb) {
+      const int i = ti + 16 * aa, c = tj + 16 * bb;
+      A[aa][bb] = (i <= m && c <= i && c < m1) ? a.Spart[size_t(i) * m1 + c] : 0.0;
+    }
+  double* dinv = yv + NP;               // [NP] reciprocal diagonal of the factor
+  const double dflag = (ti >= tj) ? 1.0 : 0.0;   // diagonal tiles: only c <= i
+  for (int j = 0; j < m; ++j) {
+    double* cb = colbuf + (j & 1) * NP;
+    const int bj = j >> 4;   // wave-uniform
+    if (tj == (j & 15)) {
+#pragma unroll
+      for (int bb = 0; bb < NT; ++bb)
+        if (bb == bj) {
+#pragma unroll
+          for (int aa = 0; aa < NT; ++aa) cb[ti + 16 * aa] = A[aa][bb];
+        }
+    }
+    __syncthreads();
+    double p = cb[j];
+    if (!(p > 0.0) || !isfinite(p)) { if (tid == 0) s_fail = 1; p = 1.0; }
+    const double rs = rsqrt_nr(p);
+    double ri[NT], cj[NT];
+#pragma unroll
+    for (int aa = 0; aa < NT; ++aa) ri[aa] = cb[ti + 16 * aa] * rs;                                   // L(i, j)
+#pragma unroll
+    for (int bb = 0; bb < NT; ++bb) cj[bb] = (tj + 16 * bb > j) ? cb[tj + 16 * bb] * rs : 0.0;        // L(c, j), c > j
+#pragma unroll
+    for (int aa = 0; aa < NT; ++aa) {
+#pragma unroll
+      for (int bb = 0; bb < aa; ++bb) A[aa][bb] -= ri[aa] * cj[bb];
+      A[aa][aa] -= ri[aa] * cj[aa] * dflag;
+    }
+    if (tj == (j & 15)) {   // stream the finished column out
+#pragma unroll
+      for (int aa = 0; aa < NT; ++aa) {
+        const int i = ti + 16 * aa;
+        if (i >= j && i <= m) Lst[size_t(j) * NP + i] = ri[aa];
+      }
+      if (ti == 0) dinv[j] = rs;
+    }
   }
-  for (int c = n + tid; c < n + W; c += 256) z[c] = 0.0;
   __syncthreads();
-  // blocked backward sweep: y_J = L11⁻ᵀ (z_J - Σ_{r>=6} Lb[J][r][:]ᵀ y[6J+r])
+  if (!l_in_lds) __threadfence();
+  __syncthreads();
+  // backward substitution Lᵀ y_c = L⁻¹b (row m of the factor): one wave, dot-product form, next column prefetched
   if (wave == 0) {
-    const int nband = W * 6;
-    double lrow[6], linv = 0.0;
-    auto fetch = [&](int J) {
-      const int r = 6 + lane;
+    constexpr int NV = (NP + 63) / 64;
+    double cur[NV], nxt[NV];
+    auto fetch = [&](int j, double v[NV]) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) lrow[c] = (J >= 0 && r < W) ? a.Lb[size_t(J) * nband + r * 6 + c] : 0.0;
-      linv = (J >= 0 && lane < 36) ? a.Linv[size_t(J) * 36 + lane] : 0.0;
+      for (int u = 0; u < NV; ++u) { const int i = lane + 64 * u; v[u] = (j >= 0 && i > j && i <= m) ? Lst[size_t(j) * NP + i] : 0.0; }
     };
-    fetch(ncp - 1);
-    for (int J = ncp - 1; J >= 0; --J) {
-      double cur[6];
+    fetch(m - 1, nxt);
+    for (int j = m - 1; j >= 0; --j) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) cur[c] = lrow[c];
-      const double curinv = linv;
-      fetch(J - 1);
-      const int r = 6 + lane;
-      const double yr = (r < W) ? z[6 * J + r] : 0.0;
-      double s[6];
+      for (int u = 0; u < NV; ++u) cur[u] = nxt[u];
+      fetch(j - 1, nxt);
+      double part = 0.0;   // lane holding i == m contributes -rhs so one reduction suffices
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        double v = cur[c] * yr;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        s[c] = z[6 * J + c] - v;
+      for (int u = 0; u < NV; ++u) {
+        const int i = lane + 64 * u;
+        if (i > j && i < m) part += cur[u] * yv[i];
+        else if (i == m) part -= cur[u];
       }
-      // y_c = Σ_{q >= c} Linv[q][c] s_q ; lane (q*6 + c) holds Linv[q][c]
-      double contrib = 0.0;
-      if (lane < 36) { const int q = lane / 6; contrib = curinv * s[q]; }
-      // sum over q for fixed c: lanes c, c+6, ..., c+30
-      double t = contrib;
-      t += __shfl(contrib, (lane + 6) & 63, 64) * ((lane + 6) < 36 ? 1.0 : 0.0);
-      double acc = contrib;
 #pragma unroll
-      for (int q = 1; q < 6; ++q) {
-        const double other = __shfl(contrib, (lane + 6 * q) & 63, 64);
-        if (lane + 6 * q < 36) acc += other;
-      }
-      (void)t;
-      if (lane < 6) z[6 * J + lane] = acc;
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+      if (lane == 0) yv[j] = -part * dinv[j];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
   }
   __syncthreads();
-  for (int c = tid; c < n; c += 256) a.y[c] = z[c];
+  for (int i = tid; i < m; i += 256) a.y[n + i] = yv[i];
   if (tid == 0 && s_fail) st->chol_failed = 1;
+}
+
+// z = L⁻¹g_s - Y·y_c : one wave per band row, all CUs.  (y[0..n) used as z storage)
+__global__ __launch_bounds__(256) void border_matvec_kernel(SolveArgs a) {
+  const LmState* st = a.st;
+  if (st->terminated) return;
+  const int m = a.m, m1 = a.m + 1, n = a.n_s();
+  const int lane = threadIdx.x & 63;
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (c >= n) return;
+  const double* row = a.Y + size_t(c) * m1;
+  const double* yc = a.y + n;
+  double part = 0.0;
+  for (int j = lane; j < m; j += 64) part += row[j] * yc[j];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+  if (lane == 0) a.y[c] = row[m] - part;
+}
+
+// Blocked backward band sweep Lᵀ y_s = z, one wave:
+//   y_J = L11⁻ᵀ (z_J - Σ_{r>=6} L(6J+r, 6J+c) y[6J+r]).
+// Lane c (0..5) owns output c: it keeps column c of the block column (prefetched one block
+// ahead) in registers and walks the 6(k-1) later unknowns in LDS with two accumulators; the
+// six partial results are exchanged with v_readlane, so no LDS round trip sits on the chain.
+template <int K>
+__global__ __launch_bounds__(64) void band_backsolve_kernel(SolveArgs a) {
+  const LmState* st = a.st;
+  if (st->terminated) return;
+  extern __shared__ double z[];  // n + W doubles
+  constexpr int W = 6 * K, NR = W - 6;
+  const int n = a.n_s(), ncp = a.n_cp;
+  const int lane = threadIdx.x;
+  for (int c = lane; c < n + W; c += 64) z[c] = (c < n) ? a.y[c] : 0.0;
+  __syncthreads();
+  constexpr int nband = W * 6;
+  const int oc = lane < 6 ? lane : 0;
+  double lcur[NR], lnxt[NR], icur[6], inxt[6];
+  auto fetch = [&](int J, double lv[NR], double iv[6]) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) lv[r] = (J >= 0) ? a.Lb[size_t(J) * nband + (6 + r) * 6 + oc] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) iv[q] = (J >= 0) ? a.Linv[size_t(J) * 36 + q * 6 + oc] : 0.0;   // Linv[q][c]
+  };
+  fetch(ncp - 1, lnxt, inxt);
+  for (int J = ncp - 1; J >= 0; --J) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) lcur[r] = lnxt[r];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) icur[q] = inxt[q];
+    fetch(J - 1, lnxt, inxt);
+    const double* yb = z + 6 * J + 6;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < NR; r += 2) { s0 += lcur[r] * yb[r]; s1 += lcur[r + 1] * yb[r + 1]; }
+    const double sc = z[6 * J + oc] - (s0 + s1);
+    // y_c = Σ_q Linv[q][c] · s_q
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int lo = __builtin_amdgcn_readlane(__double2loint(sc), q);
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(sc), q);
+      acc += icur[q] * __hiloint2double(hi, lo);
+    }
+    if (lane < 6) z[6 * J + lane] = acc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  __syncthreads();
+  for (int c = lane; c < n; c += 64) a.y[c] = z[c];
 }
 
 // delta = -y ; candidate = Plus(x, delta) ; model cost change ; step norms.
@@ -598,6 +726,7 @@ __global__ __launch_bounds__(256) void lm_control_kernel(LmState* st, LmOptionsD
   if (tid == 0) {
     s_accept = 0;
     const double cand_norm = st->cand_norm;
+    st->n_cost_evals += 1;
     st->iteration += 1;
     st->step_successful = 0; st->relative_decrease = 0.0; st->cost_change = 0.0;
     if (!st->step_valid) {
@@ -673,25 +802,38 @@ void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* block
   hipLaunchKernelGGL(post_eval_kernel, dim3(1), dim3(256), 0, s, a, x, blocks, n_blocks, o, log, log_cap, first, jacobi);
 }
 constexpr int kBorderSlice = 16;   // border columns per workgroup of the banded factorisation
-constexpr int kSchurRows = 96;     // band rows per slice of the YᵀY product
 size_t band_cholesky_lds_bytes(const SolveArgs& a) {
   const int W = a.W();
   const int nrr = W - 6;
-  return size_t(a.k + 1) * (W * 6 + kBorderSlice * 6) * sizeof(double) + size_t(nrr * (nrr + 1) / 2) * sizeof(unsigned short) + 16;
+  return size_t(a.k + 2) * (W * 6 + kBorderSlice * 6) * sizeof(double) + size_t(nrr * (nrr + 1) / 2) * sizeof(unsigned short) + 16;
 }
 size_t reduced_solve_lds_bytes(const SolveArgs& a) {
   const int m1 = a.m + 1;
-  return (size_t(m1) * (m1 | 1) + m1 + a.n_s() + a.W()) * sizeof(double);
+  return (size_t(m1) * (m1 | 1) + m1) * sizeof(double);
 }
-int schur_slices(const SolveArgs& a) { return (a.n_s() + kSchurRows - 1) / kSchurRows; }
-hipError_t configure_solve_kernels(size_t band_lds, size_t reduced_lds) {
+size_t band_backsolve_lds_bytes(const SolveArgs& a) { return size_t(a.n_s() + a.W()) * sizeof(double); }
+hipError_t configure_solve_kernels(size_t band_lds, size_t reduced_lds, size_t back_lds) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&band_cholesky_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(band_lds));
   if (e != hipSuccess) return e;
-  if (reduced_lds)
+  if (reduced_lds) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&reduced_solve_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, int(reduced_lds));
-  return e;
+    if (e != hipSuccess) return e;
+  }
+  const int big = 150 * 1024;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&reduced_solve_reg_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&reduced_solve_reg_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&reduced_solve_reg_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&reduced_solve_reg_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  for (const void* f : {reinterpret_cast<const void*>(&band_backsolve_kernel<2>), reinterpret_cast<const void*>(&band_backsolve_kernel<3>),
+                        reinterpret_cast<const void*>(&band_backsolve_kernel<4>), reinterpret_cast<const void*>(&band_backsolve_kernel<5>),
+                        reinterpret_cast<const void*>(&band_backsolve_kernel<6>), reinterpret_cast<const void*>(&band_backsolve_kernel<7>),
+                        reinterpret_cast<const void*>(&band_backsolve_kernel<8>)}) {
+    e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(back_lds));
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, double* x_cand, const BlockDev* blocks,
                   int n_blocks, bool reduced_in_lds, hipStream_t s) {
@@ -702,9 +844,36 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
   const int nwg = (m1 + kBorderSlice - 1) / kBorderSlice;
   hipLaunchKernelGGL(band_cholesky_kernel, dim3(nwg), dim3(256), band_cholesky_lds_bytes(a), s, a, kBorderSlice);
   const int nt = (m1 + 15) / 16;
-  hipLaunchKernelGGL(schur_kernel, dim3(nt * (nt + 1) / 2, schur_slices(a)), dim3(256), 0, s, a, kSchurRows);
-  hipLaunchKernelGGL(reduced_solve_kernel, dim3(1), dim3(256), reduced_in_lds ? reduced_solve_lds_bytes(a) : 0, s, a,
-                     schur_slices(a), reduced_in_lds ? 1 : 0);
+  hipLaunchKernelGGL(schur_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, a);
+  if (m1 <= 16 * 13) {
+    const int NT = m1 <= 64 ? 4 : (m1 <= 112 ? 7 : (m1 <= 160 ? 10 : 13));
+    const int NP = 16 * NT;
+    const size_t full = size_t(4 * NP + size_t(a.m) * NP) * sizeof(double);
+    const bool l_in_lds = full <= 150 * 1024;
+    const size_t lds = l_in_lds ? full : size_t(4 * NP) * sizeof(double);
+    switch (NT) {
+      case 4: hipLaunchKernelGGL(reduced_solve_reg_kernel<4>, dim3(1), dim3(256), lds, s, a, l_in_lds ? 1 : 0); break;
+      case 7: hipLaunchKernelGGL(reduced_solve_reg_kernel<7>, dim3(1), dim3(256), lds, s, a, l_in_lds ? 1 : 0); break;
+      case 10: hipLaunchKernelGGL(reduced_solve_reg_kernel<10>, dim3(1), dim3(256), lds, s, a, l_in_lds ? 1 : 0); break;
+      default: hipLaunchKernelGGL(reduced_solve_reg_kernel<13>, dim3(1), dim3(256), lds, s, a, l_in_lds ? 1 : 0); break;
+    }
+  } else {
+    hipLaunchKernelGGL(reduced_solve_kernel, dim3(1), dim3(256), reduced_in_lds ? reduced_solve_lds_bytes(a) : 0, s, a,
+                       reduced_in_lds ? 1 : 0);
+  }
+  hipLaunchKernelGGL(border_matvec_kernel, dim3((a.n_s() + 3) / 4), dim3(256), 0, s, a);
+  {
+    const size_t bl = band_backsolve_lds_bytes(a);
+    switch (a.k) {
+      case 2: hipLaunchKernelGGL(band_backsolve_kernel<2>, dim3(1), dim3(64), bl, s, a); break;
+      case 3: hipLaunchKernelGGL(band_backsolve_kernel<3>, dim3(1), dim3(64), bl, s, a); break;
+      case 4: hipLaunchKernelGGL(band_backsolve_kernel<4>, dim3(1), dim3(64), bl, s, a); break;
+      case 5: hipLaunchKernelGGL(band_backsolve_kernel<5>, dim3(1), dim3(64), bl, s, a); break;
+      case 6: hipLaunchKernelGGL(band_backsolve_kernel<6>, dim3(1), dim3(64), bl, s, a); break;
+      case 7: hipLaunchKernelGGL(band_backsolve_kernel<7>, dim3(1), dim3(64), bl, s, a); break;
+      default: hipLaunchKernelGGL(band_backsolve_kernel<8>, dim3(1), dim3(64), bl, s, a); break;
+    }
+  }
   hipLaunchKernelGGL(update_kernel, dim3(1), dim3(256), 0, s, a, x, x_cand, blocks, n_blocks);
 }
 void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const LmState* st, hipStream_t s) {

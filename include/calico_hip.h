@@ -155,6 +155,10 @@ int32_t calico_get_param_block(calico_problem* p, int32_t block_id,
                                double* out);
 int32_t calico_set_param_block(calico_problem* p, int32_t block_id,
                                const double* values);
+/* Bulk form: n blocks, values concatenated in the order of block_ids. */
+int32_t calico_set_param_blocks(calico_problem* p, int32_t n,
+                                const int32_t* block_ids,
+                                const double* values);
 
 /* Replaces Trajectory::AddParametersToProblem + GetEvaluationParams
  * (trajectory.cpp:51-79, bspline.hpp:138-161): the uniform knot vector
@@ -261,6 +265,8 @@ int32_t calico_problem_set_stream(calico_problem* p, void* stream);
  * 3 cost-only evaluation, 4 LM control + update. */
 int32_t calico_get_phase_time(calico_problem* p, int32_t phase, double* ms,
                               int64_t* launches);
+/* Which phases are bracketed by HIP events (bit i = phase i). Default: all. */
+int32_t calico_set_phase_timing(calico_problem* p, int32_t mask);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,7 @@
 #include "../include/calico_hip.h"
 #include "oracle_math.hpp"
 #include "oracle_spline.hpp"
+#include "../calico_amd/csrc/shard.hpp"  // the product's partition rule, exercised here on CPU
 
 namespace oracle {
 
@@ -78,6 +79,12 @@ struct Problem {
   std::vector<int64_t> res_offset;  // per residual block: first residual row
   int64_t n_res = 0;
   std::vector<calico_iteration> iterations;
+  // multi-rank emulation (tests): this rank evaluates only its time window and sums with the others
+  int rank = 0, world = 1;
+  int32_t (*allreduce)(void*, double*, int64_t) = nullptr;
+  void* allreduce_ctx = nullptr;
+  std::vector<char> own;  // per residual block
+  void reduce(double* buf, int64_t n) const { if (allreduce) allreduce(allreduce_ctx, buf, n); }
   int set_error(int code, const std::string& m) { error = m; return code; }
 };
 
@@ -179,6 +186,17 @@ static void BuildReduced(Problem& P) {
       P.rblocks.push_back({int(si), i});
       P.res_offset.push_back(P.n_res);
       P.n_res += s.dim();
+    }
+  }
+  {  // shard windows over spline segments (cal::shard_windows)
+    const int nseg = int(P.valid_knots.size()) - 1;
+    std::vector<int64_t> per_seg(size_t(std::max(nseg, 0)), 0);
+    for (const BlockRef& b : P.rblocks) per_seg[size_t(P.sensors[b.sensor].seg[b.obs])] += 1;
+    const std::vector<int> win = cal::shard_windows(per_seg, P.world);
+    P.own.assign(P.rblocks.size(), 0);
+    for (size_t b = 0; b < P.rblocks.size(); ++b) {
+      const int sg = P.sensors[P.rblocks[b].sensor].seg[P.rblocks[b].obs];
+      P.own[b] = (sg >= win[size_t(P.rank)] && sg < win[size_t(P.rank) + 1]) ? 1 : 0;
     }
   }
   P.reduced_blocks.clear();
@@ -363,6 +381,7 @@ static void Evaluate(const Problem& P, const std::vector<std::vector<double>>& v
     int offs[32], sizes[32], nruns, ncols;
     double c;
     for (int64_t b = lo; b < hi; ++b) {
+      if (!P.own[size_t(b)]) continue;
       const Sensor& s = P.sensors[P.rblocks[b].sensor];
       double* r = &E->residuals[size_t(P.res_offset[b])];
       double* jac = want_jac ? &E->jac[size_t(E->jac_offset[b])] : nullptr;
@@ -373,6 +392,11 @@ static void Evaluate(const Problem& P, const std::vector<std::vector<double>>& v
   if (T == 1) work(0);
   else { std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(work, t); for (auto& t : th) t.join(); }
   for (int t = 0; t < T; ++t) { E->cost += tcost[t]; if (!tok[t]) E->ok = false; }
+  {
+    double cv[2] = {E->cost, E->ok ? 0.0 : 1.0};
+    P.reduce(cv, 2);
+    E->cost = cv[0]; E->ok = cv[1] == 0.0;
+  }
   if (want_jac && E->ok) {
     for (int64_t b = 0; b < nb; ++b) {
       const Sensor& s = P.sensors[P.rblocks[b].sensor];
@@ -389,6 +413,7 @@ static void Evaluate(const Problem& P, const std::vector<std::vector<double>>& v
         c0 += E->col_size[q];
       }
     }
+    P.reduce(E->gradient.data(), int64_t(E->gradient.size()));
   }
 }
 
@@ -423,6 +448,7 @@ static void AccumulateJtJ(const Problem& P, const Evaluation& E, const double* s
   else { std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(work, t); for (auto& t : th) t.join(); }
   H->assign(size_t(n) * n, 0.0);
   for (int t = 0; t < T; ++t) for (size_t q = 0; q < H->size(); ++q) (*H)[q] += Ht[t][q];
+  P.reduce(H->data(), int64_t(H->size()));
   for (int a = 0; a < n; ++a) for (int c = a + 1; c < n; ++c) (*H)[size_t(c) * n + a] = (*H)[size_t(a) * n + c];
 }
 
@@ -606,6 +632,7 @@ static int Solve(Problem& P, const calico_solver_options& o, calico_summary* sm)
           mcc += m * (r[k] + m / 2.0);
         }
       }
+      P.reduce(&mcc, 1);
       model_cost_change = -mcc;
       it.step_is_valid = model_cost_change > 0.0;
     }
@@ -704,6 +731,14 @@ int32_t oracle_set_param_block(Problem* p, int32_t id, const double* v) {
   if (id < 0 || id >= int(p->blocks.size())) return p->set_error(CALICO_INVALID_ARGUMENT, "bad block id");
   std::copy(v, v + p->blocks[id].size, p->blocks[id].v.begin()); return CALICO_OK;
 }
+int32_t oracle_set_param_blocks(Problem* p, int32_t n, const int32_t* ids, const double* v) {
+  for (int i = 0; i < n; ++i) {
+    if (ids[i] < 0 || ids[i] >= int(p->blocks.size())) return p->set_error(CALICO_INVALID_ARGUMENT, "bad block id");
+    std::copy(v, v + p->blocks[ids[i]].size, p->blocks[ids[i]].v.begin());
+    v += p->blocks[ids[i]].size;
+  }
+  return CALICO_OK;
+}
 int32_t oracle_problem_set_spline(Problem* p, int32_t order, int32_t n_knots, const double* knots, const double* basis,
                                   const int32_t* ctrl) {
   if (order < 2 || order > 16 || n_knots < 2 * order) return p->set_error(CALICO_INVALID_ARGUMENT, "bad spline");
@@ -763,6 +798,14 @@ int32_t oracle_problem_add_imu_residuals(Problem* p, int32_t sid, int64_t n, con
   return add_obs(p, sid, n, m, st, nullptr, nullptr);
 }
 int32_t oracle_solve(Problem* p, const calico_solver_options* o, calico_summary* sm) { return oracle::Solve(*p, *o, sm); }
+int32_t oracle_problem_set_shard(Problem* p, int32_t rank, int32_t world) {
+  if (world < 1 || rank < 0 || rank >= world) return p->set_error(CALICO_INVALID_ARGUMENT, "bad rank / world size");
+  p->rank = rank; p->world = world; return CALICO_OK;
+}
+// host-buffer all-reduce (sum) callback: fn(ctx, buf, n)
+int32_t oracle_problem_set_allreduce(Problem* p, int32_t (*fn)(void*, double*, int64_t), void* ctx) {
+  p->allreduce = fn; p->allreduce_ctx = ctx; return CALICO_OK;
+}
 int32_t oracle_get_iterations(Problem* p, calico_iteration* out, int32_t max_rows, int32_t* n_out) {
   const int n = std::min<int>(max_rows, int(p->iterations.size()));
   for (int i = 0; i < n; ++i) out[i] = p->iterations[i];

@@ -1,0 +1,84 @@
+"""CPU-side checks of the drop-in boundary: libcalico_hip.so loads and exports every symbol that
+include/calico_hip.h declares, fails loudly without a GPU (no CPU fallback), and the host-side
+partition rule / option defaults behave. No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers
+from calico_amd import _capi
+
+
+@pytest.fixture(scope="module")
+def hiplib():
+    import __graft_entry__ as g
+    g.build_hip()
+    return C.CDLL(_capi.hip_library_path())
+
+
+def test_library_exports_every_declared_symbol(hiplib):
+    header = open(os.path.join(helpers.ROOT, "include", "calico_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(calico_[a-z_]+)\s*\(", header)) - {"calico_allreduce_fn"})
+    assert len(declared) >= 24
+    for name in declared:
+        assert hasattr(hiplib, name), name
+    assert sorted("calico_" + n for n in _capi.ABI_SYMBOLS) == declared
+
+
+def test_default_solver_options_match_reference(hiplib):
+    """batch_optimizer.cpp:10-17 over Ceres defaults."""
+    api = _capi.CApi(hiplib, "calico_")
+    o = api.default_options()
+    assert (o.max_num_iterations, o.function_tolerance, o.parameter_tolerance, o.gradient_tolerance) == (50, 1e-8, 1e-10, 1e-10)
+    assert (o.initial_trust_region_radius, o.min_relative_decrease, o.min_lm_diagonal, o.max_lm_diagonal) == (1e4, 1e-3, 1e-6, 1e32)
+    assert o.minimizer_progress_to_stdout == 1 and o.jacobi_scaling == 1 and o.max_num_consecutive_invalid_steps == 5
+    oo = helpers.oracle_api().default_options()
+    for name, _ in _capi.SolverOptions._fields_:
+        assert getattr(o, name) == getattr(oo, name), name
+
+
+@pytest.mark.skipif(helpers.has_gpu(), reason="checks the no-GPU behaviour")
+def test_no_gpu_means_loud_failure_not_a_fallback(hiplib):
+    api = _capi.CApi(hiplib, "calico_")
+    with pytest.raises(_capi.CalicoError) as e:
+        _capi.Problem(api, 0)
+    assert e.value.code == _capi.INTERNAL
+
+
+def test_product_never_links_the_oracle(hiplib):
+    import subprocess
+    out = subprocess.run(["ldd", _capi.hip_library_path()], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    for f in os.listdir(os.path.join(helpers.ROOT, "calico_amd")):
+        if f.endswith(".py"):
+            src = open(os.path.join(helpers.ROOT, "calico_amd", f)).read()
+            assert "oracle_lib" not in src and "libcalico_oracle" not in src, f
+    for f in os.listdir(os.path.join(helpers.ROOT, "calico_amd", "csrc")):
+        if f.endswith((".cpp", ".hip", ".hpp")):
+            src = open(os.path.join(helpers.ROOT, "calico_amd", "csrc", f)).read()
+            assert "oracle/" not in src and "oracle_" not in src, f
+
+
+def test_shard_windows_partition_rule():
+    """calico_amd/csrc/shard.hpp through the oracle's multi-rank emulation: every residual block is
+    owned by exactly one rank, windows are contiguous in time and balanced."""
+    from calico_amd import synthetic as syn
+    oracle = helpers.oracle_api()
+    scene = syn.make_scene(2, 1, True, 2, cam_rate=10.0, imu_rate=50.0, duration=4.0, segment_duration=4.0 / 23.9, max_cam_obs=3000)
+    full = syn.build_problem(oracle, scene)
+    c_full, g_full, H_full = full.problem.evaluate()
+    for world in (2, 3, 5):
+        costs, gs, Hs = [], [], []
+        for r in range(world):
+            b = syn.build_problem(oracle, scene)
+            assert oracle.lib.oracle_problem_set_shard(b.problem.h, r, world) == 0
+            c, g, H = b.problem.evaluate()
+            costs.append(c); gs.append(g); Hs.append(H)
+        assert abs(sum(costs) - c_full) <= 1e-12 * c_full
+        assert np.abs(sum(gs) - g_full).max() <= 1e-10 * np.abs(g_full).max()
+        assert np.abs(sum(Hs) - H_full).max() <= 1e-10 * np.abs(H_full).max()
+        share = np.array(costs) > 0
+        assert share.all()
