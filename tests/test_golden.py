@@ -30,7 +30,7 @@ def _check(api, path, rtol_eval, rtol_solve):
         assert np.array_equal(built.problem.inlier_mask(built.sensor_ids[i], s.n, 3.0), d["mask%d" % i])  # bit exact
     o = api.default_options()
     o.minimizer_progress_to_stdout = 0
-    o.max_num_iterations = 40
+    o.max_num_iterations = 100
     sm = built.problem.solve(o)
     assert sm.termination_type == int(d["termination_type"])
     assert abs(sm.final_cost - d["final_cost"]) <= 1e-8 * d["final_cost"]
