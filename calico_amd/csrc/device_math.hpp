@@ -6,9 +6,15 @@
 // only the Rodrigues-Jacobian pieces of the IMU residuals, whose closed-form
 // derivative is third order, use a 3-lane forward dual (D3) in registers.
 #pragma once
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
-
 #define DEV __device__ __forceinline__
+#else
+// Plain host build (include/calico/calico.hpp uses the same model code for Sensor::Project).
+#include <cmath>
+#define DEV inline
+namespace cal { using std::sqrt; using std::sin; using std::cos; using std::tan; using std::atan; using std::log; using std::fmax; }
+#endif
 
 namespace cal {
 
