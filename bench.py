@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (3 = north star)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-every", type=int, default=8)
+    ap.add_argument("--force-collective", action="store_true",
+                    help="exercise the sharding + all-reduce path even with one rank (validation)")
     args = ap.parse_args()
 
     import torch
@@ -98,9 +100,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: libcalico_hip.so is the only backend")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     api = _capi.load_hip()
@@ -108,7 +112,7 @@ def main():
     built = syn.build_problem(api, scene, device=local_rank)
     P = built.problem
     keep = []
-    if world > 1:
+    if collective:
         stream = torch.cuda.current_stream().cuda_stream
         P.set_stream(stream)
         P.set_shard(rank, world)

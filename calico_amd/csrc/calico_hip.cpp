@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -30,6 +31,7 @@ namespace cal {
 
 // ---- kernels (eval_kernels.hip / solve_kernels.hip) -------------------------
 void launch_eval(const EvalArgs& a, bool jac, hipStream_t stream);
+void launch_eval_frames(const EvalArgs& a, hipStream_t stream);
 hipError_t configure_eval_kernels(size_t max_lds_bytes);
 
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
@@ -152,7 +154,9 @@ struct calico_problem {
   size_t partial_doubles = 0;
   std::vector<int> eff_to_tan;
   std::vector<BlockDev> h_blocks;
-  std::vector<ItemDev> h_items, h_items_all;
+  std::vector<ItemDev> h_items, h_items_all, h_jac_items;
+  std::vector<FrameItemDev> h_fitems;
+  int n_fitems = 0, n_jac_items = 0;
   std::vector<double> h_x;
   int n_thin = 0, n_fat = 0;
   bool dense_in_lds = true;
@@ -164,7 +168,8 @@ struct calico_problem {
   DevBuf<uint8_t> d_cp_active, d_valid;
   DevBuf<SensorDev> d_sensors;
   DevBuf<LayoutDev> d_layouts;
-  DevBuf<ItemDev> d_items, d_items_all;
+  DevBuf<ItemDev> d_items, d_items_all, d_jac_items;
+  DevBuf<FrameItemDev> d_fitems;
   DevBuf<BlockDev> d_blocks;
   DevBuf<LmState> d_state;
   DevBuf<IterLog> d_log;
@@ -204,6 +209,8 @@ SolveArgs make_solve_args(calico_problem* p) {
   a.R = p->d_R.p; a.Lb = p->d_Lb.p; a.Linv = p->d_Linv.p; a.Y = p->d_Y.p; a.S = p->d_S.p; a.Spart = p->d_Spart.p;
   a.Swork = p->d_Swork.p; a.y = p->d_y.p; a.dadd = p->d_dadd.p;
   a.scale = p->d_scale.p; a.cp_active = p->d_cp_active.p; a.st = p->d_state.p; a.n_cp = p->n_cp; a.k = p->order; a.m = p->m;
+  static const int dbg = std::getenv("CALICO_KERNEL_TIMING") ? std::atoi(std::getenv("CALICO_KERNEL_TIMING")) : 0;
+  a.debug = dbg;
   return a;
 }
 
@@ -215,7 +222,8 @@ EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool
   a.partials = p->d_partials.p; a.item_cost = p->d_partials.p + p->partial_doubles;
   a.res_out = want_res ? p->d_res.p : nullptr; a.valid_out = want_res ? p->d_valid.p : nullptr;
   a.order = p->order; a.n_items = p->n_items; a.lds_cols = p->lds_cols; a.apply_loss = apply_loss;
-  a.st = nullptr; a.need_flag = 0; a.pad1 = 0;
+  a.st = nullptr; a.need_flag = 0; a.cost_index_base = 0;
+  a.fitems = p->d_fitems.p; a.n_fitems = p->n_fitems; a.pad2 = 0;
   return a;
 }
 
@@ -316,7 +324,7 @@ int finalize(calico_problem* p) {
     }
   }
   // ---- sort observations by (layout, segment) and cut work items ----
-  struct Key { int layout, seg, sensor; int64_t idx; };
+  struct Key { int layout, seg, sensor; int64_t idx; double stamp; };
   std::vector<Key> keys;
   int64_t n_obs = 0;
   for (const HSensor& s : p->sensors) n_obs += s.n();
@@ -326,11 +334,13 @@ int finalize(calico_problem* p) {
     s.sorted_pos.assign(size_t(s.n()), 0);
     for (int64_t i = 0; i < s.n(); ++i) {
       const int body = s.kind == CALICO_SENSOR_CAMERA ? s.body[i] : -1;
-      keys.push_back({layout_of[{int(si), body}], s.seg[i], int(si), i});
+      keys.push_back({layout_of[{int(si), body}], s.seg[i], int(si), i, s.stamps[size_t(i)]});
     }
   }
   std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
-    return a.layout != b.layout ? a.layout < b.layout : a.seg < b.seg; });
+    if (a.layout != b.layout) return a.layout < b.layout;
+    if (a.seg != b.seg) return a.seg < b.seg;
+    return a.stamp < b.stamp; });
   p->n_obs = n_obs;
   std::vector<double> m0(n_obs), m1(n_obs), m2(n_obs), st(n_obs);
   std::vector<int> point_off(n_obs, 0);
@@ -356,14 +366,53 @@ int finalize(calico_problem* p) {
   std::vector<int64_t> per_seg(size_t(nseg), 0);
   for (const ItemDev& it : p->h_items_all) per_seg[size_t(it.seg)] += it.obs_count;
   const std::vector<int> win = shard_windows(per_seg, p->world);
+  const int seg_lo = win[size_t(p->rank)], seg_hi = win[size_t(p->rank) + 1];
+  for (const ItemDev& it : p->h_items_all)
+    if (it.seg >= seg_lo && it.seg < seg_hi) p->h_items.push_back(it);
+  // Jacobian pass: camera cells are cut into FRAMES (blocks sharing the stamp) for the frame kernel
+  // when the spline order is 6 and frames are reasonably full; everything else goes to the generic kernel.
+  p->h_fitems.clear(); p->h_jac_items.clear();
   size_t poff = 0;
-  for (ItemDev it : p->h_items_all) {
-    if (it.seg < win[size_t(p->rank)] || it.seg >= win[size_t(p->rank) + 1]) continue;
-    const LayoutDev& L = layouts[it.layout];
-    it.partial_off = int64_t(poff);
-    poff += size_t(L.ncols + 1) * (L.ncols + 1);
-    p->h_items.push_back(it);
+  {
+    std::vector<char> layout_uses_frames(layouts.size(), 0);
+    if (k == 6) {
+      std::vector<int64_t> n_obs_l(layouts.size(), 0), n_frames_l(layouts.size(), 0);
+      for (int64_t q = 0; q < n_obs;) {
+        int64_t e = q;
+        while (e < n_obs && keys[e].layout == keys[q].layout && keys[e].seg == keys[q].seg && keys[e].stamp == keys[q].stamp) ++e;
+        n_obs_l[size_t(keys[q].layout)] += e - q; n_frames_l[size_t(keys[q].layout)] += 1;
+        q = e;
+      }
+      for (size_t l = 0; l < layouts.size(); ++l)
+        layout_uses_frames[l] = p->sensors[size_t(layouts[l].sensor)].kind == CALICO_SENSOR_CAMERA && n_frames_l[l] > 0 &&
+                                n_obs_l[l] >= 16 * n_frames_l[l] && layouts[l].ncols + 1 - 36 + 6 <= 30;
+    }
+    for (int64_t q = 0; q < n_obs;) {
+      const Key& kq = keys[q];
+      int64_t e = q;
+      if (layout_uses_frames[size_t(kq.layout)]) {
+        while (e < n_obs && keys[e].layout == kq.layout && keys[e].seg == kq.seg && keys[e].stamp == kq.stamp) ++e;
+        if (kq.seg >= seg_lo && kq.seg < seg_hi) {
+          FrameItemDev f;
+          f.layout = kq.layout; f.seg = kq.seg; f.obs_begin = int(q); f.obs_count = int(e - q); f.stamp = kq.stamp;
+          f.partial_off = int64_t(poff);
+          poff += size_t(layouts[size_t(kq.layout)].ncols + 1) * (layouts[size_t(kq.layout)].ncols + 1);
+          p->h_fitems.push_back(f);
+        }
+      } else {
+        while (e < n_obs && keys[e].layout == kq.layout) ++e;
+      }
+      q = e;
+    }
+    for (ItemDev it : p->h_items) {
+      if (layout_uses_frames[size_t(it.layout)]) continue;
+      it.partial_off = int64_t(poff);
+      poff += size_t(layouts[size_t(it.layout)].ncols + 1) * (layouts[size_t(it.layout)].ncols + 1);
+      p->h_jac_items.push_back(it);
+    }
   }
+  p->n_fitems = int(p->h_fitems.size());
+  p->n_jac_items = int(p->h_jac_items.size());
   for (int64_t q = 0; q < n_obs; ++q) {
     HSensor& s = p->sensors[keys[q].sensor];
     const int64_t i = keys[q].idx;
@@ -376,30 +425,34 @@ int finalize(calico_problem* p) {
   p->n_items = int(p->h_items.size());
   p->n_items_all = int(p->h_items_all.size());
   p->partial_doubles = poff;
-  if (poff + 2 * size_t(p->n_items) >= size_t(0x7fffffff))
+  if (poff + 2 * size_t(std::max(p->n_items, p->n_fitems + p->n_jac_items)) >= size_t(0x7fffffff))
     return p->set_error(CALICO_UNIMPLEMENTED, "problem too large for 32-bit gather indices");
   p->lds_cols = (max_cols + 3) & ~3;
   if (size_t(p->lds_cols) * kRowPad * sizeof(double) > kMaxLds)
     return p->set_error(CALICO_UNIMPLEMENTED, "too many Jacobian columns per residual block for the LDS staging area");
   // ---- gather lists ----
-  SolveArgs sa; sa.n_cp = n_cp; sa.k = k; sa.m = m;
+  SolveArgs sa; sa.n_cp = n_cp; sa.k = k; sa.m = m; sa.debug = 0;
   const size_t r_size = sa.r_size();
   if (r_size >= size_t(0x7fffffff)) return p->set_error(CALICO_UNIMPLEMENTED, "normal-equation buffer too large");
   struct Pair { int dst, src; };
   std::vector<Pair> pairs;
   pairs.reserve(poff / 2 + 4 * size_t(p->n_items));
-  for (int itn = 0; itn < p->n_items; ++itn) {
-    const ItemDev& it = p->h_items[size_t(itn)];
-    const LayoutDev& L = layouts[it.layout];
-    const std::vector<int>& gmap = layout_gmap[it.layout];
+  const int n_part = p->n_fitems + p->n_jac_items;
+  for (int itn = 0; itn < n_part; ++itn) {
+    const bool is_frame = itn < p->n_fitems;
+    const int it_layout = is_frame ? p->h_fitems[size_t(itn)].layout : p->h_jac_items[size_t(itn - p->n_fitems)].layout;
+    const int it_seg = is_frame ? p->h_fitems[size_t(itn)].seg : p->h_jac_items[size_t(itn - p->n_fitems)].seg;
+    const int64_t it_poff = is_frame ? p->h_fitems[size_t(itn)].partial_off : p->h_jac_items[size_t(itn - p->n_fitems)].partial_off;
+    const LayoutDev& L = layouts[size_t(it_layout)];
+    const std::vector<int>& gmap = layout_gmap[size_t(it_layout)];
     const int nc = L.ncols, n1 = nc + 1;
-    auto tan_of = [&](int c) { return c < 6 * k ? 6 * (it.seg + c / 6) + c % 6 : gmap[size_t(c - 6 * k)]; };
+    auto tan_of = [&](int c) { return c < 6 * k ? 6 * (it_seg + c / 6) + c % 6 : gmap[size_t(c - 6 * k)]; };
     for (int i = 0; i < nc; ++i) {
       const int ti = tan_of(i);
-      pairs.push_back({int(sa.off_g()) + ti, int(it.partial_off) + i * n1 + nc});
+      pairs.push_back({int(sa.off_g()) + ti, int(it_poff) + i * n1 + nc});
       for (int j = i; j < nc; ++j) {
         const int tj = tan_of(j);
-        const int src = int(it.partial_off) + i * n1 + j;
+        const int src = int(it_poff) + i * n1 + j;
         if (ti < NS && tj < NS) {
           const int a = ti / 6, b = tj / 6;  // a <= b
           pairs.push_back({int(sa.off_B()) + (a * k + (b - a)) * 36 + (ti % 6) * 6 + (tj % 6), src});
@@ -445,13 +498,14 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_stamp.upload(st, s)); HIP_TRY(p, p->d_point_off.upload(point_off, s));
   HIP_TRY(p, p->d_sensors.upload(sd, s)); HIP_TRY(p, p->d_layouts.upload(layouts, s));
   HIP_TRY(p, p->d_items.upload(p->h_items, s)); HIP_TRY(p, p->d_items_all.upload(p->h_items_all, s));
+  HIP_TRY(p, p->d_jac_items.upload(p->h_jac_items, s)); HIP_TRY(p, p->d_fitems.upload(p->h_fitems, s));
   HIP_TRY(p, p->d_blocks.upload(p->h_blocks, s));
   HIP_TRY(p, p->d_cp_active.upload(cp_active, s));
   HIP_TRY(p, p->d_out_thin.upload(out_thin, s)); HIP_TRY(p, p->d_idx_thin.upload(idx_thin, s));
   HIP_TRY(p, p->d_ptr_thin.upload(ptr_thin, s));
   HIP_TRY(p, p->d_out_fat.upload(out_fat, s)); HIP_TRY(p, p->d_idx_fat.upload(idx_fat, s));
   HIP_TRY(p, p->d_ptr_fat.upload(ptr_fat, s));
-  HIP_TRY(p, p->d_partials.alloc(poff + 2 * size_t(std::max(p->n_items, p->n_items_all))));
+  HIP_TRY(p, p->d_partials.alloc(poff + 2 * size_t(std::max(std::max(p->n_items, p->n_items_all), p->n_fitems + p->n_jac_items))));
   HIP_TRY(p, p->d_R.alloc(r_size)); HIP_TRY(p, hipMemsetAsync(p->d_R.p, 0, r_size * sizeof(double), s));
   HIP_TRY(p, p->d_R2.alloc(2));
   const int NT = 6 * n_cp + m;
@@ -501,7 +555,9 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag) {
   p->timer.begin(0, p->stream);
   EvalArgs ea = make_eval_args(p, p->d_x.p, 1, false);
   ea.st = st; ea.need_flag = need_flag;
-  launch_eval(ea, true, p->stream);
+  launch_eval_frames(ea, p->stream);                      // camera frames: item-cost slots [0, n_fitems)
+  ea.items = p->d_jac_items.p; ea.n_items = p->n_jac_items; ea.cost_index_base = p->n_fitems;
+  launch_eval(ea, true, p->stream);                       // everything else
   p->timer.end(p->stream);
   p->timer.begin(1, p->stream);
   launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->d_out_fat.p,

@@ -553,7 +553,7 @@ __global__ __launch_bounds__(64) void eval_items_kernel(EvalArgs a) {
   }
   const double item_cost = wave_sum(cost);
   const double n_invalid = wave_sum((active && !ok) ? 1.0 : 0.0);
-  if (lane == 0) { a.item_cost[2 * item_id] = item_cost; a.item_cost[2 * item_id + 1] = n_invalid; }
+  if (lane == 0) { a.item_cost[2 * (a.cost_index_base + item_id)] = item_cost; a.item_cost[2 * (a.cost_index_base + item_id) + 1] = n_invalid; }
   if constexpr (JAC) {
     if (active) {
       if (!ok) {  // drop the block: zero its rows
@@ -600,6 +600,258 @@ __global__ __launch_bounds__(64) void eval_items_kernel(EvalArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Camera frames (spline order 6). One wave per frame.
+//
+// All residual blocks of a frame share the pose p(t), its derivative and the
+// spline weights w, so their Jacobian rows are  J = J_prim · T  with
+//   J_prim = d r / d [p(6) | intrinsics | q | t | body q | body t]   (per block)
+//   T      = blockdiag(w ⊗ I6 for the 36 control-point columns, -pdot for the latency column, I)
+// The wave stages J_prim rows (≤ 30 columns instead of ≤ 74) in LDS, forms the small
+// M = [J_prim r]ᵀ[J_prim r] with 2×2 register tiles over all blocks of the frame, and expands
+// TᵀMT once per frame into the item's (c+1)×(c+1) partial block — same output layout as the
+// generic kernel, ~5× fewer FMAs and LDS reads, and every per-frame quantity (spline
+// evaluation, Rodrigues terms, rotation products) is computed once per wave, not per block.
+// ---------------------------------------------------------------------------
+constexpr int kMaxPrim = 32;   // 6 + 11 + 3 + 3 + 3 + 3 + r = 30, padded even
+
+template <int MODEL>
+DEV bool frame_camera_block(const SensorDev& S, const LayoutDev& L, const double* intr, const M3& R_rc, const M3& R_rw,
+                            const M3& R_wm, const M3& Jl, const M3& G, V3 t_rc, V3 t_wm, V3 t_wr, double px, double py,
+                            const double* xm, int apply_loss, double* Jp, int row0, int pc_intr, int pc_q, int pc_t,
+                            int pc_bq, int pc_bt, int pc_r, double* cost) {
+  const V3 Rx = mul(R_wm, mk(xm[0], xm[1], xm[2]));
+  const V3 y = mul(R_rw, (Rx + t_wm) - t_wr);
+  const V3 z = y - t_rc;
+  const V3 xc = mulT(R_rc, z);
+  double pix[2], D[2][3], dK[2][kMaxIntr];
+  if (!project<MODEL, true>(intr, xc, pix, D, dK)) return false;
+  const double r0 = (px - pix[0]) * S.info, r1 = (py - pix[1]) * S.info;
+  const double sq = r0 * r0 + r1 * r1;
+  double ls = 1.0, rho = sq;
+  if (apply_loss) rho = loss_eval(S.loss, S.loss_scale, sq, &ls);
+  *cost = 0.5 * rho;
+  const double fac = -S.info * ls;
+  auto put = [&](int col, int r, double v) { Jp[col * kRowPad + row0 + r] = v; };
+  put(pc_r, 0, r0 * ls); put(pc_r, 1, r1 * ls);
+  double DRt[2][3], DG[2][3];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) DRt[r][j] = fac * (D[r][0] * R_rc.m[j][0] + D[r][1] * R_rc.m[j][1] + D[r][2] * R_rc.m[j][2]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) DG[r][j] = fac * (D[r][0] * G.m[0][j] + D[r][1] * G.m[1][j] + D[r][2] * G.m[2][j]);
+  }
+  const M3 Sy = skew(y);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    double T1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) T1[j] = DRt[r][0] * Sy.m[0][j] + DRt[r][1] * Sy.m[1][j] + DRt[r][2] * Sy.m[2][j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) put(j, r, T1[0] * Jl.m[0][j] + T1[1] * Jl.m[1][j] + T1[2] * Jl.m[2][j]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) put(3 + j, r, -DG[r][j]);
+  }
+  if (pc_intr >= 0) {
+    constexpr int K = CamK<MODEL>::K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) { put(pc_intr + j, 0, fac * dK[0][j]); put(pc_intr + j, 1, fac * dK[1][j]); }
+  }
+  if (pc_q >= 0) {
+    const M3 Sz = skew(z);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) put(pc_q + j, r, 2.0 * (DRt[r][0] * Sz.m[0][j] + DRt[r][1] * Sz.m[1][j] + DRt[r][2] * Sz.m[2][j]));
+  }
+  if (pc_t >= 0) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) put(pc_t + j, r, -DRt[r][j]);
+  }
+  if (pc_bq >= 0) {
+    const M3 Sx = skew(Rx);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) put(pc_bq + j, r, -2.0 * (DG[r][0] * Sx.m[0][j] + DG[r][1] * Sx.m[1][j] + DG[r][2] * Sx.m[2][j]));
+  }
+  if (pc_bt >= 0) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) put(pc_bt + j, r, DG[r][j]);
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(64) void eval_frames_kernel(EvalArgs a) {
+  extern __shared__ double lds[];
+  if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
+  const int lane = threadIdx.x;
+  const FrameItemDev it = a.fitems[blockIdx.x];
+  const LayoutDev& L = a.layouts[it.layout];
+  const SensorDev& S = a.sensors[L.sensor];
+  constexpr int K = 6;
+  // prim column map
+  const int Kin = S.K;
+  int pc = 6;
+  const int pc_intr = L.c_intr >= 0 ? pc : -1; if (L.c_intr >= 0) pc += Kin;
+  const int pc_q = L.c_q >= 0 ? pc : -1; if (L.c_q >= 0) pc += 3;
+  const int pc_t = L.c_t >= 0 ? pc : -1; if (L.c_t >= 0) pc += 3;
+  const int pc_bq = L.c_bq >= 0 ? pc : -1; if (L.c_bq >= 0) pc += 3;
+  const int pc_bt = L.c_bt >= 0 ? pc : -1; if (L.c_bt >= 0) pc += 3;
+  const int pc_r = pc;
+  const int P1 = pc + 1;               // prim columns incl. residual
+  const int P2 = (P1 + 1) & ~1;        // padded even
+  double* Jp = lds;                                  // [P2][kRowPad]
+  double* Ml = lds + P2 * kRowPad;                   // [P2][P2]
+  double* Q = Ml + P2 * P2;                          // [P2]  lat row: -pdotᵀ M(0..5, :)
+  // ---- per-frame quantities (every lane computes the same values) ----
+  const int ki = it.seg + K - 1;
+  const double* Mb = a.basis + size_t(it.seg) * K * K;
+  const double lat = a.x[S.lat_off];
+  double W[2][kMaxOrder];
+  spline_weights<2>(K, a.knots[ki], a.knots[ki + 1], Mb, it.stamp - lat, W);
+  double p[6] = {0, 0, 0, 0, 0, 0}, pd[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const double* cp = a.x + a.ctrl_off[it.seg + i];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { p[c] += W[0][i] * cp[c]; pd[c] += W[1][i] * cp[c]; }
+  }
+  const double* qp = a.x + S.q_off; const double* tp = a.x + S.t_off;
+  const double* bq = a.x + L.bq_off; const double* bt = a.x + L.bt_off;
+  Q4 q_rc; q_rc.x = qp[0]; q_rc.y = qp[1]; q_rc.z = qp[2]; q_rc.w = qp[3];
+  Q4 q_wm; q_wm.x = bq[0]; q_wm.y = bq[1]; q_wm.z = bq[2]; q_wm.w = bq[3];
+  const M3 R_rc = rotmat(normalized(q_rc)), R_wm = rotmat(normalized(q_wm));
+  const V3 t_rc = mk(tp[0], tp[1], tp[2]), t_wm = mk(bt[0], bt[1], bt[2]), t_wr = mk(p[3], p[4], p[5]);
+  const V3 phi = mk(-p[0], -p[1], -p[2]);
+  const M3 R_rw = rotmat(angle_axis_to_quat(phi));
+  const M3 Jl = rod_J_matrix(rodrigues<double>(phi.x, phi.y, phi.z, false));
+  M3 G;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) G.m[i][j] = R_rc.m[0][i] * R_rw.m[0][j] + R_rc.m[1][i] * R_rw.m[1][j] + R_rc.m[2][i] * R_rw.m[2][j];
+  const double* intr = a.x + S.intr_off;
+  // ---- stage A/B over batches of 64 blocks ----
+  const int nt = P2 >> 1;
+  const int ntiles = nt * (nt + 1) / 2;
+  int t_i[2], t_j[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    int tile = lane + 64 * u, ti = 0;
+    if (tile < ntiles) { int rem = tile; while (rem >= nt - ti) { rem -= nt - ti; ++ti; } t_i[u] = ti; t_j[u] = ti + rem; }
+    else { t_i[u] = -1; t_j[u] = 0; }
+  }
+  double acc[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};
+  double cost = 0.0, n_bad = 0.0;
+  for (int b0 = 0; b0 < it.obs_count; b0 += 64) {
+    const int nb = min(64, it.obs_count - b0);
+    __syncthreads();
+    for (int i = lane; i < P2 * kRowPad; i += 64) Jp[i] = 0.0;
+    __syncthreads();
+    if (lane < nb) {
+      const int o = it.obs_begin + b0 + lane;
+      double c1 = 0.0;
+      bool ok;
+      const double px = a.m0[o], py = a.m1[o];
+      const double* xm = a.x + a.point_off[o];
+      switch (S.model) {
+        case 1: ok = frame_camera_block<1>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
+        case 2: ok = frame_camera_block<2>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
+        case 3: ok = frame_camera_block<3>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
+        case 4: ok = frame_camera_block<4>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
+        case 5: ok = frame_camera_block<5>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
+        case 6: ok = frame_camera_block<6>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
+        default: ok = frame_camera_block<7>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
+      }
+      if (ok) cost += c1; else n_bad += 1.0;   // an invalid block leaves its (zeroed) rows untouched
+    }
+    __syncthreads();
+    const int nrows = 2 * nb;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (t_i[u] < 0) continue;
+      const double* ca = Jp + (2 * t_i[u]) * kRowPad;
+      const double* cb = Jp + (2 * t_j[u]) * kRowPad;
+      double a00 = acc[u][0][0], a01 = acc[u][0][1], a10 = acc[u][1][0], a11 = acc[u][1][1];
+      for (int r = 0; r < nrows; ++r) {
+        const double x0 = ca[r], x1 = ca[kRowPad + r], y0 = cb[r], y1 = cb[kRowPad + r];
+        a00 += x0 * y0; a01 += x0 * y1; a10 += x1 * y0; a11 += x1 * y1;
+      }
+      acc[u][0][0] = a00; acc[u][0][1] = a01; acc[u][1][0] = a10; acc[u][1][1] = a11;
+    }
+  }
+  const double item_cost = wave_sum(cost);
+  const double n_invalid = wave_sum(n_bad);
+  if (lane == 0) { a.item_cost[2 * blockIdx.x] = item_cost; a.item_cost[2 * blockIdx.x + 1] = n_invalid; }
+  // ---- M to LDS (full symmetric), lat row Q ----
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (t_i[u] < 0) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int gi = 2 * t_i[u] + i, gj = 2 * t_j[u] + j;
+        Ml[gi * P2 + gj] = acc[u][i][j];
+        Ml[gj * P2 + gi] = acc[u][i][j];
+      }
+  }
+  __syncthreads();
+  if (lane < P2) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s -= pd[c] * Ml[c * P2 + lane];
+    Q[lane] = s;
+  }
+  __syncthreads();
+  double qq = 0.0;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) qq -= pd[c] * Q[c];
+  // ---- expansion TᵀMT into the item's (c+1)×(c+1) block ----
+  const int ncols = L.ncols, n1 = ncols + 1;
+  double* out = a.partials + it.partial_off;
+  auto prim_of = [&](int lc) -> int {   // local calibration column -> prim column (lc >= 36, lc != c_lat)
+    if (lc == ncols) return pc_r;
+    if (L.c_intr >= 0 && lc >= L.c_intr && lc < L.c_intr + Kin) return pc_intr + (lc - L.c_intr);
+    if (L.c_q >= 0 && lc >= L.c_q && lc < L.c_q + 3) return pc_q + (lc - L.c_q);
+    if (L.c_t >= 0 && lc >= L.c_t && lc < L.c_t + 3) return pc_t + (lc - L.c_t);
+    if (L.c_bq >= 0 && lc >= L.c_bq && lc < L.c_bq + 3) return pc_bq + (lc - L.c_bq);
+    return pc_bt + (lc - L.c_bt);
+  };
+  for (int i = 0; i < n1; ++i) {
+    // row descriptor (wave-uniform)
+    const bool i_spl = i < 36, i_lat = (i == L.c_lat);
+    const int ia = i_spl ? i % 6 : 0;
+    const double iw = i_spl ? W[0][i / 6] : 1.0;
+    const int ip = (!i_spl && !i_lat) ? prim_of(i) : 0;
+    for (int j = i + lane; j < n1; j += 64) {
+      const bool j_spl = j < 36, j_lat = (j == L.c_lat);
+      double v;
+      if (j_spl) {               // i is a spline column too (i <= j < 36)
+        v = iw * W[0][j / 6] * Ml[ia * P2 + (j % 6)];
+      } else if (j_lat) {
+        v = i_spl ? iw * Q[ia] : (i_lat ? qq : Q[ip]);
+      } else {
+        const int jp = prim_of(j);
+        v = i_spl ? iw * Ml[ia * P2 + jp] : (i_lat ? Q[jp] : Ml[ip * P2 + jp]);
+      }
+      out[size_t(i) * n1 + j] = v;
+    }
+  }
+}
+
+size_t frame_lds_bytes() { return (size_t(kMaxPrim) * kRowPad + size_t(kMaxPrim) * kMaxPrim + kMaxPrim) * sizeof(double); }
+void launch_eval_frames(const EvalArgs& a, hipStream_t stream) {
+  if (a.n_fitems == 0) return;
+  hipLaunchKernelGGL(eval_frames_kernel, dim3(a.n_fitems), dim3(64), frame_lds_bytes(), stream, a);
+}
+
 void launch_eval(const EvalArgs& a, bool jac, hipStream_t stream) {
   if (a.n_items == 0) return;
   if (jac) {
@@ -611,6 +863,9 @@ void launch_eval(const EvalArgs& a, bool jac, hipStream_t stream) {
 }
 
 hipError_t configure_eval_kernels(size_t max_lds_bytes) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_frames_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(frame_lds_bytes()));
+  if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_items_kernel<true>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, int(max_lds_bytes));
 }

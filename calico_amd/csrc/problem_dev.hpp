@@ -42,6 +42,14 @@ struct ItemDev {
   int64_t partial_off;  // offset (doubles) of this item's partial block
 };
 
+// A camera frame: residual blocks of one cell that also share the time stamp, hence the pose,
+// its time derivative and the spline weights. Their Jacobian rows factor as J = J_prim · T_frame.
+struct FrameItemDev {
+  int layout, seg, obs_begin, obs_count;
+  double stamp;
+  int64_t partial_off;
+};
+
 struct EvalArgs {
   const double* x;
   const SensorDev* sensors;
@@ -58,7 +66,9 @@ struct EvalArgs {
   uint8_t* valid_out;
   int order, n_items, lds_cols, apply_loss;
   const struct LmState* st;  // optional: skip when terminated (and, with need_flag, when no Jacobian is due)
-  int need_flag, pad1;
+  int need_flag, cost_index_base;
+  const FrameItemDev* fitems;
+  int n_fitems, pad2;
 };
 
 // LM state kept on the device; the control kernel is its only writer.
@@ -114,6 +124,7 @@ struct SolveArgs {
   const uint8_t* cp_active;  // [n_cp]
   LmState* st;
   int n_cp, k, m;
+  int debug;              // CALICO_KERNEL_TIMING=1: kernels print per-phase cycle counts (development aid)
   CAL_HD int n_s() const { return 6 * n_cp; }
   CAL_HD int W() const { return 6 * k; }
   CAL_HD int NT() const { return 6 * n_cp + m; }

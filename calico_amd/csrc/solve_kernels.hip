@@ -201,6 +201,12 @@ __global__ void prepare_kernel(SolveArgs a, LmOptionsDev o) {
 // Per step: (1) every thread factors the 6×6 pivot block redundantly,
 // (2) panel rows x = a·L11⁻ᵀ, (3) rank-6 trailing update. Two barriers per step.
 // ---------------------------------------------------------------------------
+DEVI double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 // 1/sqrt(d) to double precision: hardware estimate + two Newton steps (no division, no sqrt call).
 DEVI double rsqrt_nr(double d) {
   double r = __builtin_amdgcn_rsq(d);
@@ -251,17 +257,9 @@ __global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs)
   const int nband = W * 6, nelem = nband + nb * 6;
   constexpr int NE = 2;           // elements per thread: (48*6 + 16*6) / 256
   auto slot = [&](int J) { return lds + (J % NSL) * SL; };
-  // pair table (r1 <= r2 over rows 6..W-1) after the ring
-  unsigned short* tab = reinterpret_cast<unsigned short*>(lds + NSL * SL);
-  const int nrr = W - 6;
-  const int npairs = nrr * (nrr + 1) / 2;
-  for (int e = tid; e < npairs; e += 256) {
-    int r1 = 0, rem = e;
-    while (rem >= nrr - r1) { rem -= nrr - r1; ++r1; }
-    tab[e] = (unsigned short)(((6 + r1) << 8) | (6 + r1 + rem));
-  }
-  // per-thread element descriptors (fixed over the sweep)
-  int g_off[NE], l_off[NE];   // global offset within a block column (Lb: e ; Y: c*m1 + j0 + j, flagged), LDS offset
+  for (int i = tid; i < NSL * SL; i += 256) lds[i] = 0.0;   // padding rows must stay zero
+  // per-thread element descriptors of the streaming loads (fixed over the sweep)
+  int g_off[NE], l_off[NE];
   bool is_y[NE], has[NE];
 #pragma unroll
   for (int u = 0; u < NE; ++u) {
@@ -285,31 +283,77 @@ __global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs)
 #pragma unroll
     for (int u = 0; u < NE; ++u) if (has[u]) s[l_off[u]] = regs[u];
   };
+  // trailing-update tiles, 2×2 outputs each, fixed per thread: rows of the window are the band rows
+  // 6..W-1 followed by the bs border rows; tile (pa, pb) pairs row-pair pa (band) with row-pair pb >= pa.
+  const int nrr = W - 6, nrp = nrr / 2, nbp = bs / 2;
+  const int n_bb = nrp * (nrp + 1) / 2, n_tiles = n_bb + nrp * nbp;
+  constexpr int NTL = 2;          // tiles per thread (k = 8: 399 tiles)
+  int t_ra[NTL], t_rb[NTL];       // first row of each pair; t_rb >= W means border row (t_rb - W)
+#pragma unroll
+  for (int u = 0; u < NTL; ++u) {
+    const int t = tid + 256 * u;
+    t_ra[u] = -1; t_rb[u] = 0;
+    if (t < n_bb) {
+      int pa = 0, rem = t;
+      while (rem >= nrp - pa) { rem -= nrp - pa; ++pa; }
+      t_ra[u] = 6 + 2 * pa; t_rb[u] = 6 + 2 * (pa + rem);
+    } else if (t < n_tiles) {
+      const int q = t - n_bb;
+      t_ra[u] = 6 + 2 * (q / nbp); t_rb[u] = W + 2 * (q % nbp);
+    }
+  }
+  __syncthreads();
   double regs[NE], regs2[NE];
   for (int J = 0; J < k && J < ncp; ++J) { gload(J, regs); sstore(J, regs); }
   gload(k, regs);       // blocks k and k+1 ride in registers
   gload(k + 1, regs2);
   bool fail = false;
-  // thread roles in the panel phase
-  const int prow = 6 + tid;                 // band row (tid < W-6)
-  const int bj = tid - 64;                  // border row (64 <= tid < 64+nb)
+  long long tk0 = 0, tc[5] = {0, 0, 0, 0, 0};
+  const bool dbg = a.debug && blockIdx.x == 0 && tid == 0;
+#define TICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tc[i] += t_ - tk0; tk0 = t_; }
+  const int prow = 6 + tid;                 // band row of the panel (tid < W-6)
+  const int bj = tid - 64;                  // border row of the panel (64 <= tid < 64+nb)
+  const bool panel_thread = tid < 192;      // waves 0..2 factor the pivot block; wave 3 goes straight to the barrier
   __syncthreads();
   for (int J = 0; J < ncp; ++J) {
     double* sj = slot(J);
+    if (dbg) tk0 = __builtin_readcyclecounter();
     if (J + k < ncp) sstore(J + k, regs);
 #pragma unroll
     for (int u = 0; u < NE; ++u) regs[u] = regs2[u];
     gload(J + k + 2, regs2);
-    // (1) pivot block, redundantly in every thread
-    double L[6][6], Li[6][6];
-    chol6_and_inverse(sj, L, Li, &fail);
-    // (2) panel
+    TICK(0)
     const int nrows = min(W, 6 * (ncp - J));
-    if (tid < W - 6) {
-      if (prow < nrows) {
+    if (panel_thread) {
+      // (1) pivot block, redundantly in every panel thread
+      double L[6][6], Li[6][6];
+      chol6_and_inverse(sj, L, Li, &fail);
+      TICK(1)
+      // (2) panel
+      if (tid < W - 6) {
+        if (prow < nrows) {
+          double av[6], xv[6];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) av[c] = sj[prow * 6 + c];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            double v = 0.0;
+#pragma unroll
+            for (int q = 0; q <= c; ++q) v += av[q] * Li[c][q];
+            xv[c] = v;
+          }
+#pragma unroll
+          for (int c = 0; c < 6; ++c) sj[prow * 6 + c] = xv[c];
+          if (blockIdx.x == 0) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) a.Lb[size_t(J) * nband + prow * 6 + c] = xv[c];
+          }
+        }
+      } else if (bj >= 0 && bj < nb) {
+        double* br = sj + nband + bj * 6;
         double av[6], xv[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) av[c] = sj[prow * 6 + c];
+        for (int c = 0; c < 6; ++c) av[c] = br[c];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           double v = 0.0;
@@ -318,61 +362,61 @@ __global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs)
           xv[c] = v;
         }
 #pragma unroll
-        for (int c = 0; c < 6; ++c) sj[prow * 6 + c] = xv[c];
-        if (blockIdx.x == 0) {
+        for (int c = 0; c < 6; ++c) { br[c] = xv[c]; a.Y[size_t(6 * J + c) * m1 + j0 + bj] = xv[c]; }
+      } else if (blockIdx.x == 0 && tid >= 128 && tid < 128 + 36) {
+        const int r = (tid - 128) / 6, c = (tid - 128) % 6;
+        double lv = 0.0, iv = 0.0;
 #pragma unroll
-          for (int c = 0; c < 6; ++c) a.Lb[size_t(J) * nband + prow * 6 + c] = xv[c];
-        }
+        for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+          for (int cc = 0; cc <= rr; ++cc) if (rr == r && cc == c) { lv = L[rr][cc]; iv = Li[rr][cc]; }
+        a.Lb[size_t(J) * nband + r * 6 + c] = lv;
+        a.Linv[size_t(J) * 36 + r * 6 + c] = iv;
       }
-    } else if (bj >= 0 && bj < nb) {
-      double* br = sj + nband + bj * 6;
-      double av[6], xv[6];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) av[c] = br[c];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        double v = 0.0;
-#pragma unroll
-        for (int q = 0; q <= c; ++q) v += av[q] * Li[c][q];
-        xv[c] = v;
-      }
-#pragma unroll
-      for (int c = 0; c < 6; ++c) { br[c] = xv[c]; a.Y[size_t(6 * J + c) * m1 + j0 + bj] = xv[c]; }
-    } else if (blockIdx.x == 0 && tid >= 128 && tid < 128 + 36) {
-      const int r = (tid - 128) / 6, c = (tid - 128) % 6;
-      // pick L[r][c] / Li[r][c] without dynamic register indexing
-      double lv = 0.0, iv = 0.0;
-#pragma unroll
-      for (int rr = 0; rr < 6; ++rr)
-#pragma unroll
-        for (int cc = 0; cc <= rr; ++cc) if (rr == r && cc == c) { lv = L[rr][cc]; iv = Li[rr][cc]; }
-      a.Lb[size_t(J) * nband + r * 6 + c] = lv;
-      a.Linv[size_t(J) * 36 + r * 6 + c] = iv;
     }
+    TICK(2)
     __syncthreads();
-    // (3) trailing update of the window
-    for (int e = tid; e < npairs; e += 256) {
-      const int r1 = tab[e] >> 8, r2 = tab[e] & 255;
-      if (r2 < nrows) {
-        double d = 0.0;
+    TICK(3)
+    // (3) trailing update of the window: X Xᵀ in 2×2 tiles, row vectors read as 3 × 16-byte LDS loads
 #pragma unroll
-        for (int c = 0; c < 6; ++c) d += sj[r2 * 6 + c] * sj[r1 * 6 + c];
-        const int b1 = r1 / 6;
-        slot(J + b1)[(r2 - 6 * b1) * 6 + (r1 - 6 * b1)] -= d;
+    for (int u = 0; u < NTL; ++u) {
+      const int ra = t_ra[u];
+      if (ra < 0) continue;
+      const bool border = t_rb[u] >= W;
+      const int rb = border ? t_rb[u] - W : t_rb[u];
+      if (ra + 1 >= nrows + 0 && ra >= nrows) continue;
+      if (!border && rb >= nrows) continue;
+      const double2* pa0 = reinterpret_cast<const double2*>(sj + ra * 6);
+      const double2* pa1 = reinterpret_cast<const double2*>(sj + (ra + 1) * 6);
+      const double* rbp = border ? sj + nband + rb * 6 : sj + rb * 6;
+      const double2* pb0 = reinterpret_cast<const double2*>(rbp);
+      const double2* pb1 = reinterpret_cast<const double2*>(rbp + 6);
+      double d00 = 0.0, d01 = 0.0, d10 = 0.0, d11 = 0.0;   // d[a][b] = x[ra+a] · x[rb+b]
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const double2 a0 = pa0[q], a1 = pa1[q], b0 = pb0[q], b1 = pb1[q];
+        d00 += a0.x * b0.x + a0.y * b0.y; d01 += a0.x * b1.x + a0.y * b1.y;
+        d10 += a1.x * b0.x + a1.y * b0.y; d11 += a1.x * b1.x + a1.y * b1.y;
       }
-    }
-    for (int e = tid; e < nrr * nb; e += 256) {
-      const int r1 = 6 + e / nb, j = e % nb;
-      if (r1 < nrows) {
-        double d = 0.0;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) d += sj[nband + j * 6 + c] * sj[r1 * 6 + c];
-        const int b1 = r1 / 6;
-        slot(J + b1)[nband + j * 6 + (r1 - 6 * b1)] -= d;
+      const int b1i = ra / 6, ca = ra - 6 * b1i;            // target block column and local column of row ra (ra+1 shares it)
+      double* tgt = slot(J + b1i);
+      if (border) {
+        double* t0 = tgt + nband + rb * 6 + ca;              // entry (border rb, col ra), (rb, ra+1), (rb+1, ra), (rb+1, ra+1)
+        t0[0] -= d00; t0[1] -= d10; t0[6] -= d01; t0[7] -= d11;
+      } else {
+        const int lr = rb - 6 * b1i;                          // local row of rb inside block column b1i
+        double* t0 = tgt + lr * 6 + ca;                       // entry (row rb, col ra)
+        t0[0] -= d00;                                         // (rb, ra)
+        t0[6] -= d01;                                         // (rb+1, ra)
+        t0[7] -= d11;                                         // (rb+1, ra+1)
+        if (rb > ra) t0[1] -= d10;                            // (rb, ra+1): above the diagonal when rb == ra
       }
     }
     __syncthreads();
+    TICK(4)
   }
+  if (dbg) printf("band_cholesky cycles/step: prefetch %lld  chol6+inv %lld  panel %lld  barrier %lld  update+barrier %lld\n",
+                  tc[0] / ncp, tc[1] / ncp, tc[2] / ncp, tc[3] / ncp, tc[4] / ncp);
   if (fail && tid == 0) st->chol_failed = 1;
 }
 
@@ -469,11 +513,12 @@ __global__ __launch_bounds__(256) void reduced_solve_kernel(SolveArgs a, int use
 // Register-resident variant: thread (ti, tj) of a 16×16 grid owns the entries
 // (ti + 16a, tj + 16b) of the reduced matrix for the whole factorisation; per
 // column only the pivot column is broadcast through a double-buffered LDS
-// vector, so a step costs one barrier, 2·NT LDS reads and NT² register FMAs.
-// The factor is streamed column-major to Lst (LDS or global) for the backward
-// substitution. Valid for m+1 <= 16·NT.
-template <int NT>
-__global__ __launch_bounds__(256) void reduced_solve_reg_kernel(SolveArgs a, int l_in_lds) {
+// vector, so a step costs one barrier, 2·NT LDS reads and ~NT²/2 register FMAs.
+// The factor is kept row-major in Lrow (LDS or global); the backward substitution runs on one
+// wave in axpy form: y_i = (b_i - acc_i)/L_ii, then acc_j += L_ij y_i for j < i, the pivot value
+// travelling by v_readlane — no reduction on the dependency chain. Valid for m+1 <= 16·NT.
+template <int NT, bool L_IN_LDS>
+__global__ __launch_bounds__(256) void reduced_solve_reg_kernel(SolveArgs a) {
   LmState* st = a.st;
   if (st->terminated) return;
   extern __shared__ double lds[];
@@ -482,8 +527,11 @@ __global__ __launch_bounds__(256) void reduced_solve_reg_kernel(SolveArgs a, int
   const int ti = tid >> 4, tj = tid & 15;
   constexpr int NP = 16 * NT;
   double* colbuf = lds;                 // [2][NP]
-  double* yv = lds + 2 * NP;            // [NP]
-  double* Lst = l_in_lds ? lds + 4 * NP : a.Swork;   // column-major factor: Lst[j*NP + i]
+  double* dinv = lds + 2 * NP;          // [NP] reciprocal diagonal of the factor
+  // row-major factor Lrow[i*NP + j], rows 0..m; the address space is a template parameter so that the
+  // LDS variant compiles to ds_* instructions instead of flat ones
+  double* Lrow;
+  if constexpr (L_IN_LDS) Lrow = lds + 3 * NP; else Lrow = a.Swork;
   __shared__ int s_fail;
   if (tid == 0) s_fail = 0;
   double A[NT][NT];
@@ -494,8 +542,11 @@ __global__ __launch_bounds__(256) void reduced_solve_reg_kernel(SolveArgs a, int
       const int i = ti + 16 * aa, c = tj + 16 * bb;
       A[aa][bb] = (i <= m && c <= i && c < m1) ? a.Spart[size_t(i) * m1 + c] : 0.0;
     }
-  double* dinv = yv + NP;               // [NP] reciprocal diagonal of the factor
   const double dflag = (ti >= tj) ? 1.0 : 0.0;   // diagonal tiles: only c <= i
+  const bool dbg = a.debug && tid == 0;
+  const long long t_begin = dbg ? __builtin_readcyclecounter() : 0;
+  long long tph[4] = {0, 0, 0, 0}, tk = t_begin;
+#define RTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   for (int j = 0; j < m; ++j) {
     double* cb = colbuf + (j & 1) * NP;
     const int bj = j >> 4;   // wave-uniform
@@ -507,7 +558,9 @@ __global__ __launch_bounds__(256) void reduced_solve_reg_kernel(SolveArgs a, int
           for (int aa = 0; aa < NT; ++aa) cb[ti + 16 * aa] = A[aa][bb];
         }
     }
+    RTICK(0)
     __syncthreads();
+    RTICK(1)
     double p = cb[j];
     if (!(p > 0.0) || !isfinite(p)) { if (tid == 0) s_fail = 1; p = 1.0; }
     const double rs = rsqrt_nr(p);
@@ -522,48 +575,53 @@ __global__ __launch_bounds__(256) void reduced_solve_reg_kernel(SolveArgs a, int
       for (int bb = 0; bb < aa; ++bb) A[aa][bb] -= ri[aa] * cj[bb];
       A[aa][aa] -= ri[aa] * cj[aa] * dflag;
     }
-    if (tj == (j & 15)) {   // stream the finished column out
+    RTICK(2)
+    if (tj == (j & 15)) {   // stream the finished column out (row-major store)
 #pragma unroll
       for (int aa = 0; aa < NT; ++aa) {
         const int i = ti + 16 * aa;
-        if (i >= j && i <= m) Lst[size_t(j) * NP + i] = ri[aa];
+        if (i >= j && i <= m) Lrow[size_t(i) * NP + j] = ri[aa];
       }
       if (ti == 0) dinv[j] = rs;
     }
+    RTICK(3)
   }
   __syncthreads();
-  if (!l_in_lds) __threadfence();
+  if constexpr (!L_IN_LDS) __threadfence();
   __syncthreads();
-  // backward substitution Lᵀ y_c = L⁻¹b (row m of the factor): one wave, dot-product form, next column prefetched
+  const long long t_fact = dbg ? __builtin_readcyclecounter() : 0;
   if (wave == 0) {
     constexpr int NV = (NP + 63) / 64;
-    double cur[NV], nxt[NV];
-    auto fetch = [&](int j, double v[NV]) {
+    double acc[NV], bq[NV], dv[NV], cur[NV], nxt[NV];
 #pragma unroll
-      for (int u = 0; u < NV; ++u) { const int i = lane + 64 * u; v[u] = (j >= 0 && i > j && i <= m) ? Lst[size_t(j) * NP + i] : 0.0; }
+    for (int u = 0; u < NV; ++u) {
+      const int j = lane + 64 * u;
+      acc[u] = 0.0;
+      bq[u] = j < m ? Lrow[size_t(m) * NP + j] : 0.0;
+      dv[u] = j < m ? dinv[j] : 0.0;
+    }
+    auto fetch = [&](int i, double v[NV]) {
+#pragma unroll
+      for (int u = 0; u < NV; ++u) { const int j = lane + 64 * u; v[u] = (i >= 0 && j < i) ? Lrow[size_t(i) * NP + j] : 0.0; }
     };
     fetch(m - 1, nxt);
-    for (int j = m - 1; j >= 0; --j) {
+    for (int i = m - 1; i >= 0; --i) {
 #pragma unroll
       for (int u = 0; u < NV; ++u) cur[u] = nxt[u];
-      fetch(j - 1, nxt);
-      double part = 0.0;   // lane holding i == m contributes -rhs so one reduction suffices
+      fetch(i - 1, nxt);
+      double cand = 0.0;
 #pragma unroll
-      for (int u = 0; u < NV; ++u) {
-        const int i = lane + 64 * u;
-        if (i > j && i < m) part += cur[u] * yv[i];
-        else if (i == m) part -= cur[u];
-      }
+      for (int u = 0; u < NV; ++u) if ((i >> 6) == u) cand = (bq[u] - acc[u]) * dv[u];
+      const double yi = readlane_f64(cand, i & 63);
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-      if (lane == 0) yv[j] = -part * dinv[j];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      for (int u = 0; u < NV; ++u) acc[u] += cur[u] * yi;
+      if (lane == 0) a.y[n + i] = yi;
     }
   }
   __syncthreads();
-  for (int i = tid; i < m; i += 256) a.y[n + i] = yv[i];
+  if (dbg) printf("reduced_solve cycles/col: bcast-write %lld  barrier %lld  update %lld  store %lld | backward total %lld\n",
+                  tph[0] / (m > 0 ? m : 1), tph[1] / (m > 0 ? m : 1), tph[2] / (m > 0 ? m : 1), tph[3] / (m > 0 ? m : 1),
+                  (long long)__builtin_readcyclecounter() - t_fact);
   if (tid == 0 && s_fail) st->chol_failed = 1;
 }
 
@@ -584,57 +642,75 @@ __global__ __launch_bounds__(256) void border_matvec_kernel(SolveArgs a) {
   if (lane == 0) a.y[c] = row[m] - part;
 }
 
-// Blocked backward band sweep Lᵀ y_s = z, one wave:
-//   y_J = L11⁻ᵀ (z_J - Σ_{r>=6} L(6J+r, 6J+c) y[6J+r]).
-// Lane c (0..5) owns output c: it keeps column c of the block column (prefetched one block
-// ahead) in registers and walks the 6(k-1) later unknowns in LDS with two accumulators; the
-// six partial results are exchanged with v_readlane, so no LDS round trip sits on the chain.
+// Blocked backward band sweep Lᵀ y_s = z by ONE wave, in axpy form (no reductions on the chain):
+//   step J:  s = z_J - P_J ;  y_J = L11⁻ᵀ s ;  for the k-1 earlier blocks B: P_B += L(J, B)ᵀ y_J.
+// Lane (g, c) = (lane / 6, lane % 6), g < k-1, keeps in a register the pending sum P_B[c] of the one
+// block B ≡ g (mod k-1) inside the window [J-(k-1), J-1]; when block J's turn comes its lanes form
+// s, the six values travel by v_readlane (wave-uniform lane index), every lane gets y_J as scalars,
+// and the update is six register FMAs. Band columns are prefetched four steps ahead.
 template <int K>
 __global__ __launch_bounds__(64) void band_backsolve_kernel(SolveArgs a) {
   const LmState* st = a.st;
   if (st->terminated) return;
-  extern __shared__ double z[];  // n + W doubles
-  constexpr int W = 6 * K, NR = W - 6;
-  const int n = a.n_s(), ncp = a.n_cp;
+  constexpr int W = 6 * K, G = K - 1, nband = W * 6, PF = 4;
+  const int ncp = a.n_cp;
   const int lane = threadIdx.x;
-  for (int c = lane; c < n + W; c += 64) z[c] = (c < n) ? a.y[c] : 0.0;
-  __syncthreads();
-  constexpr int nband = W * 6;
-  const int oc = lane < 6 ? lane : 0;
-  double lcur[NR], lnxt[NR], icur[6], inxt[6];
-  auto fetch = [&](int J, double lv[NR], double iv[6]) {
+  const int g = lane / 6, c = lane % 6;
+  const bool worker = g < G;
+  const double* z = a.y;   // border_matvec_kernel left z in y[0, n)
+  // block handled by this lane at step J: B = J - d, d in [1, G], B ≡ g (mod G)
+  auto dist = [&](int J) { int d = (J - g) % G; if (d < 0) d += G; return d == 0 ? G : d; };
+  double lring[PF][6];
+  double iv[PF][6];  // lane c' < 6: Linv[J][q][c'], q = 0..5 (column c' of the inverse = row of its transpose)
+  auto fetch = [&](int J, double lv[6], double ivv[6]) {
+    const int d = dist(J), B = J - d;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) lv[r] = (J >= 0) ? a.Lb[size_t(J) * nband + (6 + r) * 6 + oc] : 0.0;
+    for (int rr = 0; rr < 6; ++rr) lv[rr] = (worker && J >= 0 && B >= 0) ? a.Lb[size_t(B) * nband + (6 * d + rr) * 6 + c] : 0.0;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) iv[q] = (J >= 0) ? a.Linv[size_t(J) * 36 + q * 6 + oc] : 0.0;   // Linv[q][c]
+    for (int q = 0; q < 6; ++q) ivv[q] = (J >= 0 && lane < 6) ? a.Linv[size_t(J) * 36 + q * 6 + lane] : 0.0;
   };
-  fetch(ncp - 1, lnxt, inxt);
-  for (int J = ncp - 1; J >= 0; --J) {
+  double P = 0.0;
+  // z of the first block this lane will consume: the largest J' <= ncp-1 with J' ≡ g (mod G)
+  int jz = ncp - 1 - (((ncp - 1 - g) % G + G) % G);
+  double zc = (worker && jz >= 0) ? z[6 * jz + c] : 0.0;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) lcur[r] = lnxt[r];
+  for (int u = 0; u < PF; ++u) fetch(ncp - 1 - u, lring[u], iv[u]);
+  for (int J0 = ncp - 1; J0 >= 0; J0 -= PF) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) icur[q] = inxt[q];
-    fetch(J - 1, lnxt, inxt);
-    const double* yb = z + 6 * J + 6;
-    double s0 = 0.0, s1 = 0.0;
+    for (int u = 0; u < PF; ++u) {
+      const int J = J0 - u;
+      if (J < 0) break;
+      double lcur[6];
 #pragma unroll
-    for (int r = 0; r < NR; r += 2) { s0 += lcur[r] * yb[r]; s1 += lcur[r + 1] * yb[r + 1]; }
-    const double sc = z[6 * J + oc] - (s0 + s1);
-    // y_c = Σ_q Linv[q][c] · s_q
-    double acc = 0.0;
+      for (int rr = 0; rr < 6; ++rr) lcur[rr] = lring[u][rr];
+      double icur[6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const int lo = __builtin_amdgcn_readlane(__double2loint(sc), q);
-      const int hi = __builtin_amdgcn_readlane(__double2hiint(sc), q);
-      acc += icur[q] * __hiloint2double(hi, lo);
+      for (int q = 0; q < 6; ++q) icur[q] = iv[u][q];
+      fetch(J - PF, lring[u], iv[u]);
+      const int gj = J % G;
+      // s_c on lanes (gj, c)
+      const double sc = zc - P;
+      double s[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) s[q] = readlane_f64(sc, 6 * gj + q);
+      if (g == gj) {   // consumed: start the pending sum of block J - G
+        P = 0.0;
+        const int jn = J - G;
+        zc = (worker && jn >= 0) ? z[6 * jn + c] : 0.0;
+      }
+      // y_J[c'] = Σ_q Linv[q][c'] s_q on lane c' < 6, then broadcast
+      double yl = 0.0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) yl += icur[q] * s[q];
+      if (lane < 6) a.y[6 * J + lane] = yl;
+      double y[6];
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) y[cc] = readlane_f64(yl, cc);
+      // pending sums of the earlier blocks
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) P += lcur[rr] * y[rr];
     }
-    if (lane < 6) z[6 * J + lane] = acc;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
-  __syncthreads();
-  for (int c = lane; c < n; c += 64) a.y[c] = z[c];
 }
 
 // delta = -y ; candidate = Plus(x, delta) ; model cost change ; step norms.
@@ -803,15 +879,13 @@ void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* block
 }
 constexpr int kBorderSlice = 16;   // border columns per workgroup of the banded factorisation
 size_t band_cholesky_lds_bytes(const SolveArgs& a) {
-  const int W = a.W();
-  const int nrr = W - 6;
-  return size_t(a.k + 2) * (W * 6 + kBorderSlice * 6) * sizeof(double) + size_t(nrr * (nrr + 1) / 2) * sizeof(unsigned short) + 16;
+  return size_t(a.k + 2) * (a.W() * 6 + kBorderSlice * 6) * sizeof(double);
 }
 size_t reduced_solve_lds_bytes(const SolveArgs& a) {
   const int m1 = a.m + 1;
   return (size_t(m1) * (m1 | 1) + m1) * sizeof(double);
 }
-size_t band_backsolve_lds_bytes(const SolveArgs& a) { return size_t(a.n_s() + a.W()) * sizeof(double); }
+size_t band_backsolve_lds_bytes(const SolveArgs&) { return 0; }
 hipError_t configure_solve_kernels(size_t band_lds, size_t reduced_lds, size_t back_lds) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&band_cholesky_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(band_lds));
@@ -822,10 +896,9 @@ hipError_t configure_solve_kernels(size_t band_lds, size_t reduced_lds, size_t b
     if (e != hipSuccess) return e;
   }
   const int big = 150 * 1024;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&reduced_solve_reg_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&reduced_solve_reg_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&reduced_solve_reg_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&reduced_solve_reg_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  for (const void* f : {reinterpret_cast<const void*>(&reduced_solve_reg_kernel<4, true>), reinterpret_cast<const void*>(&reduced_solve_reg_kernel<7, true>),
+                        reinterpret_cast<const void*>(&reduced_solve_reg_kernel<10, true>), reinterpret_cast<const void*>(&reduced_solve_reg_kernel<13, true>)})
+    (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   for (const void* f : {reinterpret_cast<const void*>(&band_backsolve_kernel<2>), reinterpret_cast<const void*>(&band_backsolve_kernel<3>),
                         reinterpret_cast<const void*>(&band_backsolve_kernel<4>), reinterpret_cast<const void*>(&band_backsolve_kernel<5>),
                         reinterpret_cast<const void*>(&band_backsolve_kernel<6>), reinterpret_cast<const void*>(&band_backsolve_kernel<7>),
@@ -848,15 +921,19 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
   if (m1 <= 16 * 13) {
     const int NT = m1 <= 64 ? 4 : (m1 <= 112 ? 7 : (m1 <= 160 ? 10 : 13));
     const int NP = 16 * NT;
-    const size_t full = size_t(4 * NP + size_t(a.m) * NP) * sizeof(double);
+    const size_t full = size_t(3 * NP + size_t(a.m + 1) * NP) * sizeof(double);
     const bool l_in_lds = full <= 150 * 1024;
-    const size_t lds = l_in_lds ? full : size_t(4 * NP) * sizeof(double);
+    const size_t lds = l_in_lds ? full : size_t(3 * NP) * sizeof(double);
+#define LAUNCH_RS(N) \
+    if (l_in_lds) hipLaunchKernelGGL((reduced_solve_reg_kernel<N, true>), dim3(1), dim3(256), lds, s, a); \
+    else hipLaunchKernelGGL((reduced_solve_reg_kernel<N, false>), dim3(1), dim3(256), lds, s, a)
     switch (NT) {
-      case 4: hipLaunchKernelGGL(reduced_solve_reg_kernel<4>, dim3(1), dim3(256), lds, s, a, l_in_lds ? 1 : 0); break;
-      case 7: hipLaunchKernelGGL(reduced_solve_reg_kernel<7>, dim3(1), dim3(256), lds, s, a, l_in_lds ? 1 : 0); break;
-      case 10: hipLaunchKernelGGL(reduced_solve_reg_kernel<10>, dim3(1), dim3(256), lds, s, a, l_in_lds ? 1 : 0); break;
-      default: hipLaunchKernelGGL(reduced_solve_reg_kernel<13>, dim3(1), dim3(256), lds, s, a, l_in_lds ? 1 : 0); break;
+      case 4: LAUNCH_RS(4); break;
+      case 7: LAUNCH_RS(7); break;
+      case 10: LAUNCH_RS(10); break;
+      default: LAUNCH_RS(13); break;
     }
+#undef LAUNCH_RS
   } else {
     hipLaunchKernelGGL(reduced_solve_kernel, dim3(1), dim3(256), reduced_in_lds ? reduced_solve_lds_bytes(a) : 0, s, a,
                        reduced_in_lds ? 1 : 0);
