@@ -161,7 +161,7 @@ struct calico_problem {
   int n_thin = 0, n_fat = 0;
   bool dense_in_lds = true;
 
-  DevBuf<double> d_x, d_xc, d_knots, d_basis, d_m0, d_m1, d_m2, d_stamp, d_partials, d_R, d_R2, d_Lb, d_Linv, d_Y, d_S, d_Spart, d_Swork, d_y,
+  DevBuf<double> d_x, d_xc, d_knots, d_basis, d_m0, d_m1, d_m2, d_stamp, d_partials, d_R, d_R2, d_Lb, d_Linv, d_Y, d_S, d_Spart, d_Swork, d_zbuf, d_y,
       d_dadd, d_scale, d_res;
   DevBuf<int> d_ctrl_off, d_point_off, d_out_thin, d_idx_thin, d_out_fat, d_idx_fat;
   DevBuf<int64_t> d_ptr_thin, d_ptr_fat;
@@ -207,7 +207,7 @@ int imu_num_params(int model) { return model == 1 ? 1 : (model == 2 ? 4 : (model
 SolveArgs make_solve_args(calico_problem* p) {
   SolveArgs a;
   a.R = p->d_R.p; a.Lb = p->d_Lb.p; a.Linv = p->d_Linv.p; a.Y = p->d_Y.p; a.S = p->d_S.p; a.Spart = p->d_Spart.p;
-  a.Swork = p->d_Swork.p; a.y = p->d_y.p; a.dadd = p->d_dadd.p;
+  a.Swork = p->d_Swork.p; a.y = p->d_y.p; a.zbuf = p->d_zbuf.p; a.dadd = p->d_dadd.p;
   a.scale = p->d_scale.p; a.cp_active = p->d_cp_active.p; a.st = p->d_state.p; a.n_cp = p->n_cp; a.k = p->order; a.m = p->m;
   static const int dbg = std::getenv("CALICO_KERNEL_TIMING") ? std::atoi(std::getenv("CALICO_KERNEL_TIMING")) : 0;
   a.debug = dbg;
@@ -512,7 +512,7 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_Lb.alloc(size_t(NS) * 6 * k)); HIP_TRY(p, p->d_Linv.alloc(size_t(n_cp) * 36));
   HIP_TRY(p, p->d_Y.alloc(size_t(NS) * (m + 1)));
   HIP_TRY(p, p->d_S.alloc(size_t(m + 1) * (m + 1)));
-  HIP_TRY(p, p->d_y.alloc(NT)); HIP_TRY(p, p->d_dadd.alloc(NT)); HIP_TRY(p, p->d_scale.alloc(NT));
+  HIP_TRY(p, p->d_y.alloc(NT)); HIP_TRY(p, p->d_zbuf.alloc(size_t(NS) + 64)); HIP_TRY(p, p->d_dadd.alloc(NT)); HIP_TRY(p, p->d_scale.alloc(NT));
   HIP_TRY(p, p->d_res.alloc(size_t(n_obs) * 3)); HIP_TRY(p, p->d_valid.alloc(size_t(n_obs)));
   HIP_TRY(p, p->d_state.alloc(1)); HIP_TRY(p, p->d_log.alloc(kLogCap));
   if (!p->h_state) HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LmState)));

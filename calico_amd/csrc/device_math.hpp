@@ -458,9 +458,12 @@ DEV void imu_project(int model, const double* __restrict__ k, V3 w, double f[3],
 // Spline weights U·M for derivatives 0..ND-1 (bspline.hpp:39-72). k <= 8.
 // ---------------------------------------------------------------------------
 constexpr int kMaxOrder = 8;
-template <int ND>
-DEV void spline_weights(int k, double knot0, double knot1, const double* __restrict__ M, double t,
+// KT > 0 fixes the order at compile time (the runtime k is then ignored); every loop is unrolled to kMaxOrder
+// with an `i < k` guard, so W / U are never indexed dynamically (no scratch) and the summation order is the same.
+template <int ND, int KT = 0>
+DEV void spline_weights(int k_rt, double knot0, double knot1, const double* __restrict__ M, double t,
                         double W[ND][kMaxOrder]) {
+  const int k = KT > 0 ? KT : k_rt;
   const double dt_inv = 1.0 / (knot1 - knot0);
   const double u = (t - knot0) * dt_inv;
   double up[kMaxOrder];
@@ -481,7 +484,8 @@ DEV void spline_weights(int k, double knot0, double knot1, const double* __restr
     for (int j = 0; j < kMaxOrder; ++j) {
       double s = 0.0;
       if (j < k) {
-        for (int i = 0; i < k; ++i) s += U[i] * M[i * k + j];
+#pragma unroll
+        for (int i = 0; i < kMaxOrder; ++i) if (i < k) s += U[i] * M[i * k + j];
       }
       W[d][j] = s;
     }

@@ -32,14 +32,17 @@ struct ItemCtx {
 };
 
 // Evaluate spline value / derivatives at t: out[d][6] = sum_i W[d][i] * ctrl_i.
-template <int ND>
+template <int ND, int KT>
 DEV void spline_eval(const ItemCtx& c, double t, double W[ND][kMaxOrder], double out[ND][6]) {
-  spline_weights<ND>(c.k, c.knot0, c.knot1, c.M, t, W);
+  const int k = KT > 0 ? KT : c.k;
+  spline_weights<ND, KT>(c.k, c.knot0, c.knot1, c.M, t, W);
 #pragma unroll
   for (int d = 0; d < ND; ++d)
 #pragma unroll
     for (int a = 0; a < 6; ++a) out[d][a] = 0.0;
-  for (int i = 0; i < c.k; ++i) {
+#pragma unroll
+  for (int i = 0; i < kMaxOrder; ++i) {
+    if (i >= k) continue;
     const double* cp = c.x + c.ctrl_off[i];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
@@ -59,7 +62,7 @@ struct RowSink {
 // ---------------------------------------------------------------------------
 // Camera: residual (2) and Jacobian rows. Returns false on invalid projection.
 // ---------------------------------------------------------------------------
-template <int MODEL, bool JAC>
+template <int MODEL, bool JAC, int KT>
 DEV bool camera_block(const ItemCtx& c, double px, double py, double stamp, const double* xm, double res[2],
                       const RowSink& sink, double* cost, int apply_loss) {
   const SensorDev& S = *c.s;
@@ -78,7 +81,7 @@ DEV bool camera_block(const ItemCtx& c, double px, double py, double stamp, cons
   const V3 t_wm = mk(bt[0], bt[1], bt[2]);
   constexpr int ND = JAC ? 2 : 1;
   double W[ND][kMaxOrder], P[ND][6];
-  spline_eval<ND>(c, stamp - lat, W, P);
+  spline_eval<ND, KT>(c, stamp - lat, W, P);
   const V3 phi = mk(-P[0][0], -P[0][1], -P[0][2]);
   const V3 t_wr = mk(P[0][3], P[0][4], P[0][5]);
   const M3 R_rw = rotmat(angle_axis_to_quat(phi));
@@ -122,7 +125,9 @@ DEV bool camera_block(const ItemCtx& c, double px, double py, double stamp, cons
       for (int j = 0; j < 3; ++j) A[r][3 + j] = -fac * DG[r][j];
     }
     // spline columns: w_i · A
-    for (int i = 0; i < c.k; ++i) {
+#pragma unroll
+    for (int i = 0; i < kMaxOrder; ++i) {
+      if (i >= (KT > 0 ? KT : c.k)) continue;
       const double w = W[0][i];
 #pragma unroll
       for (int a = 0; a < 6; ++a) { sink.put(6 * i + a, 0, w * A[0][a]); sink.put(6 * i + a, 1, w * A[1][a]); }
@@ -173,17 +178,17 @@ DEV bool camera_block(const ItemCtx& c, double px, double py, double stamp, cons
   return true;
 }
 
-template <bool JAC>
+template <bool JAC, int KT>
 DEV bool camera_dispatch(const ItemCtx& c, double px, double py, double stamp, const double* xm, double res[2],
                          const RowSink& sink, double* cost, int apply_loss) {
   switch (c.s->model) {
-    case 1: return camera_block<1, JAC>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
-    case 2: return camera_block<2, JAC>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
-    case 3: return camera_block<3, JAC>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
-    case 4: return camera_block<4, JAC>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
-    case 5: return camera_block<5, JAC>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
-    case 6: return camera_block<6, JAC>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
-    default: return camera_block<7, JAC>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
+    case 1: return camera_block<1, JAC, KT>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
+    case 2: return camera_block<2, JAC, KT>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
+    case 3: return camera_block<3, JAC, KT>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
+    case 4: return camera_block<4, JAC, KT>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
+    case 5: return camera_block<5, JAC, KT>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
+    case 6: return camera_block<6, JAC, KT>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
+    default: return camera_block<7, JAC, KT>(c, px, py, stamp, xm, res, sink, cost, apply_loss);
   }
 }
 
@@ -203,7 +208,7 @@ DEV void omega_and_dphi(V3 phi, V3 phid, V3* omega, double Wm[3][3]) {
   Wm[2][0] = oz.d0; Wm[2][1] = oz.d1; Wm[2][2] = oz.d2;
 }
 
-template <bool JAC>
+template <bool JAC, int KT>
 DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], const RowSink& sink, double* cost,
                     int apply_loss) {
   const SensorDev& S = *c.s;
@@ -215,7 +220,7 @@ DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], cons
   const M3 R_rg = rotmat(normalized(q));
   constexpr int ND = JAC ? 3 : 2;
   double W[ND][kMaxOrder], P[ND][6];
-  spline_eval<ND>(c, stamp - lat, W, P);
+  spline_eval<ND, KT>(c, stamp - lat, W, P);
   const V3 phi = mk(-P[0][0], -P[0][1], -P[0][2]);
   const V3 phid = mk(-P[1][0], -P[1][1], -P[1][2]);
   V3 omega;
@@ -255,7 +260,9 @@ DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], cons
         A0[i][j] = -(B[i][0] * Wm[0][j] + B[i][1] * Wm[1][j] + B[i][2] * Wm[2][j]);
         A1[i][j] = -(B[i][0] * Jl.m[0][j] + B[i][1] * Jl.m[1][j] + B[i][2] * Jl.m[2][j]);
       }
-    for (int i = 0; i < c.k; ++i) {
+#pragma unroll
+    for (int i = 0; i < kMaxOrder; ++i) {
+      if (i >= (KT > 0 ? KT : c.k)) continue;
       const double w0 = W[0][i], w1 = W[1][i];
 #pragma unroll
       for (int a = 0; a < 3; ++a)
@@ -267,9 +274,12 @@ DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], cons
     }
     if (L.c_intr >= 0) {
       const int K = imu_num_params(S.model);
-      for (int j = 0; j < K; ++j)
+#pragma unroll
+      for (int j = 0; j < kMaxIntr; ++j) {
+        if (j >= K) continue;
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr) sink.put(L.c_intr + j, rr, fac * dK[rr][j]);
+      }
     }
     if (L.c_q >= 0) {  // d og / d delta = -2 R_rgᵀ [omega]×
       const M3 So = skew(omega);
@@ -303,7 +313,7 @@ DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], cons
   return true;
 }
 
-template <bool JAC>
+template <bool JAC, int KT>
 DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], const RowSink& sink, double* cost,
                      int apply_loss) {
   const SensorDev& S = *c.s;
@@ -319,7 +329,7 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
   const V3 g = mk(gp[0], gp[1], gp[2]);
   constexpr int ND = JAC ? 4 : 3;
   double W[ND][kMaxOrder], P[ND][6];
-  spline_eval<ND>(c, stamp - lat, W, P);
+  spline_eval<ND, KT>(c, stamp - lat, W, P);
   const V3 phi = mk(-P[0][0], -P[0][1], -P[0][2]);
   const V3 phid = mk(-P[1][0], -P[1][1], -P[1][2]);
   const V3 phidd = mk(-P[2][0], -P[2][1], -P[2][2]);
@@ -438,7 +448,9 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
         }
         A0[i][j] = -s0; A1[i][j] = -s1; A2r[i][j] = -s2; A2t[i][j] = s3;
       }
-    for (int i = 0; i < c.k; ++i) {
+#pragma unroll
+    for (int i = 0; i < kMaxOrder; ++i) {
+      if (i >= (KT > 0 ? KT : c.k)) continue;
       const double w0 = W[0][i], w1 = W[1][i], w2 = W[2][i];
 #pragma unroll
       for (int a = 0; a < 3; ++a)
@@ -450,9 +462,12 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
     }
     if (L.c_intr >= 0) {
       const int K = imu_num_params(S.model);
-      for (int j = 0; j < K; ++j)
+#pragma unroll
+      for (int j = 0; j < kMaxIntr; ++j) {
+        if (j >= K) continue;
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr) sink.put(L.c_intr + j, rr, fac * dK[rr][j]);
+      }
     }
     if (L.c_q >= 0) {  // d f / d delta = 2 R_raᵀ [b]×
       const M3 Sb = skew(b);
@@ -506,7 +521,7 @@ DEV double wave_sum(double v) {
 // [JᵀJ | Jᵀr] block; !JAC: residuals / cost only.
 // grid = n_items, block = 64 (one wave).
 // ---------------------------------------------------------------------------
-template <bool JAC>
+template <bool JAC, int KT>
 __global__ __launch_bounds__(64) void eval_items_kernel(EvalArgs a) {
   extern __shared__ double lds[];
   if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
@@ -539,15 +554,16 @@ __global__ __launch_bounds__(64) void eval_items_kernel(EvalArgs a) {
   if (active) {
     const double st = a.stamp[o];
     if (S.kind == 0) {
-      ok = camera_dispatch<JAC>(c, a.m0[o], a.m1[o], st, a.x + a.point_off[o], res, sink, &cost, a.apply_loss);
+      ok = camera_dispatch<JAC, KT>(c, a.m0[o], a.m1[o], st, a.x + a.point_off[o], res, sink, &cost, a.apply_loss);
     } else if (S.kind == 1) {
-      ok = gyro_block<JAC>(c, mk(a.m0[o], a.m1[o], a.m2[o]), st, res, sink, &cost, a.apply_loss);
+      ok = gyro_block<JAC, KT>(c, mk(a.m0[o], a.m1[o], a.m2[o]), st, res, sink, &cost, a.apply_loss);
     } else {
-      ok = accel_block<JAC>(c, mk(a.m0[o], a.m1[o], a.m2[o]), st, res, sink, &cost, a.apply_loss);
+      ok = accel_block<JAC, KT>(c, mk(a.m0[o], a.m1[o], a.m2[o]), st, res, sink, &cost, a.apply_loss);
     }
     if (!ok) { cost = 0.0; res[0] = res[1] = res[2] = 0.0; }
     if (a.res_out) {
-      for (int r = 0; r < dim; ++r) a.res_out[size_t(o) * 3 + r] = res[r];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) if (r < dim) a.res_out[size_t(o) * 3 + r] = res[r];
       a.valid_out[o] = ok ? 1 : 0;
     }
   }
@@ -560,7 +576,8 @@ __global__ __launch_bounds__(64) void eval_items_kernel(EvalArgs a) {
         for (int col = 0; col < ncols; ++col)
           for (int r = 0; r < dim; ++r) sink.put(col, r, 0.0);
       }
-      for (int r = 0; r < dim; ++r) sink.put(ncols, r, res[r]);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) if (r < dim) sink.put(ncols, r, res[r]);
     }
     __syncthreads();
     // Stage B: P = [J r]ᵀ [J r], upper 4×4 tiles.
@@ -714,7 +731,7 @@ __global__ __launch_bounds__(64) void eval_frames_kernel(EvalArgs a) {
   const double* Mb = a.basis + size_t(it.seg) * K * K;
   const double lat = a.x[S.lat_off];
   double W[2][kMaxOrder];
-  spline_weights<2>(K, a.knots[ki], a.knots[ki + 1], Mb, it.stamp - lat, W);
+  spline_weights<2, K>(K, a.knots[ki], a.knots[ki + 1], Mb, it.stamp - lat, W);
   double p[6] = {0, 0, 0, 0, 0, 0}, pd[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < K; ++i) {
@@ -856,9 +873,11 @@ void launch_eval(const EvalArgs& a, bool jac, hipStream_t stream) {
   if (a.n_items == 0) return;
   if (jac) {
     const size_t lds = size_t(a.lds_cols) * kRowPad * sizeof(double);
-    hipLaunchKernelGGL(eval_items_kernel<true>, dim3(a.n_items), dim3(64), lds, stream, a);
+    if (a.order == 6) hipLaunchKernelGGL((eval_items_kernel<true, 6>), dim3(a.n_items), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL((eval_items_kernel<true, 0>), dim3(a.n_items), dim3(64), lds, stream, a);
   } else {
-    hipLaunchKernelGGL(eval_items_kernel<false>, dim3(a.n_items), dim3(64), 0, stream, a);
+    if (a.order == 6) hipLaunchKernelGGL((eval_items_kernel<false, 6>), dim3(a.n_items), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((eval_items_kernel<false, 0>), dim3(a.n_items), dim3(64), 0, stream, a);
   }
 }
 
@@ -866,7 +885,10 @@ hipError_t configure_eval_kernels(size_t max_lds_bytes) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_frames_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(frame_lds_bytes()));
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_items_kernel<true>),
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_items_kernel<true, 6>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, int(max_lds_bytes));
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_items_kernel<true, 0>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, int(max_lds_bytes));
 }
 

@@ -119,6 +119,7 @@ struct SolveArgs {
   double* Spart;          // [m+1][m+1] reduced system S - YtY (lower triangle)
   double* Swork;          // global fallback workspace of the reduced solve
   double* y;              // [NT] solution of the damped system (unscaled): delta = -y
+  double* zbuf;           // [n_s] z = L^-1 g_s - Y y_c (input of the backward band sweep)
   double* dadd;           // [NT] damping added to the diagonal
   double* scale;          // [NT] Jacobi scaling 1/(1+sqrt(H_jj)) from iteration 0
   const uint8_t* cp_active;  // [n_cp]

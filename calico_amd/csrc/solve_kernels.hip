@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void border_matvec_kernel(SolveArgs a) {
   for (int j = lane; j < m; j += 64) part += row[j] * yc[j];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-  if (lane == 0) a.y[c] = row[m] - part;
+  if (lane == 0) a.zbuf[c] = row[m] - part;
 }
 
 // Blocked backward band sweep Lᵀ y_s = z by ONE wave, in axpy form (no reductions on the chain):
@@ -652,57 +652,74 @@ template <int K>
 __global__ __launch_bounds__(64) void band_backsolve_kernel(SolveArgs a) {
   const LmState* st = a.st;
   if (st->terminated) return;
-  constexpr int W = 6 * K, G = K - 1, nband = W * 6, PF = 4;
+  constexpr int W = 6 * K, G = K - 1, nband = W * 6, PF = 4, NSLOT = PF + 1;
   const int ncp = a.n_cp;
   const int lane = threadIdx.x;
   const int g = lane / 6, c = lane % 6;
   const bool worker = g < G;
-  const double* z = a.y;   // border_matvec_kernel left z in y[0, n)
+  const double* __restrict__ z = a.zbuf;   // from border_matvec_kernel; distinct from the output so loads can stay in flight
+  double* __restrict__ yout = a.y;
+  const double* __restrict__ Lbp = a.Lb;
+  const double* __restrict__ Lip = a.Linv;
   // block handled by this lane at step J: B = J - d, d in [1, G], B ≡ g (mod G)
   auto dist = [&](int J) { int d = (J - g) % G; if (d < 0) d += G; return d == 0 ? G : d; };
-  double lring[PF][6];
-  double iv[PF][6];  // lane c' < 6: Linv[J][q][c'], q = 0..5 (column c' of the inverse = row of its transpose)
-  auto fetch = [&](int J, double lv[6], double ivv[6]) {
-    const int d = dist(J), B = J - d;
+  // Every load of the sweep is unconditional (addresses clamped into the arrays) and issued by fetch(), PF steps
+  // ahead: conditional loads compile to exec-masked branches and the waitcnt pass then falls back to vmcnt(0),
+  // which collapses the prefetch distance to one step. Values fetched for B < 0 / idle lanes are never consumed.
+  // The ring has PF+1 slots and the loop is unrolled by PF+1: step u consumes slot u and refills the slot consumed
+  // one step earlier (dead by then), so no register copy -- and no vmcnt(0) -- is needed at the loop back-edge.
+  double lring[NSLOT][6];
+  double iv[NSLOT][6];  // lane c' < 6: Linv[J][q][c'], q = 0..5 (column c' of the inverse = row of its transpose)
+  double zring[NSLOT];  // z of block J - G, picked up by the lanes whose block is consumed at step J
+  const int lane6 = lane < 6 ? lane : 0;
+  auto fetch = [&](int J, double lv[6], double ivv[6], double& zn) {
+    const int Jc = J > 0 ? J : 0;
+    const int d = dist(Jc);
+    const int B = Jc - d, Bc = B > 0 ? B : 0;
+    const double* lp = Lbp + size_t(Bc) * nband + (6 * d) * 6 + c;
 #pragma unroll
-    for (int rr = 0; rr < 6; ++rr) lv[rr] = (worker && J >= 0 && B >= 0) ? a.Lb[size_t(B) * nband + (6 * d + rr) * 6 + c] : 0.0;
+    for (int rr = 0; rr < 6; ++rr) lv[rr] = lp[rr * 6];
+    const double* ip = Lip + size_t(Jc) * 36 + lane6;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) ivv[q] = (J >= 0 && lane < 6) ? a.Linv[size_t(J) * 36 + q * 6 + lane] : 0.0;
+    for (int q = 0; q < 6; ++q) ivv[q] = ip[q * 6];
+    const int jn = Jc - G;
+    zn = z[6 * (jn > 0 ? jn : 0) + c];
   };
   double P = 0.0;
   // z of the first block this lane will consume: the largest J' <= ncp-1 with J' ≡ g (mod G)
   int jz = ncp - 1 - (((ncp - 1 - g) % G + G) % G);
-  double zc = (worker && jz >= 0) ? z[6 * jz + c] : 0.0;
+  double zc = z[6 * (jz > 0 ? jz : 0) + c];
+  // pin this load before the prefetches: otherwise the loop-header waitcnt merges to vmcnt(0) on every trip
+  asm volatile("" : "+v"(zc) : : "memory");
 #pragma unroll
-  for (int u = 0; u < PF; ++u) fetch(ncp - 1 - u, lring[u], iv[u]);
-  for (int J0 = ncp - 1; J0 >= 0; J0 -= PF) {
+  for (int u = 0; u < PF; ++u) fetch(ncp - 1 - u, lring[u], iv[u], zring[u]);
+  for (int J0 = ncp - 1; J0 >= 0; J0 -= NSLOT) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int J = J0 - u;
-      if (J < 0) break;
+    for (int u = 0; u < NSLOT; ++u) {
+      const int J = J0 - u;   // J < 0 in the last group: a harmless dummy step on clamped loads, no store
       double lcur[6];
 #pragma unroll
       for (int rr = 0; rr < 6; ++rr) lcur[rr] = lring[u][rr];
       double icur[6];
 #pragma unroll
       for (int q = 0; q < 6; ++q) icur[q] = iv[u][q];
-      fetch(J - PF, lring[u], iv[u]);
-      const int gj = J % G;
+      const double znext = zring[u];
+      const int rf = (u + PF) % NSLOT;
+      fetch(J - PF, lring[rf], iv[rf], zring[rf]);
+      const int gj = (J + G * NSLOT) % G;
       // s_c on lanes (gj, c)
       const double sc = zc - P;
       double s[6];
 #pragma unroll
       for (int q = 0; q < 6; ++q) s[q] = readlane_f64(sc, 6 * gj + q);
-      if (g == gj) {   // consumed: start the pending sum of block J - G
-        P = 0.0;
-        const int jn = J - G;
-        zc = (worker && jn >= 0) ? z[6 * jn + c] : 0.0;
-      }
+      // consumed: start the pending sum of block J - G
+      P = g == gj ? 0.0 : P;
+      zc = g == gj ? znext : zc;
       // y_J[c'] = Σ_q Linv[q][c'] s_q on lane c' < 6, then broadcast
       double yl = 0.0;
 #pragma unroll
       for (int q = 0; q < 6; ++q) yl += icur[q] * s[q];
-      if (lane < 6) a.y[6 * J + lane] = yl;
+      if (lane < 6 && J >= 0) yout[6 * J + lane] = yl;
       double y[6];
 #pragma unroll
       for (int cc = 0; cc < 6; ++cc) y[cc] = readlane_f64(yl, cc);
