@@ -216,6 +216,8 @@ SolveArgs make_solve_args(calico_problem* p) {
 
 EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool want_res) {
   EvalArgs a;
+  static const int dbg = std::getenv("CALICO_KERNEL_TIMING") ? std::atoi(std::getenv("CALICO_KERNEL_TIMING")) : 0;
+  a.debug = dbg;
   a.x = x; a.sensors = p->d_sensors.p; a.layouts = p->d_layouts.p; a.items = p->d_items.p;
   a.knots = p->d_knots.p; a.basis = p->d_basis.p; a.ctrl_off = p->d_ctrl_off.p;
   a.m0 = p->d_m0.p; a.m1 = p->d_m1.p; a.m2 = p->d_m2.p; a.stamp = p->d_stamp.p; a.point_off = p->d_point_off.p;
@@ -223,7 +225,7 @@ EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool
   a.res_out = want_res ? p->d_res.p : nullptr; a.valid_out = want_res ? p->d_valid.p : nullptr;
   a.order = p->order; a.n_items = p->n_items; a.lds_cols = p->lds_cols; a.apply_loss = apply_loss;
   a.st = nullptr; a.need_flag = 0; a.cost_index_base = 0;
-  a.fitems = p->d_fitems.p; a.n_fitems = p->n_fitems; a.pad2 = 0;
+  a.fitems = p->d_fitems.p; a.n_fitems = p->n_fitems;
   return a;
 }
 

@@ -630,7 +630,10 @@ __global__ __launch_bounds__(64) void eval_items_kernel(EvalArgs a) {
 // generic kernel, ~5× fewer FMAs and LDS reads, and every per-frame quantity (spline
 // evaluation, Rodrigues terms, rotation products) is computed once per wave, not per block.
 // ---------------------------------------------------------------------------
-constexpr int kMaxPrim = 32;   // 6 + 11 + 3 + 3 + 3 + 3 + r = 30, padded even
+constexpr int kMaxPrim = 32;   // 6 + 11 + 3 + 3 + 3 + 3 + r = 30, padded to two 16-wide MFMA tiles
+constexpr int kFramePad = 132; // row stride of a staged prim column: ≡ 4 (mod 32) spreads the MFMA operand read over all banks
+constexpr int kMaxLocalCols = 96;
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 template <int MODEL>
 DEV bool frame_camera_block(const SensorDev& S, const LayoutDev& L, const double* intr, const M3& R_rc, const M3& R_rw,
@@ -649,7 +652,7 @@ DEV bool frame_camera_block(const SensorDev& S, const LayoutDev& L, const double
   if (apply_loss) rho = loss_eval(S.loss, S.loss_scale, sq, &ls);
   *cost = 0.5 * rho;
   const double fac = -S.info * ls;
-  auto put = [&](int col, int r, double v) { Jp[col * kRowPad + row0 + r] = v; };
+  auto put = [&](int col, int r, double v) { Jp[col * kFramePad + row0 + r] = v; };
   put(pc_r, 0, r0 * ls); put(pc_r, 1, r1 * ls);
   double DRt[2][3], DG[2][3];
 #pragma unroll
@@ -708,6 +711,9 @@ __global__ __launch_bounds__(64) void eval_frames_kernel(EvalArgs a) {
   extern __shared__ double lds[];
   if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
   const int lane = threadIdx.x;
+  const bool dbg = a.debug && blockIdx.x == 7 && lane == 0;
+  long long tph[6] = {0, 0, 0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
+#define FTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   const FrameItemDev it = a.fitems[blockIdx.x];
   const LayoutDev& L = a.layouts[it.layout];
   const SensorDev& S = a.sensors[L.sensor];
@@ -722,10 +728,13 @@ __global__ __launch_bounds__(64) void eval_frames_kernel(EvalArgs a) {
   const int pc_bt = L.c_bt >= 0 ? pc : -1; if (L.c_bt >= 0) pc += 3;
   const int pc_r = pc;
   const int P1 = pc + 1;               // prim columns incl. residual
-  const int P2 = (P1 + 1) & ~1;        // padded even
-  double* Jp = lds;                                  // [P2][kRowPad]
-  double* Ml = lds + P2 * kRowPad;                   // [P2][P2]
-  double* Q = Ml + P2 * P2;                          // [P2]  lat row: -pdotᵀ M(0..5, :)
+  const int PT = (P1 + 15) & ~15;      // padded to MFMA tiles (16 or 32)
+  const int PE = PT + 1;               // M_ext = [[M, Qᵀ], [Q, qq]]: the latency column is prim index PT
+  const int ncols = L.ncols, n1 = ncols + 1;
+  double* Jp = lds;                                  // [PT][kFramePad]   staged rows, column-major
+  double* Me = lds + kMaxPrim * kFramePad;           // [PE][PE]
+  double* coef = Me + (kMaxPrim + 1) * (kMaxPrim + 1);   // [n1] column c of the item = coef[c] · prim column prim[c]
+  int* prim = reinterpret_cast<int*>(coef + kMaxLocalCols);
   // ---- per-frame quantities (every lane computes the same values) ----
   const int ki = it.seg + K - 1;
   const double* Mb = a.basis + size_t(it.seg) * K * K;
@@ -754,29 +763,56 @@ __global__ __launch_bounds__(64) void eval_frames_kernel(EvalArgs a) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) G.m[i][j] = R_rc.m[0][i] * R_rw.m[0][j] + R_rc.m[1][i] * R_rw.m[1][j] + R_rc.m[2][i] * R_rw.m[2][j];
   const double* intr = a.x + S.intr_off;
-  // ---- stage A/B over batches of 64 blocks ----
-  const int nt = P2 >> 1;
-  const int ntiles = nt * (nt + 1) / 2;
-  int t_i[2], t_j[2];
+  // observation of this lane in the first batch (clamped: loads stay unconditional), fetched ahead of use
+  auto obs_index = [&](int b0) { return it.obs_begin + min(b0 + lane, it.obs_count - 1); };
+  int o_nx = obs_index(0);
+  double px_nx = a.m0[o_nx], py_nx = a.m1[o_nx];
+  const double* xm_p = a.x + a.point_off[o_nx];
+  double xm_nx[3] = {xm_p[0], xm_p[1], xm_p[2]};
+  // column table of the expansion: item column lc = coef · prim column
+  for (int lc = lane; lc < n1; lc += 64) {
+    double cf = 1.0;
+    int pr;
+    if (lc < 36) {
+      const int wi = lc / 6;
+      pr = lc - 6 * wi;
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    int tile = lane + 64 * u, ti = 0;
-    if (tile < ntiles) { int rem = tile; while (rem >= nt - ti) { rem -= nt - ti; ++ti; } t_i[u] = ti; t_j[u] = ti + rem; }
-    else { t_i[u] = -1; t_j[u] = 0; }
+      for (int q = 0; q < K; ++q) cf = (wi == q) ? W[0][q] : cf;
+    } else if (lc == L.c_lat) pr = PT;
+    else if (lc == ncols) pr = pc_r;
+    else if (L.c_intr >= 0 && lc >= L.c_intr && lc < L.c_intr + Kin) pr = pc_intr + (lc - L.c_intr);
+    else if (L.c_q >= 0 && lc >= L.c_q && lc < L.c_q + 3) pr = pc_q + (lc - L.c_q);
+    else if (L.c_t >= 0 && lc >= L.c_t && lc < L.c_t + 3) pr = pc_t + (lc - L.c_t);
+    else if (L.c_bq >= 0 && lc >= L.c_bq && lc < L.c_bq + 3) pr = pc_bq + (lc - L.c_bq);
+    else pr = pc_bt + (lc - L.c_bt);
+    coef[lc] = cf; prim[lc] = pr;
   }
-  double acc[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};
+  // ---- blocks -> staged rows -> M = [J_prim r]ᵀ[J_prim r] on the matrix cores ----
+  // v_mfma_f64_16x16x4_f64: A[i][k] and B[k][j] of the product JᵀJ are the SAME staged value
+  // Jp[col = 16t + (lane & 15)][row = r0 + (lane >> 4)], so one LDS read feeds both operands.
+  const int lc16 = lane & 15, lk = lane >> 4;
+  const bool two = PT > 16;
+  f64x4 acc00 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+  const bool col0_ok = lc16 < P1, col1_ok = 16 + lc16 < P1;
+  const double* op0 = Jp + lc16 * kFramePad + lk;
+  const double* op1 = Jp + (16 + lc16) * kFramePad + lk;
   double cost = 0.0, n_bad = 0.0;
+  FTICK(0)
   for (int b0 = 0; b0 < it.obs_count; b0 += 64) {
     const int nb = min(64, it.obs_count - b0);
     __syncthreads();
-    for (int i = lane; i < P2 * kRowPad; i += 64) Jp[i] = 0.0;
-    __syncthreads();
+    FTICK(1)
+    const double px = px_nx, py = py_nx;
+    const double xm[3] = {xm_nx[0], xm_nx[1], xm_nx[2]};
+    if (b0 + 64 < it.obs_count) {   // wave-uniform: next batch's observation
+      o_nx = obs_index(b0 + 64);
+      px_nx = a.m0[o_nx]; py_nx = a.m1[o_nx];
+      xm_p = a.x + a.point_off[o_nx];
+      xm_nx[0] = xm_p[0]; xm_nx[1] = xm_p[1]; xm_nx[2] = xm_p[2];
+    }
     if (lane < nb) {
-      const int o = it.obs_begin + b0 + lane;
       double c1 = 0.0;
       bool ok;
-      const double px = a.m0[o], py = a.m1[o];
-      const double* xm = a.x + a.point_off[o];
       switch (S.model) {
         case 1: ok = frame_camera_block<1>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
         case 2: ok = frame_camera_block<2>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
@@ -786,84 +822,107 @@ __global__ __launch_bounds__(64) void eval_frames_kernel(EvalArgs a) {
         case 6: ok = frame_camera_block<6>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
         default: ok = frame_camera_block<7>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
       }
-      if (ok) cost += c1; else n_bad += 1.0;   // an invalid block leaves its (zeroed) rows untouched
+      if (ok) cost += c1;
+      else {   // an invalid block contributes nothing: zero its two rows
+        n_bad += 1.0;
+        for (int c = 0; c < P1; ++c) { Jp[c * kFramePad + 2 * lane] = 0.0; Jp[c * kFramePad + 2 * lane + 1] = 0.0; }
+      }
     }
     __syncthreads();
+    FTICK(2)
     const int nrows = 2 * nb;
+    // operands are fetched eight steps (32 rows) at a time so the LDS latency is paid once per group
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (t_i[u] < 0) continue;
-      const double* ca = Jp + (2 * t_i[u]) * kRowPad;
-      const double* cb = Jp + (2 * t_j[u]) * kRowPad;
-      double a00 = acc[u][0][0], a01 = acc[u][0][1], a10 = acc[u][1][0], a11 = acc[u][1][1];
-      for (int r = 0; r < nrows; ++r) {
-        const double x0 = ca[r], x1 = ca[kRowPad + r], y0 = cb[r], y1 = cb[kRowPad + r];
-        a00 += x0 * y0; a01 += x0 * y1; a10 += x1 * y0; a11 += x1 * y1;
+    for (int g = 0; g < 4; ++g) {
+      if (32 * g < nrows) {
+        if (!two) {
+          double v0[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v0[u] = op0[32 * g + 4 * u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const double x0 = (col0_ok && 32 * g + 4 * u + lk < nrows) ? v0[u] : 0.0;
+            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc00, 0, 0, 0);
+          }
+        } else {
+          double v0[8], v1[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { v0[u] = op0[32 * g + 4 * u]; v1[u] = op1[32 * g + 4 * u]; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const bool rok = 32 * g + 4 * u + lk < nrows;
+            const double x0 = rok ? v0[u] : 0.0;                   // columns 0..15 always exist when PT = 32
+            const double x1 = (col1_ok && rok) ? v1[u] : 0.0;
+            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc00, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, acc11, 0, 0, 0);
+          }
+        }
       }
-      acc[u][0][0] = a00; acc[u][0][1] = a01; acc[u][1][0] = a10; acc[u][1][1] = a11;
     }
+    FTICK(3)
   }
   const double item_cost = wave_sum(cost);
   const double n_invalid = wave_sum(n_bad);
   if (lane == 0) { a.item_cost[2 * blockIdx.x] = item_cost; a.item_cost[2 * blockIdx.x + 1] = n_invalid; }
-  // ---- M to LDS (full symmetric), lat row Q ----
+  // ---- M to LDS (full symmetric; C/D layout: col = lane & 15, row = (lane >> 4) + 4·reg), latency row Q ----
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    if (t_i[u] < 0) continue;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int gi = 2 * t_i[u] + i, gj = 2 * t_j[u] + j;
-        Ml[gi * P2 + gj] = acc[u][i][j];
-        Ml[gj * P2 + gi] = acc[u][i][j];
-      }
-  }
-  __syncthreads();
-  if (lane < P2) {
-    double s = 0.0;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) s -= pd[c] * Ml[c * P2 + lane];
-    Q[lane] = s;
-  }
-  __syncthreads();
-  double qq = 0.0;
-#pragma unroll
-  for (int c = 0; c < 6; ++c) qq -= pd[c] * Q[c];
-  // ---- expansion TᵀMT into the item's (c+1)×(c+1) block ----
-  const int ncols = L.ncols, n1 = ncols + 1;
-  double* out = a.partials + it.partial_off;
-  auto prim_of = [&](int lc) -> int {   // local calibration column -> prim column (lc >= 36, lc != c_lat)
-    if (lc == ncols) return pc_r;
-    if (L.c_intr >= 0 && lc >= L.c_intr && lc < L.c_intr + Kin) return pc_intr + (lc - L.c_intr);
-    if (L.c_q >= 0 && lc >= L.c_q && lc < L.c_q + 3) return pc_q + (lc - L.c_q);
-    if (L.c_t >= 0 && lc >= L.c_t && lc < L.c_t + 3) return pc_t + (lc - L.c_t);
-    if (L.c_bq >= 0 && lc >= L.c_bq && lc < L.c_bq + 3) return pc_bq + (lc - L.c_bq);
-    return pc_bt + (lc - L.c_bt);
-  };
-  for (int i = 0; i < n1; ++i) {
-    // row descriptor (wave-uniform)
-    const bool i_spl = i < 36, i_lat = (i == L.c_lat);
-    const int ia = i_spl ? i % 6 : 0;
-    const double iw = i_spl ? W[0][i / 6] : 1.0;
-    const int ip = (!i_spl && !i_lat) ? prim_of(i) : 0;
-    for (int j = i + lane; j < n1; j += 64) {
-      const bool j_spl = j < 36, j_lat = (j == L.c_lat);
-      double v;
-      if (j_spl) {               // i is a spline column too (i <= j < 36)
-        v = iw * W[0][j / 6] * Ml[ia * P2 + (j % 6)];
-      } else if (j_lat) {
-        v = i_spl ? iw * Q[ia] : (i_lat ? qq : Q[ip]);
-      } else {
-        const int jp = prim_of(j);
-        v = i_spl ? iw * Ml[ia * P2 + jp] : (i_lat ? Q[jp] : Ml[ip * P2 + jp]);
-      }
-      out[size_t(i) * n1 + j] = v;
+  for (int r = 0; r < 4; ++r) {
+    const int row = lk + 4 * r;
+    Me[row * PE + lc16] = acc00[r];
+    if (two) {
+      Me[(16 + row) * PE + lc16] = acc10[r];
+      Me[lc16 * PE + 16 + row] = acc10[r];
+      Me[(16 + row) * PE + 16 + lc16] = acc11[r];
     }
   }
+  __syncthreads();
+  if (lane < PT) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s -= pd[c] * Me[c * PE + lane];
+    Me[PT * PE + lane] = s; Me[lane * PE + PT] = s;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    double qq = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) qq -= pd[c] * Me[PT * PE + c];
+    Me[PT * PE + PT] = qq;
+  }
+  __syncthreads();
+  FTICK(4)
+  // ---- expansion TᵀMT into the item's (c+1)×(c+1) block: out(i, j) = coef_i coef_j M_ext(prim_i, prim_j), i <= j ----
+  double* out = a.partials + it.partial_off;
+  const int n_pairs = n1 * (n1 + 1) / 2;
+  int ei = 0, eoff = lane, elen = n1;     // position of pair t = lane in the row-major upper triangle
+  while (eoff >= elen) { eoff -= elen; ++ei; --elen; }
+  for (int t = lane; t < n_pairs; t += 256) {
+    int pi[4], pj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {          // pairs t, t+64, t+128, t+192 (clamped to the last pair when past the end)
+      pi[u] = min(ei, n1 - 1); pj[u] = min(ei + eoff, n1 - 1);
+      eoff += 64;
+      while (eoff >= elen && elen > 0) { eoff -= elen; ++ei; --elen; }
+    }
+    double ci[4], cj[4];
+    int qi[4], qj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { ci[u] = coef[pi[u]]; cj[u] = coef[pj[u]]; qi[u] = prim[pi[u]]; qj[u] = prim[pj[u]]; }
+    double mv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mv[u] = Me[qi[u] * PE + qj[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (t + 64 * u < n_pairs) out[size_t(pi[u]) * n1 + pj[u]] = ci[u] * cj[u] * mv[u];
+  }
+  FTICK(5)
+  if (dbg) printf("eval_frames cycles (frame of %d blocks, %d prim cols): frame-constants %lld  barrier %lld  blocks %lld  M-mfma %lld  M-to-lds %lld  expansion %lld\n",
+                  it.obs_count, P1, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
+#undef FTICK
 }
 
-size_t frame_lds_bytes() { return (size_t(kMaxPrim) * kRowPad + size_t(kMaxPrim) * kMaxPrim + kMaxPrim) * sizeof(double); }
+size_t frame_lds_bytes() { return (size_t(kMaxPrim) * kFramePad + size_t(kMaxPrim + 1) * (kMaxPrim + 1) + kMaxLocalCols + kMaxLocalCols / 2) * sizeof(double); }
 void launch_eval_frames(const EvalArgs& a, hipStream_t stream) {
   if (a.n_fitems == 0) return;
   hipLaunchKernelGGL(eval_frames_kernel, dim3(a.n_fitems), dim3(64), frame_lds_bytes(), stream, a);

@@ -68,7 +68,7 @@ struct EvalArgs {
   const struct LmState* st;  // optional: skip when terminated (and, with need_flag, when no Jacobian is due)
   int need_flag, cost_index_base;
   const FrameItemDev* fitems;
-  int n_fitems, pad2;
+  int n_fitems, debug;   // debug: CALICO_KERNEL_TIMING cycle print-outs
 };
 
 // LM state kept on the device; the control kernel is its only writer.

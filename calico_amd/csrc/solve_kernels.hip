@@ -215,13 +215,19 @@ DEVI double rsqrt_nr(double d) {
   return r;
 }
 
+// Workgroup barrier that orders LDS traffic only. __syncthreads() also drains vmcnt, which puts the full latency of
+// every in-flight global prefetch / write-back on the per-step critical path of the sequential sweeps.
+DEVI void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 DEVI void chol6_and_inverse(const double* A /* [r*6+c], lower */, double L[6][6], double Li[6][6], bool* fail) {
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     double d = A[j * 6 + j];
 #pragma unroll
     for (int q = 0; q < j; ++q) d -= L[j][q] * L[j][q];
-    if (!(d > 0.0) || !isfinite(d)) { *fail = true; d = 1.0; }
+    const bool bad = !(d > 0.0) || !isfinite(d);
+    *fail = *fail || bad;
+    d = bad ? 1.0 : d;
     const double inv = rsqrt_nr(d);
     L[j][j] = d * inv; Li[j][j] = inv;
 #pragma unroll
@@ -244,180 +250,232 @@ DEVI void chol6_and_inverse(const double* A /* [r*6+c], lower */, double L[6][6]
     }
 }
 
-__global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs) {
+// Bordered band Cholesky, blocked by control point (6 columns). Workgroup b factors the band (redundantly)
+// together with border rows [b·16, (b+1)·16); the window of k block columns lives in an LDS ring.
+// Step J:  panel X = A(:, J) L_JJ⁻ᵀ  |barrier|  trailing update A -= X Xᵀ  |barrier|.
+//  * Panel and trailing update run on the matrix cores (v_mfma_f64_16x16x4_f64, K = 6 padded to 8): rows of the
+//    window are cut into 16-row tiles (band rows 6..W-1, then the 16 border rows); a lane fetches ONE f64 per
+//    operand and k-chunk from LDS instead of whole rows, which is what bounded the scalar 2×2-tile version
+//    (LDS bandwidth: every thread re-read 4 rows per tile and the 21 entries of L⁻¹).
+//  * The latency chain -- 6×6 Cholesky with its six dependent rsqrt, then the triangular inverse -- is taken off
+//    the step by look-ahead: during the trailing update of step J, wave 3 alone applies step J's update to the
+//    NEXT pivot block, factors it and leaves L, L⁻¹ in LDS, while waves 0..2 update the rest of the window.
+//  * Global prefetches (two blocks ahead, in registers) and write-backs never stall the step: the barriers order
+//    LDS only (lds_barrier) and every streaming load is unconditional.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+//  * One wave retires roughly one instruction every 5 clocks here, so the step is kept short by construction: every
+//    LDS offset and predicate is computed once per thread before the sweep (masked operands read a zero word, masked
+//    results go to a dump word, both inside each ring slot), and blocks past the end of the band are streamed in as
+//    zeros so that the short windows at the end need no special cases.
+constexpr int kSlotPad = 16;     // per ring slot: [0] zero word, [8] dump word
+__global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs /* = kBorderSlice = 16 */) {
   LmState* st = a.st;
   if (st->terminated) return;
   extern __shared__ double lds[];
   const int k = a.k, W = 6 * k, ncp = a.n_cp, m1 = a.m + 1;
   const int j0 = blockIdx.x * bs;
-  const int nb = max(0, min(bs, m1 - j0));
-  const int SL = W * 6 + bs * 6;  // doubles per ring slot: band block [W][6] + border [bs][6]
-  const int NSL = k + 2;          // active window (k) + two blocks in flight
-  const int tid = threadIdx.x;
-  const int nband = W * 6, nelem = nband + nb * 6;
-  constexpr int NE = 2;           // elements per thread: (48*6 + 16*6) / 256
-  auto slot = [&](int J) { return lds + (J % NSL) * SL; };
-  for (int i = tid; i < NSL * SL; i += 256) lds[i] = 0.0;   // padding rows must stay zero
-  // per-thread element descriptors of the streaming loads (fixed over the sweep)
-  int g_off[NE], l_off[NE];
-  bool is_y[NE], has[NE];
+  const int nb = max(1, min(bs, m1 - j0));
+  const int nband = W * 6;
+  const int SLP = nband + bs * 6;   // payload of a ring slot: band block [W][6] + border [bs][6]
+  const int SL = SLP + kSlotPad;
+  const int ZERO = SLP, DUMP = SLP + 8;
+  const int NSL = k + 2;            // active window (k) + two blocks in flight
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc16 = lane & 15, lk = lane >> 4;
+  const int nelem = nband + nb * 6;
+  constexpr int NE = 2;             // elements per thread: (48*6 + 16*6) / 256
+  double* Lpiv = lds + NSL * SL;    // [2][80]: L (36), L⁻¹ (36), zero word (at 72), by step parity
+  for (int i = tid; i < NSL * SL + 160; i += 256) lds[i] = 0.0;
+  // ---- streaming loads / factor write-back descriptors (a thread without an element duplicates another's) ----
+  int l_off[NE], wb_l[NE];
+  bool wb_piv[NE];
+  const double* g_base[NE];
+  double* wb_base[NE];
+  size_t g_stride[NE], wb_stride[NE];
 #pragma unroll
   for (int u = 0; u < NE; ++u) {
     const int e = tid + 256 * u;
-    has[u] = e < nelem; is_y[u] = false; g_off[u] = 0; l_off[u] = 0;
-    if (has[u]) {
-      if (e < nband) { g_off[u] = e; l_off[u] = e; }
-      else { const int q = e - nband; const int c = q / nb, j = q % nb; is_y[u] = true; g_off[u] = c * m1 + j0 + j; l_off[u] = nband + j * 6 + c; }
-    }
+    auto describe = [&](int ee, int* lo, size_t* goff, size_t* stride, bool* isy) {
+      if (ee < nband) { *lo = ee; *goff = size_t(ee); *stride = size_t(nband); *isy = false; }
+      else { const int q = ee - nband; const int c = q / nb, j = q % nb; *lo = nband + j * 6 + c; *goff = size_t(c) * m1 + j0 + j; *stride = size_t(6) * m1; *isy = true; }
+    };
+    size_t goff; bool isy;
+    describe(e < nelem ? e : 0, &l_off[u], &goff, &g_stride[u], &isy);
+    if (e >= nelem) l_off[u] = DUMP;
+    g_base[u] = (isy ? a.Y : a.Lb) + goff;
+    const int ew = blockIdx.x == 0 ? e % nelem : nband + e % (nb * 6);   // write-back: workgroup 0 owns the band factor
+    describe(ew, &wb_l[u], &goff, &wb_stride[u], &isy);
+    wb_base[u] = (isy ? a.Y : a.Lb) + goff;
+    wb_piv[u] = ew < 36;                                                  // diagonal block: L comes from Lpiv, not from the slot
   }
   auto gload = [&](int J, double regs[NE]) {
+    const int Jc = J < ncp ? J : ncp - 1;
 #pragma unroll
-    for (int u = 0; u < NE; ++u) {
-      double v = 0.0;
-      if (J < ncp && has[u]) v = is_y[u] ? a.Y[size_t(6 * J) * m1 + g_off[u]] : a.Lb[size_t(J) * nband + g_off[u]];
-      regs[u] = v;
+    for (int u = 0; u < NE; ++u) regs[u] = g_base[u][size_t(Jc) * g_stride[u]];
+  };
+  // ---- MFMA tiles: 16-row tiles of the panel, band tiles 0..nbt-1 (window rows 6..), tile nbt = border slice ----
+  const int nbr = W - 6;
+  const int nbt = (nbr + 15) >> 4;
+  const int n_bb = nbt * (nbt + 1) / 2, n_upd = n_bb + nbt;
+  // slot-relative offset of X(row i of tile rt, q); ZERO when outside
+  auto x_off = [&](int rt, int i, int q) -> int {
+    if (q >= 6) return ZERO;
+    if (rt == nbt) return i < nb ? nband + i * 6 + q : ZERO;
+    const int wr = 16 * rt + i;
+    return wr < nbr ? (6 + wr) * 6 + q : ZERO;
+  };
+  // panel (wave <= nbt owns row tile `wave`)
+  int pa_off[2], pb_off[2], pd_off[4];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int q = 4 * kk + lk;
+    pa_off[kk] = x_off(wave <= nbt ? wave : nbt, lc16, q);
+    pb_off[kk] = (lc16 < 6 && q < 6) ? 36 + lc16 * 6 + q : 72;            // B(k = q, j = lc16) = L⁻¹(j, q)
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = x_off(wave <= nbt ? wave : nbt, lk + 4 * r, lc16 < 6 ? lc16 : 6);
+    pd_off[r] = o == ZERO ? DUMP : o;
+  }
+  // trailing update (waves 0..2: tiles t = wave, wave + 3, wave + 6)
+  bool up_on[3];
+  int ua_off[3][2], ub_off[3][2], ut_off[3][4], ut_bc[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int t = wave + 3 * u;
+    up_on[u] = wave < 3 && t < n_upd;
+    int R = 0, C = 0;
+    if (up_on[u]) {
+      if (t < n_bb) { int rem = t; while (rem > R) { rem -= R + 1; ++R; } C = rem; }
+      else { R = nbt; C = t - n_bb; }
     }
-  };
-  auto sstore = [&](int J, const double regs[NE]) {
-    double* s = slot(J);
 #pragma unroll
-    for (int u = 0; u < NE; ++u) if (has[u]) s[l_off[u]] = regs[u];
-  };
-  // trailing-update tiles, 2×2 outputs each, fixed per thread: rows of the window are the band rows
-  // 6..W-1 followed by the bs border rows; tile (pa, pb) pairs row-pair pa (band) with row-pair pb >= pa.
-  const int nrr = W - 6, nrp = nrr / 2, nbp = bs / 2;
-  const int n_bb = nrp * (nrp + 1) / 2, n_tiles = n_bb + nrp * nbp;
-  constexpr int NTL = 2;          // tiles per thread (k = 8: 399 tiles)
-  int t_ra[NTL], t_rb[NTL];       // first row of each pair; t_rb >= W means border row (t_rb - W)
+    for (int kk = 0; kk < 2; ++kk) { ua_off[u][kk] = x_off(R, lc16, 4 * kk + lk); ub_off[u][kk] = x_off(C, lc16, 4 * kk + lk); }
+    // target of D(row = lk + 4r, col = lc16): window column wc lives in block column 1 + wc/6 at local column wc%6
+    const int wc = 16 * C + lc16;
+    const bool c_ok = wc < nbr;
+    const int bc = c_ok ? wc / 6 : 0, ca = c_ok ? wc - 6 * bc : 0;
+    ut_bc[u] = 1 + bc;
 #pragma unroll
-  for (int u = 0; u < NTL; ++u) {
-    const int t = tid + 256 * u;
-    t_ra[u] = -1; t_rb[u] = 0;
-    if (t < n_bb) {
-      int pa = 0, rem = t;
-      while (rem >= nrp - pa) { rem -= nrp - pa; ++pa; }
-      t_ra[u] = 6 + 2 * pa; t_rb[u] = 6 + 2 * (pa + rem);
-    } else if (t < n_tiles) {
-      const int q = t - n_bb;
-      t_ra[u] = 6 + 2 * (q / nbp); t_rb[u] = W + 2 * (q % nbp);
+    for (int r = 0; r < 4; ++r) {
+      const int i = lk + 4 * r, wr = 16 * R + i;
+      bool ok; int lo;
+      if (R == nbt) { ok = c_ok && i < nb; lo = nband + i * 6; }
+      else { ok = c_ok && wr < nbr && wr >= wc && !(wr < 6 && wc < 6); lo = (wr - 6 * bc) * 6; }   // next pivot block: wave 3
+      ut_off[u][r] = ok ? lo + ca : DUMP;
     }
   }
+  // look-ahead (wave 3): lane (r, c) of the next pivot block
+  const int pr = lane < 36 ? lane / 6 : 0, pcn = lane < 36 ? lane % 6 : 0;
+  const int pv_off = (lane < 36 && pcn <= pr) ? pr * 6 + pcn : DUMP;
   __syncthreads();
   double regs[NE], regs2[NE];
-  for (int J = 0; J < k && J < ncp; ++J) { gload(J, regs); sstore(J, regs); }
+  for (int J = 0; J < k; ++J) {
+    gload(J, regs);
+    double* s0 = lds + (J % NSL) * SL;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) s0[l_off[u]] = J < ncp ? regs[u] : 0.0;
+  }
   gload(k, regs);       // blocks k and k+1 ride in registers
   gload(k + 1, regs2);
   bool fail = false;
   long long tk0 = 0, tc[5] = {0, 0, 0, 0, 0};
   const bool dbg = a.debug && blockIdx.x == 0 && tid == 0;
 #define TICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tc[i] += t_ - tk0; tk0 = t_; }
-  const int prow = 6 + tid;                 // band row of the panel (tid < W-6)
-  const int bj = tid - 64;                  // border row of the panel (64 <= tid < 64+nb)
-  const bool panel_thread = tid < 192;      // waves 0..2 factor the pivot block; wave 3 goes straight to the barrier
+  // pivot-block factorisation by wave 3: every lane factors redundantly, lanes < 36 publish one entry each
+  auto factor_pivot = [&](const double* blk, double* dst) {
+    double L[6][6], Li[6][6];
+    chol6_and_inverse(blk, L, Li, &fail);
+    double lv = 0.0, iv = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+      for (int cc = 0; cc <= rr; ++cc) { const bool hit = rr == pr && cc == pcn; lv = hit ? L[rr][cc] : lv; iv = hit ? Li[rr][cc] : iv; }
+    if (lane < 36) { dst[lane] = lv; dst[36 + lane] = iv; }
+  };
   __syncthreads();
+  if (wave == 3) factor_pivot(lds, Lpiv);
+  __syncthreads();
+  int Jm = 0;                                   // J mod NSL
   for (int J = 0; J < ncp; ++J) {
-    double* sj = slot(J);
+    double* sj = lds + Jm * SL;
+    double* piv = Lpiv + (J & 1) * 80;
     if (dbg) tk0 = __builtin_readcyclecounter();
-    if (J + k < ncp) sstore(J + k, regs);
+    {
+      // coalesced write-back of block column J-1 (panel X from its slot, L from Lpiv), one step late
+      const int Jp = J > 0 ? J - 1 : 0;
+      const double* sp = lds + (Jm > 0 ? Jm - 1 : NSL - 1) * SL;
+      const double* pp = Lpiv + ((J & 1) ^ 1) * 80;
 #pragma unroll
-    for (int u = 0; u < NE; ++u) regs[u] = regs2[u];
-    gload(J + k + 2, regs2);
+      for (int u = 0; u < NE; ++u) {
+        const double v = wb_piv[u] ? pp[wb_l[u]] : sp[wb_l[u]];
+        if (J > 0) wb_base[u][size_t(Jp) * wb_stride[u]] = v;
+      }
+      if (J > 0 && blockIdx.x == 0 && tid < 36) a.Linv[size_t(Jp) * 36 + tid] = pp[36 + tid];
+      // block J+k enters the ring (zeros past the end of the band), block J+k+2 is requested
+      int sk = Jm + k; sk = sk >= NSL ? sk - NSL : sk;
+      double* sn = lds + sk * SL;
+      const bool on = J + k < ncp;
+#pragma unroll
+      for (int u = 0; u < NE; ++u) { sn[l_off[u]] = on ? regs[u] : 0.0; regs[u] = regs2[u]; }
+      gload(J + k + 2, regs2);
+    }
     TICK(0)
-    const int nrows = min(W, 6 * (ncp - J));
-    if (panel_thread) {
-      // (1) pivot block, redundantly in every panel thread
-      double L[6][6], Li[6][6];
-      chol6_and_inverse(sj, L, Li, &fail);
-      TICK(1)
-      // (2) panel
-      if (tid < W - 6) {
-        if (prow < nrows) {
-          double av[6], xv[6];
+    // (1) panel on the matrix cores: X = A · L⁻ᵀ, one 16-row tile per wave (nbt <= 3). No inner loops around the
+    //     MFMA code: a loop makes the waitcnt pass drain vmcnt in its preheader, i.e. wait for this step's prefetch.
+    if (wave <= nbt) {
+      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int c = 0; c < 6; ++c) av[c] = sj[prow * 6 + c];
+      for (int kk = 0; kk < 2; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sj[pa_off[kk]], piv[pb_off[kk]], acc, 0, 0, 0);
 #pragma unroll
-          for (int c = 0; c < 6; ++c) {
-            double v = 0.0;
-#pragma unroll
-            for (int q = 0; q <= c; ++q) v += av[q] * Li[c][q];
-            xv[c] = v;
-          }
-#pragma unroll
-          for (int c = 0; c < 6; ++c) sj[prow * 6 + c] = xv[c];
-          if (blockIdx.x == 0) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) a.Lb[size_t(J) * nband + prow * 6 + c] = xv[c];
-          }
-        }
-      } else if (bj >= 0 && bj < nb) {
-        double* br = sj + nband + bj * 6;
-        double av[6], xv[6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) av[c] = br[c];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          double v = 0.0;
-#pragma unroll
-          for (int q = 0; q <= c; ++q) v += av[q] * Li[c][q];
-          xv[c] = v;
-        }
-#pragma unroll
-        for (int c = 0; c < 6; ++c) { br[c] = xv[c]; a.Y[size_t(6 * J + c) * m1 + j0 + bj] = xv[c]; }
-      } else if (blockIdx.x == 0 && tid >= 128 && tid < 128 + 36) {
-        const int r = (tid - 128) / 6, c = (tid - 128) % 6;
-        double lv = 0.0, iv = 0.0;
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr)
-#pragma unroll
-          for (int cc = 0; cc <= rr; ++cc) if (rr == r && cc == c) { lv = L[rr][cc]; iv = Li[rr][cc]; }
-        a.Lb[size_t(J) * nband + r * 6 + c] = lv;
-        a.Linv[size_t(J) * 36 + r * 6 + c] = iv;
-      }
+      for (int r = 0; r < 4; ++r) sj[pd_off[r]] = acc[r];
     }
+    TICK(1)
+    lds_barrier();
     TICK(2)
-    __syncthreads();
-    TICK(3)
-    // (3) trailing update of the window: X Xᵀ in 2×2 tiles, row vectors read as 3 × 16-byte LDS loads
+    if (wave == 3) {
+      // (2a) look-ahead: finish the next pivot block (rows/cols 6..11 of the window) and factor it
+      if (J + 1 < ncp) {
+        double* nxt = lds + (Jm + 1 < NSL ? Jm + 1 : 0) * SL;
+        double d = 0.0;
 #pragma unroll
-    for (int u = 0; u < NTL; ++u) {
-      const int ra = t_ra[u];
-      if (ra < 0) continue;
-      const bool border = t_rb[u] >= W;
-      const int rb = border ? t_rb[u] - W : t_rb[u];
-      if (ra + 1 >= nrows + 0 && ra >= nrows) continue;
-      if (!border && rb >= nrows) continue;
-      const double2* pa0 = reinterpret_cast<const double2*>(sj + ra * 6);
-      const double2* pa1 = reinterpret_cast<const double2*>(sj + (ra + 1) * 6);
-      const double* rbp = border ? sj + nband + rb * 6 : sj + rb * 6;
-      const double2* pb0 = reinterpret_cast<const double2*>(rbp);
-      const double2* pb1 = reinterpret_cast<const double2*>(rbp + 6);
-      double d00 = 0.0, d01 = 0.0, d10 = 0.0, d11 = 0.0;   // d[a][b] = x[ra+a] · x[rb+b]
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const double2 a0 = pa0[q], a1 = pa1[q], b0 = pb0[q], b1 = pb1[q];
-        d00 += a0.x * b0.x + a0.y * b0.y; d01 += a0.x * b1.x + a0.y * b1.y;
-        d10 += a1.x * b0.x + a1.y * b0.y; d11 += a1.x * b1.x + a1.y * b1.y;
+        for (int q = 0; q < 6; ++q) d += sj[(6 + pr) * 6 + q] * sj[(6 + pcn) * 6 + q];
+        nxt[pv_off] -= d;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave: LDS writes above are visible to the reads below
+        factor_pivot(nxt, Lpiv + ((J & 1) ^ 1) * 80);
       }
-      const int b1i = ra / 6, ca = ra - 6 * b1i;            // target block column and local column of row ra (ra+1 shares it)
-      double* tgt = slot(J + b1i);
-      if (border) {
-        double* t0 = tgt + nband + rb * 6 + ca;              // entry (border rb, col ra), (rb, ra+1), (rb+1, ra), (rb+1, ra+1)
-        t0[0] -= d00; t0[1] -= d10; t0[6] -= d01; t0[7] -= d11;
-      } else {
-        const int lr = rb - 6 * b1i;                          // local row of rb inside block column b1i
-        double* t0 = tgt + lr * 6 + ca;                       // entry (row rb, col ra)
-        t0[0] -= d00;                                         // (rb, ra)
-        t0[6] -= d01;                                         // (rb+1, ra)
-        t0[7] -= d11;                                         // (rb+1, ra+1)
-        if (rb > ra) t0[1] -= d10;                            // (rb, ra+1): above the diagonal when rb == ra
+    } else {
+      // (2b) trailing update of the rest of the window on the matrix cores: D(R, C) -= X_R X_Cᵀ
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (!up_on[u]) continue;
+        int sidx = Jm + ut_bc[u]; sidx = sidx >= NSL ? sidx - NSL : sidx;
+        double* tb = lds + sidx * SL;
+        f64x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = tb[ut_off[u][r]];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-sj[ua_off[u][kk]], sj[ub_off[u][kk]], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tb[ut_off[u][r]] = acc[r];
       }
     }
-    __syncthreads();
+    TICK(3)
+    lds_barrier();
     TICK(4)
+    Jm = Jm + 1 < NSL ? Jm + 1 : 0;
   }
-  if (dbg) printf("band_cholesky cycles/step: prefetch %lld  chol6+inv %lld  panel %lld  barrier %lld  update+barrier %lld\n",
+  {
+    const int Jp = ncp - 1;
+    const double* sp = lds + (Jm > 0 ? Jm - 1 : NSL - 1) * SL;
+    const double* pp = Lpiv + (Jp & 1) * 80;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) wb_base[u][size_t(Jp) * wb_stride[u]] = wb_piv[u] ? pp[wb_l[u]] : sp[wb_l[u]];
+    if (blockIdx.x == 0 && tid < 36) a.Linv[size_t(Jp) * 36 + tid] = pp[36 + tid];
+  }
+  if (dbg) printf("band_cholesky cycles/step: prefetch+writeback %lld  panel %lld  barrier %lld  update %lld  barrier %lld\n",
                   tc[0] / ncp, tc[1] / ncp, tc[2] / ncp, tc[3] / ncp, tc[4] / ncp);
-  if (fail && tid == 0) st->chol_failed = 1;
+  if (wave == 3 && lane == 0 && fail) st->chol_failed = 1;
 }
 
 // Sred = S - YᵀY, one 16×16 lower tile per workgroup, 64-row chunks staged in LDS with register prefetch.
@@ -622,6 +680,158 @@ __global__ __launch_bounds__(256) void reduced_solve_reg_kernel(SolveArgs a) {
   if (dbg) printf("reduced_solve cycles/col: bcast-write %lld  barrier %lld  update %lld  store %lld | backward total %lld\n",
                   tph[0] / (m > 0 ? m : 1), tph[1] / (m > 0 ? m : 1), tph[2] / (m > 0 ? m : 1), tph[3] / (m > 0 ? m : 1),
                   (long long)__builtin_readcyclecounter() - t_fact);
+  if (tid == 0 && s_fail) st->chol_failed = 1;
+}
+
+// Panel variant for m+1 <= 64·RPL: the augmented reduced matrix lives in LDS (row-major, odd stride) and is
+// factored 16 columns at a time. The latency chain of a panel -- pivot, rsqrt, column scale, update of the
+// remaining panel columns -- runs inside ONE wave with no barrier and no branch: lane l keeps rows j0+l (+64)
+// of the panel in registers and the pivot-row values travel by v_readlane. A short last panel is factored
+// 16 wide as well: its surplus columns only ever feed themselves and are never read back. The rank-16
+// trailing update runs on the matrix cores, one 16×16 tile per wave and step: D -= L_I L_Cᵀ as four
+// v_mfma_f64_16x16x4_f64 (A = -L_I rows, B = L_C rows, one f64 per lane; C/D col = lane&15,
+// row = (lane>>4) + 4·reg). Two barriers per 16 columns instead of one per column.
+// Row m is the right-hand side, so the forward substitution comes for free; the backward substitution is an
+// axpy-form sweep on one wave with the factor rows prefetched four steps ahead.
+template <int RPL>
+__global__ __launch_bounds__(256) void reduced_solve_panel_kernel(SolveArgs a) {
+  LmState* st = a.st;
+  if (st->terminated) return;
+  extern __shared__ double lds[];
+  const int m = a.m, m1 = a.m + 1, n = a.n_s();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int LD = (16 * ((m1 + 15) / 16)) | 1;   // every 16-column panel stays inside its row
+  double* A = lds;                              // [m1][LD] lower triangle
+  double* dinv = lds + size_t(m1) * LD;         // [m + 16]
+  __shared__ int s_fail;
+  if (tid == 0) s_fail = 0;
+  for (int idx = tid; idx < m1 * m1; idx += 256) {
+    const double v = a.Spart[idx];
+    const int r = idx / m1, c = idx - r * m1;
+    if (c <= r) A[r * LD + c] = v;
+  }
+  __syncthreads();
+  const bool dbg = a.debug && tid == 0;
+  long long tph[4] = {0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
+#define PTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
+  for (int j0 = 0; j0 < m; j0 += 16) {
+    const int w = min(16, m - j0);
+    if (wave == 0) {
+      double av[RPL][16];
+      int row[RPL];
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        row[r] = j0 + lane + 64 * r;
+        const double* src = A + min(row[r], m) * LD + j0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) av[r][c] = src[c];
+      }
+      bool fail = false;
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        double pv = readlane_f64(av[0][jj], jj);
+        const bool bad = !(pv > 0.0) || !isfinite(pv);
+        fail = fail || (bad && jj < w);
+        pv = bad ? 1.0 : pv;
+        const double rs = rsqrt_nr(pv);
+        double l[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) { l[r] = av[r][jj] * rs; av[r][jj] = l[r]; }
+#pragma unroll
+        for (int c = jj + 1; c < 16; ++c) {
+          const double lc = readlane_f64(l[0], c);
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) av[r][c] -= l[r] * lc;
+        }
+        if (lane == jj) dinv[j0 + jj] = rs;
+      }
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        if (row[r] <= m) {
+          double* dst = A + row[r] * LD + j0;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) dst[c] = av[r][c];
+        }
+      }
+      if (fail && lane == 0) s_fail = 1;
+    }
+    PTICK(0)
+    __syncthreads();
+    PTICK(1)
+    // trailing update of rows/cols t0..m on the matrix cores
+    const int t0 = j0 + 16;
+    if (t0 < m1) {
+      const int nt = (m1 - t0 + 15) >> 4;
+      const int T = nt * (nt + 1) / 2;
+      const int lr = lane & 15, lk = lane >> 4;
+      for (int t = wave; t < T; t += 4) {
+        int I = 0, rem = t;
+        while (rem > I) { rem -= I + 1; ++I; }
+        const int C = rem;                                       // C <= I
+        const double* pa = A + min(t0 + 16 * I + lr, m) * LD + j0 + lk;
+        const double* pb = A + min(t0 + 16 * C + lr, m) * LD + j0 + lk;
+        double* pd[4];
+        f64x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pd[r] = A + min(t0 + 16 * I + lk + 4 * r, m) * LD + t0 + 16 * C + lr;
+          acc[r] = *pd[r];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * kk], pb[4 * kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (t0 + 16 * I + lk + 4 * r <= m) *pd[r] = acc[r];
+      }
+    }
+    __syncthreads();
+    PTICK(2)
+  }
+  // backward substitution Lᵀ y = z (row m), one wave, axpy form
+  if (wave == 0) {
+    constexpr int NV = RPL, PF = 4;
+    double acc[NV], bq[NV], dv[NV], ykeep[NV], ring[PF][NV];
+    int col[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int j = lane + 64 * u;
+      col[u] = min(j, m);
+      acc[u] = 0.0; ykeep[u] = 0.0;
+      bq[u] = A[size_t(m) * LD + col[u]];
+      dv[u] = dinv[min(j, m + 15)];
+    }
+    auto fetch = [&](int i, double v[NV]) {
+      const double* src = A + max(i, 0) * LD;
+#pragma unroll
+      for (int u = 0; u < NV; ++u) v[u] = src[col[u]];
+    };
+#pragma unroll
+    for (int f = 0; f < PF; ++f) fetch(m - 1 - f, ring[f]);
+    for (int i0 = m - 1; i0 >= 0; i0 -= PF) {
+#pragma unroll
+      for (int f = 0; f < PF; ++f) {
+        const int i = i0 - f;          // i < 0 in the last group: dummy step on clamped data, results discarded
+        double cur[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) cur[u] = (lane + 64 * u < i) ? ring[f][u] : 0.0;
+        fetch(i - PF, ring[f]);
+        double cand = 0.0;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) if (((i >> 6) & (NV - 1)) == u) cand = (bq[u] - acc[u]) * dv[u];
+        const double yi = readlane_f64(cand, i & 63);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+          acc[u] += cur[u] * yi;
+          ykeep[u] = (lane + 64 * u == i) ? yi : ykeep[u];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NV; ++u) if (lane + 64 * u < m) a.y[n + lane + 64 * u] = ykeep[u];
+  }
+  PTICK(3)
+  if (dbg) printf("reduced_solve_panel cycles: panels %lld  barrier %lld  trailing %lld  backward %lld\n", tph[0], tph[1], tph[2], tph[3]);
+#undef PTICK
   if (tid == 0 && s_fail) st->chol_failed = 1;
 }
 
@@ -896,7 +1106,7 @@ void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* block
 }
 constexpr int kBorderSlice = 16;   // border columns per workgroup of the banded factorisation
 size_t band_cholesky_lds_bytes(const SolveArgs& a) {
-  return size_t(a.k + 2) * (a.W() * 6 + kBorderSlice * 6) * sizeof(double);
+  return (size_t(a.k + 2) * (a.W() * 6 + kBorderSlice * 6 + 16) + 160) * sizeof(double);
 }
 size_t reduced_solve_lds_bytes(const SolveArgs& a) {
   const int m1 = a.m + 1;
@@ -913,6 +1123,8 @@ hipError_t configure_solve_kernels(size_t band_lds, size_t reduced_lds, size_t b
     if (e != hipSuccess) return e;
   }
   const int big = 150 * 1024;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&reduced_solve_panel_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&reduced_solve_panel_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
   for (const void* f : {reinterpret_cast<const void*>(&reduced_solve_reg_kernel<4, true>), reinterpret_cast<const void*>(&reduced_solve_reg_kernel<7, true>),
                         reinterpret_cast<const void*>(&reduced_solve_reg_kernel<10, true>), reinterpret_cast<const void*>(&reduced_solve_reg_kernel<13, true>)})
     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -935,7 +1147,11 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
   hipLaunchKernelGGL(band_cholesky_kernel, dim3(nwg), dim3(256), band_cholesky_lds_bytes(a), s, a, kBorderSlice);
   const int nt = (m1 + 15) / 16;
   hipLaunchKernelGGL(schur_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, a);
-  if (m1 <= 16 * 13) {
+  if (m1 <= 128) {
+    const size_t lds = (size_t(m1) * ((16 * ((m1 + 15) / 16)) | 1) + m1 + 32) * sizeof(double);
+    if (m1 <= 64) hipLaunchKernelGGL(reduced_solve_panel_kernel<1>, dim3(1), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(reduced_solve_panel_kernel<2>, dim3(1), dim3(256), lds, s, a);
+  } else if (m1 <= 16 * 13) {
     const int NT = m1 <= 64 ? 4 : (m1 <= 112 ? 7 : (m1 <= 160 ? 10 : 13));
     const int NP = 16 * NT;
     const size_t full = size_t(3 * NP + size_t(a.m + 1) * NP) * sizeof(double);
