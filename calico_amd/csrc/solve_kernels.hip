@@ -252,22 +252,44 @@ DEVI void chol6_and_inverse(const double* A /* [r*6+c], lower */, double L[6][6]
 
 // Bordered band Cholesky, blocked by control point (6 columns). Workgroup b factors the band (redundantly)
 // together with border rows [b·16, (b+1)·16); the window of k block columns lives in an LDS ring.
-// Step J:  panel X = A(:, J) L_JJ⁻ᵀ  |barrier|  trailing update A -= X Xᵀ  |barrier|.
-//  * Panel and trailing update run on the matrix cores (v_mfma_f64_16x16x4_f64, K = 6 padded to 8): rows of the
-//    window are cut into 16-row tiles (band rows 6..W-1, then the 16 border rows); a lane fetches ONE f64 per
-//    operand and k-chunk from LDS instead of whole rows, which is what bounded the scalar 2×2-tile version
-//    (LDS bandwidth: every thread re-read 4 rows per tile and the 21 entries of L⁻¹).
-//  * The latency chain -- 6×6 Cholesky with its six dependent rsqrt, then the triangular inverse -- is taken off
-//    the step by look-ahead: during the trailing update of step J, wave 3 alone applies step J's update to the
-//    NEXT pivot block, factors it and leaves L, L⁻¹ in LDS, while waves 0..2 update the rest of the window.
-//  * Global prefetches (two blocks ahead, in registers) and write-backs never stall the step: the barriers order
-//    LDS only (lds_barrier) and every streaming load is unconditional.
+// Step J:  panel X = A(:, J) L_JJ⁻ᵀ  |barrier|  trailing update A -= X Xᵀ  |barrier|, with one job per wave:
+//  wave 0   panel by forward substitution, one lane per row (band rows, border rows, and six identity rows whose
+//           solution is L_JJ⁻¹ for the back-substitution kernel); written out of place (Xbuf).
+//  wave 1-2 streaming: coalesced write-back of block column J-1 and the ring refill (block J+k; J+k+2 requested);
+//           global loads ride in registers for two steps, the barriers order LDS only, every load is unconditional.
+//  wave 0-2 trailing update on the matrix cores (v_mfma_f64_16x16x4_f64, K = 6 padded to 8): 16-row tiles, one f64
+//           per lane, operand and k-chunk -- the scalar 2×2-tile version was bound by LDS bandwidth.
+//  wave 3   the latency chain, one step ahead and alone: X₁ (the six panel rows under the pivot) from L_JJ kept in
+//           registers, the next pivot block minus X₁X₁ᵀ, its 6×6 Cholesky (six dependent rsqrt), publication of
+//           L_{J+1,J+1} -- touching only private scratch, never waiting for the panel.
+// One wave retires roughly one instruction every 5 clocks here, so the step is kept short by construction: every LDS
+// offset and predicate is computed once per thread before the sweep (masked operands read a zero word, masked
+// results go to a dump word, both inside each ring slot), divergent branches are avoided, and blocks past the end of
+// the band are streamed in as zeros so that the short windows at the end need no special cases.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-//  * One wave retires roughly one instruction every 5 clocks here, so the step is kept short by construction: every
-//    LDS offset and predicate is computed once per thread before the sweep (masked operands read a zero word, masked
-//    results go to a dump word, both inside each ring slot), and blocks past the end of the band are streamed in as
-//    zeros so that the short windows at the end need no special cases.
-constexpr int kSlotPad = 16;     // per ring slot: [0] zero word, [8] dump word
+constexpr int kSlotPad = 16;     // per ring slot: zero words [0, 8), dump words [8, 16)
+
+// Cholesky of a 6×6 block (lower, row-major 36) in every lane: L and the reciprocal diagonal. A non-positive or
+// non-finite pivot is not patched: it turns the factor into NaN/Inf and is reported through *dmin / the caller.
+DEVI void chol6(const double* A, double L[6][6], double dinv[6], double* dmin) {
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = A[j * 6 + j];
+#pragma unroll
+    for (int q = 0; q < j; ++q) d -= L[j][q] * L[j][q];
+    *dmin = fmin(*dmin, d);
+    const double inv = rsqrt_nr(d);
+    L[j][j] = d * inv; dinv[j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double v = A[i * 6 + j];
+#pragma unroll
+      for (int q = 0; q < j; ++q) v -= L[i][q] * L[j][q];
+      L[i][j] = v * inv;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs /* = kBorderSlice = 16 */) {
   LmState* st = a.st;
   if (st->terminated) return;
@@ -277,24 +299,27 @@ __global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs 
   const int nb = max(1, min(bs, m1 - j0));
   const int nband = W * 6;
   const int SLP = nband + bs * 6;   // payload of a ring slot: band block [W][6] + border [bs][6]
-  const int SL = SLP + kSlotPad;
-  const int ZERO = SLP, DUMP = SLP + 8;
+  const int ZERO = SLP, DUMP = SLP + 8, LINV = SLP + kSlotPad;   // LINV: 36 doubles, used in Xbuf only
+  const int SL = SLP + kSlotPad + 40;
   const int NSL = k + 2;            // active window (k) + two blocks in flight
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc16 = lane & 15, lk = lane >> 4;
   const int nelem = nband + nb * 6;
-  constexpr int NE = 2;             // elements per thread: (48*6 + 16*6) / 256
-  double* Lpiv = lds + NSL * SL;    // [2][80]: L (36), L⁻¹ (36), zero word (at 72), by step parity
-  for (int i = tid; i < NSL * SL + 160; i += 256) lds[i] = 0.0;
+  constexpr int NE = 3;             // streamed elements per thread of waves 1..2: 384 >= 48*6 + 16*6
+  double* Xbuf = lds + NSL * SL;    // [2][SL]: panel X (+ L⁻¹) of the current / previous step (slot layout), by step parity
+  double* Lpiv = Xbuf + 2 * SL;     // [3][48]: L (36), reciprocal diagonal (6), by step mod 3
+  double* W3 = Lpiv + 144;          // [80]: wave-3 scratch: X₁ (36), updated pivot block (36), dump (72..79)
+  for (int i = tid; i < (NSL + 2) * SL + 224; i += 256) lds[i] = 0.0;
   // ---- streaming loads / factor write-back descriptors (a thread without an element duplicates another's) ----
   int l_off[NE], wb_l[NE];
   bool wb_piv[NE];
   const double* g_base[NE];
   double* wb_base[NE];
   size_t g_stride[NE], wb_stride[NE];
+  const int stid = tid >= 64 && tid < 192 ? tid - 64 : 0;
 #pragma unroll
   for (int u = 0; u < NE; ++u) {
-    const int e = tid + 256 * u;
+    const int e = stid + 128 * u;
     auto describe = [&](int ee, int* lo, size_t* goff, size_t* stride, bool* isy) {
       if (ee < nband) { *lo = ee; *goff = size_t(ee); *stride = size_t(nband); *isy = false; }
       else { const int q = ee - nband; const int c = q / nb, j = q % nb; *lo = nband + j * 6 + c; *goff = size_t(c) * m1 + j0 + j; *stride = size_t(6) * m1; *isy = true; }
@@ -306,15 +331,22 @@ __global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs 
     const int ew = blockIdx.x == 0 ? e % nelem : nband + e % (nb * 6);   // write-back: workgroup 0 owns the band factor
     describe(ew, &wb_l[u], &goff, &wb_stride[u], &isy);
     wb_base[u] = (isy ? a.Y : a.Lb) + goff;
-    wb_piv[u] = ew < 36;                                                  // diagonal block: L comes from Lpiv, not from the slot
+    wb_piv[u] = ew < 36;                                                  // diagonal block: L comes from Lpiv, not from X
   }
   auto gload = [&](int J, double regs[NE]) {
     const int Jc = J < ncp ? J : ncp - 1;
 #pragma unroll
     for (int u = 0; u < NE; ++u) regs[u] = g_base[u][size_t(Jc) * g_stride[u]];
   };
-  // ---- MFMA tiles: 16-row tiles of the panel, band tiles 0..nbt-1 (window rows 6..), tile nbt = border slice ----
+  // ---- panel rows of wave 0: band rows, border rows, identity rows (-> L⁻¹), idle ----
   const int nbr = W - 6;
+  const int id_j = lane - (nbr + 16);                          // identity row index, valid in [0, 6)
+  const int p_src = lane < nbr ? (6 + lane) * 6 : (lane < nbr + 16 ? nband + (lane - nbr) * 6 : ZERO);
+  int p_dst[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c)
+    p_dst[c] = lane < nbr + 16 ? p_src + c : (id_j < 6 ? LINV + c * 6 + id_j : DUMP + c);    // X(id row j, c) = L⁻¹(c, j)
+  // ---- MFMA tiles of the trailing update: band tiles 0..nbt-1 (window rows 6..), tile nbt = border slice ----
   const int nbt = (nbr + 15) >> 4;
   const int n_bb = nbt * (nbt + 1) / 2, n_upd = n_bb + nbt;
   // slot-relative offset of X(row i of tile rt, q); ZERO when outside
@@ -324,21 +356,7 @@ __global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs 
     const int wr = 16 * rt + i;
     return wr < nbr ? (6 + wr) * 6 + q : ZERO;
   };
-  // panel (wave <= nbt owns row tile `wave`)
-  int pa_off[2], pb_off[2], pd_off[4];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    const int q = 4 * kk + lk;
-    pa_off[kk] = x_off(wave <= nbt ? wave : nbt, lc16, q);
-    pb_off[kk] = (lc16 < 6 && q < 6) ? 36 + lc16 * 6 + q : 72;            // B(k = q, j = lc16) = L⁻¹(j, q)
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int o = x_off(wave <= nbt ? wave : nbt, lk + 4 * r, lc16 < 6 ? lc16 : 6);
-    pd_off[r] = o == ZERO ? DUMP : o;
-  }
-  // trailing update (waves 0..2: tiles t = wave, wave + 3, wave + 6)
-  bool up_on[3];
+  bool up_on[3];                   // waves 0..2: tiles t = wave, wave + 3, wave + 6
   int ua_off[3][2], ub_off[3][2], ut_off[3][4], ut_bc[3];
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
@@ -365,117 +383,167 @@ __global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs 
       ut_off[u][r] = ok ? lo + ca : DUMP;
     }
   }
-  // look-ahead (wave 3): lane (r, c) of the next pivot block
+  // wave 3: lane (r, c) of the 6×6 blocks it works on; idle lanes compute on entry (0, 0) and write to the dump words
   const int pr = lane < 36 ? lane / 6 : 0, pcn = lane < 36 ? lane % 6 : 0;
-  const int pv_off = (lane < 36 && pcn <= pr) ? pr * 6 + pcn : DUMP;
+  const int w3_p = lane < 36 ? 36 + lane : 72;
+  const int w3_row = lane < 6 ? lane : 0;                      // X₁ row solved by this lane
+  const int w3_xdst = lane < 6 ? lane * 6 : 72;
   __syncthreads();
   double regs[NE], regs2[NE];
   for (int J = 0; J < k; ++J) {
     gload(J, regs);
     double* s0 = lds + (J % NSL) * SL;
+    if (wave == 1 || wave == 2) {
 #pragma unroll
-    for (int u = 0; u < NE; ++u) s0[l_off[u]] = J < ncp ? regs[u] : 0.0;
+      for (int u = 0; u < NE; ++u) s0[l_off[u]] = J < ncp ? regs[u] : 0.0;
+    }
   }
   gload(k, regs);       // blocks k and k+1 ride in registers
   gload(k + 1, regs2);
-  bool fail = false;
   long long tk0 = 0, tc[5] = {0, 0, 0, 0, 0};
-  const bool dbg = a.debug && blockIdx.x == 0 && tid == 0;
+  const bool dbg = a.debug && blockIdx.x == 0 && (lane == 0);
 #define TICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tc[i] += t_ - tk0; tk0 = t_; }
-  // pivot-block factorisation by wave 3: every lane factors redundantly, lanes < 36 publish one entry each
-  auto factor_pivot = [&](const double* blk, double* dst) {
-    double L[6][6], Li[6][6];
-    chol6_and_inverse(blk, L, Li, &fail);
-    double lv = 0.0, iv = 0.0;
+  // wave 3 keeps the current pivot factor in registers
+  double Lc[6][6], dinv_c[6], dmin = 1.0;
+  auto publish = [&](double* dst) {
+    if (lane == 0) {
 #pragma unroll
-    for (int rr = 0; rr < 6; ++rr)
+      for (int rr = 0; rr < 6; ++rr)
 #pragma unroll
-      for (int cc = 0; cc <= rr; ++cc) { const bool hit = rr == pr && cc == pcn; lv = hit ? L[rr][cc] : lv; iv = hit ? Li[rr][cc] : iv; }
-    if (lane < 36) { dst[lane] = lv; dst[36 + lane] = iv; }
+        for (int cc = 0; cc <= rr; ++cc) dst[rr * 6 + cc] = Lc[rr][cc];
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) dst[36 + cc] = dinv_c[cc];
+    }
   };
+  // forward substitution x Lᵀ = a with the factor in registers / in LDS
   __syncthreads();
-  if (wave == 3) factor_pivot(lds, Lpiv);
+  if (wave == 3) { chol6(lds, Lc, dinv_c, &dmin); publish(Lpiv); }
   __syncthreads();
-  int Jm = 0;                                   // J mod NSL
+  int Jm = 0, J3 = 0;                           // J mod NSL, J mod 3
   for (int J = 0; J < ncp; ++J) {
     double* sj = lds + Jm * SL;
-    double* piv = Lpiv + (J & 1) * 80;
+    double* xb = Xbuf + (J & 1) * SL;
+    const double* piv = Lpiv + J3 * 48;
+    double* piv_next = Lpiv + (J3 == 2 ? 0 : J3 + 1) * 48;
+    const double* nxt = lds + (Jm + 1 < NSL ? Jm + 1 : 0) * SL;
     if (dbg) tk0 = __builtin_readcyclecounter();
-    {
-      // coalesced write-back of block column J-1 (panel X from its slot, L from Lpiv), one step late
-      const int Jp = J > 0 ? J - 1 : 0;
-      const double* sp = lds + (Jm > 0 ? Jm - 1 : NSL - 1) * SL;
-      const double* pp = Lpiv + ((J & 1) ^ 1) * 80;
+    if (wave == 3) {
+      // (3a) X₁ = A₁ L⁻ᵀ (rows 6..11 of block column J; lane r < 6 solves row r), then the pivot block of column
+      //      J+1 minus X₁X₁ᵀ (lane (r, c))
+      const double* a1 = sj + (6 + w3_row) * 6;
+      double x[6];
 #pragma unroll
-      for (int u = 0; u < NE; ++u) {
-        const double v = wb_piv[u] ? pp[wb_l[u]] : sp[wb_l[u]];
-        if (J > 0) wb_base[u][size_t(Jp) * wb_stride[u]] = v;
+      for (int c = 0; c < 6; ++c) {
+        double v = a1[c];
+#pragma unroll
+        for (int q = 0; q < c; ++q) v -= x[q] * Lc[c][q];
+        x[c] = v * dinv_c[c];
       }
-      if (J > 0 && blockIdx.x == 0 && tid < 36) a.Linv[size_t(Jp) * 36 + tid] = pp[36 + tid];
-      // block J+k enters the ring (zeros past the end of the band), block J+k+2 is requested
+#pragma unroll
+      for (int c = 0; c < 6; ++c) W3[w3_xdst + c] = x[c];      // idle lanes: dump words 72..77
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // one wave: the writes above are visible to the reads below
+      const double* xr = W3 + pr * 6;
+      const double* xc = W3 + pcn * 6;
+      double d = 0.0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) d += xr[q] * xc[q];
+      W3[w3_p] = nxt[pr * 6 + pcn] - d;
+      TICK(0)
+      TICK(1)
+    } else if (wave == 0) {
+      // (1) panel by forward substitution: x_c = (a_c - Σ_{q<c} x_q L(c, q)) / L(c, c); lane = row
+      double Lp[6][6], dv[6];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < rr; ++cc) Lp[rr][cc] = piv[rr * 6 + cc];
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) dv[cc] = piv[36 + cc];
+      const double* ar = sj + p_src;
+      double x[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double v = ar[c] + (c == id_j ? 1.0 : 0.0);
+#pragma unroll
+        for (int q = 0; q < c; ++q) v -= x[q] * Lp[c][q];
+        x[c] = v * dv[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) xb[p_dst[c]] = x[c];
+      TICK(0)
+      TICK(1)
+    } else {
+      // (2a) coalesced write-back of block column J-1 (panel X and L⁻¹ from Xbuf, L from Lpiv), one step late
+      const int Jp = J > 0 ? J - 1 : 0;
+      const double* sp = Xbuf + ((J & 1) ^ 1) * SL;
+      const double* pp = Lpiv + (J3 == 0 ? 2 : J3 - 1) * 48;
+      if (J > 0) {
+#pragma unroll
+        for (int u = 0; u < NE; ++u) wb_base[u][size_t(Jp) * wb_stride[u]] = wb_piv[u] ? pp[wb_l[u]] : sp[wb_l[u]];
+        if (blockIdx.x == 0 && stid < 36) a.Linv[size_t(Jp) * 36 + stid] = sp[LINV + stid];
+      }
+      // (2b) block J+k enters the ring (zeros past the end of the band), block J+k+2 is requested
       int sk = Jm + k; sk = sk >= NSL ? sk - NSL : sk;
       double* sn = lds + sk * SL;
       const bool on = J + k < ncp;
 #pragma unroll
       for (int u = 0; u < NE; ++u) { sn[l_off[u]] = on ? regs[u] : 0.0; regs[u] = regs2[u]; }
       gload(J + k + 2, regs2);
+      TICK(0)
+      TICK(1)
     }
-    TICK(0)
-    // (1) panel on the matrix cores: X = A · L⁻ᵀ, one 16-row tile per wave (nbt <= 3). No inner loops around the
-    //     MFMA code: a loop makes the waitcnt pass drain vmcnt in its preheader, i.e. wait for this step's prefetch.
-    if (wave <= nbt) {
-      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sj[pa_off[kk]], piv[pb_off[kk]], acc, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sj[pd_off[r]] = acc[r];
-    }
-    TICK(1)
     lds_barrier();
     TICK(2)
     if (wave == 3) {
-      // (2a) look-ahead: finish the next pivot block (rows/cols 6..11 of the window) and factor it
-      if (J + 1 < ncp) {
-        double* nxt = lds + (Jm + 1 < NSL ? Jm + 1 : 0) * SL;
-        double d = 0.0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) d += sj[(6 + pr) * 6 + q] * sj[(6 + pcn) * 6 + q];
-        nxt[pv_off] -= d;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave: LDS writes above are visible to the reads below
-        factor_pivot(nxt, Lpiv + ((J & 1) ^ 1) * 80);
-      }
+      // (3b) factor the next pivot block and publish it one step ahead
+      if (J + 1 < ncp) { chol6(W3 + 36, Lc, dinv_c, &dmin); publish(piv_next); }
     } else {
-      // (2b) trailing update of the rest of the window on the matrix cores: D(R, C) -= X_R X_Cᵀ
+      // (2) trailing update of the rest of the window on the matrix cores: D(R, C) -= X_R X_Cᵀ; all LDS reads first
+      f64x4 acc[3];
+      double* tb[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        int sidx = Jm + ut_bc[u]; sidx = sidx >= NSL ? sidx - NSL : sidx;
+        tb[u] = lds + sidx * SL;
+        if (!up_on[u]) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[u][r] = tb[u][ut_off[u][r]];
+      }
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         if (!up_on[u]) continue;
-        int sidx = Jm + ut_bc[u]; sidx = sidx >= NSL ? sidx - NSL : sidx;
-        double* tb = lds + sidx * SL;
-        f64x4 acc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = tb[ut_off[u][r]];
+        for (int kk = 0; kk < 2; ++kk) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xb[ua_off[u][kk]], xb[ub_off[u][kk]], acc[u], 0, 0, 0);
+      }
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-sj[ua_off[u][kk]], sj[ub_off[u][kk]], acc, 0, 0, 0);
+      for (int u = 0; u < 3; ++u) {
+        if (!up_on[u]) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tb[ut_off[u][r]] = acc[r];
+        for (int r = 0; r < 4; ++r) tb[u][ut_off[u][r]] = acc[u][r];
       }
     }
     TICK(3)
     lds_barrier();
     TICK(4)
     Jm = Jm + 1 < NSL ? Jm + 1 : 0;
+    J3 = J3 == 2 ? 0 : J3 + 1;
   }
-  {
+  if (wave == 1 || wave == 2) {
     const int Jp = ncp - 1;
-    const double* sp = lds + (Jm > 0 ? Jm - 1 : NSL - 1) * SL;
-    const double* pp = Lpiv + (Jp & 1) * 80;
+    const double* sp = Xbuf + (Jp & 1) * SL;
+    const double* pp = Lpiv + (Jp % 3) * 48;
 #pragma unroll
     for (int u = 0; u < NE; ++u) wb_base[u][size_t(Jp) * wb_stride[u]] = wb_piv[u] ? pp[wb_l[u]] : sp[wb_l[u]];
-    if (blockIdx.x == 0 && tid < 36) a.Linv[size_t(Jp) * 36 + tid] = pp[36 + tid];
+    if (blockIdx.x == 0 && stid < 36) a.Linv[size_t(Jp) * 36 + stid] = sp[LINV + stid];
   }
-  if (dbg) printf("band_cholesky cycles/step: prefetch+writeback %lld  panel %lld  barrier %lld  update %lld  barrier %lld\n",
-                  tc[0] / ncp, tc[1] / ncp, tc[2] / ncp, tc[3] / ncp, tc[4] / ncp);
-  if (wave == 3 && lane == 0 && fail) st->chol_failed = 1;
+  if (dbg) printf("band_cholesky cycles/step wave %d (0: panel | update; 1: stream | update; 3: X1+pivot update | factor+publish): A %lld  barrier %lld  B %lld  barrier %lld\n",
+                  wave, (tc[0] + tc[1]) / ncp, tc[2] / ncp, tc[3] / ncp, tc[4] / ncp);
+  if (wave == 3 && lane == 0) {
+    double chk = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) chk += dinv_c[c];
+    if (!(dmin > 0.0) || !isfinite(chk)) st->chol_failed = 1;
+  }
 }
 
 // Sred = S - YᵀY, one 16×16 lower tile per workgroup, 64-row chunks staged in LDS with register prefetch.
@@ -1106,7 +1174,7 @@ void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* block
 }
 constexpr int kBorderSlice = 16;   // border columns per workgroup of the banded factorisation
 size_t band_cholesky_lds_bytes(const SolveArgs& a) {
-  return (size_t(a.k + 2) * (a.W() * 6 + kBorderSlice * 6 + 16) + 160) * sizeof(double);
+  return (size_t(a.k + 4) * (a.W() * 6 + kBorderSlice * 6 + 16 + 40) + 224) * sizeof(double);
 }
 size_t reduced_solve_lds_bytes(const SolveArgs& a) {
   const int m1 = a.m + 1;
