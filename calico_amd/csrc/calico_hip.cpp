@@ -32,6 +32,7 @@ namespace cal {
 // ---- kernels (eval_kernels.hip / solve_kernels.hip) -------------------------
 void launch_eval(const EvalArgs& a, bool jac, hipStream_t stream);
 void launch_eval_frames(const EvalArgs& a, hipStream_t stream);
+void launch_eval_jacobian(const EvalArgs& a, hipStream_t stream);
 hipError_t configure_eval_kernels(size_t max_lds_bytes);
 
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
@@ -149,7 +150,7 @@ struct calico_problem {
   int rank = 0, world = 1;
 
   // flattened problem
-  int n_cp = 0, m = 0, n_amb = 0, n_eff = 0, n_items = 0, n_items_all = 0, lds_cols = 0;
+  int n_cp = 0, m = 0, n_amb = 0, n_eff = 0, n_items = 0, n_items_all = 0, lds_cols = 0, row_pad = kRowPad;
   int64_t n_obs = 0;
   size_t partial_doubles = 0;
   std::vector<int> eff_to_tan;
@@ -223,7 +224,7 @@ EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool
   a.m0 = p->d_m0.p; a.m1 = p->d_m1.p; a.m2 = p->d_m2.p; a.stamp = p->d_stamp.p; a.point_off = p->d_point_off.p;
   a.partials = p->d_partials.p; a.item_cost = p->d_partials.p + p->partial_doubles;
   a.res_out = want_res ? p->d_res.p : nullptr; a.valid_out = want_res ? p->d_valid.p : nullptr;
-  a.order = p->order; a.n_items = p->n_items; a.lds_cols = p->lds_cols; a.apply_loss = apply_loss;
+  a.order = p->order; a.n_items = p->n_items; a.lds_cols = p->lds_cols; a.row_pad = p->row_pad; a.pad3 = 0; a.apply_loss = apply_loss;
   a.st = nullptr; a.need_flag = 0; a.cost_index_base = 0;
   a.fitems = p->d_fitems.p; a.n_fitems = p->n_fitems;
   return a;
@@ -353,7 +354,9 @@ int finalize(calico_problem* p) {
     while (e < n_obs && keys[e].layout == keys[q].layout && keys[e].seg == keys[q].seg) ++e;
     const LayoutDev& L = layouts[keys[q].layout];
     const int dim = p->sensors[L.sensor].dim();
-    const int chunk = kRowsPerItem / dim;
+    // cameras fill the 128 staged rows; an IMU block is a long single-lane computation and there are few of them, so
+    // they are cut finer: more waves in flight, shorter JᵀJ stage, smaller LDS footprint next to the camera frames
+    const int chunk = dim == 2 ? kRowsPerItem / 2 : 16;
     max_cols = std::max(max_cols, L.ncols + 1);
     for (int64_t b = q; b < e; b += chunk) {
       ItemDev it;
@@ -429,8 +432,19 @@ int finalize(calico_problem* p) {
   p->partial_doubles = poff;
   if (poff + 2 * size_t(std::max(p->n_items, p->n_fitems + p->n_jac_items)) >= size_t(0x7fffffff))
     return p->set_error(CALICO_UNIMPLEMENTED, "problem too large for 32-bit gather indices");
-  p->lds_cols = (max_cols + 3) & ~3;
-  if (size_t(p->lds_cols) * kRowPad * sizeof(double) > kMaxLds)
+  {
+    // LDS staging of the generic Jacobian kernel: sized by the items that actually go through it
+    int jc = 4, jr = 2;
+    for (const ItemDev& it : p->h_jac_items) {
+      const LayoutDev& L = layouts[size_t(it.layout)];
+      jc = std::max(jc, L.ncols + 1);
+      jr = std::max(jr, p->sensors[size_t(L.sensor)].dim() * it.obs_count);
+    }
+    (void)max_cols;
+    p->lds_cols = (jc + 3) & ~3;
+    p->row_pad = (jr + 1) | 1;
+  }
+  if (size_t(p->lds_cols) * p->row_pad * sizeof(double) > kMaxLds)
     return p->set_error(CALICO_UNIMPLEMENTED, "too many Jacobian columns per residual block for the LDS staging area");
   // ---- gather lists ----
   SolveArgs sa; sa.n_cp = n_cp; sa.k = k; sa.m = m; sa.debug = 0;
@@ -519,7 +533,7 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_state.alloc(1)); HIP_TRY(p, p->d_log.alloc(kLogCap));
   if (!p->h_state) HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LmState)));
   // kernel attributes
-  HIP_TRY(p, configure_eval_kernels(size_t(p->lds_cols) * kRowPad * sizeof(double)));
+  HIP_TRY(p, configure_eval_kernels(size_t(p->lds_cols) * p->row_pad * sizeof(double)));
   sa = make_solve_args(p);
   const size_t band_lds = band_cholesky_lds_bytes(sa);
   if (band_lds > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "spline order too high for the banded factorisation window");
@@ -557,9 +571,13 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag) {
   p->timer.begin(0, p->stream);
   EvalArgs ea = make_eval_args(p, p->d_x.p, 1, false);
   ea.st = st; ea.need_flag = need_flag;
-  launch_eval_frames(ea, p->stream);                      // camera frames: item-cost slots [0, n_fitems)
   ea.items = p->d_jac_items.p; ea.n_items = p->n_jac_items; ea.cost_index_base = p->n_fitems;
-  launch_eval(ea, true, p->stream);                       // everything else
+  if (p->order == 6 && p->n_fitems > 0) {
+    launch_eval_jacobian(ea, p->stream);                  // camera frames (item-cost slots [0, n_fitems)) + everything else
+  } else {
+    launch_eval_frames(ea, p->stream);
+    launch_eval(ea, true, p->stream);
+  }
   p->timer.end(p->stream);
   p->timer.begin(1, p->stream);
   launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->d_out_fat.p,

@@ -54,9 +54,9 @@ DEV void spline_eval(const ItemCtx& c, double t, double W[ND][kMaxOrder], double
 }
 
 struct RowSink {
-  double* J;  // LDS, column-major [col][kRowPad]
-  int row0;
-  DEV void put(int col, int r, double v) const { J[col * kRowPad + row0 + r] = v; }
+  double* J;  // LDS, column-major [col][pad]
+  int row0, pad;
+  DEV void put(int col, int r, double v) const { J[col * pad + row0 + r] = v; }
 };
 
 // ---------------------------------------------------------------------------
@@ -516,17 +516,64 @@ DEV double wave_sum(double v) {
   return v;
 }
 
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+// [J r]ᵀ[J r] of the staged rows (column-major, stride pad) -> upper triangle of the n1×n1 item block, NT = ceil(n1/16).
+template <int NT>
+__device__ __attribute__((noinline)) void stage_b_mfma(const double* lds, int pad, int nrows, int n1, double* out) {
+  const int lane = threadIdx.x, lc16 = lane & 15, lk = lane >> 4;
+  f64x4 acc[NT][NT];
+#pragma unroll
+  for (int I = 0; I < NT; ++I)
+#pragma unroll
+    for (int J = I; J < NT; ++J) acc[I][J] = f64x4{0.0, 0.0, 0.0, 0.0};
+  // Loads are unconditional on clamped (row, column) -- always a valid staged value -- and masked by a 0/1 factor:
+  // a conditional load splits the loop body into blocks, and the accumulators then bounce between VGPRs and AGPRs
+  // (8 copies per tile and k-step).
+  const double* cp[NT];
+  double cm[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int c = 16 * t + lc16;
+    cm[t] = c < n1 ? 1.0 : 0.0;
+    cp[t] = lds + (c < n1 ? c : n1 - 1) * pad;
+  }
+  for (int r0 = 0; r0 < nrows; r0 += 4) {
+    const int r = r0 + lk;
+    const int rc = r < nrows ? r : nrows - 1;
+    const double rm = r < nrows ? 1.0 : 0.0;
+    double op[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) op[t] = cp[t][rc] * (cm[t] * rm);
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+      for (int J = I; J < NT; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I], op[J], acc[I][J], 0, 0, 0);
+  }
+  // C/D layout: col = lane & 15, row = (lane >> 4) + 4·reg
+#pragma unroll
+  for (int I = 0; I < NT; ++I)
+#pragma unroll
+    for (int J = I; J < NT; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = 16 * I + lk + 4 * r, gj = 16 * J + lc16;
+        if (gi <= gj && gj < n1) out[size_t(gi) * n1 + gj] = acc[I][J][r];
+      }
+}
+
 // ---------------------------------------------------------------------------
 // The evaluation kernel. JAC: stage Jacobian rows and form the item's
 // [JᵀJ | Jᵀr] block; !JAC: residuals / cost only.
 // grid = n_items, block = 64 (one wave).
 // ---------------------------------------------------------------------------
 template <bool JAC, int KT>
-__global__ __launch_bounds__(64) void eval_items_kernel(EvalArgs a) {
-  extern __shared__ double lds[];
+DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds) {
   if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
-  const int item_id = blockIdx.x;
   const int lane = threadIdx.x;
+  const int row_pad = a.row_pad;
+  const bool dbg = JAC && a.debug && (item_id == 3 || item_id == a.n_items - 2) && lane == 0;
+  long long tph[4] = {0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
+#define ITICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   const ItemDev it = a.items[item_id];
   const LayoutDev& L = a.layouts[it.layout];
   const SensorDev& S = a.sensors[L.sensor];
@@ -540,17 +587,15 @@ __global__ __launch_bounds__(64) void eval_items_kernel(EvalArgs a) {
   const int ncols = L.ncols;           // Jacobian columns; column ncols holds the residual
   const int cp4 = (ncols + 1 + 3) & ~3;
   const int nrows = dim * it.obs_count;
-  if constexpr (JAC) {
-    // zero the staging area (inactive lanes / padding columns contribute 0)
-    for (int i = lane; i < cp4 * kRowPad; i += 64) lds[i] = 0.0;
-    __syncthreads();
-  }
+  // (no zeroing of the staging area: every active lane writes all columns of its rows, and stage B masks the
+  //  rows / columns beyond the item)
+  ITICK(0)
   const bool active = lane < it.obs_count;
   const int o = it.obs_begin + lane;
   double res[3] = {0.0, 0.0, 0.0};
   double cost = 0.0;
   bool ok = true;
-  RowSink sink; sink.J = lds; sink.row0 = dim * lane;
+  RowSink sink; sink.J = lds; sink.row0 = dim * lane; sink.pad = row_pad;
   if (active) {
     const double st = a.stamp[o];
     if (S.kind == 0) {
@@ -567,6 +612,7 @@ __global__ __launch_bounds__(64) void eval_items_kernel(EvalArgs a) {
       a.valid_out[o] = ok ? 1 : 0;
     }
   }
+  ITICK(1)
   const double item_cost = wave_sum(cost);
   const double n_invalid = wave_sum((active && !ok) ? 1.0 : 0.0);
   if (lane == 0) { a.item_cost[2 * (a.cost_index_base + item_id)] = item_cost; a.item_cost[2 * (a.cost_index_base + item_id) + 1] = n_invalid; }
@@ -580,41 +626,21 @@ __global__ __launch_bounds__(64) void eval_items_kernel(EvalArgs a) {
       for (int r = 0; r < 3; ++r) if (r < dim) sink.put(ncols, r, res[r]);
     }
     __syncthreads();
-    // Stage B: P = [J r]ᵀ [J r], upper 4×4 tiles.
-    const int nt = cp4 >> 2;
-    const int ntiles = nt * (nt + 1) / 2;
+    // Stage B: P = [J r]ᵀ [J r] on the matrix cores, upper 16×16 tiles (same scheme as the frame kernel: operand
+    // element (col = 16t + (lane & 15), row = r0 + (lane >> 4)) serves as A of tile row t and as B of tile column t).
     const int n1 = ncols + 1;
     double* out = a.partials + it.partial_off;
-    for (int tile = lane; tile < ntiles; tile += 64) {
-      // tile index -> (ti <= tj)
-      int ti = 0, rem = tile;
-      while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
-      const int tj = ti + rem;
-      const double* ca = lds + (4 * ti) * kRowPad;
-      const double* cb = lds + (4 * tj) * kRowPad;
-      double acc[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-      for (int r = 0; r < nrows; ++r) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { av[i] = ca[i * kRowPad + r]; bv[i] = cb[i * kRowPad + r]; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int gi = 4 * ti + i, gj = 4 * tj + j;
-          if (gi < n1 && gj < n1 && gi <= gj) out[size_t(gi) * n1 + gj] = acc[i][j];
-        }
+    switch ((n1 + 15) >> 4) {
+      case 1: stage_b_mfma<1>(lds, row_pad, nrows, n1, out); break;
+      case 2: stage_b_mfma<2>(lds, row_pad, nrows, n1, out); break;
+      case 3: stage_b_mfma<3>(lds, row_pad, nrows, n1, out); break;
+      case 4: stage_b_mfma<4>(lds, row_pad, nrows, n1, out); break;
+      default: stage_b_mfma<5>(lds, row_pad, nrows, n1, out); break;
     }
+    ITICK(2)
+    if (dbg) printf("eval_items cycles (kind %d, %d obs, %d cols, pad %d): setup+zero %lld  stage A %lld  stage B %lld\n", S.kind, it.obs_count, ncols, row_pad, tph[0], tph[1], tph[2]);
   }
+#undef ITICK
 }
 
 // ---------------------------------------------------------------------------
@@ -633,7 +659,6 @@ __global__ __launch_bounds__(64) void eval_items_kernel(EvalArgs a) {
 constexpr int kMaxPrim = 32;   // 6 + 11 + 3 + 3 + 3 + 3 + r = 30, padded to two 16-wide MFMA tiles
 constexpr int kFramePad = 132; // row stride of a staged prim column: ≡ 4 (mod 32) spreads the MFMA operand read over all banks
 constexpr int kMaxLocalCols = 96;
-typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 template <int MODEL>
 DEV bool frame_camera_block(const SensorDev& S, const LayoutDev& L, const double* intr, const M3& R_rc, const M3& R_rw,
@@ -707,14 +732,13 @@ DEV bool frame_camera_block(const SensorDev& S, const LayoutDev& L, const double
   return true;
 }
 
-__global__ __launch_bounds__(64) void eval_frames_kernel(EvalArgs a) {
-  extern __shared__ double lds[];
+DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
   const int lane = threadIdx.x;
-  const bool dbg = a.debug && blockIdx.x == 7 && lane == 0;
+  const bool dbg = a.debug && fidx == 7 && lane == 0;
   long long tph[6] = {0, 0, 0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define FTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
-  const FrameItemDev it = a.fitems[blockIdx.x];
+  const FrameItemDev it = a.fitems[fidx];
   const LayoutDev& L = a.layouts[it.layout];
   const SensorDev& S = a.sensors[L.sensor];
   constexpr int K = 6;
@@ -864,7 +888,7 @@ __global__ __launch_bounds__(64) void eval_frames_kernel(EvalArgs a) {
   }
   const double item_cost = wave_sum(cost);
   const double n_invalid = wave_sum(n_bad);
-  if (lane == 0) { a.item_cost[2 * blockIdx.x] = item_cost; a.item_cost[2 * blockIdx.x + 1] = n_invalid; }
+  if (lane == 0) { a.item_cost[2 * fidx] = item_cost; a.item_cost[2 * fidx + 1] = n_invalid; }
   // ---- M to LDS (full symmetric; C/D layout: col = lane & 15, row = (lane >> 4) + 4·reg), latency row Q ----
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -922,16 +946,43 @@ __global__ __launch_bounds__(64) void eval_frames_kernel(EvalArgs a) {
 #undef FTICK
 }
 
+template <bool JAC, int KT>
+__global__ __launch_bounds__(64) void eval_items_kernel(EvalArgs a) {
+  extern __shared__ double lds[];
+  eval_items_body<JAC, KT>(a, blockIdx.x, lds);
+}
+
+__global__ __launch_bounds__(64) void eval_frames_kernel(EvalArgs a) {
+  extern __shared__ double lds[];
+  eval_frames_body(a, blockIdx.x, lds);
+}
+
+// Whole Jacobian pass in one launch (spline order 6): the generic items (IMU cells; they are few and each is a long
+// single-wave computation, so they go first) and the camera frames run side by side instead of back to back.
+__global__ __launch_bounds__(64) void eval_jacobian_kernel(EvalArgs a) {
+  extern __shared__ double lds[];
+  if (int(blockIdx.x) < a.n_items) eval_items_body<true, 6>(a, blockIdx.x, lds);
+  else eval_frames_body(a, blockIdx.x - a.n_items, lds);
+}
+
 size_t frame_lds_bytes() { return (size_t(kMaxPrim) * kFramePad + size_t(kMaxPrim + 1) * (kMaxPrim + 1) + kMaxLocalCols + kMaxLocalCols / 2) * sizeof(double); }
 void launch_eval_frames(const EvalArgs& a, hipStream_t stream) {
   if (a.n_fitems == 0) return;
   hipLaunchKernelGGL(eval_frames_kernel, dim3(a.n_fitems), dim3(64), frame_lds_bytes(), stream, a);
 }
 
+// items (a.items / a.n_items, cost slots from a.cost_index_base) and frames (a.fitems / a.n_fitems) together
+void launch_eval_jacobian(const EvalArgs& a, hipStream_t stream) {
+  if (a.n_items + a.n_fitems == 0) return;
+  size_t lds = size_t(a.lds_cols) * a.row_pad * sizeof(double);
+  if (lds < frame_lds_bytes()) lds = frame_lds_bytes();
+  hipLaunchKernelGGL(eval_jacobian_kernel, dim3(a.n_items + a.n_fitems), dim3(64), lds, stream, a);
+}
+
 void launch_eval(const EvalArgs& a, bool jac, hipStream_t stream) {
   if (a.n_items == 0) return;
   if (jac) {
-    const size_t lds = size_t(a.lds_cols) * kRowPad * sizeof(double);
+    const size_t lds = size_t(a.lds_cols) * a.row_pad * sizeof(double);
     if (a.order == 6) hipLaunchKernelGGL((eval_items_kernel<true, 6>), dim3(a.n_items), dim3(64), lds, stream, a);
     else hipLaunchKernelGGL((eval_items_kernel<true, 0>), dim3(a.n_items), dim3(64), lds, stream, a);
   } else {
@@ -943,6 +994,9 @@ void launch_eval(const EvalArgs& a, bool jac, hipStream_t stream) {
 hipError_t configure_eval_kernels(size_t max_lds_bytes) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_frames_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(frame_lds_bytes()));
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_jacobian_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          int(max_lds_bytes > frame_lds_bytes() ? max_lds_bytes : frame_lds_bytes()));
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_items_kernel<true, 6>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, int(max_lds_bytes));

@@ -17,7 +17,7 @@
 namespace cal {
 
 constexpr int kRowsPerItem = 128;   // LDS rows staged per work item (64 camera obs × 2)
-constexpr int kRowPad = 129;        // row stride (doubles) of a staged Jacobian column
+constexpr int kRowPad = 129;        // largest row stride (doubles) of a staged Jacobian column
 
 struct SensorDev {
   int kind, model, K, loss;
@@ -69,6 +69,7 @@ struct EvalArgs {
   int need_flag, cost_index_base;
   const FrameItemDev* fitems;
   int n_fitems, debug;   // debug: CALICO_KERNEL_TIMING cycle print-outs
+  int row_pad, pad3;     // row stride (doubles) of a staged Jacobian column: max rows per item + 1, odd
 };
 
 // LM state kept on the device; the control kernel is its only writer.

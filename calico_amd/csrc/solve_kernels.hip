@@ -290,7 +290,9 @@ DEVI void chol6(const double* A, double L[6][6], double dinv[6], double* dmin) {
   }
 }
 
-__global__ __launch_bounds__(256) void band_cholesky_kernel(SolveArgs a, int bs /* = kBorderSlice = 16 */) {
+// (amdgpu_waves_per_eu(2): a 256-VGPR budget makes the compiler pick the VGPR form of the MFMAs; with the default
+//  512-register budget it selects the AGPR form and copies every accumulator tile in and out.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void band_cholesky_kernel(SolveArgs a, int bs /* = kBorderSlice = 16 */) {
   LmState* st = a.st;
   if (st->terminated) return;
   extern __shared__ double lds[];
@@ -762,7 +764,7 @@ __global__ __launch_bounds__(256) void reduced_solve_reg_kernel(SolveArgs a) {
 // Row m is the right-hand side, so the forward substitution comes for free; the backward substitution is an
 // axpy-form sweep on one wave with the factor rows prefetched four steps ahead.
 template <int RPL>
-__global__ __launch_bounds__(256) void reduced_solve_panel_kernel(SolveArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void reduced_solve_panel_kernel(SolveArgs a) {
   LmState* st = a.st;
   if (st->terminated) return;
   extern __shared__ double lds[];
