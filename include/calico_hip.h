@@ -262,7 +262,9 @@ int32_t calico_problem_set_stream(calico_problem* p, void* stream);
 /* HIP-event timings of the last solve, milliseconds summed over launches,
  * and launch counts, for the named phase: 0 jacobian evaluation (residual +
  * Jacobian + JᵀJ partials), 1 reduction of partials, 2 linear solve,
- * 3 cost-only evaluation, 4 LM control + update. */
+ * 3 cost-only evaluation, 4 LM control + update, 5 calibration: the same
+ * event bracket around a trivial (~2 us) kernel, i.e. the overhead contained
+ * in every per-launch figure of the other phases. */
 int32_t calico_get_phase_time(calico_problem* p, int32_t phase, double* ms,
                               int64_t* launches);
 /* Which phases are bracketed by HIP events (bit i = phase i). Default: all. */
