@@ -33,6 +33,7 @@ namespace cal {
 void launch_eval(const EvalArgs& a, bool jac, hipStream_t stream);
 void launch_eval_frames(const EvalArgs& a, hipStream_t stream);
 void launch_eval_jacobian(const EvalArgs& a, hipStream_t stream);
+void launch_expand_cells(const EvalArgs& a, hipStream_t stream);
 hipError_t configure_eval_kernels(size_t max_lds_bytes);
 
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
@@ -157,6 +158,8 @@ struct calico_problem {
   std::vector<BlockDev> h_blocks;
   std::vector<ItemDev> h_items, h_items_all, h_jac_items;
   std::vector<FrameItemDev> h_fitems;
+  std::vector<CellDev> h_cells;
+  int cell_chunk = 1, cell_rec_max = 1;
   int n_fitems = 0, n_jac_items = 0;
   std::vector<double> h_x;
   int n_thin = 0, n_fat = 0;
@@ -171,6 +174,8 @@ struct calico_problem {
   DevBuf<LayoutDev> d_layouts;
   DevBuf<ItemDev> d_items, d_items_all, d_jac_items;
   DevBuf<FrameItemDev> d_fitems;
+  DevBuf<CellDev> d_cells;
+  DevBuf<int> d_prim_tab;
   DevBuf<BlockDev> d_blocks;
   DevBuf<LmState> d_state;
   DevBuf<IterLog> d_log;
@@ -224,7 +229,8 @@ EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool
   a.m0 = p->d_m0.p; a.m1 = p->d_m1.p; a.m2 = p->d_m2.p; a.stamp = p->d_stamp.p; a.point_off = p->d_point_off.p;
   a.partials = p->d_partials.p; a.item_cost = p->d_partials.p + p->partial_doubles;
   a.res_out = want_res ? p->d_res.p : nullptr; a.valid_out = want_res ? p->d_valid.p : nullptr;
-  a.order = p->order; a.n_items = p->n_items; a.lds_cols = p->lds_cols; a.row_pad = p->row_pad; a.pad3 = 0; a.apply_loss = apply_loss;
+  a.order = p->order; a.n_items = p->n_items; a.lds_cols = p->lds_cols; a.row_pad = p->row_pad; a.n_cells = int(p->h_cells.size()); a.cells = p->d_cells.p; a.prim_tab = p->d_prim_tab.p;
+  a.cell_chunk = p->cell_chunk; a.cell_rec_max = p->cell_rec_max; a.apply_loss = apply_loss;
   a.st = nullptr; a.need_flag = 0; a.cost_index_base = 0;
   a.fitems = p->d_fitems.p; a.n_fitems = p->n_fitems;
   return a;
@@ -376,8 +382,15 @@ int finalize(calico_problem* p) {
     if (it.seg >= seg_lo && it.seg < seg_hi) p->h_items.push_back(it);
   // Jacobian pass: camera cells are cut into FRAMES (blocks sharing the stamp) for the frame kernel
   // when the spline order is 6 and frames are reasonably full; everything else goes to the generic kernel.
-  p->h_fitems.clear(); p->h_jac_items.clear();
-  size_t poff = 0;
+  p->h_fitems.clear(); p->h_jac_items.clear(); p->h_cells.clear();
+  size_t poff = 0, comp_off = 0;
+  // compact record of a camera frame: M_ext (PE×PE) + expansion coefficients (ncols + 1); see eval_kernels.hip
+  auto frame_rec = [&](const LayoutDev& L) -> size_t {
+    const HSensor& hs = p->sensors[size_t(L.sensor)];
+    const int P1 = 7 + (L.c_intr >= 0 ? hs.K : 0) + 3 * (L.c_q >= 0) + 3 * (L.c_t >= 0) + 3 * (L.c_bq >= 0) + 3 * (L.c_bt >= 0);
+    const int PE = ((P1 + 15) & ~15) + 1;
+    return size_t(PE) * PE + size_t(L.ncols + 1);
+  };
   {
     std::vector<char> layout_uses_frames(layouts.size(), 0);
     if (k == 6) {
@@ -400,8 +413,17 @@ int finalize(calico_problem* p) {
         if (kq.seg >= seg_lo && kq.seg < seg_hi) {
           FrameItemDev f;
           f.layout = kq.layout; f.seg = kq.seg; f.obs_begin = int(q); f.obs_count = int(e - q); f.stamp = kq.stamp;
-          f.partial_off = int64_t(poff);
-          poff += size_t(layouts[size_t(kq.layout)].ncols + 1) * (layouts[size_t(kq.layout)].ncols + 1);
+          f.partial_off = int64_t(comp_off);                  // compact record, rebased below
+          comp_off += frame_rec(layouts[size_t(kq.layout)]);
+          // frames arrive sorted by (layout, segment, stamp): consecutive frames of one cell share one expanded block
+          if (p->h_cells.empty() || p->h_cells.back().layout != kq.layout || p->h_cells.back().seg != kq.seg) {
+            CellDev c;
+            c.layout = kq.layout; c.seg = kq.seg; c.frame_begin = int(p->h_fitems.size()); c.frame_count = 0;
+            c.partial_off = int64_t(poff);
+            poff += size_t(layouts[size_t(kq.layout)].ncols + 1) * (layouts[size_t(kq.layout)].ncols + 1);
+            p->h_cells.push_back(c);
+          }
+          p->h_cells.back().frame_count += 1;
           p->h_fitems.push_back(f);
         }
       } else {
@@ -418,6 +440,49 @@ int finalize(calico_problem* p) {
   }
   p->n_fitems = int(p->h_fitems.size());
   p->n_jac_items = int(p->h_jac_items.size());
+  // buffer layout: [expanded partial blocks: cells, generic items | item costs (2 per item) | compact frame records]
+  const size_t n_cost_slots = 2 * size_t(std::max(std::max(int(p->h_items.size()), int(p->h_items_all.size())), p->n_fitems + p->n_jac_items));
+  const size_t comp_base = poff + n_cost_slots;
+  p->cell_rec_max = 1;
+  for (FrameItemDev& f : p->h_fitems) {
+    f.partial_off += int64_t(comp_base);
+    p->cell_rec_max = std::max(p->cell_rec_max, int(frame_rec(layouts[size_t(f.layout)])));
+  }
+  p->cell_chunk = std::max(1, int((56 * 1024 / sizeof(double)) / size_t(p->cell_rec_max)));
+  // per-layout prim-column table of the cell kernel (mirror of prim_map / the frame kernel's column order)
+  std::vector<int> prim_tab;
+  {
+    std::vector<int> tab_off(layouts.size(), -1);
+    for (CellDev& c : p->h_cells) {
+      const LayoutDev& L = layouts[size_t(c.layout)];
+      const HSensor& hs = p->sensors[size_t(L.sensor)];
+      int pc = 6;
+      const int p_intr = pc; if (L.c_intr >= 0) pc += hs.K;
+      const int p_q = pc; if (L.c_q >= 0) pc += 3;
+      const int p_t = pc; if (L.c_t >= 0) pc += 3;
+      const int p_bq = pc; if (L.c_bq >= 0) pc += 3;
+      const int p_bt = pc; if (L.c_bt >= 0) pc += 3;
+      const int p_r = pc, PT = (pc + 1 + 15) & ~15;
+      if (tab_off[size_t(c.layout)] < 0) {
+        tab_off[size_t(c.layout)] = int(prim_tab.size());
+        for (int lc = 0; lc <= L.ncols; ++lc) {
+          int pr;
+          if (lc < 36) pr = lc % 6;
+          else if (lc == L.c_lat) pr = PT;
+          else if (lc == L.ncols) pr = p_r;
+          else if (L.c_intr >= 0 && lc >= L.c_intr && lc < L.c_intr + hs.K) pr = p_intr + (lc - L.c_intr);
+          else if (L.c_q >= 0 && lc >= L.c_q && lc < L.c_q + 3) pr = p_q + (lc - L.c_q);
+          else if (L.c_t >= 0 && lc >= L.c_t && lc < L.c_t + 3) pr = p_t + (lc - L.c_t);
+          else if (L.c_bq >= 0 && lc >= L.c_bq && lc < L.c_bq + 3) pr = p_bq + (lc - L.c_bq);
+          else pr = p_bt + (lc - L.c_bt);
+          prim_tab.push_back(pr);
+        }
+      }
+      c.prim_off = tab_off[size_t(c.layout)]; c.pad0 = 0;
+      c.n1 = L.ncols + 1; c.PE = PT + 1;
+      c.src_off = p->h_fitems[size_t(c.frame_begin)].partial_off;
+    }
+  }
   for (int64_t q = 0; q < n_obs; ++q) {
     HSensor& s = p->sensors[keys[q].sensor];
     const int64_t i = keys[q].idx;
@@ -453,12 +518,13 @@ int finalize(calico_problem* p) {
   struct Pair { int dst, src; };
   std::vector<Pair> pairs;
   pairs.reserve(poff / 2 + 4 * size_t(p->n_items));
-  const int n_part = p->n_fitems + p->n_jac_items;
+  const int n_cells = int(p->h_cells.size());
+  const int n_part = n_cells + p->n_jac_items;     // producers of expanded partial blocks
   for (int itn = 0; itn < n_part; ++itn) {
-    const bool is_frame = itn < p->n_fitems;
-    const int it_layout = is_frame ? p->h_fitems[size_t(itn)].layout : p->h_jac_items[size_t(itn - p->n_fitems)].layout;
-    const int it_seg = is_frame ? p->h_fitems[size_t(itn)].seg : p->h_jac_items[size_t(itn - p->n_fitems)].seg;
-    const int64_t it_poff = is_frame ? p->h_fitems[size_t(itn)].partial_off : p->h_jac_items[size_t(itn - p->n_fitems)].partial_off;
+    const bool is_cell = itn < n_cells;
+    const int it_layout = is_cell ? p->h_cells[size_t(itn)].layout : p->h_jac_items[size_t(itn - n_cells)].layout;
+    const int it_seg = is_cell ? p->h_cells[size_t(itn)].seg : p->h_jac_items[size_t(itn - n_cells)].seg;
+    const int64_t it_poff = is_cell ? p->h_cells[size_t(itn)].partial_off : p->h_jac_items[size_t(itn - n_cells)].partial_off;
     const LayoutDev& L = layouts[size_t(it_layout)];
     const std::vector<int>& gmap = layout_gmap[size_t(it_layout)];
     const int nc = L.ncols, n1 = nc + 1;
@@ -482,6 +548,8 @@ int finalize(calico_problem* p) {
         }
       }
     }
+  }
+  for (int itn = 0; itn < p->n_fitems + p->n_jac_items; ++itn) {   // cost / invalid count: one slot pair per frame and item
     pairs.push_back({0, int(poff) + 2 * itn});
     pairs.push_back({1, int(poff) + 2 * itn + 1});
   }
@@ -521,7 +589,8 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_ptr_thin.upload(ptr_thin, s));
   HIP_TRY(p, p->d_out_fat.upload(out_fat, s)); HIP_TRY(p, p->d_idx_fat.upload(idx_fat, s));
   HIP_TRY(p, p->d_ptr_fat.upload(ptr_fat, s));
-  HIP_TRY(p, p->d_partials.alloc(poff + 2 * size_t(std::max(std::max(p->n_items, p->n_items_all), p->n_fitems + p->n_jac_items))));
+  HIP_TRY(p, p->d_partials.alloc(comp_base + comp_off));
+  HIP_TRY(p, p->d_cells.upload(p->h_cells, s)); HIP_TRY(p, p->d_prim_tab.upload(prim_tab, s));
   HIP_TRY(p, p->d_R.alloc(r_size)); HIP_TRY(p, hipMemsetAsync(p->d_R.p, 0, r_size * sizeof(double), s));
   HIP_TRY(p, p->d_R2.alloc(2));
   const int NT = 6 * n_cp + m;
@@ -580,6 +649,7 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag) {
   }
   p->timer.end(p->stream);
   p->timer.begin(1, p->stream);
+  launch_expand_cells(ea, p->stream);                     // compact frame records -> one expanded block per cell
   launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->d_out_fat.p,
                 p->d_ptr_fat.p, p->d_idx_fat.p, p->n_fat, st, need_flag, p->stream);
   p->timer.end(p->stream);

@@ -660,6 +660,35 @@ constexpr int kMaxPrim = 32;   // 6 + 11 + 3 + 3 + 3 + 3 + r = 30, padded to two
 constexpr int kFramePad = 132; // row stride of a staged prim column: ≡ 4 (mod 32) spreads the MFMA operand read over all banks
 constexpr int kMaxLocalCols = 96;
 
+// Prim columns of a camera layout: [pose 6 | intrinsics | q | t | body q | body t | residual]; the latency column is
+// the extra row/column PT of M_ext.
+struct PrimMap { int intr, q, t, bq, bt, r, P1, PT, PE; };
+DEV PrimMap prim_map(const LayoutDev& L, const SensorDev& S) {
+  PrimMap m;
+  int pc = 6;
+  m.intr = L.c_intr >= 0 ? pc : -1; if (L.c_intr >= 0) pc += S.K;
+  m.q = L.c_q >= 0 ? pc : -1; if (L.c_q >= 0) pc += 3;
+  m.t = L.c_t >= 0 ? pc : -1; if (L.c_t >= 0) pc += 3;
+  m.bq = L.c_bq >= 0 ? pc : -1; if (L.c_bq >= 0) pc += 3;
+  m.bt = L.c_bt >= 0 ? pc : -1; if (L.c_bt >= 0) pc += 3;
+  m.r = pc;
+  m.P1 = pc + 1;                 // prim columns incl. residual
+  m.PT = (m.P1 + 15) & ~15;      // padded to MFMA tiles (16 or 32)
+  m.PE = m.PT + 1;               // M_ext = [[M, Qᵀ], [Q, qq]]
+  return m;
+}
+// prim column of local column lc of the layout (spline columns: the pose component)
+DEV int prim_of_col(const LayoutDev& L, const SensorDev& S, const PrimMap& pm, int lc) {
+  if (lc < 36) return lc % 6;
+  if (lc == L.c_lat) return pm.PT;
+  if (lc == L.ncols) return pm.r;
+  if (L.c_intr >= 0 && lc >= L.c_intr && lc < L.c_intr + S.K) return pm.intr + (lc - L.c_intr);
+  if (L.c_q >= 0 && lc >= L.c_q && lc < L.c_q + 3) return pm.q + (lc - L.c_q);
+  if (L.c_t >= 0 && lc >= L.c_t && lc < L.c_t + 3) return pm.t + (lc - L.c_t);
+  if (L.c_bq >= 0 && lc >= L.c_bq && lc < L.c_bq + 3) return pm.bq + (lc - L.c_bq);
+  return pm.bt + (lc - L.c_bt);
+}
+
 template <int MODEL>
 DEV bool frame_camera_block(const SensorDev& S, const LayoutDev& L, const double* intr, const M3& R_rc, const M3& R_rw,
                             const M3& R_wm, const M3& Jl, const M3& G, V3 t_rc, V3 t_wm, V3 t_wr, double px, double py,
@@ -742,23 +771,14 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   const LayoutDev& L = a.layouts[it.layout];
   const SensorDev& S = a.sensors[L.sensor];
   constexpr int K = 6;
-  // prim column map
+  const PrimMap pm = prim_map(L, S);
   const int Kin = S.K;
-  int pc = 6;
-  const int pc_intr = L.c_intr >= 0 ? pc : -1; if (L.c_intr >= 0) pc += Kin;
-  const int pc_q = L.c_q >= 0 ? pc : -1; if (L.c_q >= 0) pc += 3;
-  const int pc_t = L.c_t >= 0 ? pc : -1; if (L.c_t >= 0) pc += 3;
-  const int pc_bq = L.c_bq >= 0 ? pc : -1; if (L.c_bq >= 0) pc += 3;
-  const int pc_bt = L.c_bt >= 0 ? pc : -1; if (L.c_bt >= 0) pc += 3;
-  const int pc_r = pc;
-  const int P1 = pc + 1;               // prim columns incl. residual
-  const int PT = (P1 + 15) & ~15;      // padded to MFMA tiles (16 or 32)
-  const int PE = PT + 1;               // M_ext = [[M, Qᵀ], [Q, qq]]: the latency column is prim index PT
+  const int pc_intr = pm.intr, pc_q = pm.q, pc_t = pm.t, pc_bq = pm.bq, pc_bt = pm.bt, pc_r = pm.r;
+  const int P1 = pm.P1, PT = pm.PT, PE = pm.PE;
   const int ncols = L.ncols, n1 = ncols + 1;
   double* Jp = lds;                                  // [PT][kFramePad]   staged rows, column-major
   double* Me = lds + kMaxPrim * kFramePad;           // [PE][PE]
   double* coef = Me + (kMaxPrim + 1) * (kMaxPrim + 1);   // [n1] column c of the item = coef[c] · prim column prim[c]
-  int* prim = reinterpret_cast<int*>(coef + kMaxLocalCols);
   // ---- per-frame quantities (every lane computes the same values) ----
   const int ki = it.seg + K - 1;
   const double* Mb = a.basis + size_t(it.seg) * K * K;
@@ -793,23 +813,15 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   double px_nx = a.m0[o_nx], py_nx = a.m1[o_nx];
   const double* xm_p = a.x + a.point_off[o_nx];
   double xm_nx[3] = {xm_p[0], xm_p[1], xm_p[2]};
-  // column table of the expansion: item column lc = coef · prim column
+  // expansion coefficients: item column lc = coef[lc] · prim column (spline columns carry their weight w_i)
   for (int lc = lane; lc < n1; lc += 64) {
     double cf = 1.0;
-    int pr;
     if (lc < 36) {
       const int wi = lc / 6;
-      pr = lc - 6 * wi;
 #pragma unroll
       for (int q = 0; q < K; ++q) cf = (wi == q) ? W[0][q] : cf;
-    } else if (lc == L.c_lat) pr = PT;
-    else if (lc == ncols) pr = pc_r;
-    else if (L.c_intr >= 0 && lc >= L.c_intr && lc < L.c_intr + Kin) pr = pc_intr + (lc - L.c_intr);
-    else if (L.c_q >= 0 && lc >= L.c_q && lc < L.c_q + 3) pr = pc_q + (lc - L.c_q);
-    else if (L.c_t >= 0 && lc >= L.c_t && lc < L.c_t + 3) pr = pc_t + (lc - L.c_t);
-    else if (L.c_bq >= 0 && lc >= L.c_bq && lc < L.c_bq + 3) pr = pc_bq + (lc - L.c_bq);
-    else pr = pc_bt + (lc - L.c_bt);
-    coef[lc] = cf; prim[lc] = pr;
+    }
+    coef[lc] = cf;
   }
   // ---- blocks -> staged rows -> M = [J_prim r]ᵀ[J_prim r] on the matrix cores ----
   // v_mfma_f64_16x16x4_f64: A[i][k] and B[k][j] of the product JᵀJ are the SAME staged value
@@ -916,32 +928,14 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   }
   __syncthreads();
   FTICK(4)
-  // ---- expansion TᵀMT into the item's (c+1)×(c+1) block: out(i, j) = coef_i coef_j M_ext(prim_i, prim_j), i <= j ----
+  // ---- compact record: M_ext (PE×PE) then coef (n1). The expansion TᵀMT -- out(i, j) = coef_i coef_j M_ext(prim_i, prim_j)
+  //      -- is done once per CELL by expand_cells_kernel over all its frames. ----
   double* out = a.partials + it.partial_off;
-  const int n_pairs = n1 * (n1 + 1) / 2;
-  int ei = 0, eoff = lane, elen = n1;     // position of pair t = lane in the row-major upper triangle
-  while (eoff >= elen) { eoff -= elen; ++ei; --elen; }
-  for (int t = lane; t < n_pairs; t += 256) {
-    int pi[4], pj[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {          // pairs t, t+64, t+128, t+192 (clamped to the last pair when past the end)
-      pi[u] = min(ei, n1 - 1); pj[u] = min(ei + eoff, n1 - 1);
-      eoff += 64;
-      while (eoff >= elen && elen > 0) { eoff -= elen; ++ei; --elen; }
-    }
-    double ci[4], cj[4];
-    int qi[4], qj[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { ci[u] = coef[pi[u]]; cj[u] = coef[pj[u]]; qi[u] = prim[pi[u]]; qj[u] = prim[pj[u]]; }
-    double mv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) mv[u] = Me[qi[u] * PE + qj[u]];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (t + 64 * u < n_pairs) out[size_t(pi[u]) * n1 + pj[u]] = ci[u] * cj[u] * mv[u];
-  }
+  const int nme = PE * PE;
+  for (int i = lane; i < nme; i += 64) out[i] = Me[i];
+  for (int i = lane; i < n1; i += 64) out[nme + i] = coef[i];
   FTICK(5)
-  if (dbg) printf("eval_frames cycles (frame of %d blocks, %d prim cols): frame-constants %lld  barrier %lld  blocks %lld  M-mfma %lld  M-to-lds %lld  expansion %lld\n",
+  if (dbg) printf("eval_frames cycles (frame of %d blocks, %d prim cols): frame-constants %lld  barrier %lld  blocks %lld  M-mfma %lld  M-to-lds %lld  record %lld\n",
                   it.obs_count, P1, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
 #undef FTICK
 }
@@ -963,6 +957,60 @@ __global__ __launch_bounds__(64) void eval_jacobian_kernel(EvalArgs a) {
   extern __shared__ double lds[];
   if (int(blockIdx.x) < a.n_items) eval_items_body<true, 6>(a, blockIdx.x, lds);
   else eval_frames_body(a, blockIdx.x - a.n_items, lds);
+}
+
+// Expansion + sum of the compact frame records of one cell: block (i, j), i <= j, of the cell's partial is
+//   Σ_frames coef_f(i) · coef_f(j) · M_ext,f(prim_i, prim_j)   in frame order (deterministic).
+// One workgroup per cell; records are staged through LDS in chunks of a.cell_chunk frames. Everything the kernel
+// needs sits in the cell descriptor and a per-layout table: a chain of dependent global loads (item -> layout ->
+// sensor -> ...) costs more than the arithmetic here.
+__global__ __launch_bounds__(256) void expand_cells_kernel(EvalArgs a) {
+  extern __shared__ double lds[];
+  const CellDev cell = a.cells[blockIdx.x];
+  if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
+  const int tid = threadIdx.x;
+  const int n1 = cell.n1, PE = cell.PE, nme = PE * PE, rec = nme + n1;
+  const int n_pairs = n1 * (n1 + 1) / 2;
+  const int* __restrict__ prim = a.prim_tab + cell.prim_off;
+  constexpr int NQ = 12;             // pairs per thread: n1 <= 77
+  int pi[NQ], pj[NQ], pm_off[NQ];
+  double acc[NQ];
+  {
+    int ei = 0, eoff = tid, elen = n1;
+    while (eoff >= elen && elen > 0) { eoff -= elen; ++ei; --elen; }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int i = ei < n1 ? ei : n1 - 1, j = ei < n1 ? ei + eoff : n1 - 1;
+      pi[q] = i; pj[q] = j;
+      pm_off[q] = prim[i] * PE + prim[j];
+      acc[q] = 0.0;
+      eoff += 256;
+      while (eoff >= elen && elen > 0) { eoff -= elen; ++ei; --elen; }
+    }
+  }
+  const double* cell_src = a.partials + cell.src_off;
+  for (int f0 = 0; f0 < cell.frame_count; f0 += a.cell_chunk) {
+    const int nf = min(a.cell_chunk, cell.frame_count - f0);
+    __syncthreads();
+    const double* src = cell_src + size_t(f0) * rec;
+    for (int i = tid; i < nf * rec; i += 256) lds[i] = src[i];
+    __syncthreads();
+    for (int f = 0; f < nf; ++f) {
+      const double* me = lds + f * rec;
+      const double* cf = me + nme;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) acc[q] += cf[pi[q]] * cf[pj[q]] * me[pm_off[q]];
+    }
+  }
+  double* out = a.partials + cell.partial_off;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    if (tid + 256 * q < n_pairs) out[size_t(pi[q]) * n1 + pj[q]] = acc[q];
+}
+
+void launch_expand_cells(const EvalArgs& a, hipStream_t stream) {
+  if (a.n_cells == 0) return;
+  hipLaunchKernelGGL(expand_cells_kernel, dim3(a.n_cells), dim3(256), size_t(a.cell_chunk) * a.cell_rec_max * sizeof(double), stream, a);
 }
 
 size_t frame_lds_bytes() { return (size_t(kMaxPrim) * kFramePad + size_t(kMaxPrim + 1) * (kMaxPrim + 1) + kMaxLocalCols + kMaxLocalCols / 2) * sizeof(double); }
@@ -994,6 +1042,8 @@ void launch_eval(const EvalArgs& a, bool jac, hipStream_t stream) {
 hipError_t configure_eval_kernels(size_t max_lds_bytes) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_frames_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(frame_lds_bytes()));
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&expand_cells_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_jacobian_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           int(max_lds_bytes > frame_lds_bytes() ? max_lds_bytes : frame_lds_bytes()));

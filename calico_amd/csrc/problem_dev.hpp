@@ -47,7 +47,17 @@ struct ItemDev {
 struct FrameItemDev {
   int layout, seg, obs_begin, obs_count;
   double stamp;
-  int64_t partial_off;
+  int64_t partial_off;   // offset (doubles) of the frame's COMPACT record: M_ext (PE×PE) then coef (ncols+1)
+};
+
+// All frames of one cell = (layout, segment): the cell kernel expands and sums their compact records
+// into one (c+1)×(c+1) partial block, which is what the gather sees.
+struct CellDev {
+  int layout, seg, frame_begin, frame_count;
+  int64_t partial_off;   // expanded (c+1)×(c+1) block of the cell
+  int64_t src_off;       // first compact record (the cell's records are contiguous)
+  int n1, PE;            // c+1, side of M_ext
+  int prim_off, pad0;    // offset into the per-layout prim-column table
 };
 
 struct EvalArgs {
@@ -69,7 +79,10 @@ struct EvalArgs {
   int need_flag, cost_index_base;
   const FrameItemDev* fitems;
   int n_fitems, debug;   // debug: CALICO_KERNEL_TIMING cycle print-outs
-  int row_pad, pad3;     // row stride (doubles) of a staged Jacobian column: max rows per item + 1, odd
+  int row_pad, n_cells;  // row_pad: row stride (doubles) of a staged Jacobian column: max rows per item + 1, odd
+  const CellDev* cells;
+  const int* prim_tab;   // per frame layout: prim column (row/col of M_ext) of every local column
+  int cell_chunk, cell_rec_max;   // frames per LDS chunk of the cell kernel, largest compact record (doubles)
 };
 
 // LM state kept on the device; the control kernel is its only writer.

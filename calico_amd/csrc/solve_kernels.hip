@@ -36,15 +36,20 @@ DEVI double diag_entry(const SolveArgs& a, int j) {
 // list of partial-block entries (CSR), summed in a fixed order => bitwise
 // reproducible assembly with no atomics.
 // ---------------------------------------------------------------------------
+// thin outputs (<= 48 sources): eight lanes per output, strided over the sources, fixed-shape tree at the end
 __global__ void gather_thin_kernel(double* __restrict__ R, const double* __restrict__ src, const int* __restrict__ out_idx,
                                    const int64_t* __restrict__ ptr, const int* __restrict__ idx, int n_out,
                                    const LmState* st, int need_flag) {
   if (st && (st->terminated || (need_flag && !st->need_jacobian))) return;
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= n_out) return;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int o = gid >> 3, sub = gid & 7;
+  const bool live = o < n_out;
+  const int oc = live ? o : n_out - 1;
+  const int64_t q0 = ptr[oc], q1 = ptr[oc + 1];
   double s = 0.0;
-  for (int64_t q = ptr[o]; q < ptr[o + 1]; ++q) s += src[idx[q]];
-  R[out_idx[o]] = s;
+  for (int64_t q = q0 + sub; q < q1; q += 8) s += src[idx[q]];
+  s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+  if (live && sub == 0) R[out_idx[o]] = s;
 }
 __global__ void gather_fat_kernel(double* __restrict__ R, const double* __restrict__ src, const int* __restrict__ out_idx,
                                   const int64_t* __restrict__ ptr, const int* __restrict__ idx, int n_out,
@@ -763,6 +768,68 @@ __global__ __launch_bounds__(256) void reduced_solve_reg_kernel(SolveArgs a) {
 // row = (lane>>4) + 4·reg). Two barriers per 16 columns instead of one per column.
 // Row m is the right-hand side, so the forward substitution comes for free; the backward substitution is an
 // axpy-form sweep on one wave with the factor rows prefetched four steps ahead.
+// Factor one 16-column panel (columns j0..j0+15 of rows j0..m) inside ONE wave; lane l owns rows j0 + l (+ 64·r).
+// Column jj: pivot chain (readlane -> rsqrt -> scale), then only the update of column jj+1 that the next pivot needs
+// (its multiplier travels by readlane); the multipliers of the columns beyond go through a 64-double LDS buffer and
+// are applied one step later, as wave-uniform 16-byte reads, filling the next chain's latency. One wave issues a
+// VALU instruction every 4+ clocks, so the count matters: v_readlane costs two instructions (plus two copies, or an
+// SGPR spill) per multiplier and use, the LDS broadcast half an instruction. A bad pivot is not patched: it turns
+// the factor into NaN (caught by update_kernel) and is reported through the running minimum *pmin.
+template <int R>
+DEVI void panel_factor(double* A, int LD, double* dinv, double* bcast, int j0, int m, int w, int lane, double* pmin) {
+  double av[R][16];
+  int row[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    row[r] = j0 + lane + 64 * r;
+    const double* src = A + min(row[r], m) * LD + j0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) av[r][c] = src[c];
+  }
+  double lprev[R], rs_keep = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) lprev[r] = 0.0;
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) {
+    const double pv = readlane_f64(av[0][jj], jj);
+    *pmin = fmin(*pmin, jj < w ? pv : 1.0);
+    const double rs = rsqrt_nr(pv);
+    double l[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { l[r] = av[r][jj] * rs; av[r][jj] = l[r]; }
+    double* bw = bcast + (jj & 1) * 64;
+    bw[lane] = l[0];                                   // lanes 0..15 hold L(j0 + c, jj)
+    if (jj + 1 < 16) {
+      double lc = readlane_f64(l[0], jj + 1);
+      asm volatile("" : "+v"(lc));                     // park it in a VGPR: as an SGPR pair it gets spilled between its uses
+#pragma unroll
+      for (int r = 0; r < R; ++r) av[r][jj + 1] -= l[r] * lc;
+    }
+    if (jj > 0) {
+      const double* br = bcast + ((jj - 1) & 1) * 64;  // written one step ago
+#pragma unroll
+      for (int c = jj + 1; c < 16; ++c) {
+        const double lc = br[c];
+#pragma unroll
+        for (int r = 0; r < R; ++r) av[r][c] -= lprev[r] * lc;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) lprev[r] = l[r];
+    rs_keep = lane == jj ? rs : rs_keep;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (lane < 16) dinv[j0 + lane] = rs_keep;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (row[r] <= m) {
+      double* dst = A + row[r] * LD + j0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) dst[c] = av[r][c];
+    }
+  }
+}
+
 template <int RPL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void reduced_solve_panel_kernel(SolveArgs a) {
   LmState* st = a.st;
@@ -773,6 +840,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   const int LD = (16 * ((m1 + 15) / 16)) | 1;   // every 16-column panel stays inside its row
   double* A = lds;                              // [m1][LD] lower triangle
   double* dinv = lds + size_t(m1) * LD;         // [m + 16]
+  double* bcast = dinv + m1 + 16;               // [2][64] column broadcast buffer of the panel wave
   __shared__ int s_fail;
   if (tid == 0) s_fail = 0;
   for (int idx = tid; idx < m1 * m1; idx += 256) {
@@ -784,46 +852,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   const bool dbg = a.debug && tid == 0;
   long long tph[4] = {0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define PTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
+  double pmin = 1.0;
   for (int j0 = 0; j0 < m; j0 += 16) {
     const int w = min(16, m - j0);
     if (wave == 0) {
-      double av[RPL][16];
-      int row[RPL];
-#pragma unroll
-      for (int r = 0; r < RPL; ++r) {
-        row[r] = j0 + lane + 64 * r;
-        const double* src = A + min(row[r], m) * LD + j0;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) av[r][c] = src[c];
-      }
-      bool fail = false;
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) {
-        double pv = readlane_f64(av[0][jj], jj);
-        const bool bad = !(pv > 0.0) || !isfinite(pv);
-        fail = fail || (bad && jj < w);
-        pv = bad ? 1.0 : pv;
-        const double rs = rsqrt_nr(pv);
-        double l[RPL];
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) { l[r] = av[r][jj] * rs; av[r][jj] = l[r]; }
-#pragma unroll
-        for (int c = jj + 1; c < 16; ++c) {
-          const double lc = readlane_f64(l[0], c);
-#pragma unroll
-          for (int r = 0; r < RPL; ++r) av[r][c] -= l[r] * lc;
-        }
-        if (lane == jj) dinv[j0 + jj] = rs;
-      }
-#pragma unroll
-      for (int r = 0; r < RPL; ++r) {
-        if (row[r] <= m) {
-          double* dst = A + row[r] * LD + j0;
-#pragma unroll
-          for (int c = 0; c < 16; ++c) dst[c] = av[r][c];
-        }
-      }
-      if (fail && lane == 0) s_fail = 1;
+      if (RPL > 1 && j0 + 64 <= m) panel_factor<RPL>(A, LD, dinv, bcast, j0, m, w, lane, &pmin);
+      else panel_factor<1>(A, LD, dinv, bcast, j0, m, w, lane, &pmin);
     }
     PTICK(0)
     __syncthreads();
@@ -899,6 +933,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
 #pragma unroll
     for (int u = 0; u < NV; ++u) if (lane + 64 * u < m) a.y[n + lane + 64 * u] = ykeep[u];
   }
+  if (wave == 0 && lane == 0 && !(pmin > 0.0)) s_fail = 1;
+  __syncthreads();
   PTICK(3)
   if (dbg) printf("reduced_solve_panel cycles: panels %lld  barrier %lld  trailing %lld  backward %lld\n", tph[0], tph[1], tph[2], tph[3]);
 #undef PTICK
@@ -1164,7 +1200,7 @@ void launch_gather(double* R, const double* src, const int* out_idx_thin, const 
                    int n_thin, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
                    const LmState* st, int need_flag, hipStream_t s) {
   if (n_thin > 0)
-    hipLaunchKernelGGL(gather_thin_kernel, dim3((n_thin + 255) / 256), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin,
+    hipLaunchKernelGGL(gather_thin_kernel, dim3((n_thin + 31) / 32), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin,
                        idx_thin, n_thin, st, need_flag);
   if (n_fat > 0)
     hipLaunchKernelGGL(gather_fat_kernel, dim3((n_fat + 3) / 4), dim3(256), 0, s, R, src, out_idx_fat, ptr_fat, idx_fat,
@@ -1218,7 +1254,7 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
   const int nt = (m1 + 15) / 16;
   hipLaunchKernelGGL(schur_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, a);
   if (m1 <= 128) {
-    const size_t lds = (size_t(m1) * ((16 * ((m1 + 15) / 16)) | 1) + m1 + 32) * sizeof(double);
+    const size_t lds = (size_t(m1) * ((16 * ((m1 + 15) / 16)) | 1) + m1 + 32 + 128) * sizeof(double);
     if (m1 <= 64) hipLaunchKernelGGL(reduced_solve_panel_kernel<1>, dim3(1), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(reduced_solve_panel_kernel<2>, dim3(1), dim3(256), lds, s, a);
   } else if (m1 <= 16 * 13) {
