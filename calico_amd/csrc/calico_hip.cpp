@@ -48,8 +48,8 @@ hipError_t configure_solve_kernels(size_t band_lds, size_t reduced_lds, size_t b
 void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, double* x_cand, const BlockDev* blocks,
                   int n_blocks, bool dense_in_lds, hipStream_t s);
 void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const LmState* st, hipStream_t s);
-void launch_control(LmState* st, const LmOptionsDev& o, const double* R2, double* x, const double* x_cand, int n_amb,
-                    IterLog* log, int log_cap, hipStream_t s);
+void launch_control(LmState* st, const LmOptionsDev& o, double* R2, double* x, const double* x_cand, int n_amb,
+                    IterLog* log, int log_cap, const double* item_cost, int n_items, hipStream_t s);
 void launch_init_state(LmState* st, double radius, double x_norm, hipStream_t s);
 
 }  // namespace cal
@@ -928,12 +928,14 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
         ea.st = p->d_state.p;
         launch_eval(ea, false, s);
       }
-      launch_cost_reduce(p->d_partials.p + p->partial_doubles, p->n_items, p->d_R2.p, p->d_state.p, s);
+      const bool fuse_cost = p->allreduce == nullptr;    // single rank: the cost sum rides in the control kernel
+      if (!fuse_cost) launch_cost_reduce(p->d_partials.p + p->partial_doubles, p->n_items, p->d_R2.p, p->d_state.p, s);
       p->timer.end(s);
       rc = do_allreduce(p, p->d_R2.p, 2);
       if (rc != CALICO_OK) return rc;
       p->timer.begin(4, s);
-      launch_control(p->d_state.p, o, p->d_R2.p, p->d_x.p, p->d_xc.p, p->n_amb, p->d_log.p, kLogCap, s);
+      launch_control(p->d_state.p, o, p->d_R2.p, p->d_x.p, p->d_xc.p, p->n_amb, p->d_log.p, kLogCap,
+                     fuse_cost ? p->d_partials.p + p->partial_doubles : nullptr, p->n_items, s);
       p->timer.end(s);
       if (!async) {
         rc = read_state(p);

@@ -36,33 +36,36 @@ DEVI double diag_entry(const SolveArgs& a, int j) {
 // list of partial-block entries (CSR), summed in a fixed order => bitwise
 // reproducible assembly with no atomics.
 // ---------------------------------------------------------------------------
-// thin outputs (<= 48 sources): eight lanes per output, strided over the sources, fixed-shape tree at the end
-__global__ void gather_thin_kernel(double* __restrict__ R, const double* __restrict__ src, const int* __restrict__ out_idx,
-                                   const int64_t* __restrict__ ptr, const int* __restrict__ idx, int n_out,
-                                   const LmState* st, int need_flag) {
+// One launch, two roles by workgroup: the first nb_fat workgroups take the fat outputs (> 48 sources, one wave
+// each, the long ones first), the others the thin outputs (eight lanes each, strided over the sources); both end in
+// a fixed-shape shuffle tree.
+__global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, const double* __restrict__ src,
+                                                     const int* __restrict__ out_thin, const int64_t* __restrict__ ptr_thin,
+                                                     const int* __restrict__ idx_thin, int n_thin,
+                                                     const int* __restrict__ out_fat, const int64_t* __restrict__ ptr_fat,
+                                                     const int* __restrict__ idx_fat, int n_fat, int nb_fat,
+                                                     const LmState* st, int need_flag) {
   if (st && (st->terminated || (need_flag && !st->need_jacobian))) return;
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int o = gid >> 3, sub = gid & 7;
-  const bool live = o < n_out;
-  const int oc = live ? o : n_out - 1;
-  const int64_t q0 = ptr[oc], q1 = ptr[oc + 1];
-  double s = 0.0;
-  for (int64_t q = q0 + sub; q < q1; q += 8) s += src[idx[q]];
-  s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
-  if (live && sub == 0) R[out_idx[o]] = s;
-}
-__global__ void gather_fat_kernel(double* __restrict__ R, const double* __restrict__ src, const int* __restrict__ out_idx,
-                                  const int64_t* __restrict__ ptr, const int* __restrict__ idx, int n_out,
-                                  const LmState* st, int need_flag) {
-  if (st && (st->terminated || (need_flag && !st->need_jacobian))) return;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  if (wave >= n_out) return;
-  double s = 0.0;
-  for (int64_t q = ptr[wave] + lane; q < ptr[wave + 1]; q += 64) s += src[idx[q]];
+  if (int(blockIdx.x) < nb_fat) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= n_fat) return;
+    double s = 0.0;
+    for (int64_t q = ptr_fat[wave] + lane; q < ptr_fat[wave + 1]; q += 64) s += src[idx_fat[q]];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  if (lane == 0) R[out_idx[wave]] = s;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) R[out_fat[wave]] = s;
+  } else {
+    const int gid = (blockIdx.x - nb_fat) * blockDim.x + threadIdx.x;
+    const int o = gid >> 3, sub = gid & 7;
+    const bool live = o < n_thin;
+    const int oc = live ? o : n_thin - 1;
+    const int64_t q0 = ptr_thin[oc], q1 = ptr_thin[oc + 1];
+    double s = 0.0;
+    for (int64_t q = q0 + sub; q < q1; q += 8) s += src[idx_thin[q]];
+    s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+    if (live && sub == 0) R[out_thin[o]] = s;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1127,11 +1130,27 @@ __global__ __launch_bounds__(256) void cost_reduce_kernel(const double* __restri
 }
 
 // [Ceres] TrustRegionMinimizer: tolerance tests, step acceptance, radius update.
-__global__ __launch_bounds__(256) void lm_control_kernel(LmState* st, LmOptionsDev o, const double* R2, double* x,
-                                                         const double* x_cand, int n_amb, IterLog* log, int log_cap) {
+// item_cost != nullptr: single-rank path, the reduction of the per-item [cost, invalid] pairs is done here instead
+// of in a separate cost_reduce_kernel launch (with several ranks the sum goes through the all-reduce in between).
+__global__ __launch_bounds__(256) void lm_control_kernel(LmState* st, LmOptionsDev o, double* R2, double* x,
+                                                         const double* x_cand, int n_amb, IterLog* log, int log_cap,
+                                                         const double* __restrict__ item_cost, int n_items) {
   if (st->terminated) return;
   __shared__ int s_accept;
   const int tid = threadIdx.x;
+  if (item_cost) {
+    __shared__ double s_a[256], s_b[256];
+    double c = 0.0, v = 0.0;
+    for (int i = tid; i < n_items; i += 256) { c += item_cost[2 * i]; v += item_cost[2 * i + 1]; }
+    s_a[tid] = c; s_b[tid] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (tid < off) { s_a[tid] += s_a[tid + off]; s_b[tid] += s_b[tid + off]; }
+      __syncthreads();
+    }
+    if (tid == 0) { R2[0] = s_a[0]; R2[1] = s_b[0]; }
+    __syncthreads();
+  }
   if (tid == 0) {
     s_accept = 0;
     const double cand_norm = st->cand_norm;
@@ -1199,12 +1218,10 @@ __global__ void init_state_kernel(LmState* st, double radius, double x_norm) {
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
                    int n_thin, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
                    const LmState* st, int need_flag, hipStream_t s) {
-  if (n_thin > 0)
-    hipLaunchKernelGGL(gather_thin_kernel, dim3((n_thin + 31) / 32), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin,
-                       idx_thin, n_thin, st, need_flag);
-  if (n_fat > 0)
-    hipLaunchKernelGGL(gather_fat_kernel, dim3((n_fat + 3) / 4), dim3(256), 0, s, R, src, out_idx_fat, ptr_fat, idx_fat,
-                       n_fat, st, need_flag);
+  const int nb_thin = (n_thin + 31) / 32, nb_fat = (n_fat + 3) / 4;
+  if (nb_thin + nb_fat > 0)
+    hipLaunchKernelGGL(gather_kernel, dim3(nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin,
+                       out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, st, need_flag);
 }
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s) {
@@ -1295,9 +1312,9 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
 void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const LmState* st, hipStream_t s) {
   hipLaunchKernelGGL(cost_reduce_kernel, dim3(1), dim3(256), 0, s, item_cost, n_items, R2, st);
 }
-void launch_control(LmState* st, const LmOptionsDev& o, const double* R2, double* x, const double* x_cand, int n_amb,
-                    IterLog* log, int log_cap, hipStream_t s) {
-  hipLaunchKernelGGL(lm_control_kernel, dim3(1), dim3(256), 0, s, st, o, R2, x, x_cand, n_amb, log, log_cap);
+void launch_control(LmState* st, const LmOptionsDev& o, double* R2, double* x, const double* x_cand, int n_amb,
+                    IterLog* log, int log_cap, const double* item_cost, int n_items, hipStream_t s) {
+  hipLaunchKernelGGL(lm_control_kernel, dim3(1), dim3(256), 0, s, st, o, R2, x, x_cand, n_amb, log, log_cap, item_cost, n_items);
 }
 void launch_init_state(LmState* st, double radius, double x_norm, hipStream_t s) {
   hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, s, st, radius, x_norm);
