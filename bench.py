@@ -157,6 +157,12 @@ def main():
             s = P.solve(opts)
             if s.num_iterations <= 0:
                 raise RuntimeError("solve made no progress: %s" % s.message.decode())
+            # a timed iteration only counts if the optimiser is really optimising: a solve given the full budget from the
+            # perturbed start must converge, and every solve must take successful steps that lower the cost
+            if not (s.num_successful_steps > 0 and s.final_cost < s.initial_cost) or \
+                    (opts.max_num_iterations >= 50 and s.termination_type != _capi.CONVERGENCE):
+                raise RuntimeError("solve did not behave (%g -> %g, %d successful steps, termination %d): %s" % (
+                    s.initial_cost, s.final_cost, s.num_successful_steps, s.termination_type, s.message.decode()))
             done += s.num_iterations
             jac += s.num_jacobian_evaluations
             cost += s.num_cost_evaluations

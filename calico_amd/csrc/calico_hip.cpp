@@ -151,6 +151,7 @@ struct calico_problem {
   int rank = 0, world = 1;
 
   // flattened problem
+  int sep_s = 0, sep_n = 0;   // separator control points of the nested-dissection split (sep_n = 0: none)
   int n_cp = 0, m = 0, n_amb = 0, n_eff = 0, n_items = 0, n_items_all = 0, lds_cols = 0, row_pad = kRowPad;
   int64_t n_obs = 0;
   size_t partial_doubles = 0;
@@ -214,7 +215,7 @@ SolveArgs make_solve_args(calico_problem* p) {
   SolveArgs a;
   a.R = p->d_R.p; a.Lb = p->d_Lb.p; a.Linv = p->d_Linv.p; a.Y = p->d_Y.p; a.S = p->d_S.p; a.Spart = p->d_Spart.p;
   a.Swork = p->d_Swork.p; a.y = p->d_y.p; a.zbuf = p->d_zbuf.p; a.dadd = p->d_dadd.p;
-  a.scale = p->d_scale.p; a.cp_active = p->d_cp_active.p; a.st = p->d_state.p; a.n_cp = p->n_cp; a.k = p->order; a.m = p->m;
+  a.scale = p->d_scale.p; a.cp_active = p->d_cp_active.p; a.st = p->d_state.p; a.n_cp = p->n_cp; a.k = p->order; a.mc = p->m; a.sep_s = p->sep_s; a.sep_n = p->sep_n; a.m = p->m + 6 * p->sep_n;
   static const int dbg = std::getenv("CALICO_KERNEL_TIMING") ? std::atoi(std::getenv("CALICO_KERNEL_TIMING")) : 0;
   a.debug = dbg;
   return a;
@@ -290,6 +291,20 @@ int finalize(calico_problem* p) {
     m += b.tangent_size(); eff += b.tangent_size();
   }
   p->m = m; p->n_eff = eff;
+  // Nested dissection with one separator (k-1 control points in the middle of the trajectory): the two halves of
+  // the band are then factored and back-substituted side by side, the separator joins the dense border. Used when
+  // the enlarged border still fits the in-LDS reduced solve and every control point is observed.
+  p->sep_s = 0; p->sep_n = 0;
+  {
+    bool all_active = true;
+    for (int i = 0; i < n_cp; ++i) all_active = all_active && cp_active[size_t(i)] != 0;
+    const char* env = std::getenv("CALICO_BAND_SPLIT");
+    const bool allowed = !env || std::atoi(env) != 0;
+    if (allowed && all_active && n_cp >= 6 * k && m + 6 * (k - 1) + 1 <= 128) {
+      p->sep_n = k - 1;
+      p->sep_s = (n_cp - p->sep_n) / 2;
+    }
+  }
   const int NS = 6 * n_cp;
   // ---- layouts ----
   std::vector<SensorDev> sd(p->sensors.size());
@@ -512,7 +527,7 @@ int finalize(calico_problem* p) {
   if (size_t(p->lds_cols) * p->row_pad * sizeof(double) > kMaxLds)
     return p->set_error(CALICO_UNIMPLEMENTED, "too many Jacobian columns per residual block for the LDS staging area");
   // ---- gather lists ----
-  SolveArgs sa; sa.n_cp = n_cp; sa.k = k; sa.m = m; sa.debug = 0;
+  SolveArgs sa; sa.n_cp = n_cp; sa.k = k; sa.mc = m; sa.sep_s = p->sep_s; sa.sep_n = p->sep_n; sa.m = m + 6 * p->sep_n; sa.debug = 0;
   const size_t r_size = sa.r_size();
   if (r_size >= size_t(0x7fffffff)) return p->set_error(CALICO_UNIMPLEMENTED, "normal-equation buffer too large");
   struct Pair { int dst, src; };
@@ -594,10 +609,11 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_R.alloc(r_size)); HIP_TRY(p, hipMemsetAsync(p->d_R.p, 0, r_size * sizeof(double), s));
   HIP_TRY(p, p->d_R2.alloc(2));
   const int NT = 6 * n_cp + m;
+  const int mw = m + 6 * p->sep_n;     // border width the solver kernels work with
   HIP_TRY(p, p->d_Lb.alloc(size_t(NS) * 6 * k)); HIP_TRY(p, p->d_Linv.alloc(size_t(n_cp) * 36));
-  HIP_TRY(p, p->d_Y.alloc(size_t(NS) * (m + 1)));
-  HIP_TRY(p, p->d_S.alloc(size_t(m + 1) * (m + 1)));
-  HIP_TRY(p, p->d_y.alloc(NT)); HIP_TRY(p, p->d_zbuf.alloc(size_t(NS) + 64)); HIP_TRY(p, p->d_dadd.alloc(NT)); HIP_TRY(p, p->d_scale.alloc(NT));
+  HIP_TRY(p, p->d_Y.alloc(size_t(NS) * (mw + 1)));
+  HIP_TRY(p, p->d_S.alloc(size_t(mw + 1) * (mw + 1)));
+  HIP_TRY(p, p->d_y.alloc(size_t(NT) + 6 * p->sep_n)); HIP_TRY(p, p->d_zbuf.alloc(size_t(NS) + 64)); HIP_TRY(p, p->d_dadd.alloc(NT)); HIP_TRY(p, p->d_scale.alloc(NT));
   HIP_TRY(p, p->d_res.alloc(size_t(n_obs) * 3)); HIP_TRY(p, p->d_valid.alloc(size_t(n_obs)));
   HIP_TRY(p, p->d_state.alloc(1)); HIP_TRY(p, p->d_log.alloc(kLogCap));
   if (!p->h_state) HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LmState)));
@@ -608,10 +624,10 @@ int finalize(calico_problem* p) {
   if (band_lds > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "spline order too high for the banded factorisation window");
   const size_t reduced_lds = reduced_solve_lds_bytes(sa);
   p->dense_in_lds = reduced_lds <= kMaxLds - 1024;
-  HIP_TRY(p, p->d_Spart.alloc(size_t(m + 1) * (m + 1)));
+  HIP_TRY(p, p->d_Spart.alloc(size_t(mw + 1) * (mw + 1)));
   const size_t back_lds = band_backsolve_lds_bytes(sa);
   if (back_lds > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "trajectory too long for the back-substitution window");
-  HIP_TRY(p, p->d_Swork.alloc(std::max<size_t>(reduced_lds / sizeof(double) + 8, size_t(m + 1) * 16 * 13 + 8)));
+  HIP_TRY(p, p->d_Swork.alloc(std::max<size_t>(reduced_lds / sizeof(double) + 8, size_t(mw + 1) * 16 * 13 + 8)));
   sa = make_solve_args(p);
   HIP_TRY(p, configure_solve_kernels(band_lds, p->dense_in_lds ? reduced_lds : 0, back_lds));
   HIP_TRY(p, hipStreamSynchronize(s));

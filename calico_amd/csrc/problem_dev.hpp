@@ -138,16 +138,30 @@ struct SolveArgs {
   double* scale;          // [NT] Jacobi scaling 1/(1+sqrt(H_jj)) from iteration 0
   const uint8_t* cp_active;  // [n_cp]
   LmState* st;
-  int n_cp, k, m;
+  int n_cp, k;
+  int m;                  // width of the dense border the solver kernels work with = mc + 6·sep_n
+  int mc;                 // tangent size of the free calibration blocks (border width of R)
+  // Nested dissection with one separator: control points [sep_s, sep_s + sep_n), sep_n = k-1 or 0, are taken out
+  // of the band and appended to the border (columns mc..m-1). The band then falls apart into two independent
+  // segments [0, sep_s) and [sep_s + sep_n, n_cp) whose sequential sweeps run side by side.
+  int sep_s, sep_n;
   int debug;              // CALICO_KERNEL_TIMING=1: kernels print per-phase cycle counts (development aid)
   CAL_HD int n_s() const { return 6 * n_cp; }
   CAL_HD int W() const { return 6 * k; }
-  CAL_HD int NT() const { return 6 * n_cp + m; }
+  CAL_HD int NT() const { return 6 * n_cp + mc; }
   CAL_HD size_t off_g() const { return 2; }
   CAL_HD size_t off_B() const { return 2 + size_t(NT()); }
   CAL_HD size_t off_E() const { return off_B() + size_t(n_cp) * k * 36; }
-  CAL_HD size_t off_C() const { return off_E() + size_t(n_s()) * m; }
-  CAL_HD size_t r_size() const { return off_C() + size_t(m) * m; }
+  CAL_HD size_t off_C() const { return off_E() + size_t(n_s()) * mc; }
+  CAL_HD size_t r_size() const { return off_C() + size_t(mc) * mc; }
+  CAL_HD bool in_sep(int tangent_row) const { return sep_n > 0 && tangent_row >= 6 * sep_s && tangent_row < 6 * (sep_s + sep_n); }
+  CAL_HD int seg_begin(int seg) const { return seg == 0 ? 0 : sep_s + sep_n; }
+  CAL_HD int seg_end(int seg) const { return sep_n > 0 && seg == 0 ? sep_s : n_cp; }
+  CAL_HD int n_seg() const { return sep_n > 0 ? 2 : 1; }
+  // tangent index of border index b: calibration first, then the separator rows
+  CAL_HD int border_tangent(int b) const { return b < mc ? n_s() + b : 6 * sep_s + (b - mc); }
+  // where the solution of tangent index j sits in y: the separator part is solved with the border
+  CAL_HD int y_index(int j) const { return in_sep(j) ? n_s() + mc + (j - 6 * sep_s) : j; }
 };
 
 }  // namespace cal

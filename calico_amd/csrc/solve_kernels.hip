@@ -28,7 +28,7 @@ DEVI double band_entry(const SolveArgs& a, int row, int col) {  // H(row, col), 
 DEVI double diag_entry(const SolveArgs& a, int j) {
   if (j < a.n_s()) return band_entry(a, j, j);
   const int i = j - a.n_s();
-  return a.R[a.off_C() + size_t(i) * a.m + i];
+  return a.R[a.off_C() + size_t(i) * a.mc + i];
 }
 
 // ---------------------------------------------------------------------------
@@ -154,47 +154,60 @@ __global__ __launch_bounds__(256) void post_eval_kernel(SolveArgs a, const doubl
 __global__ void prepare_kernel(SolveArgs a, LmOptionsDev o) {
   const LmState* st = a.st;
   if (st->terminated) return;
-  const int n_s = a.n_s(), W = a.W(), m = a.m, m1 = a.m + 1;
+  const int n_s = a.n_s(), W = a.W(), m = a.m, mc = a.mc, m1 = a.m + 1;
   const double radius = st->radius;
   const size_t nL = size_t(a.n_cp) * W * 6, nY = size_t(n_s) * m1, nS = size_t(m1) * m1;
   const size_t total = nL + nY + nS;
+  // H between two tangent indices of the spline part (any order), zero outside the band
+  auto hss = [&](int r, int c) { return r >= c ? band_entry(a, r, c) : band_entry(a, c, r); };
+  // a control point takes part in the band unless it is unobserved or belongs to the separator
+  auto band_act = [&](int J) { return a.cp_active[J] != 0 && !a.in_sep(6 * J); };
   for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += size_t(gridDim.x) * blockDim.x) {
     if (i < nL) {
       const int J = int(i / (size_t(W) * 6)), rem = int(i % (size_t(W) * 6));
       const int r = rem / 6, cc = rem % 6;
       const int col = 6 * J + cc, row = 6 * J + r;
-      const bool act = a.cp_active[J] != 0;
+      const bool act = band_act(J);
       double v = 0.0;
-      if (row < n_s) v = (row >= col) ? band_entry(a, row, col) : band_entry(a, col, row);
+      if (row < n_s) v = hss(row, col);
       if (row == col) {
-        if (!act) { v = 1.0; a.dadd[col] = 0.0; }
+        if (!act) { v = 1.0; if (!a.in_sep(col)) a.dadd[col] = 0.0; }
         else {
           const double s = a.scale[col];
           const double d = fmin(fmax(v * s * s, o.min_lm_diagonal), o.max_lm_diagonal) / (radius * s * s);
           a.dadd[col] = d; v += d;
         }
-      } else if (!act || (row < n_s && !a.cp_active[row / 6])) v = 0.0;
+      } else if (!act || (row < n_s && !band_act(row / 6))) v = 0.0;
       a.Lb[i] = v;
     } else if (i < nL + nY) {
       const size_t q = i - nL;
       const int c = int(q / m1), j = int(q % m1);
-      const bool act = a.cp_active[c / 6] != 0;
       double v = 0.0;
-      if (act) v = (j < m) ? a.R[a.off_E() + size_t(c) * m + j] : a.R[a.off_g() + c];
+      if (band_act(c / 6)) {
+        if (j < mc) v = a.R[a.off_E() + size_t(c) * mc + j];
+        else if (j < m) v = hss(c, 6 * a.sep_s + (j - mc));     // coupling of band row c to a separator column
+        else v = a.R[a.off_g() + c];
+      }
       a.Y[q] = v;
     } else {
       const size_t q = i - nL - nY;
       const int r = int(q / m1), cc = int(q % m1);
       double v = 0.0;
       if (r < m && cc < m) {
-        v = a.R[a.off_C() + size_t(r) * m + cc];
-        if (r == cc) {
-          const double s = a.scale[n_s + r];
-          const double d = fmin(fmax(v * s * s, o.min_lm_diagonal), o.max_lm_diagonal) / (radius * s * s);
-          a.dadd[n_s + r] = d; v += d;
+        if (r < mc && cc < mc) v = a.R[a.off_C() + size_t(r) * mc + cc];
+        else if (r >= mc && cc >= mc) v = hss(6 * a.sep_s + (r - mc), 6 * a.sep_s + (cc - mc));
+        else {   // separator row against calibration column
+          const int t = 6 * a.sep_s + ((r >= mc ? r : cc) - mc), j = r >= mc ? cc : r;
+          v = a.R[a.off_E() + size_t(t) * mc + j];
         }
-      } else if (r == m && cc < m) v = a.R[a.off_g() + n_s + cc];   // right-hand side as an extra row
-      else if (r < m && cc == m) v = a.R[a.off_g() + n_s + r];
+        if (r == cc) {
+          const int tj = a.border_tangent(r);
+          const double s = a.scale[tj];
+          const double d = fmin(fmax(v * s * s, o.min_lm_diagonal), o.max_lm_diagonal) / (radius * s * s);
+          a.dadd[tj] = d; v += d;
+        }
+      } else if (r == m && cc < m) v = a.R[a.off_g() + a.border_tangent(cc)];   // right-hand side as an extra row
+      else if (r < m && cc == m) v = a.R[a.off_g() + a.border_tangent(r)];
       a.S[q] = v;
     }
   }
@@ -304,7 +317,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
   LmState* st = a.st;
   if (st->terminated) return;
   extern __shared__ double lds[];
-  const int k = a.k, W = 6 * k, ncp = a.n_cp, m1 = a.m + 1;
+  // blockIdx.y = band segment (two when a separator splits the band); everything below is relative to its first block
+  const int jb = a.seg_begin(blockIdx.y);
+  const int k = a.k, W = 6 * k, ncp = a.seg_end(blockIdx.y) - jb, m1 = a.m + 1;
+  if (ncp <= 0) return;
+  double* const Lb0 = a.Lb + size_t(jb) * W * 6;
+  double* const Y0 = a.Y + size_t(6 * jb) * m1;
+  double* const Linv0 = a.Linv + size_t(jb) * 36;
   const int j0 = blockIdx.x * bs;
   const int nb = max(1, min(bs, m1 - j0));
   const int nband = W * 6;
@@ -337,10 +356,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
     size_t goff; bool isy;
     describe(e < nelem ? e : 0, &l_off[u], &goff, &g_stride[u], &isy);
     if (e >= nelem) l_off[u] = DUMP;
-    g_base[u] = (isy ? a.Y : a.Lb) + goff;
+    g_base[u] = (isy ? Y0 : Lb0) + goff;
     const int ew = blockIdx.x == 0 ? e % nelem : nband + e % (nb * 6);   // write-back: workgroup 0 owns the band factor
     describe(ew, &wb_l[u], &goff, &wb_stride[u], &isy);
-    wb_base[u] = (isy ? a.Y : a.Lb) + goff;
+    wb_base[u] = (isy ? Y0 : Lb0) + goff;
     wb_piv[u] = ew < 36;                                                  // diagonal block: L comes from Lpiv, not from X
   }
   auto gload = [&](int J, double regs[NE]) {
@@ -490,7 +509,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
       if (J > 0) {
 #pragma unroll
         for (int u = 0; u < NE; ++u) wb_base[u][size_t(Jp) * wb_stride[u]] = wb_piv[u] ? pp[wb_l[u]] : sp[wb_l[u]];
-        if (blockIdx.x == 0 && stid < 36) a.Linv[size_t(Jp) * 36 + stid] = sp[LINV + stid];
+        if (blockIdx.x == 0 && stid < 36) Linv0[size_t(Jp) * 36 + stid] = sp[LINV + stid];
       }
       // (2b) block J+k enters the ring (zeros past the end of the band), block J+k+2 is requested
       int sk = Jm + k; sk = sk >= NSL ? sk - NSL : sk;
@@ -544,7 +563,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
     const double* pp = Lpiv + (Jp % 3) * 48;
 #pragma unroll
     for (int u = 0; u < NE; ++u) wb_base[u][size_t(Jp) * wb_stride[u]] = wb_piv[u] ? pp[wb_l[u]] : sp[wb_l[u]];
-    if (blockIdx.x == 0 && stid < 36) a.Linv[size_t(Jp) * 36 + stid] = sp[LINV + stid];
+    if (blockIdx.x == 0 && stid < 36) Linv0[size_t(Jp) * 36 + stid] = sp[LINV + stid];
   }
   if (dbg) printf("band_cholesky cycles/step wave %d (0: panel | update; 1: stream | update; 3: X1+pivot update | factor+publish): A %lld  barrier %lld  B %lld  barrier %lld\n",
                   wave, (tc[0] + tc[1]) / ncp, tc[2] / ncp, tc[3] / ncp, tc[4] / ncp);
@@ -961,25 +980,109 @@ __global__ __launch_bounds__(256) void border_matvec_kernel(SolveArgs a) {
   if (lane == 0) a.zbuf[c] = row[m] - part;
 }
 
+// delta = -y ; candidate = Plus(x, delta) ; model cost change ; step norms.
+// (256 threads; called at the end of band_backsolve_kernel once the whole solution vector is in place)
+DEVI void update_body(const SolveArgs& a, const double* __restrict__ x, double* __restrict__ x_cand,
+                      const BlockDev* __restrict__ blocks, int n_blocks) {
+  LmState* st = a.st;
+  __shared__ double s_a[256], s_b[256], s_c[256];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  const int NT = a.NT();
+  double mcc = 0.0;
+  for (int j = tid; j < NT; j += 256) {
+    const double yj = a.y[a.y_index(j)];   // the separator part of the solution sits behind the calibration part
+    if (!isfinite(yj)) s_bad = 1;
+    mcc += 0.5 * yj * (a.R[a.off_g() + j] + yj * a.dadd[j]);
+  }
+  double sn = 0.0, cn = 0.0;
+  for (int b = tid; b < n_blocks; b += 256) {
+    const BlockDev B = blocks[b];
+    const double* yb = a.y + a.y_index(B.tan_off);
+    const double* p = x + B.amb_off;
+    double* q = x_cand + B.amb_off;
+    if (B.manifold == 1) {
+      const double d0 = -yb[0], d1 = -yb[1], d2 = -yb[2];
+      const double nd = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+      double nx = p[0], ny = p[1], nz = p[2], nw = p[3];
+      if (nd > 0.0) {
+        const double sd = sin(nd) / nd, qw = cos(nd);
+        const double qx = sd * d0, qy = sd * d1, qz = sd * d2;
+        const double px = p[0], py = p[1], pz = p[2], pw = p[3];
+        nw = qw * pw - qx * px - qy * py - qz * pz;
+        nx = qw * px + qx * pw + qy * pz - qz * py;
+        ny = qw * py + qy * pw + qz * px - qx * pz;
+        nz = qw * pz + qz * pw + qx * py - qy * px;
+      }
+      q[0] = nx; q[1] = ny; q[2] = nz; q[3] = nw;
+      const double e[4] = {p[0] - nx, p[1] - ny, p[2] - nz, p[3] - nw};
+      sn += e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3];
+      cn += nx * nx + ny * ny + nz * nz + nw * nw;
+    } else {
+      for (int i = 0; i < B.size; ++i) {
+        const double v = p[i] - yb[i];
+        q[i] = v; const double e = p[i] - v; sn += e * e; cn += v * v;
+      }
+    }
+  }
+  s_a[tid] = mcc; s_b[tid] = sn; s_c[tid] = cn;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) { s_a[tid] += s_a[tid + off]; s_b[tid] += s_b[tid + off]; s_c[tid] += s_c[tid + off]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    st->model_cost_change = s_a[0];
+    st->step_norm = sqrt(s_b[0]);
+    st->candidate_cost = 0.0;
+    st->cand_norm = sqrt(s_c[0]);
+    if (a.debug > 1) printf("update: model_cost_change %.6e  step_norm %.3e  non-finite %d  chol_failed %d\n", s_a[0], sqrt(s_b[0]), s_bad, st->chol_failed);
+    if (s_bad || st->chol_failed) { st->step_valid = 0; }
+    else st->step_valid = (s_a[0] > 0.0) ? 1 : 0;
+  }
+}
+
 // Blocked backward band sweep Lᵀ y_s = z by ONE wave, in axpy form (no reductions on the chain):
 //   step J:  s = z_J - P_J ;  y_J = L11⁻ᵀ s ;  for the k-1 earlier blocks B: P_B += L(J, B)ᵀ y_J.
 // Lane (g, c) = (lane / 6, lane % 6), g < k-1, keeps in a register the pending sum P_B[c] of the one
 // block B ≡ g (mod k-1) inside the window [J-(k-1), J-1]; when block J's turn comes its lanes form
 // s, the six values travel by v_readlane (wave-uniform lane index), every lane gets y_J as scalars,
 // and the update is six register FMAs. Band columns are prefetched four steps ahead.
+template <int K> DEVI void band_backsolve_wave(const SolveArgs& a, int seg);
+// One workgroup per band segment (blockIdx.x). With a single segment the other three waves of the workgroup wait at
+// the barrier and then join the update of the candidate point (update_body) -- one launch less per iteration; with
+// two segments the update needs both sweeps and runs as its own kernel.
 template <int K>
-__global__ __launch_bounds__(64) void band_backsolve_kernel(SolveArgs a) {
+__global__ __launch_bounds__(256) void band_backsolve_kernel(SolveArgs a, const double* __restrict__ x, double* __restrict__ x_cand,
+                                                             const BlockDev* __restrict__ blocks, int n_blocks) {
   const LmState* st = a.st;
   if (st->terminated) return;
+  if (threadIdx.x < 64) band_backsolve_wave<K>(a, blockIdx.x);
+  if (a.n_seg() > 1) return;
+  __syncthreads();
+  update_body(a, x, x_cand, blocks, n_blocks);
+}
+__global__ __launch_bounds__(256) void update_kernel(SolveArgs a, const double* __restrict__ x, double* __restrict__ x_cand,
+                                                     const BlockDev* __restrict__ blocks, int n_blocks) {
+  if (a.st->terminated) return;
+  update_body(a, x, x_cand, blocks, n_blocks);
+}
+
+template <int K>
+DEVI void band_backsolve_wave(const SolveArgs& a, int seg) {
   constexpr int W = 6 * K, G = K - 1, nband = W * 6, PF = 4, NSLOT = PF + 1;
-  const int ncp = a.n_cp;
+  const int jb = a.seg_begin(seg);
+  const int ncp = a.seg_end(seg) - jb;       // blocks of this segment; all indices below are relative to jb
+  if (ncp <= 0) return;
   const int lane = threadIdx.x;
   const int g = lane / 6, c = lane % 6;
   const bool worker = g < G;
-  const double* __restrict__ z = a.zbuf;   // from border_matvec_kernel; distinct from the output so loads can stay in flight
-  double* __restrict__ yout = a.y;
-  const double* __restrict__ Lbp = a.Lb;
-  const double* __restrict__ Lip = a.Linv;
+  const double* __restrict__ z = a.zbuf + 6 * jb;   // from border_matvec_kernel; distinct from the output so loads can stay in flight
+  double* __restrict__ yout = a.y + 6 * jb;
+  const double* __restrict__ Lbp = a.Lb + size_t(jb) * nband;
+  const double* __restrict__ Lip = a.Linv + size_t(jb) * 36;
   // block handled by this lane at step J: B = J - d, d in [1, G], B ≡ g (mod G)
   auto dist = [&](int J) { int d = (J - g) % G; if (d < 0) d += G; return d == 0 ? G : d; };
   // Every load of the sweep is unconditional (addresses clamped into the arrays) and issued by fetch(), PF steps
@@ -1046,69 +1149,6 @@ __global__ __launch_bounds__(64) void band_backsolve_kernel(SolveArgs a) {
 #pragma unroll
       for (int rr = 0; rr < 6; ++rr) P += lcur[rr] * y[rr];
     }
-  }
-}
-
-// delta = -y ; candidate = Plus(x, delta) ; model cost change ; step norms.
-__global__ __launch_bounds__(256) void update_kernel(SolveArgs a, const double* __restrict__ x, double* __restrict__ x_cand,
-                                                     const BlockDev* __restrict__ blocks, int n_blocks) {
-  LmState* st = a.st;
-  if (st->terminated) return;
-  __shared__ double s_a[256], s_b[256], s_c[256];
-  __shared__ int s_bad;
-  const int tid = threadIdx.x;
-  if (tid == 0) s_bad = 0;
-  __syncthreads();
-  const int NT = a.NT();
-  double mcc = 0.0;
-  for (int j = tid; j < NT; j += 256) {
-    const double yj = a.y[j];
-    if (!isfinite(yj)) s_bad = 1;
-    mcc += 0.5 * yj * (a.R[a.off_g() + j] + yj * a.dadd[j]);
-  }
-  double sn = 0.0, cn = 0.0;
-  for (int b = tid; b < n_blocks; b += 256) {
-    const BlockDev B = blocks[b];
-    const double* yb = a.y + B.tan_off;
-    const double* p = x + B.amb_off;
-    double* q = x_cand + B.amb_off;
-    if (B.manifold == 1) {
-      const double d0 = -yb[0], d1 = -yb[1], d2 = -yb[2];
-      const double nd = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-      double nx = p[0], ny = p[1], nz = p[2], nw = p[3];
-      if (nd > 0.0) {
-        const double sd = sin(nd) / nd, qw = cos(nd);
-        const double qx = sd * d0, qy = sd * d1, qz = sd * d2;
-        const double px = p[0], py = p[1], pz = p[2], pw = p[3];
-        nw = qw * pw - qx * px - qy * py - qz * pz;
-        nx = qw * px + qx * pw + qy * pz - qz * py;
-        ny = qw * py + qy * pw + qz * px - qx * pz;
-        nz = qw * pz + qz * pw + qx * py - qy * px;
-      }
-      q[0] = nx; q[1] = ny; q[2] = nz; q[3] = nw;
-      const double e[4] = {p[0] - nx, p[1] - ny, p[2] - nz, p[3] - nw};
-      sn += e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3];
-      cn += nx * nx + ny * ny + nz * nz + nw * nw;
-    } else {
-      for (int i = 0; i < B.size; ++i) {
-        const double v = p[i] - yb[i];
-        q[i] = v; const double e = p[i] - v; sn += e * e; cn += v * v;
-      }
-    }
-  }
-  s_a[tid] = mcc; s_b[tid] = sn; s_c[tid] = cn;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (tid < off) { s_a[tid] += s_a[tid + off]; s_b[tid] += s_b[tid + off]; s_c[tid] += s_c[tid + off]; }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    st->model_cost_change = s_a[0];
-    st->step_norm = sqrt(s_b[0]);
-    st->candidate_cost = 0.0;
-    st->cand_norm = sqrt(s_c[0]);
-    if (s_bad || st->chol_failed) { st->step_valid = 0; }
-    else st->step_valid = (s_a[0] > 0.0) ? 1 : 0;
   }
 }
 
@@ -1267,7 +1307,7 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
   const int pb = int((total + 255) / 256);
   hipLaunchKernelGGL(prepare_kernel, dim3(pb < 2048 ? pb : 2048), dim3(256), 0, s, a, o);
   const int nwg = (m1 + kBorderSlice - 1) / kBorderSlice;
-  hipLaunchKernelGGL(band_cholesky_kernel, dim3(nwg), dim3(256), band_cholesky_lds_bytes(a), s, a, kBorderSlice);
+  hipLaunchKernelGGL(band_cholesky_kernel, dim3(nwg, a.n_seg()), dim3(256), band_cholesky_lds_bytes(a), s, a, kBorderSlice);
   const int nt = (m1 + 15) / 16;
   hipLaunchKernelGGL(schur_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, a);
   if (m1 <= 128) {
@@ -1298,16 +1338,16 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
   {
     const size_t bl = band_backsolve_lds_bytes(a);
     switch (a.k) {
-      case 2: hipLaunchKernelGGL(band_backsolve_kernel<2>, dim3(1), dim3(64), bl, s, a); break;
-      case 3: hipLaunchKernelGGL(band_backsolve_kernel<3>, dim3(1), dim3(64), bl, s, a); break;
-      case 4: hipLaunchKernelGGL(band_backsolve_kernel<4>, dim3(1), dim3(64), bl, s, a); break;
-      case 5: hipLaunchKernelGGL(band_backsolve_kernel<5>, dim3(1), dim3(64), bl, s, a); break;
-      case 6: hipLaunchKernelGGL(band_backsolve_kernel<6>, dim3(1), dim3(64), bl, s, a); break;
-      case 7: hipLaunchKernelGGL(band_backsolve_kernel<7>, dim3(1), dim3(64), bl, s, a); break;
-      default: hipLaunchKernelGGL(band_backsolve_kernel<8>, dim3(1), dim3(64), bl, s, a); break;
+      case 2: hipLaunchKernelGGL(band_backsolve_kernel<2>, dim3(a.n_seg()), dim3(256), bl, s, a, x, x_cand, blocks, n_blocks); break;
+      case 3: hipLaunchKernelGGL(band_backsolve_kernel<3>, dim3(a.n_seg()), dim3(256), bl, s, a, x, x_cand, blocks, n_blocks); break;
+      case 4: hipLaunchKernelGGL(band_backsolve_kernel<4>, dim3(a.n_seg()), dim3(256), bl, s, a, x, x_cand, blocks, n_blocks); break;
+      case 5: hipLaunchKernelGGL(band_backsolve_kernel<5>, dim3(a.n_seg()), dim3(256), bl, s, a, x, x_cand, blocks, n_blocks); break;
+      case 6: hipLaunchKernelGGL(band_backsolve_kernel<6>, dim3(a.n_seg()), dim3(256), bl, s, a, x, x_cand, blocks, n_blocks); break;
+      case 7: hipLaunchKernelGGL(band_backsolve_kernel<7>, dim3(a.n_seg()), dim3(256), bl, s, a, x, x_cand, blocks, n_blocks); break;
+      default: hipLaunchKernelGGL(band_backsolve_kernel<8>, dim3(a.n_seg()), dim3(256), bl, s, a, x, x_cand, blocks, n_blocks); break;
     }
   }
-  hipLaunchKernelGGL(update_kernel, dim3(1), dim3(256), 0, s, a, x, x_cand, blocks, n_blocks);
+  if (a.n_seg() > 1) hipLaunchKernelGGL(update_kernel, dim3(1), dim3(256), 0, s, a, x, x_cand, blocks, n_blocks);
 }
 void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const LmState* st, hipStream_t s) {
   hipLaunchKernelGGL(cost_reduce_kernel, dim3(1), dim3(256), 0, s, item_cost, n_items, R2, st);
