@@ -780,16 +780,6 @@ __global__ __launch_bounds__(256) void reduced_solve_reg_kernel(SolveArgs a) {
   if (tid == 0 && s_fail) st->chol_failed = 1;
 }
 
-// Panel variant for m+1 <= 64·RPL: the augmented reduced matrix lives in LDS (row-major, odd stride) and is
-// factored 16 columns at a time. The latency chain of a panel -- pivot, rsqrt, column scale, update of the
-// remaining panel columns -- runs inside ONE wave with no barrier and no branch: lane l keeps rows j0+l (+64)
-// of the panel in registers and the pivot-row values travel by v_readlane. A short last panel is factored
-// 16 wide as well: its surplus columns only ever feed themselves and are never read back. The rank-16
-// trailing update runs on the matrix cores, one 16×16 tile per wave and step: D -= L_I L_Cᵀ as four
-// v_mfma_f64_16x16x4_f64 (A = -L_I rows, B = L_C rows, one f64 per lane; C/D col = lane&15,
-// row = (lane>>4) + 4·reg). Two barriers per 16 columns instead of one per column.
-// Row m is the right-hand side, so the forward substitution comes for free; the backward substitution is an
-// axpy-form sweep on one wave with the factor rows prefetched four steps ahead.
 // Factor one 16-column panel (columns j0..j0+15 of rows j0..m) inside ONE wave; lane l owns rows j0 + l (+ 64·r).
 // Column jj: pivot chain (readlane -> rsqrt -> scale), then only the update of column jj+1 that the next pivot needs
 // (its multiplier travels by readlane); the multipliers of the columns beyond go through a 64-double LDS buffer and
@@ -852,17 +842,55 @@ DEVI void panel_factor(double* A, int LD, double* dinv, double* bcast, int j0, i
   }
 }
 
+// One 16×16 tile of the reduced matrix, block row I / block column c (16-blocks): D(I, c) -= Σ_q L(I, q) L(c, q)ᵀ over
+// the factored panels q in [q0, q1), on the matrix cores. The tile is read and written once however many panels
+// contribute (left-looking); rows past m are clamped for the operands and go to a dump word for the result.
+DEVI void update_tile(double* A, int LD, int m, int I, int c, int q0, int q1, int lane, double* dump) {
+  const int lr = lane & 15, lk = lane >> 4;
+  const double* pa = A + min(16 * I + lr, m) * LD + lk;
+  const double* pb = A + min(16 * c + lr, m) * LD + lk;
+  double* pd[4];
+  f64x4 acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * I + lk + 4 * r;
+    pd[r] = row <= m ? A + row * LD + 16 * c + lr : dump;
+    acc[r] = *pd[r];
+  }
+  for (int q = q0; q < q1; ++q) {
+    double va[4], vb[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { va[kk] = -pa[16 * q + 4 * kk]; vb[kk] = pb[16 * q + 4 * kk]; }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) *pd[r] = acc[r];
+}
+
+// Panel variant for m+1 <= 64·RPL: the augmented reduced matrix lives in LDS (row-major, odd stride) and is
+// factored 16 columns at a time with look-ahead:
+//   [block column p+1 receives the contribution of panel p, all waves] | barrier |
+//   [wave 0: panel p+1]  ∥  [waves 1..3: block column p+2 receives the contributions of panels 0..p in one pass]
+//   | barrier | ...
+// so the latency chain of the panels (pivot -> rsqrt -> scale -> update, inside ONE wave, see panel_factor) never waits
+// for the updates, which run on the matrix cores (v_mfma_f64_16x16x4_f64) and touch every tile of the matrix twice
+// (left-looking) instead of once per panel. Row m is the right-hand side, so the forward substitution comes for free.
+// Backward substitution by blocks of 16: an in-wave chain for the diagonal block, a parallel matrix-vector product
+// for the rest (see below).
 template <int RPL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void reduced_solve_panel_kernel(SolveArgs a) {
+__global__ __launch_bounds__(256) void reduced_solve_panel_kernel(SolveArgs a) {
   LmState* st = a.st;
   if (st->terminated) return;
   extern __shared__ double lds[];
   const int m = a.m, m1 = a.m + 1, n = a.n_s();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nblk = (m + 15) >> 4;
   const int LD = (16 * ((m1 + 15) / 16)) | 1;   // every 16-column panel stays inside its row
   double* A = lds;                              // [m1][LD] lower triangle
   double* dinv = lds + size_t(m1) * LD;         // [m + 16]
-  double* bcast = dinv + m1 + 16;               // [2][64] column broadcast buffer of the panel wave
+  double* bcast = dinv + m1 + 16;               // [2][64] column broadcast buffer of the panel wave / backward sweep
+  double* dump = bcast + 128 + tid;             // [256] per-thread dump word
   __shared__ int s_fail;
   if (tid == 0) s_fail = 0;
   for (int idx = tid; idx < m1 * m1; idx += 256) {
@@ -871,94 +899,80 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     if (c <= r) A[r * LD + c] = v;
   }
   __syncthreads();
-  const bool dbg = a.debug && tid == 0;
+  const bool dbg = a.debug && (tid == 0 || tid == 64);
   long long tph[4] = {0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define PTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   double pmin = 1.0;
-  for (int j0 = 0; j0 < m; j0 += 16) {
+  auto do_panel = [&](int j0) {
     const int w = min(16, m - j0);
-    if (wave == 0) {
-      if (RPL > 1 && j0 + 64 <= m) panel_factor<RPL>(A, LD, dinv, bcast, j0, m, w, lane, &pmin);
-      else panel_factor<1>(A, LD, dinv, bcast, j0, m, w, lane, &pmin);
-    }
+    if (RPL > 1 && j0 + 64 <= m) panel_factor<RPL>(A, LD, dinv, bcast, j0, m, w, lane, &pmin);
+    else panel_factor<1>(A, LD, dinv, bcast, j0, m, w, lane, &pmin);
+  };
+  // Left-looking with look-ahead, in 16-blocks: panel p = columns 16p.., row tiles I = 0..nrt-1 (the last one holds
+  // the right-hand-side row m). Iteration p:
+  //   phase 1, all waves : block column p+1 receives the contribution of panel p (it already holds those of 0..p-1)
+  //   phase 2, wave 0    : panel p+1
+  //            waves 1..3: wave 1 inverts the diagonal block of panel p; then block column p+2 receives the
+  //                        contributions of panels 0..p in one pass (each tile read and written once)
+  const int nrt = (m1 + 15) >> 4;
+  if (wave == 0) do_panel(0);
+  __syncthreads();
+  for (int p = 0; p < nblk; ++p) {
+    for (int I = p + 1 + wave; I < nrt; I += 4) update_tile(A, LD, m, I, p + 1, p, p + 1, lane, dump);
     PTICK(0)
     __syncthreads();
     PTICK(1)
-    // trailing update of rows/cols t0..m on the matrix cores
-    const int t0 = j0 + 16;
-    if (t0 < m1) {
-      const int nt = (m1 - t0 + 15) >> 4;
-      const int T = nt * (nt + 1) / 2;
-      const int lr = lane & 15, lk = lane >> 4;
-      for (int t = wave; t < T; t += 4) {
-        int I = 0, rem = t;
-        while (rem > I) { rem -= I + 1; ++I; }
-        const int C = rem;                                       // C <= I
-        const double* pa = A + min(t0 + 16 * I + lr, m) * LD + j0 + lk;
-        const double* pb = A + min(t0 + 16 * C + lr, m) * LD + j0 + lk;
-        double* pd[4];
-        f64x4 acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pd[r] = A + min(t0 + 16 * I + lk + 4 * r, m) * LD + t0 + 16 * C + lr;
-          acc[r] = *pd[r];
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * kk], pb[4 * kk], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (t0 + 16 * I + lk + 4 * r <= m) *pd[r] = acc[r];
-      }
+    if (wave == 0) {
+      if (p + 1 < nblk) do_panel(16 * (p + 1));
+    } else {
+      for (int I = p + 2 + (wave - 1); I < nrt; I += 3) update_tile(A, LD, m, I, p + 2, 0, p + 1, lane, dump);
     }
-    __syncthreads();
     PTICK(2)
+    __syncthreads();
   }
-  // backward substitution Lᵀ y = z (row m), one wave, axpy form
-  if (wave == 0) {
-    constexpr int NV = RPL, PF = 4;
-    double acc[NV], bq[NV], dv[NV], ykeep[NV], ring[PF][NV];
-    int col[NV];
+  // backward substitution Lᵀ y = z (row m) by blocks of 16; thread t < 128 owns unknown t (waves 0 and 1 work, the
+  // other two only keep the barriers company). Per block: the wave that owns its 16 unknowns solves the diagonal
+  // block by an in-wave axpy chain (pivot by v_readlane, 16 short steps) and publishes y_blk; one barrier; then every
+  // working thread adds L(blk, j) · y_blk to the pending sum of its own unknown j < j0 -- a matrix-vector product,
+  // not a chain.
+  {
+    const int j = tid;                         // unknown owned by this thread (m <= 127)
+    const int jc = min(j, m - 1);
+    double acc = 0.0, yk = 0.0;
+    const double zq = A[size_t(m) * LD + jc];
+    const double dj = dinv[jc];
+    for (int b = nblk - 1; b >= 0; --b) {
+      const int j0 = 16 * b;
+      double* ybuf = bcast + (b & 1) * 16;
+      if (wave == (j0 >> 6)) {
+        const int l0 = j0 & 63;                // lanes l0..l0+15 own the block
+        const int i_own = lane - l0;           // row/column of this lane inside the block (valid when 0 <= i_own < 16)
+        double pend = acc;                     // pending sum of this lane's unknown, grows inside the block
+        for (int i = 15; i >= 0; --i) {
+          const double cand = (zq - pend) * dj;
+          double yi = readlane_f64(cand, l0 + i);
+          yi = j0 + i < m ? yi : 0.0;
+          yk = i_own == i ? yi : yk;
+          const double lij = A[min(j0 + i, m - 1) * LD + jc];          // L(j0 + i, j)
+          pend += (i_own >= 0 && i_own < i) ? lij * yi : 0.0;
+        }
+        if (i_own >= 0 && i_own < 16) ybuf[i_own] = yk;
+      }
+      __syncthreads();
+      if (wave < 2 && j < j0) {
 #pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int j = lane + 64 * u;
-      col[u] = min(j, m);
-      acc[u] = 0.0; ykeep[u] = 0.0;
-      bq[u] = A[size_t(m) * LD + col[u]];
-      dv[u] = dinv[min(j, m + 15)];
-    }
-    auto fetch = [&](int i, double v[NV]) {
-      const double* src = A + max(i, 0) * LD;
-#pragma unroll
-      for (int u = 0; u < NV; ++u) v[u] = src[col[u]];
-    };
-#pragma unroll
-    for (int f = 0; f < PF; ++f) fetch(m - 1 - f, ring[f]);
-    for (int i0 = m - 1; i0 >= 0; i0 -= PF) {
-#pragma unroll
-      for (int f = 0; f < PF; ++f) {
-        const int i = i0 - f;          // i < 0 in the last group: dummy step on clamped data, results discarded
-        double cur[NV];
-#pragma unroll
-        for (int u = 0; u < NV; ++u) cur[u] = (lane + 64 * u < i) ? ring[f][u] : 0.0;
-        fetch(i - PF, ring[f]);
-        double cand = 0.0;
-#pragma unroll
-        for (int u = 0; u < NV; ++u) if (((i >> 6) & (NV - 1)) == u) cand = (bq[u] - acc[u]) * dv[u];
-        const double yi = readlane_f64(cand, i & 63);
-#pragma unroll
-        for (int u = 0; u < NV; ++u) {
-          acc[u] += cur[u] * yi;
-          ykeep[u] = (lane + 64 * u == i) ? yi : ykeep[u];
+        for (int i = 0; i < 16; ++i) {
+          const double yi = j0 + i < m ? ybuf[i] : 0.0;
+          acc += A[min(j0 + i, m - 1) * LD + jc] * yi;
         }
       }
     }
-#pragma unroll
-    for (int u = 0; u < NV; ++u) if (lane + 64 * u < m) a.y[n + lane + 64 * u] = ykeep[u];
+    if (j < m) a.y[n + j] = yk;
   }
   if (wave == 0 && lane == 0 && !(pmin > 0.0)) s_fail = 1;
   __syncthreads();
   PTICK(3)
-  if (dbg) printf("reduced_solve_panel cycles: panels %lld  barrier %lld  trailing %lld  backward %lld\n", tph[0], tph[1], tph[2], tph[3]);
+  if (dbg) printf("reduced_solve_panel cycles (wave %d): column update %lld  barrier %lld  panel | trailing %lld  backward %lld\n", wave, tph[0], tph[1], tph[2], tph[3]);
 #undef PTICK
   if (tid == 0 && s_fail) st->chol_failed = 1;
 }
@@ -1311,7 +1325,7 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
   const int nt = (m1 + 15) / 16;
   hipLaunchKernelGGL(schur_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, a);
   if (m1 <= 128) {
-    const size_t lds = (size_t(m1) * ((16 * ((m1 + 15) / 16)) | 1) + m1 + 32 + 128) * sizeof(double);
+    const size_t lds = (size_t(m1) * ((16 * ((m1 + 15) / 16)) | 1) + m1 + 32 + 128 + 256) * sizeof(double);
     if (m1 <= 64) hipLaunchKernelGGL(reduced_solve_panel_kernel<1>, dim3(1), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(reduced_solve_panel_kernel<2>, dim3(1), dim3(256), lds, s, a);
   } else if (m1 <= 16 * 13) {
