@@ -38,7 +38,7 @@ hipError_t configure_eval_kernels(size_t max_lds_bytes);
 
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
                    int n_thin, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
-                   const LmState* st, int need_flag, hipStream_t s);
+                   const LmState* st, int need_flag, size_t other_stride, hipStream_t s);
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s);
 size_t band_cholesky_lds_bytes(const SolveArgs& a);
@@ -49,7 +49,8 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
                   int n_blocks, bool dense_in_lds, hipStream_t s);
 void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const LmState* st, hipStream_t s);
 void launch_control(LmState* st, const LmOptionsDev& o, double* R2, double* x, const double* x_cand, int n_amb,
-                    IterLog* log, int log_cap, const double* item_cost, int n_items, hipStream_t s);
+                    IterLog* log, int log_cap, const double* item_cost, int n_items, const double* Rbase, size_t r_stride,
+                    hipStream_t s);
 void launch_init_state(LmState* st, double radius, double x_norm, hipStream_t s);
 
 }  // namespace cal
@@ -151,6 +152,8 @@ struct calico_problem {
   int rank = 0, world = 1;
 
   // flattened problem
+  bool speculative = true;    // evaluate cost AND Jacobian at the candidate point in one pass (two reduce buffers)
+  size_t r_size = 0;
   int sep_s = 0, sep_n = 0;   // separator control points of the nested-dissection split (sep_n = 0: none)
   int n_cp = 0, m = 0, n_amb = 0, n_eff = 0, n_items = 0, n_items_all = 0, lds_cols = 0, row_pad = kRowPad;
   int64_t n_obs = 0;
@@ -213,7 +216,7 @@ int imu_num_params(int model) { return model == 1 ? 1 : (model == 2 ? 4 : (model
 
 SolveArgs make_solve_args(calico_problem* p) {
   SolveArgs a;
-  a.R = p->d_R.p; a.Lb = p->d_Lb.p; a.Linv = p->d_Linv.p; a.Y = p->d_Y.p; a.S = p->d_S.p; a.Spart = p->d_Spart.p;
+  a.R = p->d_R.p; a.r_stride = p->speculative ? p->r_size : 0; a.Lb = p->d_Lb.p; a.Linv = p->d_Linv.p; a.Y = p->d_Y.p; a.S = p->d_S.p; a.Spart = p->d_Spart.p;
   a.Swork = p->d_Swork.p; a.y = p->d_y.p; a.zbuf = p->d_zbuf.p; a.dadd = p->d_dadd.p;
   a.scale = p->d_scale.p; a.cp_active = p->d_cp_active.p; a.st = p->d_state.p; a.n_cp = p->n_cp; a.k = p->order; a.mc = p->m; a.sep_s = p->sep_s; a.sep_n = p->sep_n; a.m = p->m + 6 * p->sep_n;
   static const int dbg = std::getenv("CALICO_KERNEL_TIMING") ? std::atoi(std::getenv("CALICO_KERNEL_TIMING")) : 0;
@@ -606,7 +609,12 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_ptr_fat.upload(ptr_fat, s));
   HIP_TRY(p, p->d_partials.alloc(comp_base + comp_off));
   HIP_TRY(p, p->d_cells.upload(p->h_cells, s)); HIP_TRY(p, p->d_prim_tab.upload(prim_tab, s));
-  HIP_TRY(p, p->d_R.alloc(r_size)); HIP_TRY(p, hipMemsetAsync(p->d_R.p, 0, r_size * sizeof(double), s));
+  p->r_size = r_size;
+  {
+    const char* env = std::getenv("CALICO_SPECULATIVE");
+    p->speculative = !env || std::atoi(env) != 0;
+  }
+  HIP_TRY(p, p->d_R.alloc(2 * r_size)); HIP_TRY(p, hipMemsetAsync(p->d_R.p, 0, 2 * r_size * sizeof(double), s));
   HIP_TRY(p, p->d_R2.alloc(2));
   const int NT = 6 * n_cp + m;
   const int mw = m + 6 * p->sep_n;     // border width the solver kernels work with
@@ -652,9 +660,11 @@ int do_allreduce(calico_problem* p, double* buf, int64_t n) {
 // residual + Jacobian evaluation at d_x into the reduce buffer R. With st != nullptr the
 // kernels skip themselves on the device when the solve has terminated or (need_flag) when
 // the last step was rejected, so whole iterations can be enqueued without a host round trip.
-int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag) {
+// `spec`: evaluation at the candidate point x_at = x_cand into the reduce buffer that does NOT hold R(x) (chosen on
+// the device from LmState.rcur); otherwise evaluation at x into buffer 0.
+int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, const double* x_at = nullptr, bool spec = false) {
   p->timer.begin(0, p->stream);
-  EvalArgs ea = make_eval_args(p, p->d_x.p, 1, false);
+  EvalArgs ea = make_eval_args(p, x_at ? x_at : p->d_x.p, 1, false);
   ea.st = st; ea.need_flag = need_flag;
   ea.items = p->d_jac_items.p; ea.n_items = p->n_jac_items; ea.cost_index_base = p->n_fitems;
   if (p->order == 6 && p->n_fitems > 0) {
@@ -667,11 +677,12 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag) {
   p->timer.begin(1, p->stream);
   launch_expand_cells(ea, p->stream);                     // compact frame records -> one expanded block per cell
   launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->d_out_fat.p,
-                p->d_ptr_fat.p, p->d_idx_fat.p, p->n_fat, st, need_flag, p->stream);
+                p->d_ptr_fat.p, p->d_idx_fat.p, p->n_fat, st, need_flag, spec ? p->r_size : 0, p->stream);
   p->timer.end(p->stream);
-  if (need_flag) return CALICO_OK;  // single-rank asynchronous path: no exchange
-  SolveArgs sa = make_solve_args(p);
-  return do_allreduce(p, p->d_R.p, int64_t(sa.r_size()));
+  if (!p->allreduce) return CALICO_OK;  // single rank: no exchange
+  // the host knows which buffer was filled: multi-rank runs read the state back every iteration
+  double* target = p->d_R.p + ((spec && p->h_state && !p->h_state->rcur) ? p->r_size : 0);
+  return do_allreduce(p, target, int64_t(p->r_size));
 }
 
 int read_state(calico_problem* p) {
@@ -933,11 +944,31 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   // iterations, every kernel deciding on the device whether it still has work.
   const bool async = p->allreduce == nullptr;
   const int batch = async ? std::max(1, opt->sync_every) : 1;
+  const bool spec = p->speculative;
   while (!p->h_state->terminated) {
     for (int b = 0; b < batch; ++b) {
       p->timer.begin(2, s);
       launch_solve(sa, o, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, p->dense_in_lds, s);
       p->timer.end(s);
+      if (spec) {
+        // Speculative evaluation: cost AND Jacobian at the candidate point in one pass, into the reduce buffer that
+        // does not hold R(x). Its first two entries are the candidate's [cost, invalid]; when the step is accepted the
+        // control kernel swaps the buffers and the next linear solve starts at once -- no separate cost-only pass,
+        // and with several ranks a single all-reduce per iteration. A rejected step wastes the Jacobian work.
+        rc = enqueue_jacobian_eval(p, p->d_state.p, 0, p->d_xc.p, true);
+        if (rc != CALICO_OK) return rc;
+        p->timer.begin(4, s);
+        launch_control(p->d_state.p, o, p->d_R2.p, p->d_x.p, p->d_xc.p, p->n_amb, p->d_log.p, kLogCap, nullptr, 0, p->d_R.p,
+                       p->r_size, s);
+        launch_post_eval(sa, p->d_x.p, p->d_blocks.p, n_blocks, o, p->d_log.p, kLogCap, 0, opt->jacobi_scaling, s);
+        p->timer.end(s);
+        if (!async) {
+          rc = read_state(p);
+          if (rc != CALICO_OK) return rc;
+          if (p->h_state->terminated) break;
+        }
+        continue;
+      }
       p->timer.begin(3, s);
       {
         EvalArgs ea = make_eval_args(p, p->d_xc.p, 1, false);
@@ -951,7 +982,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
       if (rc != CALICO_OK) return rc;
       p->timer.begin(4, s);
       launch_control(p->d_state.p, o, p->d_R2.p, p->d_x.p, p->d_xc.p, p->n_amb, p->d_log.p, kLogCap,
-                     fuse_cost ? p->d_partials.p + p->partial_doubles : nullptr, p->n_items, s);
+                     fuse_cost ? p->d_partials.p + p->partial_doubles : nullptr, p->n_items, nullptr, 0, s);
       p->timer.end(s);
       if (!async) {
         rc = read_state(p);
@@ -966,6 +997,9 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
     }
     rc = read_state(p);
     if (rc != CALICO_OK) return rc;
+  }
+  if (spec && p->h_state->rcur) {   // leave R(x) in buffer 0 for whoever reads it next
+    HIP_TRY(p, hipMemcpyAsync(p->d_R.p, p->d_R.p + p->r_size, p->r_size * sizeof(double), hipMemcpyDeviceToDevice, s));
   }
   sm->num_jacobian_evaluations = p->h_state->n_jac_evals;
   sm->num_cost_evaluations = p->h_state->n_cost_evals;

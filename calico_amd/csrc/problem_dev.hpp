@@ -98,7 +98,8 @@ struct LmState {
   int step_valid, step_successful, chol_failed;
   int num_consecutive_invalid, num_successful, num_unsuccessful;
   int invalid_eval;       // candidate evaluation hit an invalid projection
-  int n_log, n_jac_evals, n_cost_evals, pad;
+  int n_log, n_jac_evals, n_cost_evals;
+  int rcur;               // which of the two reduce buffers holds R(x) (speculative evaluation)
 };
 
 struct LmOptionsDev {
@@ -125,7 +126,8 @@ struct BlockDev {  // one reduced (free, used) parameter block
 // Arguments of the linear-solve kernels. The reduce buffer R is laid out as
 // [cost | invalid | g(NT) | band blocks B(n_cp,k,6,6) | border E(6n_cp,m) | corner C(m,m)].
 struct SolveArgs {
-  const double* R;
+  const double* R;        // reduce buffer 0; buffer 1 follows at r_stride doubles (0: single-buffered)
+  size_t r_stride;
   double* Lb;             // [n_cp][6k][6] band factor by block column: Lb[J][r][c] = L(6J+r, 6J+c)
   double* Linv;           // [n_cp][6][6]  inverse of every 6x6 pivot block
   double* Y;              // [n_s][m+1] L^-1 [E | g_s]

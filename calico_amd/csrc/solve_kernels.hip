@@ -19,6 +19,10 @@ namespace cal {
 
 #define DEVI __device__ __forceinline__
 
+// The reduce buffer that holds R(x): with speculative evaluation the Jacobian pass at the candidate point fills the
+// other one and the control kernel swaps them when the step is accepted.
+DEVI void use_current_R(SolveArgs& a) { if (a.r_stride && a.st->rcur) a.R += a.r_stride; }
+
 DEVI double band_entry(const SolveArgs& a, int row, int col) {  // H(row, col), row >= col, inside the band
   const int ic = col / 6, cc = col % 6, ir = row / 6, rr = row % 6;
   const int d = ir - ic;
@@ -44,8 +48,9 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
                                                      const int* __restrict__ idx_thin, int n_thin,
                                                      const int* __restrict__ out_fat, const int64_t* __restrict__ ptr_fat,
                                                      const int* __restrict__ idx_fat, int n_fat, int nb_fat,
-                                                     const LmState* st, int need_flag) {
+                                                     const LmState* st, int need_flag, size_t other_stride) {
   if (st && (st->terminated || (need_flag && !st->need_jacobian))) return;
+  if (other_stride && st && !st->rcur) R += other_stride;     // speculative: fill the buffer that does NOT hold R(x)
   if (int(blockIdx.x) < nb_fat) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -95,6 +100,7 @@ __global__ __launch_bounds__(256) void post_eval_kernel(SolveArgs a, const doubl
                                                         int jacobi_scaling) {
   LmState* st = a.st;
   if (st->terminated || (!first && !st->need_jacobian)) return;
+  use_current_R(a);
   __shared__ double s_max[256], s_sum[256];
   const int tid = threadIdx.x;
   const int NT = a.NT();
@@ -154,6 +160,7 @@ __global__ __launch_bounds__(256) void post_eval_kernel(SolveArgs a, const doubl
 __global__ void prepare_kernel(SolveArgs a, LmOptionsDev o) {
   const LmState* st = a.st;
   if (st->terminated) return;
+  use_current_R(a);
   const int n_s = a.n_s(), W = a.W(), m = a.m, mc = a.mc, m1 = a.m + 1;
   const double radius = st->radius;
   const size_t nL = size_t(a.n_cp) * W * 6, nY = size_t(n_s) * m1, nS = size_t(m1) * m1;
@@ -996,8 +1003,10 @@ __global__ __launch_bounds__(256) void border_matvec_kernel(SolveArgs a) {
 
 // delta = -y ; candidate = Plus(x, delta) ; model cost change ; step norms.
 // (256 threads; called at the end of band_backsolve_kernel once the whole solution vector is in place)
-DEVI void update_body(const SolveArgs& a, const double* __restrict__ x, double* __restrict__ x_cand,
+DEVI void update_body(const SolveArgs& a_in, const double* __restrict__ x, double* __restrict__ x_cand,
                       const BlockDev* __restrict__ blocks, int n_blocks) {
+  SolveArgs a = a_in;
+  use_current_R(a);
   LmState* st = a.st;
   __shared__ double s_a[256], s_b[256], s_c[256];
   __shared__ int s_bad;
@@ -1188,10 +1197,14 @@ __global__ __launch_bounds__(256) void cost_reduce_kernel(const double* __restri
 // of in a separate cost_reduce_kernel launch (with several ranks the sum goes through the all-reduce in between).
 __global__ __launch_bounds__(256) void lm_control_kernel(LmState* st, LmOptionsDev o, double* R2, double* x,
                                                          const double* x_cand, int n_amb, IterLog* log, int log_cap,
-                                                         const double* __restrict__ item_cost, int n_items) {
+                                                         const double* __restrict__ item_cost, int n_items,
+                                                         const double* Rbase, size_t r_stride) {
   if (st->terminated) return;
   __shared__ int s_accept;
   const int tid = threadIdx.x;
+  // speculative evaluation (r_stride != 0): the candidate's [cost, invalid] are the first two entries of the reduce
+  // buffer the Jacobian pass at the candidate point has just filled
+  if (r_stride) R2 = const_cast<double*>(Rbase + (st->rcur ? 0 : r_stride));
   if (item_cost) {
     __shared__ double s_a[256], s_b[256];
     double c = 0.0, v = 0.0;
@@ -1240,6 +1253,7 @@ __global__ __launch_bounds__(256) void lm_control_kernel(LmState* st, LmOptionsD
             s_accept = 1;
             st->step_successful = 1;
             st->need_jacobian = 1;
+            if (r_stride) st->rcur ^= 1;      // the buffer evaluated at the candidate becomes R(x)
             st->x_norm = cand_norm;
             const double t = 2.0 * st->relative_decrease - 1.0;
             st->radius = st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
@@ -1271,11 +1285,11 @@ __global__ void init_state_kernel(LmState* st, double radius, double x_norm) {
 // ---- launch helpers ---------------------------------------------------------
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
                    int n_thin, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
-                   const LmState* st, int need_flag, hipStream_t s) {
+                   const LmState* st, int need_flag, size_t other_stride, hipStream_t s) {
   const int nb_thin = (n_thin + 31) / 32, nb_fat = (n_fat + 3) / 4;
   if (nb_thin + nb_fat > 0)
     hipLaunchKernelGGL(gather_kernel, dim3(nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin,
-                       out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, st, need_flag);
+                       out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, st, need_flag, other_stride);
 }
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s) {
@@ -1367,8 +1381,10 @@ void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const 
   hipLaunchKernelGGL(cost_reduce_kernel, dim3(1), dim3(256), 0, s, item_cost, n_items, R2, st);
 }
 void launch_control(LmState* st, const LmOptionsDev& o, double* R2, double* x, const double* x_cand, int n_amb,
-                    IterLog* log, int log_cap, const double* item_cost, int n_items, hipStream_t s) {
-  hipLaunchKernelGGL(lm_control_kernel, dim3(1), dim3(256), 0, s, st, o, R2, x, x_cand, n_amb, log, log_cap, item_cost, n_items);
+                    IterLog* log, int log_cap, const double* item_cost, int n_items, const double* Rbase, size_t r_stride,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(lm_control_kernel, dim3(1), dim3(256), 0, s, st, o, R2, x, x_cand, n_amb, log, log_cap, item_cost, n_items,
+                     Rbase, r_stride);
 }
 void launch_init_state(LmState* st, double radius, double x_norm, hipStream_t s) {
   hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, s, st, radius, x_norm);
