@@ -111,25 +111,39 @@ struct PhaseTimer {
   size_t next = 0;
   double ms[kNumPhases] = {0, 0, 0, 0, 0, 0};
   int64_t count[kNumPhases] = {0, 0, 0, 0, 0, 0};
+  // the same restricted to "working" launches: kernels of iterations enqueued ahead return at once when the solve has
+  // terminated (or the step was rejected), and such brackets (shorter than a quarter of the phase's longest) are left out
+  double ms_working[kNumPhases] = {0, 0, 0, 0, 0, 0};
+  int64_t count_working[kNumPhases] = {0, 0, 0, 0, 0, 0};
+  std::vector<float> samples[kNumPhases];
   hipEvent_t get() {
     if (next == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
     return pool[next++];
   }
   int mask = 0x1f;
+  int every = 1;            // bracket only every `every`-th launch of a phase (an event pair costs ~6 us of stream time)
+  int64_t seen[kNumPhases] = {0, 0, 0, 0, 0, 0};
   bool open_rec = false;
   void begin(int phase, hipStream_t s) {
     open_rec = phase == 5 ? (mask & 1) : (mask >> phase) & 1;
+    if (open_rec && phase != 5 && every > 1) open_rec = (seen[phase]++ % every) == 0;
     if (!open_rec) return;
     Rec r; r.phase = phase; r.a = get(); r.b = nullptr; (void)hipEventRecord(r.a, s); pending.push_back(r);
   }
   void end(hipStream_t s) { if (!open_rec) return; Rec& r = pending.back(); r.b = get(); (void)hipEventRecord(r.b, s); open_rec = false; }
   void resolve() {  // call after a stream sync
     for (const Rec& r : pending) {
-      float t = 0; if (r.b && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.phase] += t; count[r.phase]++; }
+      float t = 0;
+      if (r.b && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.phase] += t; count[r.phase]++; samples[r.phase].push_back(t); }
     }
     pending.clear(); next = 0;
+    for (int ph = 0; ph < kNumPhases; ++ph) {
+      float mx = 0; for (float t : samples[ph]) mx = std::max(mx, t);
+      ms_working[ph] = 0; count_working[ph] = 0;
+      for (float t : samples[ph]) if (t >= 0.25f * mx) { ms_working[ph] += t; count_working[ph]++; }
+    }
   }
-  void reset() { for (int i = 0; i < kNumPhases; ++i) { ms[i] = 0; count[i] = 0; } }
+  void reset() { for (int i = 0; i < kNumPhases; ++i) { ms[i] = 0; count[i] = 0; seen[i] = 0; ms_working[i] = 0; count_working[i] = 0; samples[i].clear(); } }
   ~PhaseTimer() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); }
 };
 
@@ -1156,14 +1170,17 @@ int32_t calico_problem_set_stream(calico_problem* p, void* stream) {
 
 int32_t calico_set_phase_timing(calico_problem* p, int32_t mask) {
   if (!p) return CALICO_INVALID_ARGUMENT;
-  p->timer.mask = mask;
+  p->timer.mask = mask & 0xff;
+  p->timer.every = std::max(1, (mask >> 8) & 0xff);
   return CALICO_OK;
 }
 
 int32_t calico_get_phase_time(calico_problem* p, int32_t phase, double* ms, int64_t* launches) {
+  const bool working = (phase & 0x100) != 0;
+  phase &= 0xff;
   if (!p || phase < 0 || phase >= kNumPhases) return CALICO_INVALID_ARGUMENT;
-  if (ms) *ms = p->timer.ms[phase];
-  if (launches) *launches = p->timer.count[phase];
+  if (ms) *ms = working ? p->timer.ms_working[phase] : p->timer.ms[phase];
+  if (launches) *launches = working ? p->timer.count_working[phase] : p->timer.count[phase];
   return CALICO_OK;
 }
 
