@@ -46,7 +46,7 @@ size_t reduced_solve_lds_bytes(const SolveArgs& a);
 size_t band_backsolve_lds_bytes(const SolveArgs& a);
 hipError_t configure_solve_kernels(size_t band_lds, size_t reduced_lds, size_t back_lds);
 void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, double* x_cand, const BlockDev* blocks,
-                  int n_blocks, bool dense_in_lds, hipStream_t s);
+                  int n_blocks, bool dense_in_lds, hipStream_t s, bool with_post_eval, IterLog* log, int log_cap, int jacobi);
 void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const LmState* st, hipStream_t s);
 void launch_control(LmState* st, const LmOptionsDev& o, double* R2, double* x, const double* x_cand, int n_amb,
                     IterLog* log, int log_cap, const double* item_cost, int n_items, const double* Rbase, size_t r_stride,
@@ -961,8 +961,12 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   const bool spec = p->speculative;
   while (!p->h_state->terminated) {
     for (int b = 0; b < batch; ++b) {
+      // (speculative, single rank) the bookkeeping of the step accepted in the previous iteration of this batch rides
+      // in the prepare kernel of this one; the last iteration of a batch gets a stand-alone post_eval below
+      const bool ride = spec && async && b > 0;
       p->timer.begin(2, s);
-      launch_solve(sa, o, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, p->dense_in_lds, s);
+      launch_solve(sa, o, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, p->dense_in_lds, s, ride, p->d_log.p, kLogCap,
+                   opt->jacobi_scaling);
       p->timer.end(s);
       if (spec) {
         // Speculative evaluation: cost AND Jacobian at the candidate point in one pass, into the reduce buffer that
@@ -974,7 +978,8 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
         p->timer.begin(4, s);
         launch_control(p->d_state.p, o, p->d_R2.p, p->d_x.p, p->d_xc.p, p->n_amb, p->d_log.p, kLogCap, nullptr, 0, p->d_R.p,
                        p->r_size, s);
-        launch_post_eval(sa, p->d_x.p, p->d_blocks.p, n_blocks, o, p->d_log.p, kLogCap, 0, opt->jacobi_scaling, s);
+        if (!async || b == batch - 1)
+          launch_post_eval(sa, p->d_x.p, p->d_blocks.p, n_blocks, o, p->d_log.p, kLogCap, 0, opt->jacobi_scaling, s);
         p->timer.end(s);
         if (!async) {
           rc = read_state(p);

@@ -94,10 +94,8 @@ DEVI void log_and_finalize(LmState* st, const LmOptionsDev& o, IterLog* log, int
 
 // After a Jacobian evaluation at x: x_cost, gradient norms |x - Plus(x,-g)|,
 // Jacobi scaling at iteration 0, the iteration's log row.
-__global__ __launch_bounds__(256) void post_eval_kernel(SolveArgs a, const double* __restrict__ x,
-                                                        const BlockDev* __restrict__ blocks, int n_blocks,
-                                                        LmOptionsDev o, IterLog* log, int log_cap, int first,
-                                                        int jacobi_scaling) {
+DEVI void post_eval_body(SolveArgs a, const double* __restrict__ x, const BlockDev* __restrict__ blocks, int n_blocks,
+                         const LmOptionsDev& o, IterLog* log, int log_cap, int first, int jacobi_scaling) {
   LmState* st = a.st;
   if (st->terminated || (!first && !st->need_jacobian)) return;
   use_current_R(a);
@@ -151,15 +149,29 @@ __global__ __launch_bounds__(256) void post_eval_kernel(SolveArgs a, const doubl
   }
 }
 
+__global__ __launch_bounds__(256) void post_eval_kernel(SolveArgs a, const double* __restrict__ x,
+                                                        const BlockDev* __restrict__ blocks, int n_blocks,
+                                                        LmOptionsDev o, IterLog* log, int log_cap, int first,
+                                                        int jacobi_scaling) {
+  post_eval_body(a, x, blocks, n_blocks, o, log, log_cap, first, jacobi_scaling);
+}
+
 // ---------------------------------------------------------------------------
 // Build the damped working copies (one thread per entry).
 //   Lb[J][r][c] = H(6J + r, 6J + c), r = 0..6k-1, c = 0..5  (block column J of the band, lower part)
 //   Y[c][j]     = E(c, j) for j < m, g_s(c) for j = m
 //   S[r][c]     = C(r, c) (+ damping), row m / column m carry g_c
 // ---------------------------------------------------------------------------
-__global__ void prepare_kernel(SolveArgs a, LmOptionsDev o) {
+// With `with_post` the LAST workgroup does the bookkeeping of the step just accepted (post_eval_body: gradient norms,
+// tolerance tests, log row) instead: it only reads R(x) and x, like the others, so it rides along instead of
+// standing between the control kernel and the next linear solve.
+__global__ __launch_bounds__(256) void prepare_kernel(SolveArgs a, LmOptionsDev o, int with_post, const double* __restrict__ x,
+                                                      const BlockDev* __restrict__ blocks, int n_blocks, IterLog* log, int log_cap,
+                                                      int jacobi_scaling) {
   const LmState* st = a.st;
   if (st->terminated) return;
+  if (with_post && blockIdx.x == gridDim.x - 1) { post_eval_body(a, x, blocks, n_blocks, o, log, log_cap, 0, jacobi_scaling); return; }
+  const size_t n_prep_blocks = gridDim.x - (with_post ? 1 : 0);
   use_current_R(a);
   const int n_s = a.n_s(), W = a.W(), m = a.m, mc = a.mc, m1 = a.m + 1;
   const double radius = st->radius;
@@ -169,7 +181,7 @@ __global__ void prepare_kernel(SolveArgs a, LmOptionsDev o) {
   auto hss = [&](int r, int c) { return r >= c ? band_entry(a, r, c) : band_entry(a, c, r); };
   // a control point takes part in the band unless it is unobserved or belongs to the separator
   auto band_act = [&](int J) { return a.cp_active[J] != 0 && !a.in_sep(6 * J); };
-  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += size_t(gridDim.x) * blockDim.x) {
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += n_prep_blocks * blockDim.x) {
     if (i < nL) {
       const int J = int(i / (size_t(W) * 6)), rem = int(i % (size_t(W) * 6));
       const int r = rem / 6, cc = rem % 6;
@@ -1329,11 +1341,12 @@ hipError_t configure_solve_kernels(size_t band_lds, size_t reduced_lds, size_t b
   return hipSuccess;
 }
 void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, double* x_cand, const BlockDev* blocks,
-                  int n_blocks, bool reduced_in_lds, hipStream_t s) {
+                  int n_blocks, bool reduced_in_lds, hipStream_t s, bool with_post_eval, IterLog* log, int log_cap, int jacobi) {
   const int m1 = a.m + 1;
   const size_t total = size_t(a.n_cp) * a.W() * 6 + size_t(a.n_s()) * m1 + size_t(m1) * m1;
   const int pb = int((total + 255) / 256);
-  hipLaunchKernelGGL(prepare_kernel, dim3(pb < 2048 ? pb : 2048), dim3(256), 0, s, a, o);
+  hipLaunchKernelGGL(prepare_kernel, dim3((pb < 2048 ? pb : 2048) + (with_post_eval ? 1 : 0)), dim3(256), 0, s, a, o, with_post_eval ? 1 : 0,
+                     x, blocks, n_blocks, log, log_cap, jacobi);
   const int nwg = (m1 + kBorderSlice - 1) / kBorderSlice;
   hipLaunchKernelGGL(band_cholesky_kernel, dim3(nwg, a.n_seg()), dim3(256), band_cholesky_lds_bytes(a), s, a, kBorderSlice);
   const int nt = (m1 + 15) / 16;
