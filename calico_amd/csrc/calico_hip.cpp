@@ -646,7 +646,7 @@ int finalize(calico_problem* p) {
   if (band_lds > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "spline order too high for the banded factorisation window");
   const size_t reduced_lds = reduced_solve_lds_bytes(sa);
   p->dense_in_lds = reduced_lds <= kMaxLds - 1024;
-  HIP_TRY(p, p->d_Spart.alloc(size_t(mw + 1) * (mw + 1)));
+  HIP_TRY(p, p->d_Spart.alloc(4 * size_t(mw + 1) * (mw + 1)));   // up to four K-slices of the Schur complement
   const size_t back_lds = band_backsolve_lds_bytes(sa);
   if (back_lds > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "trajectory too long for the back-substitution window");
   HIP_TRY(p, p->d_Swork.alloc(std::max<size_t>(reduced_lds / sizeof(double) + 8, size_t(mw + 1) * 16 * 13 + 8)));

@@ -51,12 +51,24 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
                                                      const LmState* st, int need_flag, size_t other_stride) {
   if (st && (st->terminated || (need_flag && !st->need_jacobian))) return;
   if (other_stride && st && !st->rcur) R += other_stride;     // speculative: fill the buffer that does NOT hold R(x)
+  // Both roles issue all index loads of a lane first and all value loads second: two memory round trips per output
+  // instead of one dependent pair per source.
   if (int(blockIdx.x) < nb_fat) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= n_fat) return;
+    const int64_t q0 = ptr_fat[wave], q1 = ptr_fat[wave + 1];
     double s = 0.0;
-    for (int64_t q = ptr_fat[wave] + lane; q < ptr_fat[wave + 1]; q += 64) s += src[idx_fat[q]];
+    for (int64_t qb = q0; qb < q1; qb += 256) {     // four sources per lane and pass
+      int id[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int64_t q = qb + lane + 64 * u; id[u] = idx_fat[q < q1 ? q : q1 - 1]; }
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = src[id[u]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += qb + lane + 64 * u < q1 ? v[u] : 0.0;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) R[out_fat[wave]] = s;
@@ -65,9 +77,16 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
     const int o = gid >> 3, sub = gid & 7;
     const bool live = o < n_thin;
     const int oc = live ? o : n_thin - 1;
-    const int64_t q0 = ptr_thin[oc], q1 = ptr_thin[oc + 1];
+    const int64_t q0 = ptr_thin[oc], q1 = ptr_thin[oc + 1];     // at most 48 sources: six per lane
+    int id[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) { const int64_t q = q0 + sub + 8 * u; id[u] = idx_thin[q < q1 ? q : q1 - 1]; }
+    double v[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) v[u] = src[id[u]];
     double s = 0.0;
-    for (int64_t q = q0 + sub; q < q1; q += 8) s += src[idx_thin[q]];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) s += q0 + sub + 8 * u < q1 ? v[u] : 0.0;
     s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
     if (live && sub == 0) R[out_thin[o]] = s;
   }
@@ -595,39 +614,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
 }
 
 // Sred = S - YᵀY, one 16×16 lower tile per workgroup, 64-row chunks staged in LDS with register prefetch.
-__global__ __launch_bounds__(256) void schur_kernel(SolveArgs a) {
+constexpr int kSchurSlices = 2;   // K-slices when the in-LDS panel solver consumes the result (it sums them on load)
+// `ks` workgroups share the rows (K dimension) of every tile: slice k writes its partial S/ks-th into
+// Spart + k·(m+1)² (slice 0 carries S itself), and the consumer adds the slices up when it loads the matrix.
+__global__ __launch_bounds__(256) void schur_kernel(SolveArgs a, int ks) {
   const LmState* st = a.st;
   if (st->terminated) return;
   __shared__ double sA[64][17], sB[64][17];
   const int m1 = a.m + 1, n = a.n_s();
-  int tr = 0, rem = blockIdx.x;
+  const int tile = blockIdx.x / ks, slice = blockIdx.x % ks;
+  int tr = 0, rem = tile;
   while (rem > tr) { rem -= tr + 1; ++tr; }
   const int tc = rem;
   const int ti = threadIdx.x / 16, tj = threadIdx.x % 16;
-  // each thread stages 4 rows × (A,B) per chunk: rows ti, ti+16, ti+32, ti+48 ; column tj
+  // rows [r_begin, r_end) of this slice, in 64-row chunks
+  const int rows_per = ((n + ks - 1) / ks + 63) & ~63;
+  const int r_begin = slice * rows_per, r_end = min(n, r_begin + rows_per);
+  // each thread stages 4 rows × (A,B) per chunk: rows ti, ti+16, ti+32, ti+48 ; column tj (loads unconditional on
+  // clamped indices, masked afterwards)
   const int ca = tr * 16 + tj, cb = tc * 16 + tj;
+  const int cac = min(ca, m1 - 1), cbc = min(cb, m1 - 1);
   double pa[4], pb[4];
   auto fetch = [&](int q) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int row = q + ti + 16 * u;
-      pa[u] = (row < n && ca < m1) ? a.Y[size_t(row) * m1 + ca] : 0.0;
-      pb[u] = (row < n && cb < m1) ? a.Y[size_t(row) * m1 + cb] : 0.0;
+      const size_t ro = size_t(min(row, n - 1)) * m1;
+      const double va = a.Y[ro + cac], vb = a.Y[ro + cbc];
+      pa[u] = (row < r_end && ca < m1) ? va : 0.0;
+      pb[u] = (row < r_end && cb < m1) ? vb : 0.0;
     }
   };
   double acc = 0.0;
-  fetch(0);
-  for (int q = 0; q < n; q += 64) {
+  fetch(r_begin);
+  for (int q = r_begin; q < r_end; q += 64) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) { sA[ti + 16 * u][tj] = pa[u]; sB[ti + 16 * u][tj] = pb[u]; }
     __syncthreads();
-    if (q + 64 < n) fetch(q + 64);
+    if (q + 64 < r_end) fetch(q + 64);
 #pragma unroll 16
     for (int rr = 0; rr < 64; ++rr) acc += sA[rr][ti] * sB[rr][tj];
     __syncthreads();
   }
   const int r = tr * 16 + ti, c = tc * 16 + tj;
-  if (r < m1 && c < m1 && c <= r) a.Spart[size_t(r) * m1 + c] = a.S[size_t(r) * m1 + c] - acc;
+  if (r < m1 && c < m1 && c <= r)
+    a.Spart[size_t(slice) * m1 * m1 + size_t(r) * m1 + c] = (slice == 0 ? a.S[size_t(r) * m1 + c] : 0.0) - acc;
 }
 
 // Dense Cholesky of the reduced system (right-hand side carried as row m) and
@@ -912,10 +943,35 @@ __global__ __launch_bounds__(256) void reduced_solve_panel_kernel(SolveArgs a) {
   double* dump = bcast + 128 + tid;             // [256] per-thread dump word
   __shared__ int s_fail;
   if (tid == 0) s_fail = 0;
-  for (int idx = tid; idx < m1 * m1; idx += 256) {
-    const double v = a.Spart[idx];
-    const int r = idx / m1, c = idx - r * m1;
-    if (c <= r) A[r * LD + c] = v;
+  // load the lower triangle, summing the K-slices of the Schur complement: wave w takes rows w, w+4, ..., four rows
+  // per pass with every load of the pass issued before the first LDS store (a single workgroup pulls this matrix in,
+  // so it is the number of loads in flight that matters)
+  {
+    const size_t mm = size_t(m1) * m1;
+    for (int r0 = wave; r0 < m1; r0 += 16) {
+      double v[4][2];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = min(r0 + 4 * u, m1 - 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int c = min(lane + 64 * h, r);
+          double acc = 0.0;
+#pragma unroll
+          for (int k = 0; k < kSchurSlices; ++k) acc += a.Spart[size_t(k) * mm + size_t(r) * m1 + c];
+          v[u][h] = acc;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + 4 * u;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int c = lane + 64 * h;
+          if (r < m1 && c <= r) A[r * LD + c] = v[u][h];
+        }
+      }
+    }
   }
   __syncthreads();
   const bool dbg = a.debug && (tid == 0 || tid == 64);
@@ -1350,7 +1406,8 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
   const int nwg = (m1 + kBorderSlice - 1) / kBorderSlice;
   hipLaunchKernelGGL(band_cholesky_kernel, dim3(nwg, a.n_seg()), dim3(256), band_cholesky_lds_bytes(a), s, a, kBorderSlice);
   const int nt = (m1 + 15) / 16;
-  hipLaunchKernelGGL(schur_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, a);
+  const int ks = m1 <= 128 ? kSchurSlices : 1;
+  hipLaunchKernelGGL(schur_kernel, dim3(nt * (nt + 1) / 2 * ks), dim3(256), 0, s, a, ks);
   if (m1 <= 128) {
     const size_t lds = (size_t(m1) * ((16 * ((m1 + 15) / 16)) | 1) + m1 + 32 + 128 + 256) * sizeof(double);
     if (m1 <= 64) hipLaunchKernelGGL(reduced_solve_panel_kernel<1>, dim3(1), dim3(256), lds, s, a);
