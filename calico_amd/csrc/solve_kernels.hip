@@ -457,16 +457,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
   const int w3_xdst = lane < 6 ? lane * 6 : 72;
   __syncthreads();
   double regs[NE], regs2[NE];
-  for (int J = 0; J < k; ++J) {
-    gload(J, regs);
-    double* s0 = lds + (J % NSL) * SL;
+  {
+    // initial window: all k + 2 block loads are issued before the first LDS store (one memory round trip, not k)
+    double first[8][NE];
+#pragma unroll
+    for (int J = 0; J < 8; ++J) if (J < k) gload(J, first[J]);
+    gload(k, regs);       // blocks k and k+1 ride in registers
+    gload(k + 1, regs2);
     if (wave == 1 || wave == 2) {
 #pragma unroll
-      for (int u = 0; u < NE; ++u) s0[l_off[u]] = J < ncp ? regs[u] : 0.0;
+      for (int J = 0; J < 8; ++J) {
+        if (J < k) {
+          double* s0 = lds + (J % NSL) * SL;
+#pragma unroll
+          for (int u = 0; u < NE; ++u) s0[l_off[u]] = J < ncp ? first[J][u] : 0.0;
+        }
+      }
     }
   }
-  gload(k, regs);       // blocks k and k+1 ride in registers
-  gload(k + 1, regs2);
   long long tk0 = 0, tc[5] = {0, 0, 0, 0, 0};
   const bool dbg = a.debug && blockIdx.x == 0 && (lane == 0);
 #define TICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tc[i] += t_ - tk0; tk0 = t_; }
