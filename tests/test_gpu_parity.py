@@ -129,3 +129,17 @@ def test_noisy_robust_solve_matches_oracle(hip, oracle):
             mg = gpu.problem.inlier_mask(gpu.sensor_ids[i], s.n, 3.0)
             mr = ref.problem.inlier_mask(ref.sensor_ids[i], s.n, 3.0)
             assert np.array_equal(mg, mr)
+
+
+@pytest.mark.parametrize("order", [4, 5, 7])
+def test_other_spline_orders(order, hip, oracle):
+    """Orders other than the reference's default 6 take the generic kernels (no camera-frame path, run-time spline
+    order in the evaluation, K-templated band kernels): same parity bar -- evaluation to 1e-9, solve to 1e-6."""
+    scene = small_scene(camera_model=1, n_cameras=2, imu=True, imu_model=2, robust=True, order=order, seed=5)
+    gpu, ref = both(scene, hip, oracle)
+    assert_eval_close(gpu, ref)
+    gpu, ref, sg, sr = solve_both(scene, hip, oracle, max_iter=30)
+    assert sg.termination_type == sr.termination_type
+    assert sg.num_iterations == sr.num_iterations
+    assert abs(sg.final_cost - sr.final_cost) <= 1e-8 * sr.final_cost
+    assert_estimates_close(gpu, ref, scene)
