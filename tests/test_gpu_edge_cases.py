@@ -1,0 +1,85 @@
+"""Edge cases of the path on the GPU (`-m gpu`), each against the oracle's behaviour on the same input:
+sensors without observations, tiny and ragged problems, a residual block that cannot be evaluated at the
+starting point (camera.cpp:75 -> Internal in the reference; Ceres fails the solve), and one that becomes invalid
+at a candidate point (the step is rejected)."""
+import copy
+
+import numpy as np
+import pytest
+
+import helpers
+from calico_amd import _capi, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(**kw):
+    args = dict(cam_rate=10.0, imu_rate=50.0, duration=3.0, segment_duration=3.0 / 23.9, pixel_noise=0.1,
+                gyro_noise=1e-3, accel_noise=1e-2, seed=3)
+    args.update(kw)
+    return syn.make_scene(2, 1, True, 2, **args)
+
+
+def _solve(api, scene, max_iter=30):
+    built = syn.build_problem(api, scene)
+    o = api.default_options()
+    o.minimizer_progress_to_stdout = 0
+    o.max_num_iterations = max_iter
+    return built, built.problem.solve(o)
+
+
+def _compare(hip, oracle, scene, max_iter=30, est_rtol=1e-6):
+    g, sg = _solve(hip, scene, max_iter)
+    r, sr = _solve(oracle, scene, max_iter)
+    assert sg.termination_type == sr.termination_type, (sg.message, sr.message)
+    assert sg.num_iterations == sr.num_iterations
+    assert sg.num_residual_blocks == sr.num_residual_blocks
+    if sr.termination_type != _capi.FAILURE:
+        assert abs(sg.final_cost - sr.final_cost) <= 1e-8 * max(sr.final_cost, 1e-300)
+        eg, er = syn.read_back(g, scene)[0], syn.read_back(r, scene)[0]
+        for a, b in zip(eg, er):
+            for key in ("intrinsics", "t", "q"):
+                np.testing.assert_allclose(a[key], b[key], rtol=est_rtol, atol=1e-9)
+    return g, r, sg, sr
+
+
+def test_sensor_without_observations(hip, oracle):
+    """A registered gyroscope with zero measurements contributes parameters but no residual blocks."""
+    scene = _scene()
+    scene = copy.deepcopy(scene)
+    for s in scene.sensors:
+        if s.kind == _capi.SENSOR_GYROSCOPE:
+            s.meas = s.meas[:0]
+            s.stamps = s.stamps[:0]
+    _compare(hip, oracle, scene)
+
+
+def test_tiny_problem(hip, oracle):
+    """A handful of observations: cells with a single block, frames of a few points."""
+    scene = _scene(max_cam_obs=24, imu_rate=20.0, duration=1.0, segment_duration=0.5)
+    _compare(hip, oracle, scene, max_iter=10)
+
+
+def test_ragged_frames(hip, oracle):
+    """Frames of very different sizes (every third observation of one camera dropped, a tail cut off)."""
+    scene = copy.deepcopy(_scene())
+    cam = [s for s in scene.sensors if s.kind == _capi.SENSOR_CAMERA][1]
+    keep = np.ones(cam.n, bool)
+    keep[::3] = False
+    keep[-37:] = False
+    cam.meas, cam.stamps, cam.point_idx = cam.meas[keep], cam.stamps[keep], cam.point_idx[keep]
+    if cam.is_outlier is not None:
+        cam.is_outlier = cam.is_outlier[keep]
+    _compare(hip, oracle, scene)
+
+
+def test_block_invalid_at_start_fails_the_solve(hip, oracle):
+    """A chart point behind the camera at the initial estimate: the residual cannot be evaluated, Ceres gives up at
+    iteration 0 (FAILURE); both backends must say so and leave the parameters alone."""
+    scene = copy.deepcopy(_scene())
+    scene.points[5] = scene.points[5] + np.array([0.0, 0.0, 50.0])     # far behind every camera
+    g, r, sg, sr = _compare(hip, oracle, scene)
+    assert sr.termination_type == _capi.FAILURE
+    eg = syn.read_back(g, scene)[0]
+    for a, s in zip(eg, scene.sensors):
+        np.testing.assert_array_equal(a["intrinsics"], s.intrinsics)
