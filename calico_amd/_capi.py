@@ -119,7 +119,7 @@ ABI_SYMBOLS = [
     "problem_add_camera_residuals", "problem_add_imu_residuals", "solve",
     "get_iterations", "get_residuals", "get_inlier_mask",
     "num_effective_parameters", "evaluate", "problem_set_allreduce", "problem_set_shard",
-    "problem_set_stream", "get_phase_time", "set_phase_timing",
+    "problem_set_stream", "get_phase_time", "set_phase_timing", "project",
 ]
 
 
@@ -161,6 +161,7 @@ class CApi:
             g("problem_set_shard", C.c_int32, [P, C.c_int32, C.c_int32])
             g("problem_set_stream", C.c_int32, [P, C.c_void_p])
             g("get_phase_time", C.c_int32, [P, C.c_int32, D, C.POINTER(C.c_int64)])
+            g("project", C.c_int32, [P, C.c_int32, D, C.POINTER(C.c_uint8)])
             g("set_phase_timing", C.c_int32, [P, C.c_int32])
 
     def _get(self, name, restype, argtypes):
@@ -266,6 +267,13 @@ class Problem:
         st = self.api.get_residuals(self.h, sensor, _dp(out), valid.ctypes.data_as(C.POINTER(C.c_uint8)))
         if check:
             self._check(st)
+        return out, valid
+
+    def project(self, sensor, n, dim):
+        """Sensor::Project for the registered observations: model prediction per observation (device only)."""
+        out = np.zeros((n, dim))
+        valid = np.zeros(n, dtype=np.uint8)
+        self._check(self.api.project(self.h, sensor, _dp(out), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out, valid
 
     def inlier_mask(self, sensor, n, threshold):

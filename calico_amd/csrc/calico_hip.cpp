@@ -248,7 +248,7 @@ EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool
   a.partials = p->d_partials.p; a.item_cost = p->d_partials.p + p->partial_doubles;
   a.res_out = want_res ? p->d_res.p : nullptr; a.valid_out = want_res ? p->d_valid.p : nullptr;
   a.order = p->order; a.n_items = p->n_items; a.lds_cols = p->lds_cols; a.row_pad = p->row_pad; a.n_cells = int(p->h_cells.size()); a.cells = p->d_cells.p; a.prim_tab = p->d_prim_tab.p;
-  a.cell_chunk = p->cell_chunk; a.cell_rec_max = p->cell_rec_max; a.apply_loss = apply_loss;
+  a.cell_chunk = p->cell_chunk; a.cell_rec_max = p->cell_rec_max; a.project = 0; a.pad4 = 0; a.apply_loss = apply_loss;
   a.st = nullptr; a.need_flag = 0; a.cost_index_base = 0;
   a.fitems = p->d_fitems.p; a.n_fitems = p->n_fitems;
   return a;
@@ -1061,7 +1061,7 @@ int32_t calico_get_iterations(calico_problem* p, calico_iteration* out, int32_t 
   return CALICO_OK;
 }
 
-int32_t calico_get_residuals(calico_problem* p, int32_t sid, double* out, uint8_t* valid) {
+static int32_t residuals_or_prediction(calico_problem* p, int32_t sid, double* out, uint8_t* valid, bool predict) {
   if (!p) return CALICO_INVALID_ARGUMENT;
   if (sid < 0 || sid >= int(p->sensors.size()) || !out) return p->set_error(CALICO_INVALID_ARGUMENT, "bad sensor id");
   int rc = finalize(p);
@@ -1072,6 +1072,7 @@ int32_t calico_get_residuals(calico_problem* p, int32_t sid, double* out, uint8_
   {
     EvalArgs ea = make_eval_args(p, p->d_x.p, 0, true);
     ea.items = p->d_items_all.p; ea.n_items = p->n_items_all;  // every rank re-evaluates all blocks here
+    ea.project = predict ? 1 : 0;
     launch_eval(ea, false, p->stream);
   }
   std::vector<double> r(size_t(p->n_obs) * 3);
@@ -1088,8 +1089,18 @@ int32_t calico_get_residuals(calico_problem* p, int32_t sid, double* out, uint8_
     if (valid) valid[i] = v[size_t(q)];
     if (!v[size_t(q)]) all = false;
   }
-  // camera.cpp:73-76: a failing block makes UpdateResiduals return kInternal
+  // camera.cpp:73-76: a failing block makes UpdateResiduals return kInternal; Project just skips such points
+  // (camera.cpp:172-174), here they come back with valid = 0
+  if (predict) return CALICO_OK;
   return all ? CALICO_OK : p->set_error(CALICO_INTERNAL, "Failed to update residual");
+}
+
+int32_t calico_get_residuals(calico_problem* p, int32_t sid, double* out, uint8_t* valid) {
+  return residuals_or_prediction(p, sid, out, valid, false);
+}
+
+int32_t calico_project(calico_problem* p, int32_t sid, double* out, uint8_t* valid) {
+  return residuals_or_prediction(p, sid, out, valid, true);
 }
 
 int32_t calico_get_inlier_mask(calico_problem* p, int32_t sid, double threshold, uint8_t* mask) {

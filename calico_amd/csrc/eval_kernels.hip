@@ -29,6 +29,7 @@ struct ItemCtx {
   const double* M;        // k×k basis of the segment
   const int* ctrl_off;    // ambient offsets of the segment's k control points
   const double* x;
+  double info;            // 1/sigma of the sensor; -1 in prediction mode (measurement 0): the "residual" is the model output
 };
 
 // Evaluate spline value / derivatives at t: out[d][6] = sum_i W[d][i] * ctrl_i.
@@ -92,14 +93,14 @@ DEV bool camera_block(const ItemCtx& c, double px, double py, double stamp, cons
   const V3 xc = mulT(R_rc, z);
   double pix[2], D[2][3], dK[2][kMaxIntr];
   if (!project<MODEL, JAC>(intr, xc, pix, D, dK)) return false;
-  double r0 = (px - pix[0]) * S.info, r1 = (py - pix[1]) * S.info;
+  double r0 = (px - pix[0]) * c.info, r1 = (py - pix[1]) * c.info;
   const double sq = r0 * r0 + r1 * r1;
   double ls = 1.0, rho = sq;
   if (apply_loss) rho = loss_eval(S.loss, S.loss_scale, sq, &ls);
   *cost = 0.5 * rho;
   res[0] = r0 * ls; res[1] = r1 * ls;
   if constexpr (JAC) {
-    const double fac = -S.info * ls;
+    const double fac = -c.info * ls;
     // DRt = D·R_rcᵀ, DG = DRt·R_rw  (2×3)
     double DRt[2][3], DG[2][3];
 #pragma unroll
@@ -236,7 +237,7 @@ DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], cons
   const V3 og = -mulT(R_rg, omega);
   double f[3], Mw[3][3], dK[3][kMaxIntr];
   imu_project<JAC>(S.model, intr, og, f, Mw, dK);
-  double r[3] = {(meas.x - f[0]) * S.info, (meas.y - f[1]) * S.info, (meas.z - f[2]) * S.info};
+  double r[3] = {(meas.x - f[0]) * c.info, (meas.y - f[1]) * c.info, (meas.z - f[2]) * c.info};
   const double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
   double ls = 1.0, rho = sq;
   if (apply_loss) rho = loss_eval(S.loss, S.loss_scale, sq, &ls);
@@ -244,7 +245,7 @@ DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], cons
 #pragma unroll
   for (int i = 0; i < 3; ++i) res[i] = r[i] * ls;
   if constexpr (JAC) {
-    const double fac = -S.info * ls;
+    const double fac = -c.info * ls;
     // B = fac · Mw · (-R_rgᵀ)  : dr/d omega_rw
     double B[3][3];
 #pragma unroll
@@ -371,7 +372,7 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
   const V3 fs = mulT(R_ra, b);
   double f[3], Mw[3][3], dK[3][kMaxIntr];
   imu_project<JAC>(S.model, intr, fs, f, Mw, dK);
-  double r[3] = {(meas.x - f[0]) * S.info, (meas.y - f[1]) * S.info, (meas.z - f[2]) * S.info};
+  double r[3] = {(meas.x - f[0]) * c.info, (meas.y - f[1]) * c.info, (meas.z - f[2]) * c.info};
   const double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
   double ls = 1.0, rho = sq;
   if (apply_loss) rho = loss_eval(S.loss, S.loss_scale, sq, &ls);
@@ -379,7 +380,7 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
 #pragma unroll
   for (int i = 0; i < 3; ++i) res[i] = r[i] * ls;
   if constexpr (JAC) {
-    const double fac = -S.info * ls;
+    const double fac = -c.info * ls;
     // Bm = fac · Mw · R_raᵀ : dr/db
     double Bm[3][3];
 #pragma unroll
@@ -578,7 +579,7 @@ DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds) {
   const LayoutDev& L = a.layouts[it.layout];
   const SensorDev& S = a.sensors[L.sensor];
   ItemCtx c;
-  c.s = &S; c.L = &L; c.k = a.order; c.x = a.x;
+  c.s = &S; c.L = &L; c.k = a.order; c.x = a.x; c.info = a.project ? -1.0 : S.info;
   const int ki = it.seg + a.order - 1;
   c.knot0 = a.knots[ki]; c.knot1 = a.knots[ki + 1];
   c.M = a.basis + size_t(it.seg) * a.order * a.order;
@@ -598,12 +599,13 @@ DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds) {
   RowSink sink; sink.J = lds; sink.row0 = dim * lane; sink.pad = row_pad;
   if (active) {
     const double st = a.stamp[o];
+    const double z0 = a.project ? 0.0 : a.m0[o], z1 = a.project ? 0.0 : a.m1[o], z2 = a.project ? 0.0 : a.m2[o];
     if (S.kind == 0) {
-      ok = camera_dispatch<JAC, KT>(c, a.m0[o], a.m1[o], st, a.x + a.point_off[o], res, sink, &cost, a.apply_loss);
+      ok = camera_dispatch<JAC, KT>(c, z0, z1, st, a.x + a.point_off[o], res, sink, &cost, a.apply_loss);
     } else if (S.kind == 1) {
-      ok = gyro_block<JAC, KT>(c, mk(a.m0[o], a.m1[o], a.m2[o]), st, res, sink, &cost, a.apply_loss);
+      ok = gyro_block<JAC, KT>(c, mk(z0, z1, z2), st, res, sink, &cost, a.apply_loss);
     } else {
-      ok = accel_block<JAC, KT>(c, mk(a.m0[o], a.m1[o], a.m2[o]), st, res, sink, &cost, a.apply_loss);
+      ok = accel_block<JAC, KT>(c, mk(z0, z1, z2), st, res, sink, &cost, a.apply_loss);
     }
     if (!ok) { cost = 0.0; res[0] = res[1] = res[2] = 0.0; }
     if (a.res_out) {

@@ -218,6 +218,14 @@ int32_t calico_get_iterations(calico_problem* p, calico_iteration* out,
  * filling both arrays). */
 int32_t calico_get_residuals(calico_problem* p, int32_t sensor_id, double* out,
                              uint8_t* valid);
+/* Sensor::Project for the registered observations (camera.cpp:155-208, gyroscope.cpp:56-82,
+ * accelerometer.cpp:76-123): the model's prediction -- pixel (2) or IMU reading (3) per observation, in insertion
+ * order -- at the current parameter values, i.e. exactly the quantity the residual compares the measurement with
+ * (pose at stamp - latency, spline segment of the stamp). Evaluated by the residual kernel in prediction mode, so
+ * measurements generated with it give residuals that are exactly zero. Points that do not project (the reference
+ * skips them) come back with valid[i] = 0. `valid` may be NULL. */
+int32_t calico_project(calico_problem* p, int32_t sensor, double* out, uint8_t* valid);
+
 /* The outlier-tagging step that follows the path in the reference's demos
  * (kalibr_multicam_demo.ipynb:666-674 -> Camera::MarkOutliersById):
  * mask[i] = 1 iff the residual is valid and ||r_i|| <= threshold. */
