@@ -120,6 +120,7 @@ ABI_SYMBOLS = [
     "get_iterations", "get_residuals", "get_inlier_mask",
     "num_effective_parameters", "evaluate", "problem_set_allreduce", "problem_set_shard",
     "problem_set_stream", "get_phase_time", "set_phase_timing", "project",
+    "problem_set_outlier_mask", "mark_outliers",
 ]
 
 
@@ -162,6 +163,8 @@ class CApi:
             g("problem_set_stream", C.c_int32, [P, C.c_void_p])
             g("get_phase_time", C.c_int32, [P, C.c_int32, D, C.POINTER(C.c_int64)])
             g("project", C.c_int32, [P, C.c_int32, D, C.POINTER(C.c_uint8)])
+            g("problem_set_outlier_mask", C.c_int32, [P, C.c_int32, C.POINTER(C.c_uint8)])
+            g("mark_outliers", C.c_int32, [P, C.c_int32, C.c_double, C.POINTER(C.c_int64)])
             g("set_phase_timing", C.c_int32, [P, C.c_int32])
 
     def _get(self, name, restype, argtypes):
@@ -275,6 +278,20 @@ class Problem:
         valid = np.zeros(n, dtype=np.uint8)
         self._check(self.api.project(self.h, sensor, _dp(out), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out, valid
+
+    def set_outlier_mask(self, sensor, is_outlier=None):
+        """MarkOutliersById / ClearOutliers (device only): one byte per observation, None clears."""
+        if is_outlier is None:
+            self._check(self.api.problem_set_outlier_mask(self.h, sensor, None))
+        else:
+            m = np.ascontiguousarray(is_outlier, dtype=np.uint8)
+            self._check(self.api.problem_set_outlier_mask(self.h, sensor, m.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def mark_outliers(self, sensor, threshold):
+        """One tagging pass on the device; returns the number of observations tagged by this call."""
+        n = C.c_int64(0)
+        self._check(self.api.mark_outliers(self.h, sensor, float(threshold), C.byref(n)))
+        return n.value
 
     def inlier_mask(self, sensor, n, threshold):
         mask = np.zeros(n, dtype=np.uint8)

@@ -34,6 +34,8 @@ void launch_eval(const EvalArgs& a, bool jac, hipStream_t stream);
 void launch_eval_frames(const EvalArgs& a, hipStream_t stream);
 void launch_eval_jacobian(const EvalArgs& a, hipStream_t stream);
 void launch_expand_cells(const EvalArgs& a, hipStream_t stream);
+void launch_mark_outliers(const double* res, const uint8_t* valid, uint8_t* active, int begin, int end, int dim,
+                          double threshold, int* n_marked, hipStream_t s);
 hipError_t configure_eval_kernels(size_t max_lds_bytes);
 
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
@@ -81,6 +83,8 @@ struct HSensor {
   std::vector<double> meas, stamps;
   std::vector<int> body, point, seg;
   std::vector<int64_t> sorted_pos;  // original observation -> position in the sorted device arrays
+  std::vector<uint8_t> active;      // 0 = tagged as outlier (outlier_ids_, camera.h:185): left out of the problem
+  int64_t sorted_begin = 0, sorted_end = 0;   // this sensor's contiguous range in the sorted arrays
   int dim() const { return kind == CALICO_SENSOR_CAMERA ? 2 : 3; }
   int64_t n() const { return int64_t(stamps.size()); }
 };
@@ -187,7 +191,9 @@ struct calico_problem {
       d_dadd, d_scale, d_res;
   DevBuf<int> d_ctrl_off, d_point_off, d_out_thin, d_idx_thin, d_out_fat, d_idx_fat;
   DevBuf<int64_t> d_ptr_thin, d_ptr_fat;
-  DevBuf<uint8_t> d_cp_active, d_valid;
+  DevBuf<uint8_t> d_cp_active, d_valid, d_active;
+  DevBuf<int> d_counter;
+  bool active_dirty = true;
   DevBuf<SensorDev> d_sensors;
   DevBuf<LayoutDev> d_layouts;
   DevBuf<ItemDev> d_items, d_items_all, d_jac_items;
@@ -248,7 +254,7 @@ EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool
   a.partials = p->d_partials.p; a.item_cost = p->d_partials.p + p->partial_doubles;
   a.res_out = want_res ? p->d_res.p : nullptr; a.valid_out = want_res ? p->d_valid.p : nullptr;
   a.order = p->order; a.n_items = p->n_items; a.lds_cols = p->lds_cols; a.row_pad = p->row_pad; a.n_cells = int(p->h_cells.size()); a.cells = p->d_cells.p; a.prim_tab = p->d_prim_tab.p;
-  a.cell_chunk = p->cell_chunk; a.cell_rec_max = p->cell_rec_max; a.project = 0; a.pad4 = 0; a.apply_loss = apply_loss;
+  a.cell_chunk = p->cell_chunk; a.cell_rec_max = p->cell_rec_max; a.project = 0; a.pad4 = 0; a.active = p->d_active.p; a.apply_loss = apply_loss;
   a.st = nullptr; a.need_flag = 0; a.cost_index_base = 0;
   a.fitems = p->d_fitems.p; a.n_fitems = p->n_fitems;
   return a;
@@ -515,10 +521,12 @@ int finalize(calico_problem* p) {
       c.src_off = p->h_fitems[size_t(c.frame_begin)].partial_off;
     }
   }
+  for (HSensor& s : p->sensors) { s.sorted_begin = n_obs; s.sorted_end = 0; }
   for (int64_t q = 0; q < n_obs; ++q) {
     HSensor& s = p->sensors[keys[q].sensor];
     const int64_t i = keys[q].idx;
     s.sorted_pos[size_t(i)] = q;
+    s.sorted_begin = std::min(s.sorted_begin, q); s.sorted_end = std::max(s.sorted_end, q + 1);   // layouts are per sensor: contiguous
     const int dim = s.dim();
     m0[q] = s.meas[i * dim]; m1[q] = s.meas[i * dim + 1]; m2[q] = dim == 3 ? s.meas[i * dim + 2] : 0.0;
     st[q] = s.stamps[i];
@@ -637,6 +645,8 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_S.alloc(size_t(mw + 1) * (mw + 1)));
   HIP_TRY(p, p->d_y.alloc(size_t(NT) + 6 * p->sep_n)); HIP_TRY(p, p->d_zbuf.alloc(size_t(NS) + 64)); HIP_TRY(p, p->d_dadd.alloc(NT)); HIP_TRY(p, p->d_scale.alloc(NT));
   HIP_TRY(p, p->d_res.alloc(size_t(n_obs) * 3)); HIP_TRY(p, p->d_valid.alloc(size_t(n_obs)));
+  HIP_TRY(p, p->d_active.alloc(size_t(n_obs))); HIP_TRY(p, p->d_counter.alloc(1));
+  p->active_dirty = true;
   HIP_TRY(p, p->d_state.alloc(1)); HIP_TRY(p, p->d_log.alloc(kLogCap));
   if (!p->h_state) HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LmState)));
   // kernel attributes
@@ -658,6 +668,14 @@ int finalize(calico_problem* p) {
 }
 
 int upload_x(calico_problem* p) {
+  if (p->active_dirty) {   // outlier tags, in the sorted order of the device arrays
+    std::vector<uint8_t> act(size_t(std::max<int64_t>(p->n_obs, 1)), 1);
+    for (const HSensor& s : p->sensors)
+      for (int64_t i = 0; i < s.n(); ++i) act[size_t(s.sorted_pos[size_t(i)])] = s.active[size_t(i)];
+    HIP_TRY(p, hipMemcpyAsync(p->d_active.p, act.data(), size_t(p->n_obs), hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(p, hipStreamSynchronize(p->stream));   // `act` is a local
+    p->active_dirty = false;
+  }
   for (const HBlock& b : p->blocks) std::copy(b.v.begin(), b.v.end(), p->h_x.begin() + b.amb_off);
   HIP_TRY(p, hipMemcpyAsync(p->d_x.p, p->h_x.data(), p->h_x.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
   HIP_TRY(p, hipMemcpyAsync(p->d_xc.p, p->h_x.data(), p->h_x.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
@@ -708,7 +726,10 @@ int read_state(calico_problem* p) {
 
 void fill_counts(calico_problem* p, calico_summary* sm) {
   int nrb = 0, nr = 0;
-  for (const HSensor& s : p->sensors) { nrb += int(s.n()); nr += int(s.n()) * s.dim(); }
+  for (const HSensor& s : p->sensors) {   // tagged outliers are not part of the problem (camera.cpp:121-124)
+    int64_t na = 0; for (uint8_t a : s.active) na += a ? 1 : 0;
+    nrb += int(na); nr += int(na) * s.dim();
+  }
   sm->num_residual_blocks = nrb; sm->num_residuals = nr;
   sm->num_residual_blocks_reduced = nrb; sm->num_residuals_reduced = nr;
   sm->num_parameter_blocks = int(p->blocks.size());
@@ -891,6 +912,7 @@ static int32_t add_obs(calico_problem* p, int32_t sid, int64_t n, const double* 
     s.stamps.push_back(stamps[i]);
     if (body) { s.body.push_back(body[i]); s.point.push_back(point[i]); }
     for (int c = 0; c < dim; ++c) s.meas.push_back(meas[i * dim + c]);
+    s.active.push_back(1);
   }
   p->dirty = true;
   return CALICO_OK;
@@ -1087,7 +1109,7 @@ static int32_t residuals_or_prediction(calico_problem* p, int32_t sid, double* o
     const int64_t q = s.sorted_pos[size_t(i)];
     for (int c = 0; c < dim; ++c) out[i * dim + c] = v[size_t(q)] ? r[size_t(q) * 3 + c] : 0.0;
     if (valid) valid[i] = v[size_t(q)];
-    if (!v[size_t(q)]) all = false;
+    if (!v[size_t(q)] && s.active[size_t(i)]) all = false;     // tagged outliers have no residual and are no failure
   }
   // camera.cpp:73-76: a failing block makes UpdateResiduals return kInternal; Project just skips such points
   // (camera.cpp:172-174), here they come back with valid = 0
@@ -1115,8 +1137,46 @@ int32_t calico_get_inlier_mask(calico_problem* p, int32_t sid, double threshold,
   for (int64_t i = 0; i < s.n(); ++i) {
     double sq = 0;
     for (int c = 0; c < dim; ++c) sq += r[i * dim + c] * r[i * dim + c];
-    mask[i] = (v[size_t(i)] && std::sqrt(sq) <= threshold) ? 1 : 0;
+    mask[i] = (s.active[size_t(i)] && v[size_t(i)] && std::sqrt(sq) <= threshold) ? 1 : 0;
   }
+  return CALICO_OK;
+}
+
+int32_t calico_problem_set_outlier_mask(calico_problem* p, int32_t sid, const uint8_t* is_outlier) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  if (sid < 0 || sid >= int(p->sensors.size())) return p->set_error(CALICO_INVALID_ARGUMENT, "bad sensor id");
+  HSensor& s = p->sensors[sid];
+  for (int64_t i = 0; i < s.n(); ++i) s.active[size_t(i)] = (is_outlier && is_outlier[i]) ? 0 : 1;
+  p->active_dirty = true;
+  return CALICO_OK;
+}
+
+int32_t calico_mark_outliers(calico_problem* p, int32_t sid, double threshold, int64_t* n_marked) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  if (sid < 0 || sid >= int(p->sensors.size())) return p->set_error(CALICO_INVALID_ARGUMENT, "bad sensor id");
+  int rc = finalize(p);
+  if (rc != CALICO_OK) return rc;
+  HIP_TRY(p, hipSetDevice(p->device));
+  rc = upload_x(p);
+  if (rc != CALICO_OK) return rc;
+  HSensor& s = p->sensors[sid];
+  {
+    EvalArgs ea = make_eval_args(p, p->d_x.p, 0, true);   // residuals without the loss function (camera.cpp:70-80)
+    ea.items = p->d_items_all.p; ea.n_items = p->n_items_all;
+    launch_eval(ea, false, p->stream);
+  }
+  HIP_TRY(p, hipMemsetAsync(p->d_counter.p, 0, sizeof(int), p->stream));
+  launch_mark_outliers(p->d_res.p, p->d_valid.p, p->d_active.p, int(s.sorted_begin), int(s.sorted_end), s.dim(), threshold,
+                       p->d_counter.p, p->stream);
+  // mirror the tags on the host (they decide counts and survive a re-finalisation)
+  const int64_t nrange = std::max<int64_t>(0, s.sorted_end - s.sorted_begin);
+  std::vector<uint8_t> act(size_t(std::max<int64_t>(nrange, 1)));
+  int marked = 0;
+  if (nrange > 0) HIP_TRY(p, hipMemcpyAsync(act.data(), p->d_active.p + s.sorted_begin, size_t(nrange), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(p, hipMemcpyAsync(&marked, p->d_counter.p, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(p, hipStreamSynchronize(p->stream));
+  for (int64_t i = 0; i < s.n(); ++i) s.active[size_t(i)] = act[size_t(s.sorted_pos[size_t(i)] - s.sorted_begin)];
+  if (n_marked) *n_marked = marked;
   return CALICO_OK;
 }
 

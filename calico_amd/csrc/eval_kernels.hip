@@ -593,11 +593,14 @@ DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds) {
   ITICK(0)
   const bool active = lane < it.obs_count;
   const int o = it.obs_begin + lane;
+  // observations tagged as outliers (camera.cpp:121-124: skipped by AddResidualsToProblem) stay in the arrays but
+  // contribute nothing: zero rows, zero cost, not an evaluation failure
+  const bool on = active && (!a.active || a.active[o] != 0);
   double res[3] = {0.0, 0.0, 0.0};
   double cost = 0.0;
   bool ok = true;
   RowSink sink; sink.J = lds; sink.row0 = dim * lane; sink.pad = row_pad;
-  if (active) {
+  if (on) {
     const double st = a.stamp[o];
     const double z0 = a.project ? 0.0 : a.m0[o], z1 = a.project ? 0.0 : a.m1[o], z2 = a.project ? 0.0 : a.m2[o];
     if (S.kind == 0) {
@@ -608,19 +611,19 @@ DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds) {
       ok = accel_block<JAC, KT>(c, mk(z0, z1, z2), st, res, sink, &cost, a.apply_loss);
     }
     if (!ok) { cost = 0.0; res[0] = res[1] = res[2] = 0.0; }
-    if (a.res_out) {
+  }
+  if (active && a.res_out) {
 #pragma unroll
-      for (int r = 0; r < 3; ++r) if (r < dim) a.res_out[size_t(o) * 3 + r] = res[r];
-      a.valid_out[o] = ok ? 1 : 0;
-    }
+    for (int r = 0; r < 3; ++r) if (r < dim) a.res_out[size_t(o) * 3 + r] = res[r];
+    a.valid_out[o] = (on && ok) ? 1 : 0;
   }
   ITICK(1)
   const double item_cost = wave_sum(cost);
-  const double n_invalid = wave_sum((active && !ok) ? 1.0 : 0.0);
+  const double n_invalid = wave_sum((on && !ok) ? 1.0 : 0.0);
   if (lane == 0) { a.item_cost[2 * (a.cost_index_base + item_id)] = item_cost; a.item_cost[2 * (a.cost_index_base + item_id) + 1] = n_invalid; }
   if constexpr (JAC) {
     if (active) {
-      if (!ok) {  // drop the block: zero its rows
+      if (!ok || !on) {  // drop the block: zero its rows
         for (int col = 0; col < ncols; ++col)
           for (int r = 0; r < dim; ++r) sink.put(col, r, 0.0);
       }
@@ -848,7 +851,11 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
       xm_p = a.x + a.point_off[o_nx];
       xm_nx[0] = xm_p[0]; xm_nx[1] = xm_p[1]; xm_nx[2] = xm_p[2];
     }
-    if (lane < nb) {
+    const bool on = lane < nb && (!a.active || a.active[it.obs_begin + b0 + lane] != 0);   // not tagged as an outlier
+    if (lane < nb && !on) {
+      for (int c = 0; c < P1; ++c) { Jp[c * kFramePad + 2 * lane] = 0.0; Jp[c * kFramePad + 2 * lane + 1] = 0.0; }
+    }
+    if (on) {
       double c1 = 0.0;
       bool ok;
       switch (S.model) {
@@ -1013,6 +1020,22 @@ __global__ __launch_bounds__(256) void expand_cells_kernel(EvalArgs a) {
 void launch_expand_cells(const EvalArgs& a, hipStream_t stream) {
   if (a.n_cells == 0) return;
   hipLaunchKernelGGL(expand_cells_kernel, dim3(a.n_cells), dim3(256), size_t(a.cell_chunk) * a.cell_rec_max * sizeof(double), stream, a);
+}
+
+// Outlier tagging on the device (the notebooks' loop: residual norm > tau -> MarkOutliersById): observations
+// [begin, end) of one sensor in sorted order; res/valid come from the residual write-back without loss.
+__global__ void mark_outliers_kernel(const double* __restrict__ res, const uint8_t* __restrict__ valid, uint8_t* active,
+                                     int begin, int end, int dim, double threshold, int* n_marked) {
+  const int q = begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= end || !active[q]) return;
+  double sq = 0.0;
+  for (int c = 0; c < dim; ++c) sq += res[size_t(q) * 3 + c] * res[size_t(q) * 3 + c];
+  const bool inlier = valid[q] && sqrt(sq) <= threshold;
+  if (!inlier) { active[q] = 0; atomicAdd(n_marked, 1); }
+}
+void launch_mark_outliers(const double* res, const uint8_t* valid, uint8_t* active, int begin, int end, int dim,
+                          double threshold, int* n_marked, hipStream_t s) {
+  if (end > begin) hipLaunchKernelGGL(mark_outliers_kernel, dim3((end - begin + 255) / 256), dim3(256), 0, s, res, valid, active, begin, end, dim, threshold, n_marked);
 }
 
 size_t frame_lds_bytes() { return (size_t(kMaxPrim) * kFramePad + size_t(kMaxPrim + 1) * (kMaxPrim + 1) + kMaxLocalCols + kMaxLocalCols / 2) * sizeof(double); }

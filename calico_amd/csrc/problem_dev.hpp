@@ -84,6 +84,7 @@ struct EvalArgs {
   const int* prim_tab;   // per frame layout: prim column (row/col of M_ext) of every local column
   int cell_chunk, cell_rec_max;   // frames per LDS chunk of the cell kernel, largest compact record (doubles)
   int project, pad4;     // prediction mode of the cost-only kernel: measurements read as 0, 1/sigma as -1 -> output = model
+  const uint8_t* active; // per observation (sorted order): 0 = tagged as outlier, left out; nullptr = all in
 };
 
 // LM state kept on the device; the control kernel is its only writer.

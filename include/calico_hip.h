@@ -218,6 +218,16 @@ int32_t calico_get_iterations(calico_problem* p, calico_iteration* out,
  * filling both arrays). */
 int32_t calico_get_residuals(calico_problem* p, int32_t sensor_id, double* out,
                              uint8_t* valid);
+/* Outlier tags (Camera::MarkOutliersById / ClearOutliers, camera.cpp:281-301; outlier_ids_, camera.h:185): tagged
+ * observations stay registered but are left out of the problem, as AddResidualsToProblem does (camera.cpp:121-124) --
+ * no residual block, no residual, not counted in the summary. `is_outlier` has one byte per observation of the
+ * sensor in insertion order; NULL clears all tags. */
+int32_t calico_problem_set_outlier_mask(calico_problem* p, int32_t sensor, const uint8_t* is_outlier);
+/* One pass of the demos' tagging loop (kalibr_multicam_demo.ipynb:666-674) on the device: residuals at the current
+ * estimates without the loss function, every still-untagged observation of `sensor` with ||r|| > threshold (or that
+ * cannot be evaluated) is tagged. *n_marked = number of observations tagged by this call. Follow with calico_solve. */
+int32_t calico_mark_outliers(calico_problem* p, int32_t sensor, double threshold, int64_t* n_marked);
+
 /* Sensor::Project for the registered observations (camera.cpp:155-208, gyroscope.cpp:56-82,
  * accelerometer.cpp:76-123): the model's prediction -- pixel (2) or IMU reading (3) per observation, in insertion
  * order -- at the current parameter values, i.e. exactly the quantity the residual compares the measurement with

@@ -83,3 +83,52 @@ def test_block_invalid_at_start_fails_the_solve(hip, oracle):
     eg = syn.read_back(g, scene)[0]
     for a, s in zip(eg, scene.sensors):
         np.testing.assert_array_equal(a["intrinsics"], s.intrinsics)
+
+
+def test_outlier_tagging_loop_on_device(hip, oracle):
+    """The demos' loop (kalibr_multicam_demo.ipynb:636-677): solve, tag ||r|| > tau, solve again -- on the device via
+    calico_mark_outliers, against the oracle doing it the reference's way (new problem without the tagged ids,
+    camera.cpp:121-124, started from the first solution). Tags bit-exact, estimates within 1e-6."""
+    tau = 3.0
+    scene = _scene(outlier_fraction=0.04, seed=21)
+    g = syn.build_problem(hip, scene)
+    r = syn.build_problem(oracle, scene)
+    o = hip.default_options(); o.minimizer_progress_to_stdout = 0; o.max_num_iterations = 40
+    oo = oracle.default_options(); oo.minimizer_progress_to_stdout = 0; oo.max_num_iterations = 40
+    sg1, sr1 = g.problem.solve(o), r.problem.solve(oo)
+    assert sg1.termination_type == sr1.termination_type == _capi.CONVERGENCE
+    cams = [i for i, s in enumerate(scene.sensors) if s.kind == _capi.SENSOR_CAMERA]
+    # pass 1: tags on the device vs the oracle's inlier mask
+    scene2 = copy.deepcopy(scene)
+    est, ctrl = syn.read_back(r, scene)
+    n_tagged = 0
+    for i in cams:
+        s = scene.sensors[i]
+        marked = g.problem.mark_outliers(g.sensor_ids[i], tau)
+        ref_inlier = r.problem.inlier_mask(r.sensor_ids[i], s.n, tau).astype(bool)
+        assert marked == int((~ref_inlier).sum())
+        assert np.array_equal(g.problem.inlier_mask(g.sensor_ids[i], s.n, tau).astype(bool), ref_inlier)   # bit-exact
+        assert (~ref_inlier)[s.is_outlier].mean() > 0.9       # the gross outliers are among the tagged
+        n_tagged += marked
+        s2 = scene2.sensors[i]
+        s2.meas, s2.stamps, s2.point_idx = s.meas[ref_inlier], s.stamps[ref_inlier], s.point_idx[ref_inlier]
+        s2.is_outlier = s.is_outlier[ref_inlier]
+    assert n_tagged > 0
+    # second solve: device continues on the tagged problem; the oracle gets a new problem from its first solution
+    for s2, e in zip(scene2.sensors, est):
+        s2.intrinsics, s2.t, s2.q, s2.latency = e["intrinsics"].copy(), e["t"].copy(), e["q"].copy(), float(e["latency"])
+    scene2.ctrl = ctrl.copy()
+    r2 = syn.build_problem(oracle, scene2)
+    sg2, sr2 = g.problem.solve(o), r2.problem.solve(oo)
+    assert sg2.num_residual_blocks == sr2.num_residual_blocks == sg1.num_residual_blocks - n_tagged
+    assert sg2.termination_type == sr2.termination_type
+    assert abs(sg2.final_cost - sr2.final_cost) <= 1e-6 * sr2.final_cost
+    eg, _ = syn.read_back(g, scene)
+    er, _ = syn.read_back(r2, scene2)
+    for a, b in zip(eg, er):
+        for key in ("intrinsics", "t", "q"):
+            np.testing.assert_allclose(a[key], b[key], rtol=1e-6, atol=1e-9)
+    # clearing the tags restores the full problem
+    for i in cams:
+        g.problem.set_outlier_mask(g.sensor_ids[i], None)
+    assert g.problem.solve(o).num_residual_blocks == sg1.num_residual_blocks
