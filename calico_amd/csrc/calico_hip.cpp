@@ -124,12 +124,12 @@ struct PhaseTimer {
     if (next == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
     return pool[next++];
   }
-  int mask = 0x1f;
+  int mask = 0;              // no event brackets unless asked for (calico_set_phase_timing): each pair costs ~6 us of stream time
   int every = 1;            // bracket only every `every`-th launch of a phase (an event pair costs ~6 us of stream time)
   int64_t seen[kNumPhases] = {0, 0, 0, 0, 0, 0};
   bool open_rec = false;
   void begin(int phase, hipStream_t s) {
-    open_rec = phase == 5 ? (mask & 1) : (mask >> phase) & 1;
+    open_rec = (mask >> phase) & 1;
     if (open_rec && phase != 5 && every > 1) open_rec = (seen[phase]++ % every) == 0;
     if (!open_rec) return;
     Rec r; r.phase = phase; r.a = get(); r.b = nullptr; (void)hipEventRecord(r.a, s); pending.push_back(r);
@@ -194,6 +194,7 @@ struct calico_problem {
   DevBuf<uint8_t> d_cp_active, d_valid, d_active;
   DevBuf<int> d_counter;
   bool active_dirty = true;
+  bool xc_stale = true;       // the candidate buffer must be re-seeded with the constant blocks' values
   DevBuf<SensorDev> d_sensors;
   DevBuf<LayoutDev> d_layouts;
   DevBuf<ItemDev> d_items, d_items_all, d_jac_items;
@@ -646,7 +647,7 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_y.alloc(size_t(NT) + 6 * p->sep_n)); HIP_TRY(p, p->d_zbuf.alloc(size_t(NS) + 64)); HIP_TRY(p, p->d_dadd.alloc(NT)); HIP_TRY(p, p->d_scale.alloc(NT));
   HIP_TRY(p, p->d_res.alloc(size_t(n_obs) * 3)); HIP_TRY(p, p->d_valid.alloc(size_t(n_obs)));
   HIP_TRY(p, p->d_active.alloc(size_t(n_obs))); HIP_TRY(p, p->d_counter.alloc(1));
-  p->active_dirty = true;
+  p->active_dirty = true; p->xc_stale = true;
   HIP_TRY(p, p->d_state.alloc(1)); HIP_TRY(p, p->d_log.alloc(kLogCap));
   if (!p->h_state) HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LmState)));
   // kernel attributes
@@ -678,7 +679,13 @@ int upload_x(calico_problem* p) {
   }
   for (const HBlock& b : p->blocks) std::copy(b.v.begin(), b.v.end(), p->h_x.begin() + b.amb_off);
   HIP_TRY(p, hipMemcpyAsync(p->d_x.p, p->h_x.data(), p->h_x.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(p, hipMemcpyAsync(p->d_xc.p, p->h_x.data(), p->h_x.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  // d_xc needs no upload: every parameter block, constant ones included, is rewritten by the update kernel... except
+  // the constant blocks, which the update never touches -- so it is seeded once per finalisation (below) and whenever
+  // a constant block may have changed
+  if (p->xc_stale) {
+    HIP_TRY(p, hipMemcpyAsync(p->d_xc.p, p->h_x.data(), p->h_x.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    p->xc_stale = false;
+  }
   return CALICO_OK;
 }
 
@@ -818,6 +825,7 @@ int32_t calico_get_param_block(calico_problem* p, int32_t id, double* out) {
 int32_t calico_set_param_block(calico_problem* p, int32_t id, const double* v) {
   if (!p || id < 0 || id >= int(p->blocks.size()) || !v) return p ? p->set_error(CALICO_INVALID_ARGUMENT, "bad block id") : CALICO_INVALID_ARGUMENT;
   std::copy(v, v + p->blocks[id].size, p->blocks[id].v.begin());
+  if (p->blocks[id].constant || !p->blocks[id].used) p->xc_stale = true;   // the update kernel never rewrites these
   return CALICO_OK;
 }
 
@@ -829,6 +837,7 @@ int32_t calico_set_param_blocks(calico_problem* p, int32_t n, const int32_t* ids
     HBlock& b = p->blocks[ids[i]];
     std::copy(v, v + b.size, b.v.begin());
     v += b.size;
+    if (b.constant || !b.used) p->xc_stale = true;
   }
   return CALICO_OK;
 }
@@ -959,10 +968,12 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   launch_init_state(p->d_state.p, opt->initial_trust_region_radius, std::sqrt(xn), s);
   // what a hipEventRecord pair costs around a ~2 us kernel on this stream: lets the caller take the bracket
   // overhead out of the per-launch phase times (phase 5)
-  for (int r = 0; r < 4; ++r) {
-    p->timer.begin(5, s);
-    launch_init_state(p->d_state.p, opt->initial_trust_region_radius, std::sqrt(xn), s);
-    p->timer.end(s);
+  if ((p->timer.mask >> 5) & 1) {
+    for (int r = 0; r < 4; ++r) {
+      p->timer.begin(5, s);
+      launch_init_state(p->d_state.p, opt->initial_trust_region_radius, std::sqrt(xn), s);
+      p->timer.end(s);
+    }
   }
   SolveArgs sa = make_solve_args(p);
   // iteration 0

@@ -288,7 +288,7 @@ int32_t calico_problem_set_stream(calico_problem* p, void* stream);
  * phase's longest one are left out. */
 int32_t calico_get_phase_time(calico_problem* p, int32_t phase, double* ms,
                               int64_t* launches);
-/* Which phases are bracketed by HIP events (bits 0..5: bit i = phase i; default: all) and, in bits 8..15, a sampling
+/* Which phases are bracketed by HIP events (bits 0..5: bit i = phase i; default: none) and, in bits 8..15, a sampling
  * interval N: only every N-th launch of a phase is bracketed (0 or 1: every launch). An event pair costs about 6 us of
  * stream time, so a throughput measurement brackets a sample of the launches, not all of them. */
 int32_t calico_set_phase_timing(calico_problem* p, int32_t mask);
