@@ -975,9 +975,13 @@ __global__ __launch_bounds__(64) void eval_jacobian_kernel(EvalArgs a) {
 // sensor -> ...) costs more than the arithmetic here.
 __global__ __launch_bounds__(256) void expand_cells_kernel(EvalArgs a) {
   extern __shared__ double lds[];
+  const long long t_start = __builtin_readcyclecounter();
   const CellDev cell = a.cells[blockIdx.x];
   if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
   const int tid = threadIdx.x;
+  const bool dbg = a.debug && blockIdx.x == 5 && tid == 0;
+  long long tph[5] = {0, 0, 0, 0, 0}, tk = t_start;
+#define CTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   const int n1 = cell.n1, PE = cell.PE, nme = PE * PE, rec = nme + n1;
   const int n_pairs = n1 * (n1 + 1) / 2;
   const int* __restrict__ prim = a.prim_tab + cell.prim_off;
@@ -985,18 +989,24 @@ __global__ __launch_bounds__(256) void expand_cells_kernel(EvalArgs a) {
   int pi[NQ], pj[NQ], pm_off[NQ];
   double acc[NQ];
   {
+    // pair decoding first (pure ALU, data-dependent loops), THEN all table loads together: interleaved, every pair's
+    // two loads would wait behind the previous pair's
     int ei = 0, eoff = tid, elen = n1;
     while (eoff >= elen && elen > 0) { eoff -= elen; ++ei; --elen; }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int i = ei < n1 ? ei : n1 - 1, j = ei < n1 ? ei + eoff : n1 - 1;
-      pi[q] = i; pj[q] = j;
-      pm_off[q] = prim[i] * PE + prim[j];
+      pi[q] = ei < n1 ? ei : n1 - 1; pj[q] = ei < n1 ? ei + eoff : n1 - 1;
       acc[q] = 0.0;
       eoff += 256;
       while (eoff >= elen && elen > 0) { eoff -= elen; ++ei; --elen; }
     }
+    int ti[NQ], tj[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { ti[q] = prim[pi[q]]; tj[q] = prim[pj[q]]; }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) pm_off[q] = ti[q] * PE + tj[q];
   }
+  CTICK(0)
   const double* cell_src = a.partials + cell.src_off;
   for (int f0 = 0; f0 < cell.frame_count; f0 += a.cell_chunk) {
     const int nf = min(a.cell_chunk, cell.frame_count - f0);
@@ -1004,6 +1014,7 @@ __global__ __launch_bounds__(256) void expand_cells_kernel(EvalArgs a) {
     const double* src = cell_src + size_t(f0) * rec;
     for (int i = tid; i < nf * rec; i += 256) lds[i] = src[i];
     __syncthreads();
+    CTICK(1)
     for (int f = 0; f < nf; ++f) {
       const double* me = lds + f * rec;
       const double* cf = me + nme;
@@ -1011,10 +1022,15 @@ __global__ __launch_bounds__(256) void expand_cells_kernel(EvalArgs a) {
       for (int q = 0; q < NQ; ++q) acc[q] += cf[pi[q]] * cf[pj[q]] * me[pm_off[q]];
     }
   }
+  CTICK(2)
   double* out = a.partials + cell.partial_off;
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
     if (tid + 256 * q < n_pairs) out[size_t(pi[q]) * n1 + pj[q]] = acc[q];
+  CTICK(3)
+  if (dbg) printf("expand_cells cycles (cell of %d frames, n1 %d): setup+tables %lld  record copy %lld  accumulate %lld  store %lld\n",
+                  cell.frame_count, n1, tph[0], tph[1], tph[2], tph[3]);
+#undef CTICK
 }
 
 void launch_expand_cells(const EvalArgs& a, hipStream_t stream) {
