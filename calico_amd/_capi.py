@@ -120,7 +120,7 @@ ABI_SYMBOLS = [
     "get_iterations", "get_residuals", "get_inlier_mask",
     "num_effective_parameters", "evaluate", "problem_set_allreduce", "problem_set_shard",
     "problem_set_stream", "get_phase_time", "set_phase_timing", "project",
-    "problem_set_outlier_mask", "mark_outliers",
+    "problem_set_outlier_mask", "mark_outliers", "fit_spline",
 ]
 
 
@@ -165,6 +165,7 @@ class CApi:
             g("project", C.c_int32, [P, C.c_int32, D, C.POINTER(C.c_uint8)])
             g("problem_set_outlier_mask", C.c_int32, [P, C.c_int32, C.POINTER(C.c_uint8)])
             g("mark_outliers", C.c_int32, [P, C.c_int32, C.c_double, C.POINTER(C.c_int64)])
+            g("fit_spline", C.c_int32, [C.c_int32, C.c_int32, C.c_int32, D, D, C.c_int64, D, D, D])
             g("set_phase_timing", C.c_int32, [P, C.c_int32])
 
     def _get(self, name, restype, argtypes):

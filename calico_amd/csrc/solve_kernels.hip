@@ -251,15 +251,6 @@ __global__ __launch_bounds__(256) void prepare_kernel(SolveArgs a, LmOptionsDev 
   }
 }
 
-// ---------------------------------------------------------------------------
-// Bordered banded Cholesky, blocked by control point (6 columns per step).
-// Workgroup w owns border columns [w·bs, (w+1)·bs) of Y = L⁻¹[E | g_s]; every
-// workgroup re-factors the (cheap) band so no inter-workgroup traffic exists.
-// The k block columns of the active window live in an LDS ring; the next block
-// is prefetched two steps ahead through registers.
-// Per step: (1) every thread factors the 6×6 pivot block redundantly,
-// (2) panel rows x = a·L11⁻ᵀ, (3) rank-6 trailing update. Two barriers per step.
-// ---------------------------------------------------------------------------
 DEVI double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -277,37 +268,6 @@ DEVI double rsqrt_nr(double d) {
 // Workgroup barrier that orders LDS traffic only. __syncthreads() also drains vmcnt, which puts the full latency of
 // every in-flight global prefetch / write-back on the per-step critical path of the sequential sweeps.
 DEVI void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-DEVI void chol6_and_inverse(const double* A /* [r*6+c], lower */, double L[6][6], double Li[6][6], bool* fail) {
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    double d = A[j * 6 + j];
-#pragma unroll
-    for (int q = 0; q < j; ++q) d -= L[j][q] * L[j][q];
-    const bool bad = !(d > 0.0) || !isfinite(d);
-    *fail = *fail || bad;
-    d = bad ? 1.0 : d;
-    const double inv = rsqrt_nr(d);
-    L[j][j] = d * inv; Li[j][j] = inv;
-#pragma unroll
-    for (int i = j + 1; i < 6; ++i) {
-      double v = A[i * 6 + j];
-#pragma unroll
-      for (int q = 0; q < j; ++q) v -= L[i][q] * L[j][q];
-      L[i][j] = v * inv;
-    }
-  }
-  // inverse of the lower-triangular factor
-#pragma unroll
-  for (int j = 0; j < 6; ++j)
-#pragma unroll
-    for (int i = j + 1; i < 6; ++i) {
-      double v = 0.0;
-#pragma unroll
-      for (int q = j; q < i; ++q) v += L[i][q] * Li[q][j];
-      Li[i][j] = -v * Li[i][i];
-    }
-}
 
 // Bordered band Cholesky, blocked by control point (6 columns). Workgroup b factors the band (redundantly)
 // together with border rows [b·16, (b+1)·16); the window of k block columns lives in an LDS ring.

@@ -325,7 +325,7 @@ class BSpline6 {
     for (auto& c : ctrl_) { problem.AddParameterBlock(c.data(), 6); n += 6; }
     return n;
   }
-  /// bspline.hpp:19-37,163-297 (normal equations; the rank-deficient trajectory end is ridge-regularised)
+  /// bspline.hpp:19-37,163-297 (knot vector and basis matrices here, the least-squares solve on the device)
   Status FitToData(const std::vector<double>& time, const std::vector<std::array<double, 6>>& data, int order, double knot_frequency) {
     if (time.empty()) return InvalidArgumentError("Attempted to fit data on empty time vector.");
     if (data.empty()) return InvalidArgumentError("Attempted to fit on empty data.");
@@ -347,40 +347,16 @@ class BSpline6 {
       const std::vector<double> M = Basis(order, s + deg);
       std::copy(M.begin(), M.end(), basis_.begin() + size_t(s) * order * order);
     }
+    // least-squares control points on the device (calico_fit_spline: banded normal equations + banded Cholesky; the
+    // reference factors the dense design matrix by column-pivoted QR, bspline.hpp:287-293)
     const int ncp = nk - order, nd = int(time.size());
-    std::vector<double> A(size_t(ncp) * ncp, 0.0), B(size_t(ncp) * 6, 0.0);
-    for (int j = 0; j < nd; ++j) {
-      int si = GetSplineIndex(time[size_t(j)]);
-      if (si < 0) si = nseg - 1;
-      const int ki = si + deg;
-      const double u = (time[size_t(j)] - knots_[size_t(ki)]) / (knots_[size_t(ki + 1)] - knots_[size_t(ki)]);
-      std::vector<double> U(size_t(order), 1.0), w(size_t(order), 0.0);
-      for (int i = 1; i < order; ++i) U[size_t(i)] = u * U[size_t(i - 1)];
-      for (int c = 0; c < order; ++c) for (int r = 0; r < order; ++r) w[size_t(c)] += U[size_t(r)] * basis_[(size_t(si) * order + r) * order + c];
-      for (int a = 0; a < order; ++a) {
-        for (int b = 0; b < order; ++b) A[size_t(si + a) * ncp + si + b] += w[size_t(a)] * w[size_t(b)];
-        for (int c = 0; c < 6; ++c) B[size_t(si + a) * 6 + c] += w[size_t(a)] * data[size_t(j)][size_t(c)];
-      }
-    }
-    double tr = 0; for (int i = 0; i < ncp; ++i) tr += A[size_t(i) * ncp + i];
-    for (int i = 0; i < ncp; ++i) A[size_t(i) * ncp + i] += 1e-12 * tr / ncp;
-    for (int j = 0; j < ncp; ++j) {  // dense Cholesky (initialisation only)
-      double d = A[size_t(j) * ncp + j];
-      for (int q = 0; q < j; ++q) d -= A[size_t(j) * ncp + q] * A[size_t(j) * ncp + q];
-      if (!(d > 0)) return InternalError("spline fit: normal equations not positive definite");
-      d = std::sqrt(d); A[size_t(j) * ncp + j] = d;
-      for (int i = j + 1; i < ncp; ++i) {
-        double s = A[size_t(i) * ncp + j];
-        for (int q = 0; q < j; ++q) s -= A[size_t(i) * ncp + q] * A[size_t(j) * ncp + q];
-        A[size_t(i) * ncp + j] = s / d;
-      }
-    }
+    std::vector<double> flat(size_t(nd) * 6), ctrl(size_t(ncp) * 6);
+    for (int j = 0; j < nd; ++j) for (int c = 0; c < 6; ++c) flat[size_t(j) * 6 + c] = data[size_t(j)][size_t(c)];
+    const int32_t rc = calico_fit_spline(0, order, nk, knots_.data(), basis_.data(), nd, time.data(), flat.data(), ctrl.data());
+    if (rc == CALICO_INVALID_ARGUMENT) return InvalidArgumentError("spline fit: stamps must be sorted and inside the knot range");
+    if (rc != CALICO_OK) return InternalError("spline fit failed on the device");
     ctrl_.assign(size_t(ncp), {});
-    for (int c = 0; c < 6; ++c) {
-      std::vector<double> y(static_cast<size_t>(ncp));
-      for (int i = 0; i < ncp; ++i) { double s = B[size_t(i) * 6 + c]; for (int q = 0; q < i; ++q) s -= A[size_t(i) * ncp + q] * y[size_t(q)]; y[size_t(i)] = s / A[size_t(i) * ncp + i]; }
-      for (int i = ncp - 1; i >= 0; --i) { double s = y[size_t(i)]; for (int q = i + 1; q < ncp; ++q) s -= A[size_t(q) * ncp + i] * ctrl_[size_t(q)][size_t(c)]; ctrl_[size_t(i)][size_t(c)] = s / A[size_t(i) * ncp + i]; }
-    }
+    for (int i = 0; i < ncp; ++i) for (int c = 0; c < 6; ++c) ctrl_[size_t(i)][size_t(c)] = ctrl[size_t(i) * 6 + c];
     return OkStatus();
   }
   /// bspline.hpp:39-72 at one time; error codes of bspline.hpp:74-85

@@ -218,6 +218,17 @@ int32_t calico_get_iterations(calico_problem* p, calico_iteration* out,
  * filling both arrays). */
 int32_t calico_get_residuals(calico_problem* p, int32_t sensor_id, double* out,
                              uint8_t* valid);
+/* Spline initialisation on the device: BSpline::FitToData / FitSpline (bspline.hpp:19-37, 246-297), behind
+ * Trajectory::FitSpline (trajectory.cpp:14-49). Least-squares control points (n_knots - order rows of 6) of the
+ * spline on the given knot vector / basis matrices (as for calico_problem_set_spline) through n sorted samples
+ * `data6` (n x 6: axis-angle, position) at `stamps`. The reference factors the dense n x n_ctrl design matrix by
+ * column-pivoted QR; here the banded normal equations are assembled in a fixed order and solved by a banded Cholesky
+ * (control points the samples do not determine, e.g. at an under-sampled trajectory end, are decoupled). kInvalidArgument for unsorted stamps,
+ * stamps outside the valid knots or bad sizes; kUnimplemented when the band does not fit the on-chip solve. Needs no
+ * problem handle. */
+int32_t calico_fit_spline(int32_t device, int32_t order, int32_t n_knots, const double* knots, const double* basis,
+                          int64_t n, const double* stamps, const double* data6, double* ctrl_out);
+
 /* Outlier tags (Camera::MarkOutliersById / ClearOutliers, camera.cpp:281-301; outlier_ids_, camera.h:185): tagged
  * observations stay registered but are left out of the problem, as AddResidualsToProblem does (camera.cpp:121-124) --
  * no residual block, no residual, not counted in the summary. `is_outlier` has one byte per observation of the
