@@ -13,6 +13,30 @@
 
 using namespace calico;
 
+// --host-only runs on machines without a GPU: the spline fit is then done by the CPU oracle (oracle/ is the tests'
+// checker), installed through BSpline6::fit_solver(). The GPU run keeps the default, calico_fit_spline.
+extern "C" {
+void* oracle_spline_create();
+void oracle_spline_destroy(void*);
+int32_t oracle_spline_fit_vectors(void*, int32_t n, const double* stamps, const double* data6, double knot_frequency, int32_t order);
+int32_t oracle_spline_sizes(void*, int32_t* order, int32_t* n_knots, int32_t* n_ctrl, int32_t* n_seg);
+int32_t oracle_spline_get(void*, double* knots, double* basis, double* ctrl);
+}
+static int32_t oracle_fit(int32_t order, int32_t n_knots, const double* knots, const double*, int64_t n, const double* stamps,
+                          const double* data6, double* ctrl_out) {
+  const double kf = std::round(1e6 / (knots[order] - knots[order - 1])) * 1e-6;
+  void* s = oracle_spline_create();
+  int32_t rc = oracle_spline_fit_vectors(s, int32_t(n), stamps, data6, kf, order), o = 0, nk = 0, nc = 0, ns = 0;
+  if (rc == 0) rc = oracle_spline_sizes(s, &o, &nk, &nc, &ns);
+  if (rc == 0 && (nk != n_knots || o != order)) rc = CALICO_INTERNAL;
+  if (rc == 0) {
+    std::vector<double> k, b; k.resize(size_t(nk)); b.resize(size_t(ns) * o * o);
+    rc = oracle_spline_get(s, k.data(), b.data(), ctrl_out);
+  }
+  oracle_spline_destroy(s);
+  return rc == 0 ? CALICO_OK : CALICO_INTERNAL;
+}
+
 static int failures = 0;
 #define CHECK(cond)                                                         \
   do {                                                                      \
@@ -60,6 +84,7 @@ static double posediff(const Pose3d& a, const Pose3d& b) {
 
 int main(int argc, char** argv) {
   const bool host_only = argc > 1 && !std::strcmp(argv[1], "--host-only");
+  if (host_only) BSpline6::fit_solver() = &oracle_fit;
   DefaultSyntheticTest fixture;
   // typedefs_test.cpp:37-60
   { Pose3d p; double* a = p.rotation().coeffs().data(); double* b = p.translation().data(); Pose3d q = p; (void)q;

@@ -14,10 +14,13 @@ EXE = os.path.join(helpers.ROOT, "tests", "cpp", "build", "toy_stereo_imu")
 def _build():
     import __graft_entry__ as g
     g.build_hip()
+    helpers.build_oracle()
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
     libdir = os.path.join(helpers.ROOT, "calico_amd")
+    oradir = os.path.join(helpers.ROOT, "oracle")  # only --host-only uses it (spline fit without a GPU)
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wno-unknown-pragmas", "-I", os.path.join(helpers.ROOT, "include"),
-                           SRC, "-o", EXE, "-L", libdir, "-lcalico_hip", "-Wl,-rpath," + libdir])
+                           SRC, "-o", EXE, "-L", libdir, "-lcalico_hip", "-Wl,-rpath," + libdir,
+                           "-L", oradir, "-lcalico_oracle", "-Wl,-rpath," + oradir])
 
 
 def test_facade_compiles_and_host_logic():
