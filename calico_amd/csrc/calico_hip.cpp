@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <map>
 #include <string>
 #include <vector>
@@ -324,7 +325,7 @@ int finalize(calico_problem* p) {
     for (int i = 0; i < n_cp; ++i) all_active = all_active && cp_active[size_t(i)] != 0;
     const char* env = std::getenv("CALICO_BAND_SPLIT");
     const bool allowed = !env || std::atoi(env) != 0;
-    if (allowed && all_active && n_cp >= 6 * k && m + 6 * (k - 1) + 1 <= 128) {
+    if (allowed && all_active && n_cp >= 6 * k && m + 6 * (k - 1) + 1 <= 1024) {
       p->sep_n = k - 1;
       p->sep_s = (n_cp - p->sep_n) / 2;
     }
@@ -334,7 +335,13 @@ int finalize(calico_problem* p) {
   std::vector<SensorDev> sd(p->sensors.size());
   std::vector<LayoutDev> layouts;
   std::vector<std::vector<int>> layout_gmap;             // local calibration column -> solver tangent index
-  std::map<std::pair<int, int>, int> layout_of;          // (sensor, body) -> layout id
+  // (sensor, body, free model point or -1) -> layout id. A free model point is one more calibration block of the
+  // residual blocks that observe it, so those blocks get a layout (and cells) of their own per point.
+  std::map<std::array<int, 3>, int> layout_of;
+  auto layout_key = [&](size_t si, const HSensor& s, int64_t i) -> std::array<int, 3> {
+    if (s.kind != CALICO_SENSOR_CAMERA) return {int(si), -1, -1};
+    return {int(si), s.body[i], p->blocks[s.point[i]].constant ? -1 : s.point[i]};
+  };
   auto is_free = [&](int id) { return id >= 0 && !p->blocks[id].constant; };
   for (size_t si = 0; si < p->sensors.size(); ++si) {
     const HSensor& s = p->sensors[si];
@@ -345,11 +352,10 @@ int finalize(calico_problem* p) {
     d.info = s.info; d.loss_scale = s.loss_scale;
     for (int64_t i = 0; i < s.n(); ++i) {
       const int body = s.kind == CALICO_SENSOR_CAMERA ? s.body[i] : -1;
-      if (s.kind == CALICO_SENSOR_CAMERA && !p->blocks[s.point[i]].constant)
-        return p->set_error(CALICO_UNIMPLEMENTED, "free model points (model_definition_is_constant=false) are not supported yet");
-      if (layout_of.count({int(si), body})) continue;
+      const std::array<int, 3> lkey = layout_key(si, s, i);
+      if (layout_of.count(lkey)) continue;
       LayoutDev L;
-      L.sensor = int(si); L.pad0 = 0;
+      L.sensor = int(si); L.c_pt = -1;
       std::vector<int> gmap;
       int c = 6 * k;
       auto add = [&](int id, int* slot) {
@@ -363,11 +369,12 @@ int finalize(calico_problem* p) {
       if (s.kind == CALICO_SENSOR_CAMERA) {
         add(p->bodies[body].q, &L.c_bq); add(p->bodies[body].t, &L.c_bt);
         L.bq_off = p->blocks[p->bodies[body].q].amb_off; L.bt_off = p->blocks[p->bodies[body].t].amb_off;
+        if (lkey[2] >= 0) add(lkey[2], &L.c_pt);
       } else if (s.kind == CALICO_SENSOR_ACCELEROMETER) {
         add(s.grav, &L.c_grav);
       }
       L.ncols = c;
-      layout_of[{int(si), body}] = int(layouts.size());
+      layout_of[lkey] = int(layouts.size());
       layouts.push_back(L); layout_gmap.push_back(gmap);
     }
   }
@@ -381,8 +388,7 @@ int finalize(calico_problem* p) {
     HSensor& s = p->sensors[si];
     s.sorted_pos.assign(size_t(s.n()), 0);
     for (int64_t i = 0; i < s.n(); ++i) {
-      const int body = s.kind == CALICO_SENSOR_CAMERA ? s.body[i] : -1;
-      keys.push_back({layout_of[{int(si), body}], s.seg[i], int(si), i, s.stamps[size_t(i)]});
+      keys.push_back({layout_of[layout_key(si, s, i)], s.seg[i], int(si), i, s.stamps[size_t(i)]});
     }
   }
   std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
@@ -442,7 +448,7 @@ int finalize(calico_problem* p) {
       }
       for (size_t l = 0; l < layouts.size(); ++l)
         layout_uses_frames[l] = p->sensors[size_t(layouts[l].sensor)].kind == CALICO_SENSOR_CAMERA && n_frames_l[l] > 0 &&
-                                n_obs_l[l] >= 16 * n_frames_l[l] && layouts[l].ncols + 1 - 36 + 6 <= 30;
+                                n_obs_l[l] >= 16 * n_frames_l[l] && layouts[l].ncols + 1 - 36 + 6 <= 30 && layouts[l].c_pt < 0;
     }
     for (int64_t q = 0; q < n_obs;) {
       const Key& kq = keys[q];

@@ -175,6 +175,13 @@ DEV bool camera_block(const ItemCtx& c, double px, double py, double stamp, cons
 #pragma unroll
         for (int j = 0; j < 3; ++j) sink.put(L.c_bt + j, r, fac * DG[r][j]);
     }
+    if (L.c_pt >= 0) {  // d xc / d x_m = G R_wm
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          sink.put(L.c_pt + j, r, fac * (DG[r][0] * R_wm.m[0][j] + DG[r][1] * R_wm.m[1][j] + DG[r][2] * R_wm.m[2][j]));
+    }
   }
   return true;
 }

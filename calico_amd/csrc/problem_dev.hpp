@@ -27,13 +27,13 @@ struct SensorDev {
 };
 
 // Local column layout of one (sensor, rigid body) pair. Column order:
-// [spline 6k | intrinsics | q | t | latency | body q | body t | gravity];
+// [spline 6k | intrinsics | q | t | latency | body q | body t | gravity | model point];
 // an entry is -1 when that block is constant (no column).
 struct LayoutDev {
   int sensor, ncols;
   int c_intr, c_q, c_t, c_lat, c_bq, c_bt, c_grav;
   int bq_off, bt_off;  // ambient offsets of the rigid body pose (cameras)
-  int pad0;
+  int c_pt;            // free model point (cameras): the layout is then per (sensor, body, point)
 };
 
 // One work item = up to kRowsPerItem residual rows of one cell.

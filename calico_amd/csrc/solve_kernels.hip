@@ -1020,6 +1020,195 @@ __global__ __launch_bounds__(256) void reduced_solve_panel_kernel(SolveArgs a) {
   if (tid == 0 && s_fail) st->chol_failed = 1;
 }
 
+// ---------------------------------------------------------------------------
+// Large reduced systems (m + 1 > 128: many cameras, free chart points): blocked right-looking Cholesky over all CUs,
+// one launch per 32-column panel j. Workgroup (I, K), I >= K, owns the 64×64 tile of the trailing matrix at rows
+// t0 + 64·I, columns t0 + 64·K (t0 = first row under the panel). Each of its four waves takes the pivot block A_jj
+// in lanes 0-31 (one row per lane, 32 registers) and 32 rows of the panel under it in lanes 32-63, and runs the
+// column Cholesky on the 64 rows at once, pivots and multipliers travelling by v_readlane: lanes 0-31 end up with
+// L_jj (recomputed by every wave, which costs no time), lanes 32-63 with their rows of A_ij·L_jj⁻ᵀ. The four row
+// blocks are those of tile rows I (waves 0, 1) and tile rows K (waves 2, 3); they meet in LDS and wave (a, b)
+// subtracts P_{I,a}·P_{K,b}ᵀ from its 32×32 quarter of the tile, in place. The first tile column also files the
+// panel into the factor L (Swork). The right-hand side rides as row m, so L(m, :) is the forward-substituted vector.
+// `nsl`: K-slices of the Schur complement to add up on the first touch (panel 0 touches every entry).
+constexpr int kRB = 32;
+__global__ __launch_bounds__(256) void reduced_block_step_kernel(SolveArgs a, int j, int nsl) {
+  LmState* st = a.st;
+  if (st->terminated) return;
+  __shared__ double sP[4][kRB][kRB + 1];
+  __shared__ __attribute__((aligned(16))) double sCol[4][2][64];
+  const int m = a.m, m1 = a.m + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = kRB * j, t0 = c0 + kRB;
+  int I = 0, rem = blockIdx.x;
+  while (rem > I) { rem -= I + 1; ++I; }
+  const int K = rem;
+  const int rI = t0 + 64 * I, rK = t0 + 64 * K;
+  double* A = a.Spart;
+  const size_t msq = size_t(m1) * m1;
+  double* L = a.Swork;
+  // ---- loads: this wave's 64 rows of panel j, and this lane's 4×4 piece of the tile ----
+  const int rb = (wave < 2 ? rI : rK) + kRB * (wave & 1);
+  const int myrow = lane < kRB ? c0 + lane : rb + (lane - kRB);
+  const bool row_ok = myrow < m1;
+  const double* src = A + size_t(min(myrow, m1 - 1)) * m1;
+  double G[kRB];
+#pragma unroll
+  for (int c = 0; c < kRB; ++c) {
+    const int col = c0 + c;                // may run past the row end: masked below, and Spart has slack behind it
+    double v = src[col];
+    if (nsl > 1) v += src[msq + col];
+    const bool ok = row_ok && c0 + c < m1 && (lane >= kRB || c <= lane);
+    G[c] = ok ? v : 0.0;
+  }
+  const int qa = wave >> 1, qb = wave & 1, r4 = lane >> 3, c4 = lane & 7;
+  const int ur0 = rI + kRB * qa + 4 * r4, uc0 = rK + kRB * qb + 4 * c4;
+  double pre[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const size_t o = size_t(min(ur0 + i, m1 - 1)) * m1 + uc0 + jj;
+      double v = A[o];
+      if (nsl > 1) v += A[msq + o];
+      pre[i][jj] = v;
+    }
+  // ---- column Cholesky of the 64 rows ----
+  // Column c: the unscaled column goes to a wave-private LDS vector; the pivot and the multiplier of column c+1 (the
+  // latency chain) travel by v_readlane, the other multipliers come back as broadcast ds_read_b128 — one VALU
+  // instruction per update instead of three.
+  double (*cb)[64] = sCol[wave];
+  double pmin = 1.0, psum = 0.0;
+#pragma unroll
+  for (int c = 0; c < kRB; ++c) {
+    double* buf = cb[c & 1];
+    buf[lane] = G[c];
+    __builtin_amdgcn_wave_barrier();
+    double p = readlane_f64(G[c], c);
+    const bool live = c0 + c < m;          // column m is the right-hand side, beyond it padding
+    p = live ? p : 1.0;
+    pmin = fmin(pmin, p); psum += p;       // a NaN pivot poisons psum, a non-positive one shows in pmin
+    const double rs = rsqrt_nr(p);
+    const double t = G[c] * (rs * rs);
+    if (c + 1 < kRB) G[c + 1] -= t * readlane_f64(G[c], c + 1);
+#pragma unroll
+    for (int e = 0; e < kRB; e += 2) {       // multipliers of rows e, e+1 (constant bounds: everything unrolls)
+      if (e >= c + 2) {
+        const double2 u = *reinterpret_cast<const double2*>(buf + e);
+        G[e] -= t * u.x;
+        G[e + 1] -= t * u.y;
+      } else if (e + 1 >= c + 2) {
+        G[e + 1] -= t * buf[e + 1];
+      }
+    }
+    G[c] *= rs;
+    // pin the updated columns here: without it the compiler sinks every update to the column's first use (a
+    // left-looking schedule that keeps all 496 multipliers alive: 512 VGPRs and spills)
+#pragma unroll
+    for (int e = 0; e < kRB; e += 8)
+      if (e + 7 >= c + 2)
+        asm volatile("" : "+v"(G[e]), "+v"(G[e + 1]), "+v"(G[e + 2]), "+v"(G[e + 3]), "+v"(G[e + 4]), "+v"(G[e + 5]), "+v"(G[e + 6]), "+v"(G[e + 7]));
+  }
+  // ---- file the panel, exchange the row blocks ----
+  if (lane >= kRB) {
+#pragma unroll
+    for (int c = 0; c < kRB; ++c) sP[wave][lane - kRB][c] = G[c];
+    if (K == 0 && wave < 2 && row_ok) {   // masked entries go to a dump word past the factor: no branch per store
+#pragma unroll
+      for (int c = 0; c < kRB; ++c) L[c0 + c < m1 ? size_t(myrow) * m1 + c0 + c : msq + lane] = G[c];
+    }
+  } else if (blockIdx.x == 0 && wave == 0 && row_ok) {
+#pragma unroll
+    for (int c = 0; c < kRB; ++c) L[c <= lane ? size_t(myrow) * m1 + c0 + c : msq + lane] = G[c];
+  }
+  if (blockIdx.x == 0 && tid == 0 && (!(pmin > 0.0) || !isfinite(psum))) st->chol_failed = 1;
+  __syncthreads();
+  // ---- tile update ----
+  double acc[4][4] = {};
+  const double (*PI)[kRB + 1] = sP[qa];
+  const double (*PK)[kRB + 1] = sP[2 + qb];
+#pragma unroll 8
+  for (int k = 0; k < kRB; ++k) {
+    double ra[4], rc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ra[i] = PI[4 * r4 + i][k]; rc[i] = PK[4 * c4 + i][k]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc[i][jj] += ra[i] * rc[jj];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int ur = ur0 + i, uc = uc0 + jj;
+      double* dst = (ur < m1 && uc <= ur) ? A + size_t(ur) * m1 + uc : L + msq + lane;
+      *dst = pre[i][jj] - acc[i][jj];
+    }
+}
+
+// Backward substitution Lᵀ y_c = L(m, :) for the blocked factor, one workgroup, panel by panel from the end:
+// the half-wave whose threads own the panel's columns solves the 32×32 triangle in axpy form (one column of L_jj per
+// lane, the solved unknown travelling by v_readlane), then every thread adds the panel's contribution to the
+// pending sums of the columns it owns (column c belongs to thread c mod 256).
+constexpr int kRBCols = 4;   // columns per thread: m <= 1024
+__global__ __launch_bounds__(256) void reduced_block_back_kernel(SolveArgs a) {
+  LmState* st = a.st;
+  if (st->terminated) return;
+  __shared__ double sy[2][kRB];
+  const int m = a.m, m1 = a.m + 1, n = a.n_s();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double* L = a.Swork;
+  double acc[kRBCols] = {};
+  const int np = (m + kRB - 1) / kRB;
+  for (int jb = np - 1; jb >= 0; --jb) {
+    const int c0 = kRB * jb;
+    double* ybuf = sy[jb & 1];
+    if (wave == ((c0 & 255) >> 6)) {
+      const int l0 = c0 & 63, ci = lane - l0;       // this lane's column inside the panel (valid when 0 <= ci < 32)
+      const int col = min(c0 + min(max(ci, 0), kRB - 1), m - 1);
+      double Lc[kRB];
+#pragma unroll
+      for (int i = 0; i < kRB; ++i) Lc[i] = L[size_t(min(c0 + i, m - 1)) * m1 + col];
+      const double zq = L[size_t(m) * m1 + col];
+      double pend = 0.0;
+#pragma unroll
+      for (int u = 0; u < kRBCols; ++u) pend = (col >> 8) == u ? acc[u] : pend;
+      double dj = 1.0;
+#pragma unroll
+      for (int i = 0; i < kRB; ++i) dj = ci == i ? Lc[i] : dj;
+      dj = 1.0 / dj;
+      double yk = 0.0;
+#pragma unroll
+      for (int i = kRB - 1; i >= 0; --i) {
+        const double cand = (zq - pend) * dj;
+        double yi = readlane_f64(cand, l0 + i);
+        yi = c0 + i < m ? yi : 0.0;
+        yk = ci == i ? yi : yk;
+        pend += (ci >= 0 && ci < i) ? Lc[i] * yi : 0.0;
+      }
+      if (ci >= 0 && ci < kRB) {
+        ybuf[ci] = yk;
+        if (c0 + ci < m) a.y[n + c0 + ci] = yk;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kRBCols; ++u) {
+      const int col = tid + 256 * u;
+      if (col < c0) {
+        double t[kRB];
+#pragma unroll
+        for (int i = 0; i < kRB; ++i) t[i] = L[size_t(min(c0 + i, m - 1)) * m1 + col];
+        double sacc = 0.0;
+#pragma unroll
+        for (int i = 0; i < kRB; ++i) sacc += t[i] * ybuf[i];
+        acc[u] += sacc;
+      }
+    }
+  }
+}
+
 // z = L⁻¹g_s - Y·y_c : one wave per band row, all CUs.  (y[0..n) used as z storage)
 __global__ __launch_bounds__(256) void border_matvec_kernel(SolveArgs a) {
   const LmState* st = a.st;
@@ -1374,12 +1563,21 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
   const int nwg = (m1 + kBorderSlice - 1) / kBorderSlice;
   hipLaunchKernelGGL(band_cholesky_kernel, dim3(nwg, a.n_seg()), dim3(256), band_cholesky_lds_bytes(a), s, a, kBorderSlice);
   const int nt = (m1 + 15) / 16;
-  const int ks = m1 <= 128 ? kSchurSlices : 1;
+  static const int blocked_from = [] { const char* e = std::getenv("CALICO_REDUCED_BLOCKED_FROM"); return e ? std::atoi(e) : 129; }();
+  const bool blocked = m1 >= blocked_from && m1 > 128 && a.m <= 256 * kRBCols;
+  const int ks = (m1 <= 128 || blocked) ? kSchurSlices : 1;
   hipLaunchKernelGGL(schur_kernel, dim3(nt * (nt + 1) / 2 * ks), dim3(256), 0, s, a, ks);
   if (m1 <= 128) {
     const size_t lds = (size_t(m1) * ((16 * ((m1 + 15) / 16)) | 1) + m1 + 32 + 128 + 256) * sizeof(double);
     if (m1 <= 64) hipLaunchKernelGGL(reduced_solve_panel_kernel<1>, dim3(1), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(reduced_solve_panel_kernel<2>, dim3(1), dim3(256), lds, s, a);
+  } else if (blocked) {
+    const int steps = (a.m + kRB - 1) / kRB;
+    for (int j = 0; j < steps; ++j) {
+      const int rows = m1 - kRB * (j + 1), T = rows > 0 ? (rows + 63) / 64 : 0;
+      hipLaunchKernelGGL(reduced_block_step_kernel, dim3(T > 0 ? T * (T + 1) / 2 : 1), dim3(256), 0, s, a, j, j == 0 ? ks : 1);
+    }
+    hipLaunchKernelGGL(reduced_block_back_kernel, dim3(1), dim3(256), 0, s, a);
   } else if (m1 <= 16 * 13) {
     const int NT = m1 <= 64 ? 4 : (m1 <= 112 ? 7 : (m1 <= 160 ? 10 : 13));
     const int NP = 16 * NT;

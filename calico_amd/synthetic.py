@@ -458,7 +458,7 @@ class Scene:
     gravity: np.ndarray
     sensors: List[SensorSpec] = field(default_factory=list)
     body_pose_constant: bool = True
-    points_constant: bool = True
+    points_constant: object = True   # bool, or one flag per model point
 
     @property
     def num_blocks(self):
@@ -484,7 +484,8 @@ def build_problem(api, scene, device=0, obs_slices=None):
     a slice of its observations (multi-GPU sharding)."""
     P = _capi.Problem(api, device)
     # WorldModel::AddParametersToProblem (world_model.cpp:40-77)
-    point_blocks = np.array([P.add_param_block(p, constant=scene.points_constant) for p in scene.points], np.int32)
+    pc = np.broadcast_to(np.asarray(scene.points_constant, bool), (len(scene.points),))
+    point_blocks = np.array([P.add_param_block(p, constant=bool(c)) for p, c in zip(scene.points, pc)], np.int32)
     bt = P.add_param_block(scene.body_t, constant=scene.body_pose_constant)
     bq = P.add_param_block(scene.body_q, _capi.MANIFOLD_EIGEN_QUATERNION, scene.body_pose_constant)
     grav = P.add_param_block(scene.gravity, constant=True)  # Q6: gravity can never be enabled
@@ -562,7 +563,7 @@ def _initial_intrinsics(kind, model, truth):
 def make_scene(n_cameras=1, camera_model=1, imu=False, imu_model=2, duration=None, cam_rate=None, imu_rate=None,
                knot_frequency=10.0, order=6, chart="plane", pixel_noise=0.0, gyro_noise=0.0, accel_noise=0.0,
                seed=0xCA11C0, robust=False, outlier_fraction=0.0, perturb=True, estimate_spline_from_truth=True,
-               max_cam_obs=None, segment_duration=0.75, repeats=1, free_chart_pose=False):
+               max_cam_obs=None, segment_duration=0.75, repeats=1, free_chart_pose=False, free_points=False):
     """Synthetic rig problem in the style of ToyStereoCameraAndImuCalibration
     (batch_optimizer_test.cpp:32-213): camera 0 is the rig frame with free
     intrinsics; further cameras also estimate extrinsics + latency; the IMU
@@ -645,8 +646,21 @@ def make_scene(n_cameras=1, camera_model=1, imu=False, imu_model=2, duration=Non
                                       0.0 if perturb else lat_true, truth, q_true, t_true,
                                       lat_true, True, True, True, sigma=noise if noise > 0 else 1.0,
                                       loss=1 if robust else 0, loss_scale=1.0, meas=m, stamps=st))
-    return Scene(order, knots, basis, ctrl_true.copy(), ctrl_true, points, body_q, body_t, gravity, sensors,
-                 body_pose_constant=not free_chart_pose)
+    points_constant = True
+    points_init = points
+    if free_points:
+        # model_definition_is_constant = false (world_model.cpp:52-61). Three non-collinear anchor points stay fixed
+        # so that the chart keeps its gauge; the others start a few millimetres off.
+        p0 = points[0]
+        i1 = int(np.argmax(np.linalg.norm(points - p0, axis=1)))
+        d = (points[i1] - p0) / np.linalg.norm(points[i1] - p0)
+        off = (points - p0) - np.outer((points - p0) @ d, d)
+        i2 = int(np.argmax(np.linalg.norm(off, axis=1)))
+        points_constant = np.zeros(len(points), bool)
+        points_constant[[0, i1, i2]] = True
+        points_init = points + np.where(points_constant[:, None], 0.0, 2e-3 * rng.standard_normal(points.shape))
+    return Scene(order, knots, basis, ctrl_true.copy(), ctrl_true, points_init, body_q, body_t, gravity, sensors,
+                 body_pose_constant=not free_chart_pose, points_constant=points_constant)
 
 
 def config_scene(index, seed=None):

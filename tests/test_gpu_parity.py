@@ -47,6 +47,34 @@ def test_free_chart_pose_parity(hip, oracle):
     assert_eval_close(gpu, ref)
 
 
+def test_free_model_points_parity(hip, oracle):
+    """model_definition_is_constant = false (world_model.cpp:52-61): every model point is a 3-vector block."""
+    scene = small_scene(camera_model=1, n_cameras=2, imu=False, free_points=True)
+    gpu, ref = both(scene, hip, oracle)
+    assert_eval_close(gpu, ref)
+    scene = small_scene(camera_model=3, n_cameras=1, imu=True, free_points=True, free_chart_pose=True)
+    gpu, ref = both(scene, hip, oracle)
+    assert_eval_close(gpu, ref)
+
+
+def test_free_model_points_solve_matches_oracle(hip, oracle):
+    scene = small_scene(camera_model=1, n_cameras=2, imu=True, free_points=True, seed=5)
+    gpu, ref, sg, sr = solve_both(scene, hip, oracle, max_iter=25)
+    assert sg.num_parameter_blocks_reduced == sr.num_parameter_blocks_reduced
+    assert sg.num_effective_parameters_reduced == sr.num_effective_parameters_reduced
+    ig, ir = gpu.problem.iterations(), ref.problem.iterations()
+    assert len(ig) == len(ir)
+    for a, b in zip(ig, ir):
+        assert a.step_is_successful == b.step_is_successful
+        assert abs(a.cost - b.cost) <= 1e-6 * abs(b.cost)
+    assert sg.final_cost < sg.initial_cost * 1e-2
+    assert_estimates_close(gpu, ref, scene)
+    pg = np.stack([gpu.problem.get_param_block(int(b), 3) for b in gpu.point_blocks])
+    pr = np.stack([ref.problem.get_param_block(int(b), 3) for b in ref.point_blocks])
+    assert np.abs(pg - pr).max() <= 1e-6 * np.abs(pr).max()
+    assert np.abs(pg - scene.points).max() > 0      # the free points did move
+
+
 @pytest.mark.parametrize("imu_model", [1, 2, 3])
 @pytest.mark.parametrize("robust", [False, True])
 def test_imu_models_jtj_parity(imu_model, robust, hip, oracle):
