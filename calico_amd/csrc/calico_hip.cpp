@@ -53,7 +53,7 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
 void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const LmState* st, hipStream_t s);
 void launch_control(LmState* st, const LmOptionsDev& o, double* R2, double* x, const double* x_cand, int n_amb,
                     IterLog* log, int log_cap, const double* item_cost, int n_items, const double* Rbase, size_t r_stride,
-                    hipStream_t s);
+                    hipStream_t s, bool commit_by_copy = false);
 void launch_init_state(LmState* st, double radius, double x_norm, hipStream_t s);
 
 }  // namespace cal
@@ -720,13 +720,19 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, c
   }
   p->timer.end(p->stream);
   p->timer.begin(1, p->stream);
+  // the host knows which buffer is filled: multi-rank runs either read the state back every iteration or (batched)
+  // always evaluate the candidate into buffer 1
+  double* target = p->d_R.p + ((spec && p->h_state && !p->h_state->rcur) ? p->r_size : 0);
+  if (p->allreduce && p->world > 1) {
+    // a rank's gather only writes the entries its own residual blocks contribute to; the others must enter the sum
+    // as zeros, not as what the previous reduction left there
+    HIP_TRY(p, hipMemsetAsync(target, 0, p->r_size * sizeof(double), p->stream));
+  }
   launch_expand_cells(ea, p->stream);                     // compact frame records -> one expanded block per cell
   launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->d_out_fat.p,
                 p->d_ptr_fat.p, p->d_idx_fat.p, p->n_fat, st, need_flag, spec ? p->r_size : 0, p->stream);
   p->timer.end(p->stream);
   if (!p->allreduce) return CALICO_OK;  // single rank: no exchange
-  // the host knows which buffer was filled: multi-rank runs read the state back every iteration
-  double* target = p->d_R.p + ((spec && p->h_state && !p->h_state->rcur) ? p->r_size : 0);
   return do_allreduce(p, target, int64_t(p->r_size));
 }
 
@@ -992,17 +998,22 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   if (rc != CALICO_OK) return rc;
   const int n_blocks = int(p->h_blocks.size());
   // One LM iteration = linear solve + candidate cost + control (+ Jacobian evaluation if the
-  // step was accepted). Multi-rank runs need the host between the phases (the all-reduce must
-  // not run when the evaluation was skipped); single-rank runs enqueue `sync_every` complete
-  // iterations, every kernel deciding on the device whether it still has work.
-  const bool async = p->allreduce == nullptr;
-  const int batch = async ? std::max(1, opt->sync_every) : 1;
+  // step was accepted). `sync_every` complete iterations are enqueued per host round trip, every kernel deciding on
+  // the device whether it still has work. With several ranks this needs the speculative evaluation: the candidate is
+  // then always evaluated into reduce buffer 1, so the collective gets a fixed address and runs in every enqueued
+  // iteration on every rank (re-reducing a stale buffer 1 behind a terminated solve is harmless), and an accepted
+  // candidate is committed by a copy (commit_kernel) instead of the pointer swap. Without the speculative evaluation
+  // a multi-rank run needs the host between the phases (the all-reduce must not run when the evaluation was skipped).
   const bool spec = p->speculative;
+  const bool multi = p->allreduce != nullptr;
+  static const bool multi_async_ok = [] { const char* e = std::getenv("CALICO_MULTIRANK_ASYNC"); return !e || std::atoi(e) != 0; }();
+  const bool async = !multi || (spec && multi_async_ok);
+  const int batch = async ? std::max(1, opt->sync_every) : 1;
   while (!p->h_state->terminated) {
     for (int b = 0; b < batch; ++b) {
       // (speculative, single rank) the bookkeeping of the step accepted in the previous iteration of this batch rides
       // in the prepare kernel of this one; the last iteration of a batch gets a stand-alone post_eval below
-      const bool ride = spec && async && b > 0;
+      const bool ride = spec && !multi && b > 0;
       p->timer.begin(2, s);
       launch_solve(sa, o, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, p->dense_in_lds, s, ride, p->d_log.p, kLogCap,
                    opt->jacobi_scaling);
@@ -1016,8 +1027,8 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
         if (rc != CALICO_OK) return rc;
         p->timer.begin(4, s);
         launch_control(p->d_state.p, o, p->d_R2.p, p->d_x.p, p->d_xc.p, p->n_amb, p->d_log.p, kLogCap, nullptr, 0, p->d_R.p,
-                       p->r_size, s);
-        if (!async || b == batch - 1)
+                       p->r_size, s, /*commit_by_copy=*/multi && async);
+        if (multi || b == batch - 1)
           launch_post_eval(sa, p->d_x.p, p->d_blocks.p, n_blocks, o, p->d_log.p, kLogCap, 0, opt->jacobi_scaling, s);
         p->timer.end(s);
         if (!async) {

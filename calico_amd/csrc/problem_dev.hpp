@@ -102,6 +102,7 @@ struct LmState {
   int invalid_eval;       // candidate evaluation hit an invalid projection
   int n_log, n_jac_evals, n_cost_evals;
   int rcur;               // which of the two reduce buffers holds R(x) (speculative evaluation)
+  int commit_pending;     // multi-rank speculative evaluation: the accepted candidate's buffer 1 is to be copied over buffer 0
 };
 
 struct LmOptionsDev {

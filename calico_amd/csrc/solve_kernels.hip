@@ -13,6 +13,9 @@
 //   (S_c H S_c + D²) y = S_c g,  D² = clamp(diag(S_c H S_c)) / radius,  delta = -S_c y.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "problem_dev.hpp"
 
 namespace cal {
@@ -172,6 +175,7 @@ __global__ __launch_bounds__(256) void post_eval_kernel(SolveArgs a, const doubl
                                                         const BlockDev* __restrict__ blocks, int n_blocks,
                                                         LmOptionsDev o, IterLog* log, int log_cap, int first,
                                                         int jacobi_scaling) {
+  if (threadIdx.x == 0 && a.st->commit_pending) a.st->commit_pending = 0;   // see commit_kernel
   post_eval_body(a, x, blocks, n_blocks, o, log, log_cap, first, jacobi_scaling);
 }
 
@@ -1047,6 +1051,9 @@ __global__ __launch_bounds__(256) void reduced_block_step_kernel(SolveArgs a, in
   double* A = a.Spart;
   const size_t msq = size_t(m1) * m1;
   double* L = a.Swork;
+  const bool dbg = a.debug && blockIdx.x == 0 && j <= 1;
+  long long tph[6] = {}, tk = dbg ? __builtin_readcyclecounter() : 0;
+#define BTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   // ---- loads: this wave's 64 rows of panel j, and this lane's 4×4 piece of the tile ----
   const int rb = (wave < 2 ? rI : rK) + kRB * (wave & 1);
   const int myrow = lane < kRB ? c0 + lane : rb + (lane - kRB);
@@ -1073,42 +1080,72 @@ __global__ __launch_bounds__(256) void reduced_block_step_kernel(SolveArgs a, in
       if (nsl > 1) v += A[msq + o];
       pre[i][jj] = v;
     }
+  if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  BTICK(0)
   // ---- column Cholesky of the 64 rows ----
   // Column c: the unscaled column goes to a wave-private LDS vector; the pivot and the multiplier of column c+1 (the
   // latency chain) travel by v_readlane, the other multipliers come back as broadcast ds_read_b128 — one VALU
   // instruction per update instead of three.
   double (*cb)[64] = sCol[wave];
   double pmin = 1.0, psum = 0.0;
+  // pivot path of column 0; inside the loop the one of column c+1 is started before the bulk of column c's updates,
+  // so that the rsqrt chain runs under them
+  double rs, t;
+  {
+    double p = readlane_f64(G[0], 0);
+    p = c0 < m ? p : 1.0;                  // column m is the right-hand side, beyond it padding
+    pmin = fmin(pmin, p); psum += p;       // a NaN pivot poisons psum, a non-positive one shows in pmin
+    rs = rsqrt_nr(p);
+    t = G[0] * (rs * rs);
+  }
 #pragma unroll
   for (int c = 0; c < kRB; ++c) {
     double* buf = cb[c & 1];
     buf[lane] = G[c];
     __builtin_amdgcn_wave_barrier();
-    double p = readlane_f64(G[c], c);
-    const bool live = c0 + c < m;          // column m is the right-hand side, beyond it padding
-    p = live ? p : 1.0;
-    pmin = fmin(pmin, p); psum += p;       // a NaN pivot poisons psum, a non-positive one shows in pmin
-    const double rs = rsqrt_nr(p);
-    const double t = G[c] * (rs * rs);
-    if (c + 1 < kRB) G[c + 1] -= t * readlane_f64(G[c], c + 1);
-#pragma unroll
-    for (int e = 0; e < kRB; e += 2) {       // multipliers of rows e, e+1 (constant bounds: everything unrolls)
-      if (e >= c + 2) {
-        const double2 u = *reinterpret_cast<const double2*>(buf + e);
-        G[e] -= t * u.x;
-        G[e + 1] -= t * u.y;
-      } else if (e + 1 >= c + 2) {
-        G[e + 1] -= t * buf[e + 1];
-      }
+    double rs_n = 1.0, t_n = 0.0;
+    if (c + 1 < kRB) {
+      G[c + 1] -= t * readlane_f64(G[c], c + 1);
+      double p = readlane_f64(G[c + 1], c + 1);
+      p = c0 + c + 1 < m ? p : 1.0;
+      pmin = fmin(pmin, p); psum += p;
+      rs_n = rsqrt_nr(p);
+      t_n = G[c + 1] * (rs_n * rs_n);
     }
-    G[c] *= rs;
-    // pin the updated columns here: without it the compiler sinks every update to the column's first use (a
-    // left-looking schedule that keeps all 496 multipliers alive: 512 VGPRs and spills)
+    // Multipliers of rows e, e+1 (constant bounds: everything unrolls). The four waves of the workgroup share one
+    // LDS pipe, whose return path takes 4 clocks per broadcast double and wave; a v_readlane pair takes 8 clocks of
+    // the wave's own SIMD. Alternating between the two balances the pipes.
+    // The pins (empty asm over the updated columns and the pivot column) come after every group of 8 rows: without
+    // them the compiler sinks every update to the column's first use (a left-looking schedule that keeps all 496
+    // multipliers alive: 512 VGPRs and spills) or hoists all readlanes (SGPR spills through v_writelane).
+    double gc = G[c];
+    double2 U[kRB / 4];                     // all LDS reads of the column are issued before the first pin
 #pragma unroll
-    for (int e = 0; e < kRB; e += 8)
-      if (e + 7 >= c + 2)
-        asm volatile("" : "+v"(G[e]), "+v"(G[e + 1]), "+v"(G[e + 2]), "+v"(G[e + 3]), "+v"(G[e + 4]), "+v"(G[e + 5]), "+v"(G[e + 6]), "+v"(G[e + 7]));
+    for (int e = 0; e < kRB; e += 4)
+      if (e >= c + 2) U[e / 4] = *reinterpret_cast<const double2*>(buf + e);
+#pragma unroll
+    for (int e8 = 0; e8 < kRB; e8 += 8) {
+      if (e8 + 7 < c + 2) continue;
+#pragma unroll
+      for (int e = e8; e < e8 + 8; e += 2) {
+        if (e >= c + 2) {
+          if ((e >> 1) & 1) {
+            G[e] -= t * readlane_f64(gc, e);
+            G[e + 1] -= t * readlane_f64(gc, e + 1);
+          } else {
+            G[e] -= t * U[e / 4].x;
+            G[e + 1] -= t * U[e / 4].y;
+          }
+        } else if (e + 1 >= c + 2) {
+          G[e + 1] -= t * readlane_f64(gc, e + 1);
+        }
+      }
+      asm volatile("" : "+v"(gc), "+v"(G[e8]), "+v"(G[e8 + 1]), "+v"(G[e8 + 2]), "+v"(G[e8 + 3]), "+v"(G[e8 + 4]), "+v"(G[e8 + 5]), "+v"(G[e8 + 6]), "+v"(G[e8 + 7]));
+    }
+    G[c] = gc * rs;
+    rs = rs_n; t = t_n;
   }
+  BTICK(1)
   // ---- file the panel, exchange the row blocks ----
   if (lane >= kRB) {
 #pragma unroll
@@ -1123,6 +1160,7 @@ __global__ __launch_bounds__(256) void reduced_block_step_kernel(SolveArgs a, in
   }
   if (blockIdx.x == 0 && tid == 0 && (!(pmin > 0.0) || !isfinite(psum))) st->chol_failed = 1;
   __syncthreads();
+  BTICK(2)
   // ---- tile update ----
   double acc[4][4] = {};
   const double (*PI)[kRB + 1] = sP[qa];
@@ -1145,6 +1183,9 @@ __global__ __launch_bounds__(256) void reduced_block_step_kernel(SolveArgs a, in
       double* dst = (ur < m1 && uc <= ur) ? A + size_t(ur) * m1 + uc : L + msq + lane;
       *dst = pre[i][jj] - acc[i][jj];
     }
+  BTICK(3)
+  if (dbg && lane == 0) printf("reduced_block_step %d cycles (wave %d): loads %lld  factor %lld  file+barrier %lld  update+store %lld\n", j, wave, tph[0], tph[1], tph[2], tph[3]);
+#undef BTICK
 }
 
 // Backward substitution Lᵀ y_c = L(m, :) for the blocked factor, one workgroup, panel by panel from the end:
@@ -1423,7 +1464,7 @@ __global__ __launch_bounds__(256) void cost_reduce_kernel(const double* __restri
 __global__ __launch_bounds__(256) void lm_control_kernel(LmState* st, LmOptionsDev o, double* R2, double* x,
                                                          const double* x_cand, int n_amb, IterLog* log, int log_cap,
                                                          const double* __restrict__ item_cost, int n_items,
-                                                         const double* Rbase, size_t r_stride) {
+                                                         const double* Rbase, size_t r_stride, int no_swap) {
   if (st->terminated) return;
   __shared__ int s_accept;
   const int tid = threadIdx.x;
@@ -1478,7 +1519,9 @@ __global__ __launch_bounds__(256) void lm_control_kernel(LmState* st, LmOptionsD
             s_accept = 1;
             st->step_successful = 1;
             st->need_jacobian = 1;
-            if (r_stride) st->rcur ^= 1;      // the buffer evaluated at the candidate becomes R(x)
+            // the buffer evaluated at the candidate becomes R(x): by a pointer swap, or (several ranks: the host hands
+            // the collective a fixed address, so the candidate is always evaluated into buffer 1) by commit_kernel
+            if (r_stride) { if (no_swap) st->commit_pending = 1; else st->rcur ^= 1; }
             st->x_norm = cand_norm;
             const double t = 2.0 * st->relative_decrease - 1.0;
             st->radius = st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
@@ -1498,6 +1541,14 @@ __global__ __launch_bounds__(256) void lm_control_kernel(LmState* st, LmOptionsD
   if (s_accept) {
     for (int i = tid; i < n_amb; i += 256) x[i] = x_cand[i];
   }
+}
+
+// Several ranks, speculative evaluation: copy the accepted candidate's reduce buffer (1) over R(x) (0). The flag is
+// taken down by the post_eval kernel that follows, so that the copy happens once per accepted step even when the
+// iterations enqueued behind a terminated solve keep re-reducing buffer 1.
+__global__ __launch_bounds__(256) void commit_kernel(const LmState* st, double* R, size_t n) {
+  if (!st->commit_pending) return;
+  for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256) R[i] = R[n + i];
 }
 
 __global__ void init_state_kernel(LmState* st, double radius, double x_norm) {
@@ -1618,9 +1669,12 @@ void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const 
 }
 void launch_control(LmState* st, const LmOptionsDev& o, double* R2, double* x, const double* x_cand, int n_amb,
                     IterLog* log, int log_cap, const double* item_cost, int n_items, const double* Rbase, size_t r_stride,
-                    hipStream_t s) {
+                    hipStream_t s, bool commit_by_copy) {
   hipLaunchKernelGGL(lm_control_kernel, dim3(1), dim3(256), 0, s, st, o, R2, x, x_cand, n_amb, log, log_cap, item_cost, n_items,
-                     Rbase, r_stride);
+                     Rbase, r_stride, commit_by_copy ? 1 : 0);
+  if (commit_by_copy && r_stride)
+    hipLaunchKernelGGL(commit_kernel, dim3(unsigned(std::min<size_t>(512, (r_stride + 255) / 256))), dim3(256), 0, s, st,
+                       const_cast<double*>(Rbase), r_stride);
 }
 void launch_init_state(LmState* st, double radius, double x_norm, hipStream_t s) {
   hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, s, st, radius, x_norm);

@@ -1,0 +1,129 @@
+"""The N > 1 path of libcalico_hip.so on one GPU box.
+
+1. world = 1 with the all-reduce callback installed: the multi-rank control flow (fixed-address collective target,
+   commit by copy, iterations enqueued in batches) must walk exactly the iterations of the plain single-rank solve.
+2. Two processes sharing the one GPU, each evaluating its own time window of residual blocks (shard.hpp), exchanging
+   [cost | Jtr | JtJ] through the callback (device buffer -> host -> gloo all-reduce -> device buffer): both ranks must
+   reach the estimates of the single-rank solve (1e-9 relative: the sum is associated differently), in the batched
+   mode and in the one-iteration-per-round-trip mode (CALICO_MULTIRANK_ASYNC=0).
+On the 8-GPU node the same callback slot carries torch.distributed's RCCL all-reduce (bench.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _DevArray:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def _scene():
+    from calico_amd import synthetic as syn
+    return syn.make_scene(2, 1, True, 2, cam_rate=10.0, imu_rate=50.0, duration=3.0, segment_duration=3.0 / 23.9,
+                          pixel_noise=0.1, gyro_noise=1e-3, accel_noise=1e-2, robust=True, seed=3)
+
+
+def _solve(P, api, sync_every):
+    o = api.default_options()
+    o.minimizer_progress_to_stdout = 0
+    o.max_num_iterations = 25
+    o.sync_every = sync_every
+    s = P.solve(o)
+    return s, [(i.iteration, i.step_is_successful, i.cost) for i in P.iterations()]
+
+
+def test_collective_control_flow_equals_plain_solve(hip):
+    from calico_amd import synthetic as syn
+    scene = _scene()
+    plain = syn.build_problem(hip, scene)
+    s0, it0 = _solve(plain.problem, hip, 8)
+    calls = []
+
+    def allreduce(ctx, buf, n, strm):   # one rank: the sum over ranks is the buffer itself
+        calls.append(n)
+        return 0
+    coll = syn.build_problem(hip, scene)
+    coll.problem.set_shard(0, 1)
+    coll.problem.set_allreduce(allreduce)
+    s1, it1 = _solve(coll.problem, hip, 8)
+    assert len(calls) >= s1.num_iterations
+    assert s1.termination_type == s0.termination_type and s1.num_iterations == s0.num_iterations
+    assert [(a, b) for a, b, _ in it0] == [(a, b) for a, b, _ in it1]
+    for (_, _, c0), (_, _, c1) in zip(it0, it1):
+        assert c0 == c1          # same kernels on the same data: bit-identical costs
+    e0, c0 = syn.read_back(plain, scene)
+    e1, c1 = syn.read_back(coll, scene)
+    assert np.array_equal(c0, c1)
+    for a, b in zip(e0, e1):
+        assert np.array_equal(a["intrinsics"], b["intrinsics"])
+
+
+def _worker(rank, world, port, q, batched):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["CALICO_MULTIRANK_ASYNC"] = "1" if batched else "0"
+    import torch
+    import torch.distributed as dist
+    import helpers
+    from calico_amd import synthetic as syn
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")   # torch's HIP runtime first, as in bench.py; the library then shares it
+    api = helpers.hip_api()
+    scene = _scene()
+    built = syn.build_problem(api, scene)
+    P = built.problem
+    P.set_stream(torch.cuda.current_stream().cuda_stream)
+    P.set_shard(rank, world)
+
+    def allreduce(ctx, buf, n, strm):
+        t = torch.as_tensor(_DevArray(buf, n), device="cuda")
+        h = t.cpu()              # waits for the kernels enqueued so far on the problem's stream
+        dist.all_reduce(h)
+        t.copy_(h)
+        return 0
+    P.set_allreduce(allreduce)
+    s, its = _solve(P, api, 4)
+    est, ctrl = syn.read_back(built, scene)
+    q.put((rank, s.final_cost, s.num_iterations, s.termination_type, [e["intrinsics"] for e in est], ctrl, its))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batched", [True, False])
+def test_two_ranks_on_one_gpu_equal_single_rank(batched, hip):
+    import multiprocessing as mp
+    from calico_amd import synthetic as syn
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 2000) + (1 if batched else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, batched)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    scene = _scene()
+    single = syn.build_problem(hip, scene)
+    s, its = _solve(single.problem, hip, 4)
+    est, ctrl = syn.read_back(single, scene)
+    for rank, final_cost, n_it, term, intr, c, rits in results:
+        assert term == s.termination_type and n_it == s.num_iterations
+        assert abs(final_cost - s.final_cost) <= 1e-9 * s.final_cost
+        assert [(a, b) for a, b, _ in rits] == [(a, b) for a, b, _ in its]
+        for (_, _, c0), (_, _, c1) in zip(its, rits):
+            assert abs(c0 - c1) <= 1e-9 * abs(c0)
+        assert np.abs(c - ctrl).max() <= 1e-9 * np.abs(ctrl).max()
+        for a, b in zip(intr, est):
+            assert np.abs(a - b["intrinsics"]).max() <= 1e-9 * np.abs(b["intrinsics"]).max()
+    # both ranks hold the same estimates bit for bit (deterministic all-reduce, replicated solve)
+    assert np.array_equal(results[0][5], results[1][5])
