@@ -1113,7 +1113,9 @@ int32_t calico_get_iterations(calico_problem* p, calico_iteration* out, int32_t 
 
 static int32_t residuals_or_prediction(calico_problem* p, int32_t sid, double* out, uint8_t* valid, bool predict) {
   if (!p) return CALICO_INVALID_ARGUMENT;
-  if (sid < 0 || sid >= int(p->sensors.size()) || !out) return p->set_error(CALICO_INVALID_ARGUMENT, "bad sensor id");
+  if (sid < 0 || sid >= int(p->sensors.size())) return p->set_error(CALICO_INVALID_ARGUMENT, "bad sensor id");
+  if (p->sensors[size_t(sid)].n() == 0) return CALICO_OK;   // a sensor without measurements has nothing to report
+  if (!out) return p->set_error(CALICO_INVALID_ARGUMENT, "null output buffer");
   int rc = finalize(p);
   if (rc != CALICO_OK) return rc;
   HIP_TRY(p, hipSetDevice(p->device));
