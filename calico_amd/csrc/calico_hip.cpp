@@ -53,7 +53,7 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
 void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const LmState* st, hipStream_t s);
 void launch_control(LmState* st, const LmOptionsDev& o, double* R2, double* x, const double* x_cand, int n_amb,
                     IterLog* log, int log_cap, const double* item_cost, int n_items, const double* Rbase, size_t r_stride,
-                    hipStream_t s, bool commit_by_copy = false);
+                    hipStream_t s, bool commit_by_copy = false, int* progress = nullptr, int seq = 0);
 void launch_init_state(LmState* st, double radius, double x_norm, hipStream_t s);
 
 }  // namespace cal
@@ -206,6 +206,11 @@ struct calico_problem {
   DevBuf<LmState> d_state;
   DevBuf<IterLog> d_log;
   LmState* h_state = nullptr;  // pinned
+  int* h_progress = nullptr;   // pinned, device-visible: [iterations the control kernel is through with, terminated]
+  int* d_progress = nullptr;
+  double* h_xpin = nullptr;    // pinned staging for the parameter vector (upload at the start of a call, download at its end)
+  size_t h_xpin_n = 0;
+  IterLog* h_log = nullptr;    // pinned
   std::vector<calico_iteration> iterations;
   PhaseTimer timer;
 
@@ -243,6 +248,7 @@ SolveArgs make_solve_args(calico_problem* p) {
   a.scale = p->d_scale.p; a.cp_active = p->d_cp_active.p; a.st = p->d_state.p; a.n_cp = p->n_cp; a.k = p->order; a.mc = p->m; a.sep_s = p->sep_s; a.sep_n = p->sep_n; a.m = p->m + 6 * p->sep_n;
   static const int dbg = std::getenv("CALICO_KERNEL_TIMING") ? std::atoi(std::getenv("CALICO_KERNEL_TIMING")) : 0;
   a.debug = dbg;
+  a.progress = nullptr;
   return a;
 }
 
@@ -559,7 +565,7 @@ int finalize(calico_problem* p) {
   if (size_t(p->lds_cols) * p->row_pad * sizeof(double) > kMaxLds)
     return p->set_error(CALICO_UNIMPLEMENTED, "too many Jacobian columns per residual block for the LDS staging area");
   // ---- gather lists ----
-  SolveArgs sa; sa.n_cp = n_cp; sa.k = k; sa.mc = m; sa.sep_s = p->sep_s; sa.sep_n = p->sep_n; sa.m = m + 6 * p->sep_n; sa.debug = 0;
+  SolveArgs sa; sa.n_cp = n_cp; sa.k = k; sa.mc = m; sa.sep_s = p->sep_s; sa.sep_n = p->sep_n; sa.m = m + 6 * p->sep_n; sa.debug = 0; sa.progress = nullptr;
   const size_t r_size = sa.r_size();
   if (r_size >= size_t(0x7fffffff)) return p->set_error(CALICO_UNIMPLEMENTED, "normal-equation buffer too large");
   struct Pair { int dst, src; };
@@ -656,6 +662,17 @@ int finalize(calico_problem* p) {
   p->active_dirty = true; p->xc_stale = true;
   HIP_TRY(p, p->d_state.alloc(1)); HIP_TRY(p, p->d_log.alloc(kLogCap));
   if (!p->h_state) HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LmState)));
+  if (!p->h_log) HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_log), size_t(kLogCap) * sizeof(IterLog)));
+  if (p->h_xpin_n < size_t(p->n_amb)) {
+    if (p->h_xpin) (void)hipHostFree(p->h_xpin);
+    p->h_xpin = nullptr; p->h_xpin_n = 0;
+    HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_xpin), std::max<size_t>(1, size_t(p->n_amb)) * sizeof(double)));
+    p->h_xpin_n = size_t(p->n_amb);
+  }
+  if (!p->h_progress) {
+    HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_progress), 64, hipHostMallocMapped));
+    HIP_TRY(p, hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_progress), p->h_progress, 0));
+  }
   // kernel attributes
   HIP_TRY(p, configure_eval_kernels(size_t(p->lds_cols) * p->row_pad * sizeof(double)));
   sa = make_solve_args(p);
@@ -684,12 +701,15 @@ int upload_x(calico_problem* p) {
     p->active_dirty = false;
   }
   for (const HBlock& b : p->blocks) std::copy(b.v.begin(), b.v.end(), p->h_x.begin() + b.amb_off);
-  HIP_TRY(p, hipMemcpyAsync(p->d_x.p, p->h_x.data(), p->h_x.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  // through the pinned staging buffer: a true asynchronous DMA (every API call ends with a stream synchronisation, so
+  // the buffer is never rewritten while a transfer is pending)
+  std::copy(p->h_x.begin(), p->h_x.end(), p->h_xpin);
+  HIP_TRY(p, hipMemcpyAsync(p->d_x.p, p->h_xpin, p->h_x.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
   // d_xc needs no upload: every parameter block, constant ones included, is rewritten by the update kernel... except
   // the constant blocks, which the update never touches -- so it is seeded once per finalisation (below) and whenever
   // a constant block may have changed
   if (p->xc_stale) {
-    HIP_TRY(p, hipMemcpyAsync(p->d_xc.p, p->h_x.data(), p->h_x.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(p, hipMemcpyAsync(p->d_xc.p, p->h_xpin, p->h_x.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
     p->xc_stale = false;
   }
   return CALICO_OK;
@@ -798,6 +818,9 @@ void calico_problem_destroy(calico_problem* p) {
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   if (p->h_state) (void)hipHostFree(p->h_state);
+  if (p->h_progress) (void)hipHostFree(p->h_progress);
+  if (p->h_xpin) (void)hipHostFree(p->h_xpin);
+  if (p->h_log) (void)hipHostFree(p->h_log);
   if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
 }
@@ -988,15 +1011,57 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
     }
   }
   SolveArgs sa = make_solve_args(p);
+  const int n_blocks = int(p->h_blocks.size());
+  // Single rank, speculative evaluation: the host never blocks inside the solve. The control kernel publishes the
+  // number of the iteration it has finished with (and post_eval / control the termination flag) in host-mapped
+  // memory; the host keeps `depth` iterations enqueued ahead of that and stops when the flag goes up. Compared with
+  // batches of `sync_every` iterations and a blocking read-back per batch this takes the read-back gaps out of the
+  // stream and leaves at most `depth` iterations of early-exit kernels behind a terminated solve.
+  static const int stream_depth = [] { const char* e = std::getenv("CALICO_STREAM_DEPTH"); return e ? std::atoi(e) : 2; }();
+  const bool streaming = p->speculative && p->allreduce == nullptr && stream_depth > 0 && p->h_progress != nullptr;
+  if (streaming) {
+    __atomic_store_n(p->h_progress, 0, __ATOMIC_RELEASE);
+    __atomic_store_n(p->h_progress + 1, 0, __ATOMIC_RELEASE);
+    sa.progress = p->d_progress;
+  }
   // iteration 0
   rc = enqueue_jacobian_eval(p, nullptr, 0);
   if (rc != CALICO_OK) return rc;
   p->timer.begin(4, s);
   launch_post_eval(sa, p->d_x.p, p->d_blocks.p, int(p->h_blocks.size()), o, p->d_log.p, kLogCap, 1, opt->jacobi_scaling, s);
   p->timer.end(s);
-  rc = read_state(p);
-  if (rc != CALICO_OK) return rc;
-  const int n_blocks = int(p->h_blocks.size());
+  if (streaming) {
+    int enq = 0;
+    const auto t_spin0 = std::chrono::steady_clock::now();
+    int64_t spins = 0;
+    for (;;) {
+      bool done = false;
+      for (;;) {
+        if (__atomic_load_n(p->h_progress + 1, __ATOMIC_ACQUIRE)) { done = true; break; }
+        if (enq - __atomic_load_n(p->h_progress, __ATOMIC_ACQUIRE) < stream_depth) break;
+        if ((++spins & 0xfffff) == 0) {   // a device fault must not leave the host spinning
+          const hipError_t qe = hipStreamQuery(s);
+          if (qe != hipSuccess && qe != hipErrorNotReady) return p->set_error(CALICO_INTERNAL, hipGetErrorString(qe));
+          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_spin0).count() > 600.0)
+            return p->set_error(CALICO_INTERNAL, "solve loop: no progress from the device");
+        }
+      }
+      if (done) break;
+      p->timer.begin(2, s);
+      launch_solve(sa, o, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, p->dense_in_lds, s, /*with_post_eval=*/enq > 0, p->d_log.p,
+                   kLogCap, opt->jacobi_scaling);
+      p->timer.end(s);
+      rc = enqueue_jacobian_eval(p, p->d_state.p, 0, p->d_xc.p, true);
+      if (rc != CALICO_OK) return rc;
+      p->timer.begin(4, s);
+      launch_control(p->d_state.p, o, p->d_R2.p, p->d_x.p, p->d_xc.p, p->n_amb, p->d_log.p, kLogCap, nullptr, 0, p->d_R.p, p->r_size,
+                     s, false, p->d_progress, ++enq);
+      p->timer.end(s);
+    }
+  } else {
+    rc = read_state(p);
+    if (rc != CALICO_OK) return rc;
+  }
   // One LM iteration = linear solve + candidate cost + control (+ Jacobian evaluation if the
   // step was accepted). `sync_every` complete iterations are enqueued per host round trip, every kernel deciding on
   // the device whether it still has work. With several ranks this needs the speculative evaluation: the candidate is
@@ -1009,7 +1074,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   static const bool multi_async_ok = [] { const char* e = std::getenv("CALICO_MULTIRANK_ASYNC"); return !e || std::atoi(e) != 0; }();
   const bool async = !multi || (spec && multi_async_ok);
   const int batch = async ? std::max(1, opt->sync_every) : 1;
-  while (!p->h_state->terminated) {
+  while (!streaming && !p->h_state->terminated) {
     for (int b = 0; b < batch; ++b) {
       // (speculative, single rank) the bookkeeping of the step accepted in the previous iteration of this batch rides
       // in the prepare kernel of this one; the last iteration of a batch gets a stand-alone post_eval below
@@ -1067,19 +1132,23 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
     rc = read_state(p);
     if (rc != CALICO_OK) return rc;
   }
+  // results: final state, iteration log and parameters come back in one go (pinned buffers, one synchronisation)
+  const int log_rows = std::min(kLogCap, std::max(0, opt->max_num_iterations) + 2);
+  HIP_TRY(p, hipMemcpyAsync(p->h_state, p->d_state.p, sizeof(LmState), hipMemcpyDeviceToHost, s));
+  HIP_TRY(p, hipMemcpyAsync(p->h_log, p->d_log.p, size_t(log_rows) * sizeof(IterLog), hipMemcpyDeviceToHost, s));
+  HIP_TRY(p, hipMemcpyAsync(p->h_xpin, p->d_x.p, p->h_x.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(p, hipStreamSynchronize(s));
+  p->timer.resolve();
   if (spec && p->h_state->rcur) {   // leave R(x) in buffer 0 for whoever reads it next
     HIP_TRY(p, hipMemcpyAsync(p->d_R.p, p->d_R.p + p->r_size, p->r_size * sizeof(double), hipMemcpyDeviceToDevice, s));
   }
   sm->num_jacobian_evaluations = p->h_state->n_jac_evals;
   sm->num_cost_evaluations = p->h_state->n_cost_evals;
   const double t_solve = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
-  // results
   const LmState st = *p->h_state;
-  std::vector<IterLog> log(size_t(std::max(0, std::min(st.n_log, kLogCap))));
-  if (!log.empty()) HIP_TRY(p, hipMemcpyAsync(log.data(), p->d_log.p, log.size() * sizeof(IterLog), hipMemcpyDeviceToHost, s));
-  HIP_TRY(p, hipMemcpyAsync(p->h_x.data(), p->d_x.p, p->h_x.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(p, hipStreamSynchronize(s));
+  std::copy(p->h_xpin, p->h_xpin + p->h_x.size(), p->h_x.begin());
   for (HBlock& b : p->blocks) std::copy(p->h_x.begin() + b.amb_off, p->h_x.begin() + b.amb_off + b.size, b.v.begin());
+  const std::vector<IterLog> log(p->h_log, p->h_log + std::max(0, std::min(st.n_log, log_rows)));
   for (const IterLog& r : log) {
     calico_iteration it;
     it.iteration = r.iteration; it.step_is_valid = r.step_is_valid; it.step_is_successful = r.step_is_successful; it.reserved = 0;

@@ -151,6 +151,9 @@ struct SolveArgs {
   // segments [0, sep_s) and [sep_s + sep_n, n_cp) whose sequential sweeps run side by side.
   int sep_s, sep_n;
   int debug;              // CALICO_KERNEL_TIMING=1: kernels print per-phase cycle counts (development aid)
+  // host-mapped progress words, or nullptr: [0] = sequence number of the last LM iteration the control kernel has
+  // finished with, [1] = LmState.terminated. The host polls them instead of synchronising (single-rank solve loop).
+  int* progress;
   CAL_HD int n_s() const { return 6 * n_cp; }
   CAL_HD int W() const { return 6 * k; }
   CAL_HD int NT() const { return 6 * n_cp + mc; }

@@ -99,6 +99,8 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
 // LM bookkeeping shared by the kernels below ([Ceres] trust_region_minimizer.cc
 // FinalizeIterationAndCheckIfMinimizerCanContinue).
 // ---------------------------------------------------------------------------
+DEVI void publish(int* word, int value) { __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 DEVI void log_and_finalize(LmState* st, const LmOptionsDev& o, IterLog* log, int log_cap) {
   if (st->iteration > 0) { if (st->step_successful) st->num_successful++; else st->num_unsuccessful++; }
   if (st->n_log < log_cap) {
@@ -168,6 +170,7 @@ DEVI void post_eval_body(SolveArgs a, const double* __restrict__ x, const BlockD
       if (first) { st->initial_cost = st->x_cost; st->min_cost = st->x_cost; }
       log_and_finalize(st, o, log, log_cap);
     }
+    if (a.progress && st->terminated) publish(a.progress + 1, 1);   // the host stops enqueueing iterations
   }
 }
 
@@ -1464,10 +1467,14 @@ __global__ __launch_bounds__(256) void cost_reduce_kernel(const double* __restri
 __global__ __launch_bounds__(256) void lm_control_kernel(LmState* st, LmOptionsDev o, double* R2, double* x,
                                                          const double* x_cand, int n_amb, IterLog* log, int log_cap,
                                                          const double* __restrict__ item_cost, int n_items,
-                                                         const double* Rbase, size_t r_stride, int no_swap) {
-  if (st->terminated) return;
-  __shared__ int s_accept;
+                                                         const double* Rbase, size_t r_stride, int no_swap, int* progress,
+                                                         int seq) {
   const int tid = threadIdx.x;
+  if (st->terminated) {
+    if (progress && tid == 0) { publish(progress + 1, 1); publish(progress, seq); }
+    return;
+  }
+  __shared__ int s_accept;
   // speculative evaluation (r_stride != 0): the candidate's [cost, invalid] are the first two entries of the reduce
   // buffer the Jacobian pass at the candidate point has just filled
   if (r_stride) R2 = const_cast<double*>(Rbase + (st->rcur ? 0 : r_stride));
@@ -1541,6 +1548,7 @@ __global__ __launch_bounds__(256) void lm_control_kernel(LmState* st, LmOptionsD
   if (s_accept) {
     for (int i = tid; i < n_amb; i += 256) x[i] = x_cand[i];
   }
+  if (progress && tid == 0) { if (st->terminated) publish(progress + 1, 1); publish(progress, seq); }
 }
 
 // Several ranks, speculative evaluation: copy the accepted candidate's reduce buffer (1) over R(x) (0). The flag is
@@ -1669,9 +1677,9 @@ void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const 
 }
 void launch_control(LmState* st, const LmOptionsDev& o, double* R2, double* x, const double* x_cand, int n_amb,
                     IterLog* log, int log_cap, const double* item_cost, int n_items, const double* Rbase, size_t r_stride,
-                    hipStream_t s, bool commit_by_copy) {
+                    hipStream_t s, bool commit_by_copy, int* progress, int seq) {
   hipLaunchKernelGGL(lm_control_kernel, dim3(1), dim3(256), 0, s, st, o, R2, x, x_cand, n_amb, log, log_cap, item_cost, n_items,
-                     Rbase, r_stride, commit_by_copy ? 1 : 0);
+                     Rbase, r_stride, commit_by_copy ? 1 : 0, progress, seq);
   if (commit_by_copy && r_stride)
     hipLaunchKernelGGL(commit_kernel, dim3(unsigned(std::min<size_t>(512, (r_stride + 255) / 256))), dim3(256), 0, s, st,
                        const_cast<double*>(Rbase), r_stride);
