@@ -962,8 +962,8 @@ __global__ __launch_bounds__(256) void reduced_solve_panel_kernel(SolveArgs a) {
   // the right-hand-side row m). Iteration p:
   //   phase 1, all waves : block column p+1 receives the contribution of panel p (it already holds those of 0..p-1)
   //   phase 2, wave 0    : panel p+1
-  //            waves 1..3: wave 1 inverts the diagonal block of panel p; then block column p+2 receives the
-  //                        contributions of panels 0..p in one pass (each tile read and written once)
+  //            waves 1..3: block column p+2 receives the contributions of panels 0..p in one pass (each tile read and
+  //                        written once)
   const int nrt = (m1 + 15) >> 4;
   if (wave == 0) do_panel(0);
   __syncthreads();
@@ -982,39 +982,41 @@ __global__ __launch_bounds__(256) void reduced_solve_panel_kernel(SolveArgs a) {
   }
   // backward substitution Lᵀ y = z (row m) by blocks of 16; thread t < 128 owns unknown t (waves 0 and 1 work, the
   // other two only keep the barriers company). Per block: the wave that owns its 16 unknowns solves the diagonal
-  // block by an in-wave axpy chain (pivot by v_readlane, 16 short steps) and publishes y_blk; one barrier; then every
-  // working thread adds L(blk, j) · y_blk to the pending sum of its own unknown j < j0 -- a matrix-vector product,
-  // not a chain.
+  // block by an in-wave axpy chain on u = (z - pending sum) / L_jj, the value each lane would get if nothing more
+  // were to come: step i broadcasts y_i = u(lane of i) by v_readlane and every lane still waiting takes
+  // u -= (L(i, j) / L_jj) y_i -- one readlane pair and one FMA on the chain, the scaled multipliers being prepared
+  // before it starts. One barrier; then every working thread adds L(blk, j)ᵀ y_blk to the pending sum of its own
+  // unknown j < j0 -- a matrix-vector product, not a chain, with the entries of L fetched before the barrier.
   {
     const int j = tid;                         // unknown owned by this thread (m <= 127)
     const int jc = min(j, m - 1);
     double acc = 0.0, yk = 0.0;
-    const double zq = A[size_t(m) * LD + jc];
+    const double zq = j < m ? A[size_t(m) * LD + jc] : 0.0;
     const double dj = dinv[jc];
     for (int b = nblk - 1; b >= 0; --b) {
       const int j0 = 16 * b;
       double* ybuf = bcast + (b & 1) * 16;
+      double lcol[16];                         // L(j0 + i, j), i = 0..15
+#pragma unroll
+      for (int i = 0; i < 16; ++i) lcol[i] = A[min(j0 + i, m - 1) * LD + jc];
       if (wave == (j0 >> 6)) {
         const int l0 = j0 & 63;                // lanes l0..l0+15 own the block
         const int i_own = lane - l0;           // row/column of this lane inside the block (valid when 0 <= i_own < 16)
-        double pend = acc;                     // pending sum of this lane's unknown, grows inside the block
+        double ld[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ld[i] = (i_own >= 0 && i_own < i && j0 + i < m) ? -lcol[i] * dj : 0.0;
+        double u = (zq - acc) * dj;            // 0 for the rows past m-1
+#pragma unroll
         for (int i = 15; i >= 0; --i) {
-          const double cand = (zq - pend) * dj;
-          double yi = readlane_f64(cand, l0 + i);
-          yi = j0 + i < m ? yi : 0.0;
-          yk = i_own == i ? yi : yk;
-          const double lij = A[min(j0 + i, m - 1) * LD + jc];          // L(j0 + i, j)
-          pend += (i_own >= 0 && i_own < i) ? lij * yi : 0.0;
+          const double yi = readlane_f64(u, l0 + i);
+          u += ld[i] * yi;
         }
-        if (i_own >= 0 && i_own < 16) ybuf[i_own] = yk;
+        if (i_own >= 0 && i_own < 16) { yk = u; ybuf[i_own] = u; }
       }
       __syncthreads();
       if (wave < 2 && j < j0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const double yi = j0 + i < m ? ybuf[i] : 0.0;
-          acc += A[min(j0 + i, m - 1) * LD + jc] * yi;
-        }
+        for (int i = 0; i < 16; ++i) acc += lcol[i] * ybuf[i];   // y of the rows past m-1 is 0
       }
     }
     if (j < m) a.y[n + j] = yk;
