@@ -41,7 +41,7 @@ hipError_t configure_eval_kernels(size_t max_lds_bytes);
 
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
                    int n_thin, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
-                   const LmState* st, int need_flag, size_t other_stride, hipStream_t s);
+                   const LmState* st, int need_flag, size_t other_stride, hipStream_t s, const ControlTail* tail = nullptr);
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s);
 size_t band_cholesky_lds_bytes(const SolveArgs& a);
@@ -194,6 +194,8 @@ struct calico_problem {
   DevBuf<int64_t> d_ptr_thin, d_ptr_fat;
   DevBuf<uint8_t> d_cp_active, d_valid, d_active;
   DevBuf<int> d_counter;
+  DevBuf<int> d_sync;
+  int gather_owner_block = 0;
   bool active_dirty = true;
   bool xc_stale = true;       // the candidate buffer must be re-seeded with the constant blocks' values
   DevBuf<SensorDev> d_sensors;
@@ -249,6 +251,7 @@ SolveArgs make_solve_args(calico_problem* p) {
   static const int dbg = std::getenv("CALICO_KERNEL_TIMING") ? std::atoi(std::getenv("CALICO_KERNEL_TIMING")) : 0;
   a.debug = dbg;
   a.progress = nullptr;
+  a.sync_counters = p->d_sync.p;
   return a;
 }
 
@@ -565,7 +568,7 @@ int finalize(calico_problem* p) {
   if (size_t(p->lds_cols) * p->row_pad * sizeof(double) > kMaxLds)
     return p->set_error(CALICO_UNIMPLEMENTED, "too many Jacobian columns per residual block for the LDS staging area");
   // ---- gather lists ----
-  SolveArgs sa; sa.n_cp = n_cp; sa.k = k; sa.mc = m; sa.sep_s = p->sep_s; sa.sep_n = p->sep_n; sa.m = m + 6 * p->sep_n; sa.debug = 0; sa.progress = nullptr;
+  SolveArgs sa; sa.n_cp = n_cp; sa.k = k; sa.mc = m; sa.sep_s = p->sep_s; sa.sep_n = p->sep_n; sa.m = m + 6 * p->sep_n; sa.debug = 0; sa.progress = nullptr; sa.sync_counters = nullptr;
   const size_t r_size = sa.r_size();
   if (r_size >= size_t(0x7fffffff)) return p->set_error(CALICO_UNIMPLEMENTED, "normal-equation buffer too large");
   struct Pair { int dst, src; };
@@ -622,6 +625,8 @@ int finalize(calico_problem* p) {
     q = e;
   }
   p->n_thin = int(out_thin.size()); p->n_fat = int(out_fat.size());
+  // outputs 0 and 1 (cost, invalid count) head whichever list they are in: fat role = first workgroups of the gather
+  p->gather_owner_block = (!out_fat.empty() && out_fat[0] == 0) ? 0 : int((out_fat.size() + 3) / 4);
   // ---- upload ----
   hipStream_t s = p->stream;
   p->h_x.assign(size_t(p->n_amb), 0.0);
@@ -659,6 +664,7 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_y.alloc(size_t(NT) + 6 * p->sep_n)); HIP_TRY(p, p->d_zbuf.alloc(size_t(NS) + 64)); HIP_TRY(p, p->d_dadd.alloc(NT)); HIP_TRY(p, p->d_scale.alloc(NT));
   HIP_TRY(p, p->d_res.alloc(size_t(n_obs) * 3)); HIP_TRY(p, p->d_valid.alloc(size_t(n_obs)));
   HIP_TRY(p, p->d_active.alloc(size_t(n_obs))); HIP_TRY(p, p->d_counter.alloc(1));
+  HIP_TRY(p, p->d_sync.alloc(4)); HIP_TRY(p, hipMemsetAsync(p->d_sync.p, 0, 4 * sizeof(int), s));
   p->active_dirty = true; p->xc_stale = true;
   HIP_TRY(p, p->d_state.alloc(1)); HIP_TRY(p, p->d_log.alloc(kLogCap));
   if (!p->h_state) HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LmState)));
@@ -727,7 +733,8 @@ int do_allreduce(calico_problem* p, double* buf, int64_t n) {
 // the last step was rejected, so whole iterations can be enqueued without a host round trip.
 // `spec`: evaluation at the candidate point x_at = x_cand into the reduce buffer that does NOT hold R(x) (chosen on
 // the device from LmState.rcur); otherwise evaluation at x into buffer 0.
-int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, const double* x_at = nullptr, bool spec = false) {
+int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, const double* x_at = nullptr, bool spec = false,
+                          const ControlTail* tail = nullptr) {
   p->timer.begin(0, p->stream);
   EvalArgs ea = make_eval_args(p, x_at ? x_at : p->d_x.p, 1, false);
   ea.st = st; ea.need_flag = need_flag;
@@ -750,7 +757,7 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, c
   }
   launch_expand_cells(ea, p->stream);                     // compact frame records -> one expanded block per cell
   launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->d_out_fat.p,
-                p->d_ptr_fat.p, p->d_idx_fat.p, p->n_fat, st, need_flag, spec ? p->r_size : 0, p->stream);
+                p->d_ptr_fat.p, p->d_idx_fat.p, p->n_fat, st, need_flag, spec ? p->r_size : 0, p->stream, tail);
   p->timer.end(p->stream);
   if (!p->allreduce) return CALICO_OK;  // single rank: no exchange
   return do_allreduce(p, target, int64_t(p->r_size));
@@ -1030,6 +1037,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   p->timer.begin(4, s);
   launch_post_eval(sa, p->d_x.p, p->d_blocks.p, int(p->h_blocks.size()), o, p->d_log.p, kLogCap, 1, opt->jacobi_scaling, s);
   p->timer.end(s);
+  static const bool fused_control = [] { const char* e = std::getenv("CALICO_FUSED_CONTROL"); return !e || std::atoi(e) != 0; }();
   if (streaming) {
     int enq = 0;
     const auto t_spin0 = std::chrono::steady_clock::now();
@@ -1051,12 +1059,19 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
       launch_solve(sa, o, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, p->dense_in_lds, s, /*with_post_eval=*/enq > 0, p->d_log.p,
                    kLogCap, opt->jacobi_scaling);
       p->timer.end(s);
-      rc = enqueue_jacobian_eval(p, p->d_state.p, 0, p->d_xc.p, true);
+      // the control stage rides in the last workgroup of the gather kernel
+      ControlTail tail;
+      tail.enabled = 1; tail.n_amb = p->n_amb; tail.log_cap = kLogCap; tail.seq = ++enq; tail.o = o; tail.x = p->d_x.p;
+      tail.x_cand = p->d_xc.p; tail.log = p->d_log.p; tail.Rbase = p->d_R.p; tail.r_stride = p->r_size;
+      tail.progress = p->d_progress; tail.owner_block = p->gather_owner_block;
+      rc = enqueue_jacobian_eval(p, p->d_state.p, 0, p->d_xc.p, true, fused_control ? &tail : nullptr);
       if (rc != CALICO_OK) return rc;
-      p->timer.begin(4, s);
-      launch_control(p->d_state.p, o, p->d_R2.p, p->d_x.p, p->d_xc.p, p->n_amb, p->d_log.p, kLogCap, nullptr, 0, p->d_R.p, p->r_size,
-                     s, false, p->d_progress, ++enq);
-      p->timer.end(s);
+      if (!fused_control) {
+        p->timer.begin(4, s);
+        launch_control(p->d_state.p, o, p->d_R2.p, p->d_x.p, p->d_xc.p, p->n_amb, p->d_log.p, kLogCap, nullptr, 0, p->d_R.p,
+                       p->r_size, s, false, p->d_progress, enq);
+        p->timer.end(s);
+      }
     }
   } else {
     rc = read_state(p);

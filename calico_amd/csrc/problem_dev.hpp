@@ -102,6 +102,8 @@ struct LmState {
   int invalid_eval;       // candidate evaluation hit an invalid projection
   int n_log, n_jac_evals, n_cost_evals;
   int rcur;               // which of the two reduce buffers holds R(x) (speculative evaluation)
+  int rfill;              // the reduce buffer the speculative evaluation of this iteration fills (= rcur ^ 1, latched by the update
+                          // stage: the control stage may flip rcur while workgroups of the gather are still starting)
   int commit_pending;     // multi-rank speculative evaluation: the accepted candidate's buffer 1 is to be copied over buffer 0
 };
 
@@ -118,6 +120,21 @@ struct IterLog {  // mirrors calico_iteration
 
 struct BlockDev {  // one reduced (free, used) parameter block
   int amb_off, size, manifold, tan_off;
+};
+
+// LM control stage riding in the gather kernel (single rank, speculative evaluation): the workgroup that sums the
+// candidate's [cost, invalid] (outputs 0 and 1 of the gather, always in one workgroup) takes the accept / reject
+// decision at once, while the other workgroups are still assembling the normal equations.
+struct ControlTail {
+  int enabled, n_amb, log_cap, seq;
+  LmOptionsDev o;
+  double* x;
+  const double* x_cand;
+  IterLog* log;
+  const double* Rbase;
+  size_t r_stride;
+  int* progress;
+  int owner_block;   // workgroup that produces outputs 0 and 1
 };
 
 #if defined(__HIPCC__)
@@ -154,6 +171,7 @@ struct SolveArgs {
   // host-mapped progress words, or nullptr: [0] = sequence number of the last LM iteration the control kernel has
   // finished with, [1] = LmState.terminated. The host polls them instead of synchronising (single-rank solve loop).
   int* progress;
+  int* sync_counters;     // [4] zero-initialised, self-resetting arrival counters of the kernels that end with a last-workgroup stage
   CAL_HD int n_s() const { return 6 * n_cp; }
   CAL_HD int W() const { return 6 * k; }
   CAL_HD int NT() const { return 6 * n_cp + mc; }

@@ -46,20 +46,31 @@ DEVI double diag_entry(const SolveArgs& a, int j) {
 // One launch, two roles by workgroup: the first nb_fat workgroups take the fat outputs (> 48 sources, one wave
 // each, the long ones first), the others the thin outputs (eight lanes each, strided over the sources); both end in
 // a fixed-shape shuffle tree.
+DEVI void control_body(LmState* st, const LmOptionsDev& o, double* R2, double* x, const double* x_cand, int n_amb, IterLog* log,
+                       int log_cap, const double* __restrict__ item_cost, int n_items, const double* Rbase, size_t r_stride,
+                       int no_swap, int* progress, int seq);
+DEVI void publish(int* word, int value);
+// `tail`: the LM control stage rides in the workgroup that finishes last (see ControlTail).
 __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, const double* __restrict__ src,
                                                      const int* __restrict__ out_thin, const int64_t* __restrict__ ptr_thin,
                                                      const int* __restrict__ idx_thin, int n_thin,
                                                      const int* __restrict__ out_fat, const int64_t* __restrict__ ptr_fat,
                                                      const int* __restrict__ idx_fat, int n_fat, int nb_fat,
-                                                     const LmState* st, int need_flag, size_t other_stride) {
-  if (st && (st->terminated || (need_flag && !st->need_jacobian))) return;
-  if (other_stride && st && !st->rcur) R += other_stride;     // speculative: fill the buffer that does NOT hold R(x)
+                                                     const LmState* st, int need_flag, size_t other_stride, ControlTail tail) {
+  if (st && (st->terminated || (need_flag && !st->need_jacobian))) {
+    if (tail.enabled && tail.progress && st->terminated && blockIdx.x == 0 && threadIdx.x == 0) {
+      publish(tail.progress + 1, 1); publish(tail.progress, tail.seq);
+    }
+    return;
+  }
+  if (other_stride && st && st->rfill) R += other_stride;     // speculative: fill the buffer that does NOT hold R(x)
   // Both roles issue all index loads of a lane first and all value loads second: two memory round trips per output
   // instead of one dependent pair per source.
   if (int(blockIdx.x) < nb_fat) {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int wave_raw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (wave >= n_fat) return;
+    const bool live = wave_raw < n_fat;
+    const int wave = live ? wave_raw : n_fat - 1;
     const int64_t q0 = ptr_fat[wave], q1 = ptr_fat[wave + 1];
     double s = 0.0;
     for (int64_t qb = q0; qb < q1; qb += 256) {     // four sources per lane and pass
@@ -74,7 +85,7 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) R[out_fat[wave]] = s;
+    if (live && lane == 0) R[out_fat[wave]] = s;
   } else {
     const int gid = (blockIdx.x - nb_fat) * blockDim.x + threadIdx.x;
     const int o = gid >> 3, sub = gid & 7;
@@ -92,6 +103,11 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
     for (int u = 0; u < 6; ++u) s += q0 + sub + 8 * u < q1 ? v[u] : 0.0;
     s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
     if (live && sub == 0) R[out_thin[o]] = s;
+  }
+  if (tail.enabled && int(blockIdx.x) == tail.owner_block) {
+    __syncthreads();      // outputs 0 and 1 were written by this workgroup
+    control_body(const_cast<LmState*>(st), tail.o, nullptr, tail.x, tail.x_cand, tail.n_amb, tail.log, tail.log_cap, nullptr, 0,
+                 tail.Rbase, tail.r_stride, 0, tail.progress, tail.seq);
   }
 }
 
@@ -1328,6 +1344,7 @@ DEVI void update_body(const SolveArgs& a_in, const double* __restrict__ x, doubl
     __syncthreads();
   }
   if (tid == 0) {
+    st->rfill = st->rcur ^ 1;
     st->model_cost_change = s_a[0];
     st->step_norm = sqrt(s_b[0]);
     st->candidate_cost = 0.0;
@@ -1354,8 +1371,20 @@ __global__ __launch_bounds__(256) void band_backsolve_kernel(SolveArgs a, const 
   const LmState* st = a.st;
   if (st->terminated) return;
   if (threadIdx.x < 64) band_backsolve_wave<K>(a, blockIdx.x);
-  if (a.n_seg() > 1) return;
   __syncthreads();
+  if (a.n_seg() > 1) {
+    // the workgroup that finishes last has the whole solution vector in front of it and goes on to the update
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+      __threadfence();
+      const int arrived = atomicAdd(a.sync_counters, 1);
+      s_last = arrived == a.n_seg() - 1;
+      if (s_last) atomicExch(a.sync_counters, 0);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+  }
   update_body(a, x, x_cand, blocks, n_blocks);
 }
 __global__ __launch_bounds__(256) void update_kernel(SolveArgs a, const double* __restrict__ x, double* __restrict__ x_cand,
@@ -1466,11 +1495,9 @@ __global__ __launch_bounds__(256) void cost_reduce_kernel(const double* __restri
 // [Ceres] TrustRegionMinimizer: tolerance tests, step acceptance, radius update.
 // item_cost != nullptr: single-rank path, the reduction of the per-item [cost, invalid] pairs is done here instead
 // of in a separate cost_reduce_kernel launch (with several ranks the sum goes through the all-reduce in between).
-__global__ __launch_bounds__(256) void lm_control_kernel(LmState* st, LmOptionsDev o, double* R2, double* x,
-                                                         const double* x_cand, int n_amb, IterLog* log, int log_cap,
-                                                         const double* __restrict__ item_cost, int n_items,
-                                                         const double* Rbase, size_t r_stride, int no_swap, int* progress,
-                                                         int seq) {
+DEVI void control_body(LmState* st, const LmOptionsDev& o, double* R2, double* x, const double* x_cand, int n_amb, IterLog* log,
+                       int log_cap, const double* __restrict__ item_cost, int n_items, const double* Rbase, size_t r_stride,
+                       int no_swap, int* progress, int seq) {
   const int tid = threadIdx.x;
   if (st->terminated) {
     if (progress && tid == 0) { publish(progress + 1, 1); publish(progress, seq); }
@@ -1479,7 +1506,7 @@ __global__ __launch_bounds__(256) void lm_control_kernel(LmState* st, LmOptionsD
   __shared__ int s_accept;
   // speculative evaluation (r_stride != 0): the candidate's [cost, invalid] are the first two entries of the reduce
   // buffer the Jacobian pass at the candidate point has just filled
-  if (r_stride) R2 = const_cast<double*>(Rbase + (st->rcur ? 0 : r_stride));
+  if (r_stride) R2 = const_cast<double*>(Rbase + (st->rfill ? r_stride : 0));
   if (item_cost) {
     __shared__ double s_a[256], s_b[256];
     double c = 0.0, v = 0.0;
@@ -1552,6 +1579,13 @@ __global__ __launch_bounds__(256) void lm_control_kernel(LmState* st, LmOptionsD
   }
   if (progress && tid == 0) { if (st->terminated) publish(progress + 1, 1); publish(progress, seq); }
 }
+__global__ __launch_bounds__(256) void lm_control_kernel(LmState* st, LmOptionsDev o, double* R2, double* x,
+                                                         const double* x_cand, int n_amb, IterLog* log, int log_cap,
+                                                         const double* __restrict__ item_cost, int n_items,
+                                                         const double* Rbase, size_t r_stride, int no_swap, int* progress,
+                                                         int seq) {
+  control_body(st, o, R2, x, x_cand, n_amb, log, log_cap, item_cost, n_items, Rbase, r_stride, no_swap, progress, seq);
+}
 
 // Several ranks, speculative evaluation: copy the accepted candidate's reduce buffer (1) over R(x) (0). The flag is
 // taken down by the post_eval kernel that follows, so that the copy happens once per accepted step even when the
@@ -1563,7 +1597,7 @@ __global__ __launch_bounds__(256) void commit_kernel(const LmState* st, double* 
 
 __global__ void init_state_kernel(LmState* st, double radius, double x_norm) {
   LmState s = {};
-  s.radius = radius; s.decrease_factor = 2.0; s.x_norm = x_norm; s.need_jacobian = 1;
+  s.radius = radius; s.decrease_factor = 2.0; s.x_norm = x_norm; s.need_jacobian = 1; s.rfill = 1;
   s.min_cost = 1.7976931348623157e308;
   *st = s;
 }
@@ -1571,11 +1605,13 @@ __global__ void init_state_kernel(LmState* st, double radius, double x_norm) {
 // ---- launch helpers ---------------------------------------------------------
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
                    int n_thin, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
-                   const LmState* st, int need_flag, size_t other_stride, hipStream_t s) {
+                   const LmState* st, int need_flag, size_t other_stride, hipStream_t s, const ControlTail* tail) {
   const int nb_thin = (n_thin + 31) / 32, nb_fat = (n_fat + 3) / 4;
+  ControlTail t;
+  if (tail) t = *tail; else { t = ControlTail(); t.enabled = 0; }
   if (nb_thin + nb_fat > 0)
     hipLaunchKernelGGL(gather_kernel, dim3(nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin,
-                       out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, st, need_flag, other_stride);
+                       out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, st, need_flag, other_stride, t);
 }
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s) {
@@ -1672,7 +1708,6 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
       default: hipLaunchKernelGGL(band_backsolve_kernel<8>, dim3(a.n_seg()), dim3(256), bl, s, a, x, x_cand, blocks, n_blocks); break;
     }
   }
-  if (a.n_seg() > 1) hipLaunchKernelGGL(update_kernel, dim3(1), dim3(256), 0, s, a, x, x_cand, blocks, n_blocks);
 }
 void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const LmState* st, hipStream_t s) {
   hipLaunchKernelGGL(cost_reduce_kernel, dim3(1), dim3(256), 0, s, item_cost, n_items, R2, st);

@@ -27,3 +27,6 @@ for name, st, en in rows[i0:]:
     else: a[0] += 1; a[1] += (en - st) / 1e3
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-32s working %3d calls %8.1f us (avg %6.1f) | short(<4.5us) %3d calls %6.1f us" % (k, v[0], v[1], v[1] / max(1, v[0]), v[2], v[3]))
+print([round((en - st) / 1e3, 1) for name, st, en in rows[i0:] if "band_cholesky" in name])
+print([round((en - st) / 1e3, 1) for name, st, en in rows[i0:] if "prepare" in name])
+print([round((en - st) / 1e3, 1) for name, st, en in rows[i0:] if "lm_control" in name])
