@@ -416,7 +416,8 @@ int finalize(calico_problem* p) {
     const int dim = p->sensors[L.sensor].dim();
     // cameras fill the 128 staged rows; an IMU block is a long single-lane computation and there are few of them, so
     // they are cut finer: more waves in flight, shorter JᵀJ stage, smaller LDS footprint next to the camera frames
-    const int chunk = dim == 2 ? kRowsPerItem / 2 : 16;
+    static const int imu_chunk = [] { const char* e = std::getenv("CALICO_IMU_CHUNK"); return e ? std::max(1, std::min(32, std::atoi(e))) : 16; }();
+    const int chunk = dim == 2 ? kRowsPerItem / 2 : imu_chunk;
     max_cols = std::max(max_cols, L.ncols + 1);
     for (int64_t b = q; b < e; b += chunk) {
       ItemDev it;
@@ -686,7 +687,7 @@ int finalize(calico_problem* p) {
   if (band_lds > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "spline order too high for the banded factorisation window");
   const size_t reduced_lds = reduced_solve_lds_bytes(sa);
   p->dense_in_lds = reduced_lds <= kMaxLds - 1024;
-  HIP_TRY(p, p->d_Spart.alloc(4 * size_t(mw + 1) * (mw + 1)));   // up to four K-slices of the Schur complement
+  HIP_TRY(p, p->d_Spart.alloc(4 * size_t(mw + 1) * (mw + 1) + 64));   // four K-slices of the Schur complement (+ slack: the blocked factorisation reads whole 32-column panels)
   const size_t back_lds = band_backsolve_lds_bytes(sa);
   if (back_lds > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "trajectory too long for the back-substitution window");
   HIP_TRY(p, p->d_Swork.alloc(std::max<size_t>(reduced_lds / sizeof(double) + 8, size_t(mw + 1) * 16 * 13 + 8)));

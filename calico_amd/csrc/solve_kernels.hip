@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
 }
 
 // Sred = S - YᵀY, one 16×16 lower tile per workgroup, 64-row chunks staged in LDS with register prefetch.
-constexpr int kSchurSlices = 2;   // K-slices when the in-LDS panel solver consumes the result (it sums them on load)
+constexpr int kSchurSlices = 4;   // K-slices when the in-LDS panel solver consumes the result (it sums them on load)
 // `ks` workgroups share the rows (K dimension) of every tile: slice k writes its partial S/ks-th into
 // Spart + k·(m+1)² (slice 0 carries S itself), and the consumer adds the slices up when it loads the matrix.
 __global__ __launch_bounds__(256) void schur_kernel(SolveArgs a, int ks) {
@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(256) void reduced_block_step_kernel(SolveArgs a, in
   for (int c = 0; c < kRB; ++c) {
     const int col = c0 + c;                // may run past the row end: masked below, and Spart has slack behind it
     double v = src[col];
-    if (nsl > 1) v += src[msq + col];
+    for (int k = 1; k < nsl; ++k) v += src[size_t(k) * msq + col];
     const bool ok = row_ok && c0 + c < m1 && (lane >= kRB || c <= lane);
     G[c] = ok ? v : 0.0;
   }
@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(256) void reduced_block_step_kernel(SolveArgs a, in
     for (int jj = 0; jj < 4; ++jj) {
       const size_t o = size_t(min(ur0 + i, m1 - 1)) * m1 + uc0 + jj;
       double v = A[o];
-      if (nsl > 1) v += A[msq + o];
+      for (int k = 1; k < nsl; ++k) v += A[size_t(k) * msq + o];
       pre[i][jj] = v;
     }
   if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
