@@ -216,7 +216,8 @@ def main():
         achieved = alg_bytes / (jac_ms * 1e-3) / 1e9 if jac_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        # the PMC figure was collected on the default workload with one rank: it does not describe other runs
+        if os.path.exists(tpath) and args.config == 3 and world == 1:
             try:
                 traffic = json.load(open(tpath)).get("eval_jacobian_kernel_bytes_per_launch")
             except Exception:

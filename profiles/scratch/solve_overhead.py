@@ -4,7 +4,7 @@ import numpy as np
 import helpers
 from calico_amd import synthetic as syn
 hip = helpers.hip_api()
-sc = syn.config_scene(3)
+sc = syn.config_scene(int(os.environ.get("CFG", "3")))
 built = syn.build_problem(hip, sc)
 P = built.problem
 init = [(int(b), sc.ctrl[i].copy()) for i, b in enumerate(built.ctrl_blocks)]
