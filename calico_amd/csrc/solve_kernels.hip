@@ -18,6 +18,10 @@
 
 #include "problem_dev.hpp"
 
+#ifndef CALICO_RSQRT_NEWTON_STEPS
+#define CALICO_RSQRT_NEWTON_STEPS 1
+#endif
+
 namespace cal {
 
 #define DEVI __device__ __forceinline__
@@ -280,11 +284,16 @@ DEVI double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(d) to double precision: hardware estimate + two Newton steps (no division, no sqrt call).
+// 1/sqrt(d): hardware estimate (2^-24 relative, profiles/microbench/rsq_accuracy.hip) + Newton steps, no division and no
+// sqrt call. Two steps give 1 ulp; one step gives 4e-15 relative, which is what the factorisation chains use: a
+// Cholesky factor carries rounding errors of that order anyway (n·eps), and every pivot sits on a latency chain.
 DEVI double rsqrt_nr(double d) {
   double r = __builtin_amdgcn_rsq(d);
-  r = r * (1.5 - 0.5 * d * r * r);
-  r = r * (1.5 - 0.5 * d * r * r);
+  const double h = 0.5 * d;
+  r = r * (1.5 - h * r * r);
+#if CALICO_RSQRT_NEWTON_STEPS > 1
+  r = r * (1.5 - h * r * r);
+#endif
   return r;
 }
 
