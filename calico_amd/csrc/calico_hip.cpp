@@ -46,6 +46,7 @@ void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* block
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s);
 size_t band_cholesky_lds_bytes(const SolveArgs& a);
 size_t reduced_solve_lds_bytes(const SolveArgs& a);
+size_t frame_lds_doubles(int P1, int n1);
 size_t band_backsolve_lds_bytes(const SolveArgs& a);
 hipError_t configure_solve_kernels(size_t band_lds, size_t reduced_lds, size_t back_lds);
 void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, double* x_cand, const BlockDev* blocks,
@@ -182,7 +183,8 @@ struct calico_problem {
   std::vector<ItemDev> h_items, h_items_all, h_jac_items;
   std::vector<FrameItemDev> h_fitems;
   std::vector<CellDev> h_cells;
-  int cell_chunk = 1, cell_rec_max = 1;
+  int cell_chunk = 1, cell_rec_max = 1, row_cell_chunk = 1;
+  int frame_lds_doubles = 0;
   int n_fitems = 0, n_jac_items = 0;
   std::vector<double> h_x;
   int n_thin = 0, n_fat = 0;
@@ -265,7 +267,7 @@ EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool
   a.partials = p->d_partials.p; a.item_cost = p->d_partials.p + p->partial_doubles;
   a.res_out = want_res ? p->d_res.p : nullptr; a.valid_out = want_res ? p->d_valid.p : nullptr;
   a.order = p->order; a.n_items = p->n_items; a.lds_cols = p->lds_cols; a.row_pad = p->row_pad; a.n_cells = int(p->h_cells.size()); a.cells = p->d_cells.p; a.prim_tab = p->d_prim_tab.p;
-  a.cell_chunk = p->cell_chunk; a.cell_rec_max = p->cell_rec_max; a.project = 0; a.pad4 = 0; a.active = p->d_active.p; a.apply_loss = apply_loss;
+  a.cell_chunk = p->cell_chunk; a.cell_rec_max = p->cell_rec_max; a.project = 0; a.row_cell_chunk = p->row_cell_chunk; a.frame_lds_doubles = p->frame_lds_doubles; a.pad5 = 0; a.active = p->d_active.p; a.apply_loss = apply_loss;
   a.st = nullptr; a.need_flag = 0; a.cost_index_base = 0;
   a.fitems = p->d_fitems.p; a.n_fitems = p->n_fitems;
   return a;
@@ -408,6 +410,7 @@ int finalize(calico_problem* p) {
   std::vector<double> m0(n_obs), m1(n_obs), m2(n_obs), st(n_obs);
   std::vector<int> point_off(n_obs, 0);
   p->h_items.clear(); p->h_items_all.clear();
+  static const int imu_chunk_items = [] { const char* e = std::getenv("CALICO_IMU_CHUNK"); return e ? std::max(1, std::min(40, std::atoi(e))) : 24; }();
   int max_cols = 0;
   for (int64_t q = 0; q < n_obs;) {
     int64_t e = q;
@@ -416,13 +419,12 @@ int finalize(calico_problem* p) {
     const int dim = p->sensors[L.sensor].dim();
     // cameras fill the 128 staged rows; an IMU block is a long single-lane computation and there are few of them, so
     // they are cut finer: more waves in flight, shorter JᵀJ stage, smaller LDS footprint next to the camera frames
-    static const int imu_chunk = [] { const char* e = std::getenv("CALICO_IMU_CHUNK"); return e ? std::max(1, std::min(32, std::atoi(e))) : 16; }();
-    const int chunk = dim == 2 ? kRowsPerItem / 2 : imu_chunk;
+    const int chunk = dim == 2 ? kRowsPerItem / 2 : imu_chunk_items;
     max_cols = std::max(max_cols, L.ncols + 1);
     for (int64_t b = q; b < e; b += chunk) {
       ItemDev it;
       it.layout = keys[q].layout; it.seg = keys[q].seg; it.obs_begin = int(b); it.obs_count = int(std::min<int64_t>(chunk, e - b));
-      it.partial_off = 0;
+      it.partial_off = 0; it.rows_off = -1;
       p->h_items_all.push_back(it);
     }
     q = e;
@@ -474,7 +476,7 @@ int finalize(calico_problem* p) {
           if (p->h_cells.empty() || p->h_cells.back().layout != kq.layout || p->h_cells.back().seg != kq.seg) {
             CellDev c;
             c.layout = kq.layout; c.seg = kq.seg; c.frame_begin = int(p->h_fitems.size()); c.frame_count = 0;
-            c.partial_off = int64_t(poff);
+            c.partial_off = int64_t(poff); c.prim_off = 0;
             poff += size_t(layouts[size_t(kq.layout)].ncols + 1) * (layouts[size_t(kq.layout)].ncols + 1);
             p->h_cells.push_back(c);
           }
@@ -486,10 +488,31 @@ int finalize(calico_problem* p) {
       }
       q = e;
     }
+    // IMU work items hand their staged rows to the cell kernel ("row cells": one expanded block per (layout, segment)
+    // instead of one per item); everything else forms its own block
+    static const bool row_cells_ok = [] { const char* e = std::getenv("CALICO_ROW_CELLS"); return !e || std::atoi(e) != 0; }();
     for (ItemDev it : p->h_items) {
       if (layout_uses_frames[size_t(it.layout)]) continue;
-      it.partial_off = int64_t(poff);
-      poff += size_t(layouts[size_t(it.layout)].ncols + 1) * (layouts[size_t(it.layout)].ncols + 1);
+      const LayoutDev& L = layouts[size_t(it.layout)];
+      const HSensor& hs = p->sensors[size_t(L.sensor)];
+      const int n1 = L.ncols + 1;
+      if (row_cells_ok && hs.kind != CALICO_SENSOR_CAMERA && n1 <= 112) {
+        it.partial_off = 0; it.rows_off = 0;   // row store offset assigned below, once the staging dimensions are known
+        if (p->h_cells.empty() || p->h_cells.back().prim_off >= 0 || p->h_cells.back().layout != it.layout ||
+            p->h_cells.back().seg != it.seg) {
+          CellDev c;
+          c.layout = it.layout; c.seg = it.seg; c.frame_begin = int(p->h_jac_items.size()); c.frame_count = 0;
+          c.partial_off = int64_t(poff); c.src_off = 0; c.n1 = n1; c.PE = hs.dim() * imu_chunk_items; c.prim_off = -1; c.pad0 = 0;
+          poff += size_t(n1) * n1;
+          p->h_cells.push_back(c);
+        }
+        p->h_cells.back().frame_count += 1;
+        p->h_cells.back().pad0 += hs.dim() * it.obs_count;
+      } else {
+        it.rows_off = -1;
+        it.partial_off = int64_t(poff);
+        poff += size_t(n1) * n1;
+      }
       p->h_jac_items.push_back(it);
     }
   }
@@ -499,16 +522,30 @@ int finalize(calico_problem* p) {
   const size_t n_cost_slots = 2 * size_t(std::max(std::max(int(p->h_items.size()), int(p->h_items_all.size())), p->n_fitems + p->n_jac_items));
   const size_t comp_base = poff + n_cost_slots;
   p->cell_rec_max = 1;
+  p->frame_lds_doubles = 0;
   for (FrameItemDev& f : p->h_fitems) {
+    {
+      const LayoutDev& L = layouts[size_t(f.layout)];
+      const HSensor& hs = p->sensors[size_t(L.sensor)];
+      const int P1 = 7 + (L.c_intr >= 0 ? hs.K : 0) + 3 * (L.c_q >= 0) + 3 * (L.c_t >= 0) + 3 * (L.c_bq >= 0) + 3 * (L.c_bt >= 0);
+      p->frame_lds_doubles = std::max(p->frame_lds_doubles, int(frame_lds_doubles(P1, L.ncols + 1)));
+    }
     f.partial_off += int64_t(comp_base);
     p->cell_rec_max = std::max(p->cell_rec_max, int(frame_rec(layouts[size_t(f.layout)])));
   }
   p->cell_chunk = std::max(1, int((56 * 1024 / sizeof(double)) / size_t(p->cell_rec_max)));
+  {
+    // no more LDS than the fullest cell needs: the cell kernel's workgroups should all be resident at once
+    int most = 1;
+    for (const CellDev& c : p->h_cells) if (c.prim_off >= 0) most = std::max(most, c.frame_count);
+    p->cell_chunk = std::min(p->cell_chunk, most);
+  }
   // per-layout prim-column table of the cell kernel (mirror of prim_map / the frame kernel's column order)
   std::vector<int> prim_tab;
   {
     std::vector<int> tab_off(layouts.size(), -1);
     for (CellDev& c : p->h_cells) {
+      if (c.prim_off < 0) continue;   // row cell
       const LayoutDev& L = layouts[size_t(c.layout)];
       const HSensor& hs = p->sensors[size_t(L.sensor)];
       int pc = 6;
@@ -568,6 +605,23 @@ int finalize(calico_problem* p) {
   }
   if (size_t(p->lds_cols) * p->row_pad * sizeof(double) > kMaxLds)
     return p->set_error(CALICO_UNIMPLEMENTED, "too many Jacobian columns per residual block for the LDS staging area");
+  // row store of the items that leave [J r]ᵀ[J r] to the cell kernel: behind the compact frame records
+  size_t row_store = 0;
+  {
+    const size_t stride = size_t(p->lds_cols) * p->row_pad;
+    for (size_t i = 0; i < p->h_jac_items.size(); ++i) {
+      ItemDev& it = p->h_jac_items[i];
+      if (it.rows_off < 0) continue;
+      it.rows_off = int64_t(comp_base + comp_off + row_store);
+      row_store += stride;
+    }
+    for (CellDev& c : p->h_cells)
+      if (c.prim_off < 0) c.src_off = p->h_jac_items[size_t(c.frame_begin)].rows_off;
+    p->row_cell_chunk = std::max(1, int((56 * 1024 / sizeof(double)) / std::max<size_t>(1, stride)));
+    int most = 1;
+    for (const CellDev& c : p->h_cells) if (c.prim_off < 0) most = std::max(most, c.frame_count);
+    p->row_cell_chunk = std::min(p->row_cell_chunk, most);
+  }
   // ---- gather lists ----
   SolveArgs sa; sa.n_cp = n_cp; sa.k = k; sa.mc = m; sa.sep_s = p->sep_s; sa.sep_n = p->sep_n; sa.m = m + 6 * p->sep_n; sa.debug = 0; sa.progress = nullptr; sa.sync_counters = nullptr;
   const size_t r_size = sa.r_size();
@@ -579,6 +633,7 @@ int finalize(calico_problem* p) {
   const int n_part = n_cells + p->n_jac_items;     // producers of expanded partial blocks
   for (int itn = 0; itn < n_part; ++itn) {
     const bool is_cell = itn < n_cells;
+    if (!is_cell && p->h_jac_items[size_t(itn - n_cells)].rows_off >= 0) continue;   // its block is the row cell's
     const int it_layout = is_cell ? p->h_cells[size_t(itn)].layout : p->h_jac_items[size_t(itn - n_cells)].layout;
     const int it_seg = is_cell ? p->h_cells[size_t(itn)].seg : p->h_jac_items[size_t(itn - n_cells)].seg;
     const int64_t it_poff = is_cell ? p->h_cells[size_t(itn)].partial_off : p->h_jac_items[size_t(itn - n_cells)].partial_off;
@@ -648,7 +703,7 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_ptr_thin.upload(ptr_thin, s));
   HIP_TRY(p, p->d_out_fat.upload(out_fat, s)); HIP_TRY(p, p->d_idx_fat.upload(idx_fat, s));
   HIP_TRY(p, p->d_ptr_fat.upload(ptr_fat, s));
-  HIP_TRY(p, p->d_partials.alloc(comp_base + comp_off));
+  HIP_TRY(p, p->d_partials.alloc(comp_base + comp_off + row_store));
   HIP_TRY(p, p->d_cells.upload(p->h_cells, s)); HIP_TRY(p, p->d_prim_tab.upload(prim_tab, s));
   p->r_size = r_size;
   {

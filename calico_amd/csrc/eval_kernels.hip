@@ -15,6 +15,9 @@
 //   accelerometer_cost_functor.h:62-147, bspline.hpp:39-72, geometry.h:137-222.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "device_math.hpp"
 #include "problem_dev.hpp"
 
@@ -592,6 +595,9 @@ DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds) {
   c.M = a.basis + size_t(it.seg) * a.order * a.order;
   c.ctrl_off = a.ctrl_off + it.seg;
   const int dim = (S.kind == 0) ? 2 : 3;
+  // The IMU blocks are the longest single-lane chains of the launch (accelerometer ≈ 45k clocks): where such a wave
+  // shares a SIMD with a camera wave it gets the issue slots first, the launch ends when the last of them does.
+  if (JAC) { if (S.kind == 2) __builtin_amdgcn_s_setprio(3); else if (S.kind == 1) __builtin_amdgcn_s_setprio(2); }
   const int ncols = L.ncols;           // Jacobian columns; column ncols holds the residual
   const int cp4 = (ncols + 1 + 3) & ~3;
   const int nrows = dim * it.obs_count;
@@ -641,6 +647,16 @@ DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds) {
     // Stage B: P = [J r]ᵀ [J r] on the matrix cores, upper 16×16 tiles (same scheme as the frame kernel: operand
     // element (col = 16t + (lane & 15), row = r0 + (lane >> 4)) serves as A of tile row t and as B of tile column t).
     const int n1 = ncols + 1;
+    if (it.rows_off >= 0) {
+      // the rows go to the cell kernel, which forms [J r]ᵀ[J r] for all work items of the cell at once with four
+      // waves: on the long single-lane chain of an IMU block this wave would spend another quarter of its time here
+      double* dst = a.partials + it.rows_off;
+      const int nw = n1 * row_pad;
+      for (int i = lane; i < nw; i += 64) dst[i] = lds[i];
+      ITICK(2)
+      if (dbg) printf("eval_items cycles (kind %d, %d obs, %d cols, pad %d): setup+zero %lld  stage A %lld  rows out %lld\n", S.kind, it.obs_count, ncols, row_pad, tph[0], tph[1], tph[2]);
+      return;
+    }
     double* out = a.partials + it.partial_off;
     switch ((n1 + 15) >> 4) {
       case 1: stage_b_mfma<1>(lds, row_pad, nrows, n1, out); break;
@@ -788,9 +804,12 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   const int pc_intr = pm.intr, pc_q = pm.q, pc_t = pm.t, pc_bq = pm.bq, pc_bt = pm.bt, pc_r = pm.r;
   const int P1 = pm.P1, PT = pm.PT, PE = pm.PE;
   const int ncols = L.ncols, n1 = ncols + 1;
-  double* Jp = lds;                                  // [PT][kFramePad]   staged rows, column-major
-  double* Me = lds + kMaxPrim * kFramePad;           // [PE][PE]
-  double* coef = Me + (kMaxPrim + 1) * (kMaxPrim + 1);   // [n1] column c of the item = coef[c] · prim column prim[c]
+  // LDS: the staged rows of the P1 prim columns; M_ext takes their place once the products are in the accumulators;
+  // the expansion coefficients behind both. Sized by the layout, not by the worst case: at 43 KB per workgroup only
+  // three fit a CU and the launch ran in two rounds.
+  double* Jp = lds;                                  // [P1][kFramePad]   staged rows, column-major
+  double* Me = lds;                                  // [PE][PE]          (after the last MFMA)
+  double* coef = lds + max(P1 * kFramePad, PE * PE); // [n1] column c of the item = coef[c] · prim column prim[c]
   // ---- per-frame quantities (every lane computes the same values) ----
   const int ki = it.seg + K - 1;
   const double* Mb = a.basis + size_t(it.seg) * K * K;
@@ -842,8 +861,8 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   const bool two = PT > 16;
   f64x4 acc00 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
   const bool col0_ok = lc16 < P1, col1_ok = 16 + lc16 < P1;
-  const double* op0 = Jp + lc16 * kFramePad + lk;
-  const double* op1 = Jp + (16 + lc16) * kFramePad + lk;
+  const double* op0 = Jp + min(lc16, P1 - 1) * kFramePad + lk;        // columns past P1 - 1 are masked below
+  const double* op1 = Jp + min(16 + lc16, P1 - 1) * kFramePad + lk;
   double cost = 0.0, n_bad = 0.0;
   FTICK(0)
   for (int b0 = 0; b0 < it.obs_count; b0 += 64) {
@@ -971,8 +990,14 @@ __global__ __launch_bounds__(64) void eval_frames_kernel(EvalArgs a) {
 // single-wave computation, so they go first) and the camera frames run side by side instead of back to back.
 __global__ __launch_bounds__(64) void eval_jacobian_kernel(EvalArgs a) {
   extern __shared__ double lds[];
+  const unsigned long long t0 = a.debug >= 3 ? __builtin_amdgcn_s_memrealtime() : 0;
   if (int(blockIdx.x) < a.n_items) eval_items_body<true, 6>(a, blockIdx.x, lds);
   else eval_frames_body(a, blockIdx.x - a.n_items, lds);
+  if (a.debug >= 3 && threadIdx.x == 0) {   // CALICO_KERNEL_TIMING=3: placement and life span of every wave (100 MHz clock)
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);
+    printf("WAVE %d %s t0 %llu t1 %llu hw %08x xcc %08x\n", int(blockIdx.x), int(blockIdx.x) < a.n_items ? "item" : "frame", t0, t1, hw, xcc);
+  }
 }
 
 // Expansion + sum of the compact frame records of one cell: block (i, j), i <= j, of the cell's partial is
@@ -980,11 +1005,90 @@ __global__ __launch_bounds__(64) void eval_jacobian_kernel(EvalArgs a) {
 // One workgroup per cell; records are staged through LDS in chunks of a.cell_chunk frames. Everything the kernel
 // needs sits in the cell descriptor and a per-layout table: a chain of dependent global loads (item -> layout ->
 // sensor -> ...) costs more than the arithmetic here.
-__global__ __launch_bounds__(256) void expand_cells_kernel(EvalArgs a) {
+// [J r]ᵀ[J r] of a cell whose work items filed their staged rows (IMU): the upper 16×16 tiles are dealt to the four
+// waves, every wave walks the items of the cell in order (rows in order: deterministic) with its tiles' accumulators
+// in registers; the row stores pass through LDS a.row_cell_chunk items at a time.
+template <int MAXT>
+DEV void row_cell_body(const EvalArgs& a, const CellDev& cell, double* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc16 = lane & 15, lk = lane >> 4;
+  const int n1 = cell.n1, NT = (n1 + 15) >> 4, ntile = NT * (NT + 1) / 2;
+  const int pad = a.row_pad, stride = a.lds_cols * a.row_pad, words = n1 * pad;
+  // tiles t = wave, wave + 4, ...: (I, J), I <= J, in row-major order of the upper triangle
+  int tI[MAXT], tJ[MAXT];
+  f64x4 acc[MAXT];
+  {
+    int t = 0, I = 0, J = 0;
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) {
+      const int want = wave + 4 * q;
+      while (t < want && I < NT) { ++t; if (++J == NT) { ++I; J = I; } }
+      tI[q] = want < ntile ? I : 0; tJ[q] = want < ntile ? J : 0;
+      acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+    }
+  }
+  const double* src = a.partials + cell.src_off;
+  const bool dbg = a.debug && int(blockIdx.x) == a.n_cells - 3 && lane == 0;
+  long long tph[4] = {0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
+#define RTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
+  for (int i0 = 0; i0 < cell.frame_count; i0 += a.row_cell_chunk) {
+    const int ni = min(a.row_cell_chunk, cell.frame_count - i0);
+    __syncthreads();
+    RTICK(0)
+    for (int it = 0; it < ni; ++it) {
+      const double* s = src + size_t(i0 + it) * stride;
+      // eight loads in flight per thread: a load-store loop waits out the full memory latency on every trip
+      for (int b = tid; b < words; b += 256 * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = s[min(b + 256 * u, words - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (b + 256 * u < words) lds[it * words + b + 256 * u] = v[u];
+      }
+    }
+    __syncthreads();
+    RTICK(1)
+    for (int it = 0; it < ni; ++it) {
+      const int nrows = min(cell.PE, cell.pad0 - (i0 + it) * cell.PE);
+      const double* base = lds + it * words;
+      for (int r0 = 0; r0 < nrows; r0 += 4) {
+        const int r = r0 + lk;
+        const int rc = r < nrows ? r : nrows - 1;
+        const double rm = r < nrows ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < MAXT; ++q) {
+          const int ci = 16 * tI[q] + lc16, cj = 16 * tJ[q] + lc16;
+          const double oi = base[(ci < n1 ? ci : n1 - 1) * pad + rc] * (ci < n1 ? rm : 0.0);
+          const double oj = base[(cj < n1 ? cj : n1 - 1) * pad + rc] * (cj < n1 ? rm : 0.0);
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(oi, oj, acc[q], 0, 0, 0);
+        }
+      }
+    }
+  }
+  RTICK(2)
+  if (dbg) printf("row_cell cycles (wave %d, %d items, %d rows, n1 %d): setup %lld  staging %lld  mfma %lld\n", wave, cell.frame_count, cell.pad0, n1, tph[0], tph[1], tph[2]);
+#undef RTICK
+  double* out = a.partials + cell.partial_off;
+#pragma unroll
+  for (int q = 0; q < MAXT; ++q) {
+    if (wave + 4 * q >= ntile) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gi = 16 * tI[q] + lk + 4 * r, gj = 16 * tJ[q] + lc16;
+      if (gi <= gj && gj < n1) out[size_t(gi) * n1 + gj] = acc[q][r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void expand_cells_kernel(EvalArgs a) {
   extern __shared__ double lds[];
   const long long t_start = __builtin_readcyclecounter();
   const CellDev cell = a.cells[blockIdx.x];
   if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
+  if (cell.prim_off < 0) {
+    if (cell.n1 <= 64) row_cell_body<3>(a, cell, lds); else row_cell_body<7>(a, cell, lds);
+    return;
+  }
   const int tid = threadIdx.x;
   const bool dbg = a.debug && blockIdx.x == 5 && tid == 0;
   long long tph[5] = {0, 0, 0, 0, 0}, tk = t_start;
@@ -1042,7 +1146,9 @@ __global__ __launch_bounds__(256) void expand_cells_kernel(EvalArgs a) {
 
 void launch_expand_cells(const EvalArgs& a, hipStream_t stream) {
   if (a.n_cells == 0) return;
-  hipLaunchKernelGGL(expand_cells_kernel, dim3(a.n_cells), dim3(256), size_t(a.cell_chunk) * a.cell_rec_max * sizeof(double), stream, a);
+  const size_t frame_bytes = size_t(a.cell_chunk) * a.cell_rec_max * sizeof(double);
+  const size_t row_bytes = size_t(a.row_cell_chunk) * a.lds_cols * a.row_pad * sizeof(double);
+  hipLaunchKernelGGL(expand_cells_kernel, dim3(a.n_cells), dim3(256), std::max(frame_bytes, row_bytes), stream, a);
 }
 
 // Outlier tagging on the device (the notebooks' loop: residual norm > tau -> MarkOutliersById): observations
@@ -1062,16 +1168,26 @@ void launch_mark_outliers(const double* res, const uint8_t* valid, uint8_t* acti
 }
 
 size_t frame_lds_bytes() { return (size_t(kMaxPrim) * kFramePad + size_t(kMaxPrim + 1) * (kMaxPrim + 1) + kMaxLocalCols + kMaxLocalCols / 2) * sizeof(double); }
+// LDS doubles of a frame workgroup whose layout has P1 prim columns (residual included) and n1 local columns
+size_t frame_lds_doubles(int P1, int n1) {
+  const int PE = ((P1 + 15) & ~15) + 1;
+  return size_t(std::max(P1 * kFramePad, PE * PE)) + size_t(n1) + 16;
+}
+static size_t frame_launch_bytes(const EvalArgs& a) {
+  return a.frame_lds_doubles > 0 ? size_t(a.frame_lds_doubles) * sizeof(double) : frame_lds_bytes();
+}
 void launch_eval_frames(const EvalArgs& a, hipStream_t stream) {
   if (a.n_fitems == 0) return;
-  hipLaunchKernelGGL(eval_frames_kernel, dim3(a.n_fitems), dim3(64), frame_lds_bytes(), stream, a);
+  hipLaunchKernelGGL(eval_frames_kernel, dim3(a.n_fitems), dim3(64), frame_launch_bytes(a), stream, a);
 }
 
 // items (a.items / a.n_items, cost slots from a.cost_index_base) and frames (a.fitems / a.n_fitems) together
 void launch_eval_jacobian(const EvalArgs& a, hipStream_t stream) {
   if (a.n_items + a.n_fitems == 0) return;
   size_t lds = size_t(a.lds_cols) * a.row_pad * sizeof(double);
-  if (lds < frame_lds_bytes()) lds = frame_lds_bytes();
+  if (a.n_fitems > 0 && lds < frame_launch_bytes(a)) lds = frame_launch_bytes(a);
+  static const size_t lds_floor = [] { const char* e = std::getenv("CALICO_EVAL_LDS_KB"); return e ? size_t(std::atoi(e)) * 1024 : size_t(0); }();
+  if (lds < lds_floor) lds = lds_floor;
   hipLaunchKernelGGL(eval_jacobian_kernel, dim3(a.n_items + a.n_fitems), dim3(64), lds, stream, a);
 }
 
@@ -1094,7 +1210,7 @@ hipError_t configure_eval_kernels(size_t max_lds_bytes) {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&expand_cells_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_jacobian_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          int(max_lds_bytes > frame_lds_bytes() ? max_lds_bytes : frame_lds_bytes()));
+                          int(std::max<size_t>(std::max(max_lds_bytes, frame_lds_bytes()), 80 * 1024)));
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_items_kernel<true, 6>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, int(max_lds_bytes));

@@ -40,6 +40,8 @@ struct LayoutDev {
 struct ItemDev {
   int layout, seg, obs_begin, obs_count;
   int64_t partial_off;  // offset (doubles) of this item's partial block
+  int64_t rows_off;     // >= 0: the item files its staged rows [J r] here instead (lds_cols × row_pad doubles, column-major)
+                        // and the cell kernel forms [J r]ᵀ[J r] of the whole cell; -1: the item forms its own block
 };
 
 // A camera frame: residual blocks of one cell that also share the time stamp, hence the pose,
@@ -52,6 +54,9 @@ struct FrameItemDev {
 
 // All frames of one cell = (layout, segment): the cell kernel expands and sums their compact records
 // into one (c+1)×(c+1) partial block, which is what the gather sees.
+// A cell of IMU items (prim_off = -1) reuses the descriptor: frame_begin / frame_count count its work items, src_off is
+// the row store of the first one (contiguous, lds_cols × row_pad doubles each), PE the rows of a full item and pad0 the
+// rows of the whole cell.
 struct CellDev {
   int layout, seg, frame_begin, frame_count;
   int64_t partial_off;   // expanded (c+1)×(c+1) block of the cell
@@ -83,8 +88,10 @@ struct EvalArgs {
   const CellDev* cells;
   const int* prim_tab;   // per frame layout: prim column (row/col of M_ext) of every local column
   int cell_chunk, cell_rec_max;   // frames per LDS chunk of the cell kernel, largest compact record (doubles)
-  int project, pad4;     // prediction mode of the cost-only kernel: measurements read as 0, 1/sigma as -1 -> output = model
+  int project, row_cell_chunk;   // prediction mode of the cost-only kernel (measurements read as 0, 1/sigma as -1 -> output =
+                                 // model); work items per LDS pass of a row cell
   const uint8_t* active; // per observation (sorted order): 0 = tagged as outlier, left out; nullptr = all in
+  int frame_lds_doubles, pad5;   // LDS of a frame workgroup for the widest frame layout of the problem (0: worst case)
 };
 
 // LM state kept on the device; the control kernel is its only writer.
