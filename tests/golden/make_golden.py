@@ -26,12 +26,16 @@ CASES = {
     "kb_mono_imu_vn_robust": dict(n_cameras=1, camera_model=3, imu=True, imu_model=2, robust=True, outlier_fraction=0.03),
     "double_sphere_mono": dict(n_cameras=2, camera_model=4, imu=False),
     "eucm_free_chart": dict(n_cameras=2, camera_model=7, imu=False, free_chart_pose=True),
+    "opencv5_free_model_points": dict(n_cameras=2, camera_model=1, imu=True, imu_model=2, free_points=True),
 }
 
 
 def main():
     api = helpers.oracle_api()
+    only = sys.argv[1:]
     for name, kw in CASES.items():
+        if only and name not in only:
+            continue
         scene = syn.make_scene(cam_rate=5.0, imu_rate=25.0, duration=2.0, segment_duration=2.0 / 23.9, pixel_noise=0.1,
                                gyro_noise=1e-3, accel_noise=1e-2, seed=1234, max_cam_obs=400, **kw)
         built = syn.build_problem(api, scene)
@@ -49,7 +53,8 @@ def main():
         assert sm.termination_type == 0, (name, sm.message)  # fixtures must be converged solves
         est, ctrl = syn.read_back(built, scene)
         out.update(final_cost=sm.final_cost, termination_type=sm.termination_type, num_iterations=sm.num_iterations,
-                   ctrl_final=ctrl)
+                   ctrl_final=ctrl,
+                   points_final=np.stack([built.problem.get_param_block(int(b), 3) for b in built.point_blocks]))
         for i, e in enumerate(est):
             out["intr_final%d" % i] = e["intrinsics"]
             out["q_final%d" % i] = e["q"]

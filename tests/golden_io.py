@@ -11,7 +11,8 @@ _SENSOR_SCALARS = ["kind", "model", "latency", "latency_true", "enable_intrinsic
 def scene_to_dict(scene):
     d = dict(order=scene.order, knots=scene.knots, basis=scene.basis, ctrl=scene.ctrl, ctrl_true=scene.ctrl_true,
              points=scene.points, body_q=scene.body_q, body_t=scene.body_t, gravity=scene.gravity,
-             body_pose_constant=scene.body_pose_constant, n_sensors=len(scene.sensors))
+             body_pose_constant=scene.body_pose_constant, n_sensors=len(scene.sensors),
+             points_constant=np.broadcast_to(np.asarray(scene.points_constant, bool), (len(scene.points),)).copy())
     for i, s in enumerate(scene.sensors):
         for k in _SENSOR_ARRAYS:
             d["s%d_%s" % (i, k)] = np.asarray(getattr(s, k))
@@ -32,4 +33,5 @@ def scene_from_dict(d):
             float(sc["sigma"]), int(sc["loss"]), float(sc["loss_scale"]), d["s%d_meas" % i], d["s%d_stamps" % i],
             pidx.astype(np.int32) if len(pidx) else None))
     return syn.Scene(int(d["order"]), d["knots"], d["basis"], d["ctrl"].copy(), d["ctrl_true"], d["points"], d["body_q"],
-                     d["body_t"], d["gravity"], sensors, body_pose_constant=bool(d["body_pose_constant"]))
+                     d["body_t"], d["gravity"], sensors, body_pose_constant=bool(d["body_pose_constant"]),
+                     points_constant=d["points_constant"] if "points_constant" in d else True)

@@ -42,6 +42,9 @@ def _check(api, path, rtol_eval, rtol_solve):
         assert abs(e["latency"] - d["lat_final%d" % i][0]) <= rtol_solve * max(1e-3, abs(d["lat_final%d" % i][0]))
         assert np.array_equal(built.problem.inlier_mask(built.sensor_ids[i], scene.sensors[i].n, 3.0), d["mask_final%d" % i])
     assert np.abs(ctrl - d["ctrl_final"]).max() <= rtol_solve * max(1.0, np.abs(d["ctrl_final"]).max())
+    if "points_final" in d:   # free model points
+        pts = np.stack([built.problem.get_param_block(int(b), 3) for b in built.point_blocks])
+        assert np.abs(pts - d["points_final"]).max() <= rtol_solve * max(1.0, np.abs(d["points_final"]).max())
 
 
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
@@ -57,4 +60,4 @@ def test_hip_reproduces_golden(path, hip):
 
 
 def test_fixtures_present():
-    assert len(FIXTURES) >= 4
+    assert len(FIXTURES) >= 5
