@@ -111,6 +111,9 @@ struct LmState {
   int rcur;               // which of the two reduce buffers holds R(x) (speculative evaluation)
   int rfill;              // the reduce buffer the speculative evaluation of this iteration fills (= rcur ^ 1, latched by the update
                           // stage: the control stage may flip rcur while workgroups of the gather are still starting)
+  // partial sums of the update stage, one slot per band segment (the control stage adds them up in slot order)
+  double upd_mcc[2], upd_sn[2], upd_cn[2];
+  int upd_bad[2], upd_parts;
   int commit_pending;     // multi-rank speculative evaluation: the accepted candidate's buffer 1 is to be copied over buffer 0
 };
 

@@ -1299,8 +1299,12 @@ __global__ __launch_bounds__(256) void border_matvec_kernel(SolveArgs a) {
 
 // delta = -y ; candidate = Plus(x, delta) ; model cost change ; step norms.
 // (256 threads; called at the end of band_backsolve_kernel once the whole solution vector is in place)
+// `part` of `n_parts`: with two band segments each back-substitution workgroup updates the control points of its own
+// segment as soon as its sweep is done (part 0 also takes the separator and the calibration blocks, whose solution
+// comes from the reduced solve) and leaves its partial sums in LmState; the control stage adds them up. No
+// inter-workgroup synchronisation, hence no fences on the way.
 DEVI void update_body(const SolveArgs& a_in, const double* __restrict__ x, double* __restrict__ x_cand,
-                      const BlockDev* __restrict__ blocks, int n_blocks) {
+                      const BlockDev* __restrict__ blocks, int n_blocks, int part, int n_parts) {
   SolveArgs a = a_in;
   use_current_R(a);
   LmState* st = a.st;
@@ -1310,8 +1314,14 @@ DEVI void update_body(const SolveArgs& a_in, const double* __restrict__ x, doubl
   if (tid == 0) s_bad = 0;
   __syncthreads();
   const int NT = a.NT();
+  auto mine = [&](int tangent) {
+    if (n_parts == 1) return true;
+    const int owner = (tangent < a.n_s() && !a.in_sep(tangent) && tangent / 6 >= a.sep_s) ? 1 : 0;
+    return owner == part;
+  };
   double mcc = 0.0;
   for (int j = tid; j < NT; j += 256) {
+    if (!mine(j)) continue;
     const double yj = a.y[a.y_index(j)];   // the separator part of the solution sits behind the calibration part
     if (!isfinite(yj)) s_bad = 1;
     mcc += 0.5 * yj * (a.R[a.off_g() + j] + yj * a.dadd[j]);
@@ -1319,6 +1329,7 @@ DEVI void update_body(const SolveArgs& a_in, const double* __restrict__ x, doubl
   double sn = 0.0, cn = 0.0;
   for (int b = tid; b < n_blocks; b += 256) {
     const BlockDev B = blocks[b];
+    if (!mine(B.tan_off)) continue;
     const double* yb = a.y + a.y_index(B.tan_off);
     const double* p = x + B.amb_off;
     double* q = x_cand + B.amb_off;
@@ -1353,15 +1364,21 @@ DEVI void update_body(const SolveArgs& a_in, const double* __restrict__ x, doubl
     __syncthreads();
   }
   if (tid == 0) {
-    st->rfill = st->rcur ^ 1;
-    st->model_cost_change = s_a[0];
-    st->step_norm = sqrt(s_b[0]);
-    st->candidate_cost = 0.0;
-    st->cand_norm = sqrt(s_c[0]);
-    if (a.debug > 1) printf("update: model_cost_change %.6e  step_norm %.3e  non-finite %d  chol_failed %d\n", s_a[0], sqrt(s_b[0]), s_bad, st->chol_failed);
-    if (s_bad || st->chol_failed) { st->step_valid = 0; }
-    else st->step_valid = (s_a[0] > 0.0) ? 1 : 0;
+    st->upd_mcc[part] = s_a[0]; st->upd_sn[part] = s_b[0]; st->upd_cn[part] = s_c[0]; st->upd_bad[part] = s_bad;
+    if (part == 0) { st->rfill = st->rcur ^ 1; st->upd_parts = n_parts; }
   }
+}
+// The update stage's partial sums -> model cost change, norms and the validity of the step (control stage, one thread).
+DEVI void finish_update(LmState* st, int debug) {
+  double mcc = 0.0, sn = 0.0, cn = 0.0;
+  int bad = 0;
+  for (int p = 0; p < st->upd_parts; ++p) { mcc += st->upd_mcc[p]; sn += st->upd_sn[p]; cn += st->upd_cn[p]; bad |= st->upd_bad[p]; }
+  st->model_cost_change = mcc;
+  st->step_norm = sqrt(sn);
+  st->candidate_cost = 0.0;
+  st->cand_norm = sqrt(cn);
+  if (debug > 1) printf("update: model_cost_change %.6e  step_norm %.3e  non-finite %d  chol_failed %d\n", mcc, sqrt(sn), bad, st->chol_failed);
+  st->step_valid = (bad || st->chol_failed) ? 0 : (mcc > 0.0 ? 1 : 0);
 }
 
 // Blocked backward band sweep Lᵀ y_s = z by ONE wave, in axpy form (no reductions on the chain):
@@ -1381,25 +1398,12 @@ __global__ __launch_bounds__(256) void band_backsolve_kernel(SolveArgs a, const 
   if (st->terminated) return;
   if (threadIdx.x < 64) band_backsolve_wave<K>(a, blockIdx.x);
   __syncthreads();
-  if (a.n_seg() > 1) {
-    // the workgroup that finishes last has the whole solution vector in front of it and goes on to the update
-    __shared__ int s_last;
-    if (threadIdx.x == 0) {
-      __threadfence();
-      const int arrived = atomicAdd(a.sync_counters, 1);
-      s_last = arrived == a.n_seg() - 1;
-      if (s_last) atomicExch(a.sync_counters, 0);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-  }
-  update_body(a, x, x_cand, blocks, n_blocks);
+  update_body(a, x, x_cand, blocks, n_blocks, blockIdx.x, a.n_seg());
 }
 __global__ __launch_bounds__(256) void update_kernel(SolveArgs a, const double* __restrict__ x, double* __restrict__ x_cand,
                                                      const BlockDev* __restrict__ blocks, int n_blocks) {
   if (a.st->terminated) return;
-  update_body(a, x, x_cand, blocks, n_blocks);
+  update_body(a, x, x_cand, blocks, n_blocks, 0, 1);
 }
 
 template <int K>
@@ -1531,6 +1535,7 @@ DEVI void control_body(LmState* st, const LmOptionsDev& o, double* R2, double* x
   }
   if (tid == 0) {
     s_accept = 0;
+    finish_update(st, 0);
     const double cand_norm = st->cand_norm;
     st->n_cost_evals += 1;
     st->iteration += 1;
