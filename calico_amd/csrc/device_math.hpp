@@ -90,8 +90,14 @@ DEV Q4 angle_axis_to_quat(V3 a) {
   if (t2 > 0.0) {
     const double t = sqrt(t2);
     const double h = 0.5 * t;
-    const double k = sin(h) / t;
-    q.w = cos(h); q.x = a.x * k; q.y = a.y * k; q.z = a.z * k;
+    double sh, ch;
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos(h, &sh, &ch);
+#else
+    sh = sin(h); ch = cos(h);
+#endif
+    const double k = sh / t;
+    q.w = ch; q.x = a.x * k; q.y = a.y * k; q.z = a.z * k;
   } else {
     q.w = 1.0; q.x = 0.5 * a.x; q.y = 0.5 * a.y; q.z = 0.5 * a.z;
   }
@@ -118,6 +124,21 @@ DEV D3 dcos(D3 a) { D3 r; r.v = cos(a.v); const double s = -sin(a.v); r.d0 = a.d
 DEV double dsqrt(double a) { return sqrt(a); }
 DEV double dsin(double a) { return sin(a); }
 DEV double dcos(double a) { return cos(a); }
+// sine and cosine of one angle share the argument reduction (on the device a double-precision sin or cos is some
+// 150 instructions, and the IMU blocks sit on a single-lane latency chain)
+DEV void dsincos(double a, double* s, double* c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincos(a, s, c);
+#else
+  *s = sin(a); *c = cos(a);
+#endif
+}
+DEV void dsincos(D3 a, D3* s, D3* c) {
+  double sv, cv;
+  dsincos(a.v, &sv, &cv);
+  s->v = sv; s->d0 = a.d0 * cv; s->d1 = a.d1 * cv; s->d2 = a.d2 * cv;
+  c->v = cv; c->d0 = -a.d0 * sv; c->d1 = -a.d1 * sv; c->d2 = -a.d2 * sv;
+}
 DEV double val(double a) { return a; }
 DEV double val(D3 a) { return a.v; }
 template <class T> DEV T lit(double v);
@@ -157,7 +178,7 @@ template <class T> DEV Rodrigues<T> rodrigues(T px, T py, T pz, bool want_hessia
   const T th = dsqrt(t2);
   T st, ct;
   if (val(th) < 1e-7) { st = small_sin(th); ct = small_cos(th); }
-  else { st = dsin(th); ct = dcos(th); }
+  else { dsincos(th, &st, &ct); }
   const T it = lit<T>(1.0) / th;
   R.hx = it * px; R.hy = it * py; R.hz = it * pz;
   R.a = it * (lit<T>(1.0) - ct);
@@ -172,6 +193,13 @@ template <class T> DEV Rodrigues<T> rodrigues(T px, T py, T pz, bool want_hessia
     R.c0 = R.c1 = R.c2 = R.c3 = lit<T>(0.0);
   }
   return R;
+}
+// the plain-double coefficients of a dual evaluation (same phi): saves recomputing the trigonometry
+DEV Rodrigues<double> rod_value(const Rodrigues<D3>& R) {
+  Rodrigues<double> r;
+  r.hx = R.hx.v; r.hy = R.hy.v; r.hz = R.hz.v; r.a = R.a.v; r.b = R.b.v;
+  r.c0 = R.c0.v; r.c1 = R.c1.v; r.c2 = R.c2.v; r.c3 = R.c3.v; r.zero = R.zero;
+  return r;
 }
 // y = J(phi)·v, with K·v = h×v.
 template <class T> DEV void rod_J_apply(const Rodrigues<T>& R, T vx, T vy, T vz, T* ox, T* oy, T* oz) {

@@ -207,10 +207,11 @@ DEV bool camera_dispatch(const ItemCtx& c, double px, double py, double stamp, c
 // IMU kinematics shared by the gyroscope and accelerometer blocks.
 // ---------------------------------------------------------------------------
 // omega = J(phi)·phid and W = d omega / d phi (via D3 over phi).
-DEV void omega_and_dphi(V3 phi, V3 phid, V3* omega, double Wm[3][3]) {
+DEV void omega_and_dphi(V3 phi, V3 phid, V3* omega, double Wm[3][3], Rodrigues<double>* Rv) {
   D3 px = mkd(phi.x), py = mkd(phi.y), pz = mkd(phi.z);
   px.d0 = 1.0; py.d1 = 1.0; pz.d2 = 1.0;
   const Rodrigues<D3> R = rodrigues<D3>(px, py, pz, false);
+  *Rv = rod_value(R);
   D3 ox, oy, oz;
   rod_J_apply<D3>(R, mkd(phid.x), mkd(phid.y), mkd(phid.z), &ox, &oy, &oz);
   *omega = mk(ox.v, oy.v, oz.v);
@@ -238,8 +239,9 @@ DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], cons
   double Wm[3][3];
   M3 Jl;
   if constexpr (JAC) {
-    omega_and_dphi(phi, phid, &omega, Wm);
-    Jl = rod_J_matrix(rodrigues<double>(phi.x, phi.y, phi.z, false));
+    Rodrigues<double> Rv;
+    omega_and_dphi(phi, phid, &omega, Wm, &Rv);
+    Jl = rod_J_matrix(Rv);
   } else {
     const Rodrigues<double> R = rodrigues<double>(phi.x, phi.y, phi.z, false);
     rod_J_apply<double>(R, phid.x, phid.y, phid.z, &omega.x, &omega.y, &omega.z);
@@ -348,10 +350,13 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
   const M3 R_rw = rotmat(angle_axis_to_quat(phi));
   V3 omega, alpha;
   double dw_dphi[3][3], da_dphi[3][3];
+  Rodrigues<double> Rd;   // the coefficients at phi as plain doubles (Jacobian path)
+  Rd.zero = true;
   if constexpr (JAC) {
     D3 px = mkd(phi.x), py = mkd(phi.y), pz = mkd(phi.z);
     px.d0 = 1.0; py.d1 = 1.0; pz.d2 = 1.0;
     const Rodrigues<D3> R = rodrigues<D3>(px, py, pz, true);
+    Rd = rod_value(R);
     D3 o[3], jdd[3], Hv[3][3];
     rod_J_apply<D3>(R, mkd(phid.x), mkd(phid.y), mkd(phid.z), &o[0], &o[1], &o[2]);
     rod_J_apply<D3>(R, mkd(phidd.x), mkd(phidd.y), mkd(phidd.z), &jdd[0], &jdd[1], &jdd[2]);
@@ -407,7 +412,6 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
       for (int j = 0; j < 3; ++j)
         dbdw[i][j] = (i == j ? ot : 0.0) + comp(omega, i) * comp(t, j) - 2.0 * comp(t, i) * comp(omega, j);
     // explicit Hessian slices for d alpha / d phid:  H[i][j][l] = (H_i e_l)_j
-    const Rodrigues<double> Rd = rodrigues<double>(phi.x, phi.y, phi.z, true);
     const M3 Jl = rod_J_matrix(Rd);
     double Hm[3][3][3];
 #pragma unroll

@@ -28,3 +28,10 @@ cus = collections.Counter((k[0], k[1], k[2]) for k in slot.elements())
 print("distinct CUs used", len(cus), "max waves per CU", max(cus.values()), "hist", sorted(collections.Counter(cus.values()).items()))
 late = sorted(L.values(), key=lambda r: -r[3])[:12]
 for r in late: print("  late:", r[0], r[1], "start %.1f end %.1f" % ((r[2]-t00)/100.0, (r[3]-t00)/100.0), "simd-mates", slot[(r[5]&0xf, (r[4]>>13)&7, (r[4]>>8)&15, (r[4]>>4)&3)])
+import collections as _c
+h = _c.Counter(round((r[2] - t00) / 100.0) for r in L.values())
+print("start-time histogram (us: waves):", sorted(h.items()))
+hi = _c.Counter(round((r[2] - t00) / 100.0) for r in L.values() if r[1] == "item")
+print("items only:", sorted(hi.items()))
+late_xcc = _c.Counter((r[5] & 0xf) for r in L.values() if (r[2] - t00) / 100.0 > 4)
+print("late starters per XCC:", sorted(late_xcc.items()))
