@@ -928,12 +928,15 @@ DEVI void update_tile(double* A, int LD, int m, int I, int c, int q0, int q1, in
 // (left-looking) instead of once per panel. Row m is the right-hand side, so the forward substitution comes for free.
 // Backward substitution by blocks of 16: an in-wave chain for the diagonal block, a parallel matrix-vector product
 // for the rest (see below).
+// `t0`, `nsl`: the kernel factors the trailing matrix from row/column t0 on (the blocked path hands over the last
+// <= 128 rows once its panels have been eliminated; t0 = 0 otherwise) and adds up `nsl` K-slices on load.
 template <int RPL>
-__global__ __launch_bounds__(256) void reduced_solve_panel_kernel(SolveArgs a) {
+__global__ __launch_bounds__(256) void reduced_solve_panel_kernel(SolveArgs a, int t0, int nsl) {
   LmState* st = a.st;
   if (st->terminated) return;
   extern __shared__ double lds[];
-  const int m = a.m, m1 = a.m + 1, n = a.n_s();
+  const int M1 = a.m + 1;                        // row stride of the matrix in global memory
+  const int m = a.m - t0, m1 = m + 1, n = a.n_s() + t0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nblk = (m + 15) >> 4;
   const int LD = (16 * ((m1 + 15) / 16)) | 1;   // every 16-column panel stays inside its row
@@ -947,7 +950,8 @@ __global__ __launch_bounds__(256) void reduced_solve_panel_kernel(SolveArgs a) {
   // per pass with every load of the pass issued before the first LDS store (a single workgroup pulls this matrix in,
   // so it is the number of loads in flight that matters)
   {
-    const size_t mm = size_t(m1) * m1;
+    const size_t mm = size_t(M1) * M1;
+    const double* src0 = a.Spart + size_t(t0) * M1 + t0;
     for (int r0 = wave; r0 < m1; r0 += 16) {
       double v[4][2];
 #pragma unroll
@@ -958,7 +962,7 @@ __global__ __launch_bounds__(256) void reduced_solve_panel_kernel(SolveArgs a) {
           const int c = min(lane + 64 * h, r);
           double acc = 0.0;
 #pragma unroll
-          for (int k = 0; k < kSchurSlices; ++k) acc += a.Spart[size_t(k) * mm + size_t(r) * m1 + c];
+          for (int k = 0; k < kSchurSlices; ++k) acc += k < nsl ? src0[size_t(k) * mm + size_t(r) * M1 + c] : 0.0;
           v[u][h] = acc;
         }
       }
@@ -1223,7 +1227,9 @@ __global__ __launch_bounds__(256) void reduced_block_step_kernel(SolveArgs a, in
 // lane, the solved unknown travelling by v_readlane), then every thread adds the panel's contribution to the
 // pending sums of the columns it owns (column c belongs to thread c mod 256).
 constexpr int kRBCols = 4;   // columns per thread: m <= 1024
-__global__ __launch_bounds__(256) void reduced_block_back_kernel(SolveArgs a) {
+// `np`: panels eliminated by the step kernels; the unknowns from kRB·np on were solved by the in-LDS kernel and enter
+// the pending sums first.
+__global__ __launch_bounds__(256) void reduced_block_back_kernel(SolveArgs a, int np) {
   LmState* st = a.st;
   if (st->terminated) return;
   __shared__ double sy[2][kRB];
@@ -1231,7 +1237,25 @@ __global__ __launch_bounds__(256) void reduced_block_back_kernel(SolveArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const double* L = a.Swork;
   double acc[kRBCols] = {};
-  const int np = (m + kRB - 1) / kRB;
+  for (int i0 = kRB * np; i0 < m; i0 += kRB) {
+    __syncthreads();
+    if (tid < kRB) sy[0][tid] = i0 + tid < m ? a.y[n + i0 + tid] : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kRBCols; ++u) {
+      const int col = tid + 256 * u;
+      if (col < kRB * np) {
+        double t[kRB];
+#pragma unroll
+        for (int i = 0; i < kRB; ++i) t[i] = L[size_t(min(i0 + i, m - 1)) * m1 + col];
+        double sacc = 0.0;
+#pragma unroll
+        for (int i = 0; i < kRB; ++i) sacc += t[i] * sy[0][i];
+        acc[u] += sacc;
+      }
+    }
+  }
+  __syncthreads();
   for (int jb = np - 1; jb >= 0; --jb) {
     const int c0 = kRB * jb;
     double* ybuf = sy[jb & 1];
@@ -1680,15 +1704,20 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
   hipLaunchKernelGGL(schur_kernel, dim3(nt * (nt + 1) / 2 * ks), dim3(256), 0, s, a, ks);
   if (m1 <= 128) {
     const size_t lds = (size_t(m1) * ((16 * ((m1 + 15) / 16)) | 1) + m1 + 32 + 128 + 256) * sizeof(double);
-    if (m1 <= 64) hipLaunchKernelGGL(reduced_solve_panel_kernel<1>, dim3(1), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(reduced_solve_panel_kernel<2>, dim3(1), dim3(256), lds, s, a);
+    if (m1 <= 64) hipLaunchKernelGGL(reduced_solve_panel_kernel<1>, dim3(1), dim3(256), lds, s, a, 0, ks);
+    else hipLaunchKernelGGL(reduced_solve_panel_kernel<2>, dim3(1), dim3(256), lds, s, a, 0, ks);
   } else if (blocked) {
-    const int steps = (a.m + kRB - 1) / kRB;
+    // panels are eliminated over all CUs until what is left fits the in-LDS solver, which finishes the factorisation
+    // and solves for its unknowns; the blocked backward sweep takes it from there
+    const int steps = (m1 - 128 + kRB - 1) / kRB, t0 = kRB * steps, mt1 = m1 - t0;
     for (int j = 0; j < steps; ++j) {
       const int rows = m1 - kRB * (j + 1), T = rows > 0 ? (rows + 63) / 64 : 0;
       hipLaunchKernelGGL(reduced_block_step_kernel, dim3(T > 0 ? T * (T + 1) / 2 : 1), dim3(256), 0, s, a, j, j == 0 ? ks : 1);
     }
-    hipLaunchKernelGGL(reduced_block_back_kernel, dim3(1), dim3(256), 0, s, a);
+    const size_t lds = (size_t(mt1) * ((16 * ((mt1 + 15) / 16)) | 1) + mt1 + 32 + 128 + 256) * sizeof(double);
+    if (mt1 <= 64) hipLaunchKernelGGL(reduced_solve_panel_kernel<1>, dim3(1), dim3(256), lds, s, a, t0, 1);
+    else hipLaunchKernelGGL(reduced_solve_panel_kernel<2>, dim3(1), dim3(256), lds, s, a, t0, 1);
+    hipLaunchKernelGGL(reduced_block_back_kernel, dim3(1), dim3(256), 0, s, a, steps);
   } else if (m1 <= 16 * 13) {
     const int NT = m1 <= 64 ? 4 : (m1 <= 112 ? 7 : (m1 <= 160 ? 10 : 13));
     const int NP = 16 * NT;
