@@ -248,7 +248,7 @@ def main():
                 "cost_evaluations": cost,
                 "residual_blocks_evaluated_per_s": n_blocks * (jac + cost) / elapsed,
                 "parallelism": "obs-shard x%d + all-reduce(JtJ,Jtr,cost)" % world if world > 1 else "single GPU",
-                "sync_every": args.sync_every,
+                "host_loop": "non-blocking: device-published progress, two iterations enqueued ahead" if world == 1 and not args.force_collective else "batches of %d iterations per host read-back" % args.sync_every,
                 "phase_ms_per_launch_warmup": {
                     "jacobian_eval": wu_ms[0] / max(1, wu_n[0]),
                     "gather": wu_ms[1] / max(1, wu_n[1]),

@@ -962,7 +962,8 @@ __global__ __launch_bounds__(256) void reduced_solve_panel_kernel(SolveArgs a, i
           const int c = min(lane + 64 * h, r);
           double acc = 0.0;
 #pragma unroll
-          for (int k = 0; k < kSchurSlices; ++k) acc += k < nsl ? src0[size_t(k) * mm + size_t(r) * M1 + c] : 0.0;
+          for (int k = 0; k < kSchurSlices; ++k)   // unconditional loads (a predicated load becomes a branch): slice index clamped, masked
+            acc += src0[size_t(min(k, nsl - 1)) * mm + size_t(r) * M1 + c] * (k < nsl ? 1.0 : 0.0);
           v[u][h] = acc;
         }
       }
