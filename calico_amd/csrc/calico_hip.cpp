@@ -608,7 +608,8 @@ int finalize(calico_problem* p) {
   // row store of the items that leave [J r]ᵀ[J r] to the cell kernel: behind the compact frame records
   size_t row_store = 0;
   {
-    const size_t stride = size_t(p->lds_cols) * p->row_pad;
+    const size_t stride = (size_t(p->lds_cols) * p->row_pad + 1) & ~size_t(1);   // even: the rows travel as 16-byte words
+    row_store = (comp_base + comp_off) & 1;                                      // ... from an even offset
     for (size_t i = 0; i < p->h_jac_items.size(); ++i) {
       ItemDev& it = p->h_jac_items[i];
       if (it.rows_off < 0) continue;

@@ -654,9 +654,17 @@ DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds) {
     if (it.rows_off >= 0) {
       // the rows go to the cell kernel, which forms [J r]ᵀ[J r] for all work items of the cell at once with four
       // waves: on the long single-lane chain of an IMU block this wave would spend another quarter of its time here
-      double* dst = a.partials + it.rows_off;
-      const int nw = n1 * row_pad;
-      for (int i = lane; i < nw; i += 64) dst[i] = lds[i];
+      double* dst = a.partials + it.rows_off;                  // 16-byte aligned (host)
+      const int nw2 = (n1 * row_pad + 1) >> 1;                 // in double2 words; the staging area is at least that long
+      const double2* s2 = reinterpret_cast<const double2*>(lds);
+      double2* d2 = reinterpret_cast<double2*>(dst);
+      for (int i = lane; i < nw2; i += 256) {                  // four 16-byte copies in flight per lane
+        double2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = s2[min(i + 64 * u, nw2 - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i + 64 * u < nw2) d2[i + 64 * u] = v[u];
+      }
       ITICK(2)
       if (dbg) printf("eval_items cycles (kind %d, %d obs, %d cols, pad %d): setup+zero %lld  stage A %lld  rows out %lld\n", S.kind, it.obs_count, ncols, row_pad, tph[0], tph[1], tph[2]);
       return;
@@ -1017,7 +1025,7 @@ DEV void row_cell_body(const EvalArgs& a, const CellDev& cell, double* lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc16 = lane & 15, lk = lane >> 4;
   const int n1 = cell.n1, NT = (n1 + 15) >> 4, ntile = NT * (NT + 1) / 2;
-  const int pad = a.row_pad, stride = a.lds_cols * a.row_pad, words = n1 * pad;
+  const int pad = a.row_pad, stride = (a.lds_cols * a.row_pad + 1) & ~1, words = n1 * pad;   // stride: see finalize (even)
   // tiles t = wave, wave + 4, ...: (I, J), I <= J, in row-major order of the upper triangle
   int tI[MAXT], tJ[MAXT];
   f64x4 acc[MAXT];
