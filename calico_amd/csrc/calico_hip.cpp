@@ -733,7 +733,7 @@ int finalize(calico_problem* p) {
     p->h_xpin_n = size_t(p->n_amb);
   }
   if (!p->h_progress) {
-    HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_progress), 64, hipHostMallocMapped));
+    HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_progress), 64, hipHostMallocMapped | hipHostMallocCoherent));   // fine-grained: the host polls it while kernels run
     HIP_TRY(p, hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_progress), p->h_progress, 0));
   }
   // kernel attributes
