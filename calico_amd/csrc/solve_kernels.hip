@@ -620,45 +620,52 @@ constexpr int kSchurSlices = 4;   // K-slices when the in-LDS panel solver consu
 __global__ __launch_bounds__(256) void schur_kernel(SolveArgs a, int ks) {
   const LmState* st = a.st;
   if (st->terminated) return;
-  __shared__ double sA[64][17], sB[64][17];
+  // One 16×16 tile of YᵀY per workgroup and K-slice, on the matrix cores straight from global memory: lane l holds
+  // Y[row k0 + (l >> 4)][16·t + (l & 15)], which is operand A of tile row t and operand B of tile column t of
+  // v_mfma_f64_16x16x4_f64 -- coalesced 128-byte row segments, no LDS staging (the scalar version was bound by two
+  // LDS reads per FMA). The four waves split the slice's rows and meet in LDS; fixed summation order.
+  __shared__ double sacc[4][256];
   const int m1 = a.m + 1, n = a.n_s();
   const int tile = blockIdx.x / ks, slice = blockIdx.x % ks;
   int tr = 0, rem = tile;
   while (rem > tr) { rem -= tr + 1; ++tr; }
   const int tc = rem;
-  const int ti = threadIdx.x / 16, tj = threadIdx.x % 16;
-  // rows [r_begin, r_end) of this slice, in 64-row chunks
-  const int rows_per = ((n + ks - 1) / ks + 63) & ~63;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc16 = lane & 15, lk = lane >> 4;
+  const int rows_per = ((n + ks - 1) / ks + 15) & ~15;
   const int r_begin = slice * rows_per, r_end = min(n, r_begin + rows_per);
-  // each thread stages 4 rows × (A,B) per chunk: rows ti, ti+16, ti+32, ti+48 ; column tj (loads unconditional on
-  // clamped indices, masked afterwards)
-  const int ca = tr * 16 + tj, cb = tc * 16 + tj;
-  const int cac = min(ca, m1 - 1), cbc = min(cb, m1 - 1);
-  double pa[4], pb[4];
-  auto fetch = [&](int q) {
+  const int per_wave = (((r_end - r_begin + 3) / 4 + 3) / 4) * 4;     // rows of one wave, a multiple of 4
+  const int w_begin = r_begin + wave * per_wave, w_end = min(r_end, w_begin + per_wave);
+  const int ca = 16 * tr + lc16, cb = 16 * tc + lc16;
+  const double ma = ca < m1 ? 1.0 : 0.0, mb = cb < m1 ? 1.0 : 0.0;
+  const double* pa = a.Y + min(ca, m1 - 1);
+  const double* pb = a.Y + min(cb, m1 - 1);
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = w_begin; k0 < w_end; k0 += 32) {      // eight k-steps of loads in flight
+    double va[8], vb[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int row = q + ti + 16 * u;
+    for (int u = 0; u < 8; ++u) {
+      const int row = k0 + 4 * u + lk;
       const size_t ro = size_t(min(row, n - 1)) * m1;
-      const double va = a.Y[ro + cac], vb = a.Y[ro + cbc];
-      pa[u] = (row < r_end && ca < m1) ? va : 0.0;
-      pb[u] = (row < r_end && cb < m1) ? vb : 0.0;
+      va[u] = pa[ro]; vb[u] = pb[ro];
     }
-  };
-  double acc = 0.0;
-  fetch(r_begin);
-  for (int q = r_begin; q < r_end; q += 64) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { sA[ti + 16 * u][tj] = pa[u]; sB[ti + 16 * u][tj] = pb[u]; }
-    __syncthreads();
-    if (q + 64 < r_end) fetch(q + 64);
-#pragma unroll 16
-    for (int rr = 0; rr < 64; ++rr) acc += sA[rr][ti] * sB[rr][tj];
-    __syncthreads();
+    for (int u = 0; u < 8; ++u) {
+      const double rm = k0 + 4 * u + lk < w_end ? 1.0 : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u] * (ma * rm), vb[u] * mb, acc, 0, 0, 0);
+    }
   }
-  const int r = tr * 16 + ti, c = tc * 16 + tj;
-  if (r < m1 && c < m1 && c <= r)
-    a.Spart[size_t(slice) * m1 * m1 + size_t(r) * m1 + c] = (slice == 0 ? a.S[size_t(r) * m1 + c] : 0.0) - acc;
+  // C/D layout: col = lane & 15, row = (lane >> 4) + 4·reg
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sacc[wave][(lk + 4 * r) * 16 + lc16] = acc[r];
+  __syncthreads();
+  {
+    const int ti = tid >> 4, tj = tid & 15;
+    const int r = tr * 16 + ti, c = tc * 16 + tj;
+    const double sum = ((sacc[0][tid] + sacc[1][tid]) + sacc[2][tid]) + sacc[3][tid];
+    if (r < m1 && c < m1 && c <= r)
+      a.Spart[size_t(slice) * m1 * m1 + size_t(r) * m1 + c] = (slice == 0 ? a.S[size_t(r) * m1 + c] : 0.0) - sum;
+  }
 }
 
 // Dense Cholesky of the reduced system (right-hand side carried as row m) and
