@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
 }
 
 // Sred = S - YᵀY, one 16×16 lower tile per workgroup, 64-row chunks staged in LDS with register prefetch.
-constexpr int kSchurSlices = 4;   // K-slices when the in-LDS panel solver consumes the result (it sums them on load)
+constexpr int kSchurSlices = 2;   // K-slices when the in-LDS panel solver consumes the result (it sums them on load)
 // `ks` workgroups share the rows (K dimension) of every tile: slice k writes its partial S/ks-th into
 // Spart + k·(m+1)² (slice 0 carries S itself), and the consumer adds the slices up when it loads the matrix.
 __global__ __launch_bounds__(256) void schur_kernel(SolveArgs a, int ks) {
