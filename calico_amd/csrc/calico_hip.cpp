@@ -557,6 +557,7 @@ int finalize(calico_problem* p) {
       const int p_r = pc, PT = (pc + 1 + 15) & ~15;
       if (tab_off[size_t(c.layout)] < 0) {
         tab_off[size_t(c.layout)] = int(prim_tab.size());
+        std::vector<int> prim;
         for (int lc = 0; lc <= L.ncols; ++lc) {
           int pr;
           if (lc < 36) pr = lc % 6;
@@ -567,8 +568,12 @@ int finalize(calico_problem* p) {
           else if (L.c_t >= 0 && lc >= L.c_t && lc < L.c_t + 3) pr = p_t + (lc - L.c_t);
           else if (L.c_bq >= 0 && lc >= L.c_bq && lc < L.c_bq + 3) pr = p_bq + (lc - L.c_bq);
           else pr = p_bt + (lc - L.c_bt);
-          prim_tab.push_back(pr);
+          prim.push_back(pr);
         }
+        // pair table of the cell kernel: row-major upper triangle of the (c+1)×(c+1) block
+        const int n1 = L.ncols + 1, PEc = PT + 1;
+        for (int i = 0; i < n1; ++i)
+          for (int j = i; j < n1; ++j) prim_tab.push_back(i | (j << 8) | ((prim[size_t(i)] * PEc + prim[size_t(j)]) << 16));
       }
       c.prim_off = tab_off[size_t(c.layout)]; c.pad0 = 0;
       c.n1 = L.ncols + 1; c.PE = PT + 1;

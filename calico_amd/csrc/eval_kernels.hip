@@ -1107,27 +1107,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
 #define CTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   const int n1 = cell.n1, PE = cell.PE, nme = PE * PE, rec = nme + n1;
   const int n_pairs = n1 * (n1 + 1) / 2;
-  const int* __restrict__ prim = a.prim_tab + cell.prim_off;
+  // per-layout pair table (host): entry t of the row-major upper triangle = i | j << 8 | (prim_i·PE + prim_j) << 16.
+  // One coalesced load per pair, all issued together (decoding the pairs in the kernel took data-dependent loops and
+  // two more dependent table loads).
+  const int* __restrict__ ptab = a.prim_tab + cell.prim_off;
   constexpr int NQ = 12;             // pairs per thread: n1 <= 77
   int pi[NQ], pj[NQ], pm_off[NQ];
   double acc[NQ];
   {
-    // pair decoding first (pure ALU, data-dependent loops), THEN all table loads together: interleaved, every pair's
-    // two loads would wait behind the previous pair's
-    int ei = 0, eoff = tid, elen = n1;
-    while (eoff >= elen && elen > 0) { eoff -= elen; ++ei; --elen; }
+    int e[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      pi[q] = ei < n1 ? ei : n1 - 1; pj[q] = ei < n1 ? ei + eoff : n1 - 1;
-      acc[q] = 0.0;
-      eoff += 256;
-      while (eoff >= elen && elen > 0) { eoff -= elen; ++ei; --elen; }
-    }
-    int ti[NQ], tj[NQ];
+    for (int q = 0; q < NQ; ++q) e[q] = ptab[min(tid + 256 * q, n_pairs - 1)];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { ti[q] = prim[pi[q]]; tj[q] = prim[pj[q]]; }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) pm_off[q] = ti[q] * PE + tj[q];
+    for (int q = 0; q < NQ; ++q) { pi[q] = e[q] & 255; pj[q] = (e[q] >> 8) & 255; pm_off[q] = e[q] >> 16; acc[q] = 0.0; }
   }
   CTICK(0)
   const double* cell_src = a.partials + cell.src_off;
