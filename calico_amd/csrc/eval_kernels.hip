@@ -1049,13 +1049,13 @@ DEV void row_cell_body(const EvalArgs& a, const CellDev& cell, double* lds) {
     RTICK(0)
     for (int it = 0; it < ni; ++it) {
       const double* s = src + size_t(i0 + it) * stride;
-      // eight loads in flight per thread: a load-store loop waits out the full memory latency on every trip
-      for (int b = tid; b < words; b += 256 * 8) {
-        double v[8];
+      // sixteen loads in flight per thread: a load-store loop waits out the full memory latency on every trip
+      for (int b = tid; b < words; b += 256 * 16) {
+        double v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = s[min(b + 256 * u, words - 1)];
+        for (int u = 0; u < 16; ++u) v[u] = s[min(b + 256 * u, words - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (b + 256 * u < words) lds[it * words + b + 256 * u] = v[u];
+        for (int u = 0; u < 16; ++u) if (b + 256 * u < words) lds[it * words + b + 256 * u] = v[u];
       }
     }
     __syncthreads();
