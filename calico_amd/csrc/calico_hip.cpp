@@ -196,7 +196,6 @@ struct calico_problem {
   DevBuf<int64_t> d_ptr_thin, d_ptr_fat;
   DevBuf<uint8_t> d_cp_active, d_valid, d_active;
   DevBuf<int> d_counter;
-  DevBuf<int> d_sync;
   int gather_owner_block = 0;
   bool active_dirty = true;
   bool xc_stale = true;       // the candidate buffer must be re-seeded with the constant blocks' values
@@ -253,7 +252,6 @@ SolveArgs make_solve_args(calico_problem* p) {
   static const int dbg = std::getenv("CALICO_KERNEL_TIMING") ? std::atoi(std::getenv("CALICO_KERNEL_TIMING")) : 0;
   a.debug = dbg;
   a.progress = nullptr;
-  a.sync_counters = p->d_sync.p;
   return a;
 }
 
@@ -629,7 +627,7 @@ int finalize(calico_problem* p) {
     p->row_cell_chunk = std::min(p->row_cell_chunk, most);
   }
   // ---- gather lists ----
-  SolveArgs sa; sa.n_cp = n_cp; sa.k = k; sa.mc = m; sa.sep_s = p->sep_s; sa.sep_n = p->sep_n; sa.m = m + 6 * p->sep_n; sa.debug = 0; sa.progress = nullptr; sa.sync_counters = nullptr;
+  SolveArgs sa; sa.n_cp = n_cp; sa.k = k; sa.mc = m; sa.sep_s = p->sep_s; sa.sep_n = p->sep_n; sa.m = m + 6 * p->sep_n; sa.debug = 0; sa.progress = nullptr;
   const size_t r_size = sa.r_size();
   if (r_size >= size_t(0x7fffffff)) return p->set_error(CALICO_UNIMPLEMENTED, "normal-equation buffer too large");
   struct Pair { int dst, src; };
@@ -726,7 +724,6 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_y.alloc(size_t(NT) + 6 * p->sep_n)); HIP_TRY(p, p->d_zbuf.alloc(size_t(NS) + 64)); HIP_TRY(p, p->d_dadd.alloc(NT)); HIP_TRY(p, p->d_scale.alloc(NT));
   HIP_TRY(p, p->d_res.alloc(size_t(n_obs) * 3)); HIP_TRY(p, p->d_valid.alloc(size_t(n_obs)));
   HIP_TRY(p, p->d_active.alloc(size_t(n_obs))); HIP_TRY(p, p->d_counter.alloc(1));
-  HIP_TRY(p, p->d_sync.alloc(4)); HIP_TRY(p, hipMemsetAsync(p->d_sync.p, 0, 4 * sizeof(int), s));
   p->active_dirty = true; p->xc_stale = true;
   HIP_TRY(p, p->d_state.alloc(1)); HIP_TRY(p, p->d_log.alloc(kLogCap));
   if (!p->h_state) HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LmState)));

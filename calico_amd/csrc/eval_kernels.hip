@@ -1190,8 +1190,6 @@ void launch_eval_jacobian(const EvalArgs& a, hipStream_t stream) {
   if (a.n_items + a.n_fitems == 0) return;
   size_t lds = size_t(a.lds_cols) * a.row_pad * sizeof(double);
   if (a.n_fitems > 0 && lds < frame_launch_bytes(a)) lds = frame_launch_bytes(a);
-  static const size_t lds_floor = [] { const char* e = std::getenv("CALICO_EVAL_LDS_KB"); return e ? size_t(std::atoi(e)) * 1024 : size_t(0); }();
-  if (lds < lds_floor) lds = lds_floor;
   hipLaunchKernelGGL(eval_jacobian_kernel, dim3(a.n_items + a.n_fitems), dim3(64), lds, stream, a);
 }
 

@@ -181,7 +181,6 @@ struct SolveArgs {
   // host-mapped progress words, or nullptr: [0] = sequence number of the last LM iteration the control kernel has
   // finished with, [1] = LmState.terminated. The host polls them instead of synchronising (single-rank solve loop).
   int* progress;
-  int* sync_counters;     // [4] zero-initialised, self-resetting arrival counters of the kernels that end with a last-workgroup stage
   CAL_HD int n_s() const { return 6 * n_cp; }
   CAL_HD int W() const { return 6 * k; }
   CAL_HD int NT() const { return 6 * n_cp + mc; }

@@ -843,7 +843,7 @@ __global__ __launch_bounds__(256) void reduced_solve_reg_kernel(SolveArgs a) {
 // are applied one step later, as wave-uniform 16-byte reads, filling the next chain's latency. One wave issues a
 // VALU instruction every 4+ clocks, so the count matters: v_readlane costs two instructions (plus two copies, or an
 // SGPR spill) per multiplier and use, the LDS broadcast half an instruction. A bad pivot is not patched: it turns
-// the factor into NaN (caught by update_kernel) and is reported through the running minimum *pmin.
+// the factor into NaN (caught by the update stage) and is reported through the running minimum *pmin.
 template <int R>
 DEVI void panel_factor(double* A, int LD, double* dinv, double* bcast, int j0, int m, int w, int lane, double* pmin) {
   double av[R][16];
@@ -1431,11 +1431,6 @@ __global__ __launch_bounds__(256) void band_backsolve_kernel(SolveArgs a, const 
   if (threadIdx.x < 64) band_backsolve_wave<K>(a, blockIdx.x);
   __syncthreads();
   update_body(a, x, x_cand, blocks, n_blocks, blockIdx.x, a.n_seg());
-}
-__global__ __launch_bounds__(256) void update_kernel(SolveArgs a, const double* __restrict__ x, double* __restrict__ x_cand,
-                                                     const BlockDev* __restrict__ blocks, int n_blocks) {
-  if (a.st->terminated) return;
-  update_body(a, x, x_cand, blocks, n_blocks, 0, 1);
 }
 
 template <int K>
