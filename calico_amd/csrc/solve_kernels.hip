@@ -322,22 +322,27 @@ constexpr int kSlotPad = 16;     // per ring slot: zero words [0, 8), dump words
 
 // Cholesky of a 6×6 block (lower, row-major 36) in every lane: L and the reciprocal diagonal. A non-positive or
 // non-finite pivot is not patched: it turns the factor into NaN/Inf and is reported through *dmin / the caller.
+// Right-looking: column j is scaled and the trailing triangle updated at once, so that the next pivot is ready one
+// FMA after its multiplier -- the dependency chain per column is rsqrt + mul + fma instead of two dot products that
+// grow with j (this routine sits on the per-step latency chain of the banded factorisation).
 DEVI void chol6(const double* A, double L[6][6], double dinv[6], double* dmin) {
+  double a[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int k = 0; k <= i; ++k) a[i][k] = A[i * 6 + k];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    double d = A[j * 6 + j];
-#pragma unroll
-    for (int q = 0; q < j; ++q) d -= L[j][q] * L[j][q];
+    const double d = a[j][j];
     *dmin = fmin(*dmin, d);
     const double inv = rsqrt_nr(d);
     L[j][j] = d * inv; dinv[j] = inv;
 #pragma unroll
-    for (int i = j + 1; i < 6; ++i) {
-      double v = A[i * 6 + j];
+    for (int i = j + 1; i < 6; ++i) L[i][j] = a[i][j] * inv;
 #pragma unroll
-      for (int q = 0; q < j; ++q) v -= L[i][q] * L[j][q];
-      L[i][j] = v * inv;
-    }
+    for (int i = j + 1; i < 6; ++i)
+#pragma unroll
+      for (int k = j + 1; k <= i; ++k) a[i][k] -= L[i][j] * L[k][j];
   }
 }
 
@@ -500,11 +505,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
       const double* a1 = sj + (6 + w3_row) * 6;
       double x[6];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        double v = a1[c];
+      for (int c = 0; c < 6; ++c) x[c] = a1[c];
 #pragma unroll
-        for (int q = 0; q < c; ++q) v -= x[q] * Lc[c][q];
-        x[c] = v * dinv_c[c];
+      for (int c = 0; c < 6; ++c) {        // axpy form: one mul + one fma on the chain per column
+        x[c] *= dinv_c[c];
+#pragma unroll
+        for (int q = c + 1; q < 6; ++q) x[q] -= x[c] * Lc[q][c];
       }
 #pragma unroll
       for (int c = 0; c < 6; ++c) W3[w3_xdst + c] = x[c];      // idle lanes: dump words 72..77
@@ -529,11 +535,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
       const double* ar = sj + p_src;
       double x[6];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        double v = ar[c] + (c == id_j ? 1.0 : 0.0);
+      for (int c = 0; c < 6; ++c) x[c] = ar[c] + (c == id_j ? 1.0 : 0.0);
 #pragma unroll
-        for (int q = 0; q < c; ++q) v -= x[q] * Lp[c][q];
-        x[c] = v * dv[c];
+      for (int c = 0; c < 6; ++c) {        // axpy form: one mul + one fma on the chain per column
+        x[c] *= dv[c];
+#pragma unroll
+        for (int q = c + 1; q < 6; ++q) x[q] -= x[c] * Lp[q][c];
       }
 #pragma unroll
       for (int c = 0; c < 6; ++c) xb[p_dst[c]] = x[c];
