@@ -408,7 +408,7 @@ int finalize(calico_problem* p) {
   std::vector<double> m0(n_obs), m1(n_obs), m2(n_obs), st(n_obs);
   std::vector<int> point_off(n_obs, 0);
   p->h_items.clear(); p->h_items_all.clear();
-  static const int imu_chunk_items = [] { const char* e = std::getenv("CALICO_IMU_CHUNK"); return e ? std::max(1, std::min(40, std::atoi(e))) : 24; }();
+  const int imu_chunk_items = [] { const char* e = std::getenv("CALICO_IMU_CHUNK"); return e ? std::max(1, std::min(40, std::atoi(e))) : 24; }();
   int max_cols = 0;
   for (int64_t q = 0; q < n_obs;) {
     int64_t e = q;
@@ -488,7 +488,7 @@ int finalize(calico_problem* p) {
     }
     // IMU work items hand their staged rows to the cell kernel ("row cells": one expanded block per (layout, segment)
     // instead of one per item); everything else forms its own block
-    static const bool row_cells_ok = [] { const char* e = std::getenv("CALICO_ROW_CELLS"); return !e || std::atoi(e) != 0; }();
+    const bool row_cells_ok = [] { const char* e = std::getenv("CALICO_ROW_CELLS"); return !e || std::atoi(e) != 0; }();
     for (ItemDev it : p->h_items) {
       if (layout_uses_frames[size_t(it.layout)]) continue;
       const LayoutDev& L = layouts[size_t(it.layout)];
@@ -1083,7 +1083,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   // memory; the host keeps `depth` iterations enqueued ahead of that and stops when the flag goes up. Compared with
   // batches of `sync_every` iterations and a blocking read-back per batch this takes the read-back gaps out of the
   // stream and leaves at most `depth` iterations of early-exit kernels behind a terminated solve.
-  static const int stream_depth = [] { const char* e = std::getenv("CALICO_STREAM_DEPTH"); return e ? std::atoi(e) : 2; }();
+  const int stream_depth = [] { const char* e = std::getenv("CALICO_STREAM_DEPTH"); return e ? std::atoi(e) : 2; }();
   const bool streaming = p->speculative && p->allreduce == nullptr && stream_depth > 0 && p->h_progress != nullptr;
   if (streaming) {
     __atomic_store_n(p->h_progress, 0, __ATOMIC_RELEASE);
@@ -1096,7 +1096,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   p->timer.begin(4, s);
   launch_post_eval(sa, p->d_x.p, p->d_blocks.p, int(p->h_blocks.size()), o, p->d_log.p, kLogCap, 1, opt->jacobi_scaling, s);
   p->timer.end(s);
-  static const bool fused_control = [] { const char* e = std::getenv("CALICO_FUSED_CONTROL"); return !e || std::atoi(e) != 0; }();
+  const bool fused_control = [] { const char* e = std::getenv("CALICO_FUSED_CONTROL"); return !e || std::atoi(e) != 0; }();
   if (streaming) {
     int enq = 0;
     const auto t_spin0 = std::chrono::steady_clock::now();
@@ -1145,7 +1145,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   // a multi-rank run needs the host between the phases (the all-reduce must not run when the evaluation was skipped).
   const bool spec = p->speculative;
   const bool multi = p->allreduce != nullptr;
-  static const bool multi_async_ok = [] { const char* e = std::getenv("CALICO_MULTIRANK_ASYNC"); return !e || std::atoi(e) != 0; }();
+  const bool multi_async_ok = [] { const char* e = std::getenv("CALICO_MULTIRANK_ASYNC"); return !e || std::atoi(e) != 0; }();
   const bool async = !multi || (spec && multi_async_ok);
   const int batch = async ? std::max(1, opt->sync_every) : 1;
   while (!streaming && !p->h_state->terminated) {
