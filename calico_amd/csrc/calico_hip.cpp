@@ -86,6 +86,7 @@ struct HSensor {
   std::vector<int> body, point, seg;
   std::vector<int64_t> sorted_pos;  // original observation -> position in the sorted device arrays
   std::vector<uint8_t> active;      // 0 = tagged as outlier (outlier_ids_, camera.h:185): left out of the problem
+  int64_t n_active = -1;            // cached count of the blocks that are in the problem (-1: recount)
   int64_t sorted_begin = 0, sorted_end = 0;   // this sensor's contiguous range in the sorted arrays
   int dim() const { return kind == CALICO_SENSOR_CAMERA ? 2 : 3; }
   int64_t n() const { return int64_t(stamps.size()); }
@@ -831,8 +832,9 @@ int read_state(calico_problem* p) {
 
 void fill_counts(calico_problem* p, calico_summary* sm) {
   int nrb = 0, nr = 0;
-  for (const HSensor& s : p->sensors) {   // tagged outliers are not part of the problem (camera.cpp:121-124)
-    int64_t na = 0; for (uint8_t a : s.active) na += a ? 1 : 0;
+  for (HSensor& s : p->sensors) {   // tagged outliers are not part of the problem (camera.cpp:121-124)
+    if (s.n_active < 0) { int64_t c = 0; for (uint8_t a : s.active) c += a ? 1 : 0; s.n_active = c; }   // per solve otherwise: 100k bytes
+    const int64_t na = s.n_active;
     nrb += int(na); nr += int(na) * s.dim();
   }
   sm->num_residual_blocks = nrb; sm->num_residuals = nr;
@@ -1022,7 +1024,7 @@ static int32_t add_obs(calico_problem* p, int32_t sid, int64_t n, const double* 
     s.stamps.push_back(stamps[i]);
     if (body) { s.body.push_back(body[i]); s.point.push_back(point[i]); }
     for (int c = 0; c < dim; ++c) s.meas.push_back(meas[i * dim + c]);
-    s.active.push_back(1);
+    s.active.push_back(1); s.n_active = -1;
   }
   p->dirty = true;
   return CALICO_OK;
@@ -1320,6 +1322,7 @@ int32_t calico_problem_set_outlier_mask(calico_problem* p, int32_t sid, const ui
   if (sid < 0 || sid >= int(p->sensors.size())) return p->set_error(CALICO_INVALID_ARGUMENT, "bad sensor id");
   HSensor& s = p->sensors[sid];
   for (int64_t i = 0; i < s.n(); ++i) s.active[size_t(i)] = (is_outlier && is_outlier[i]) ? 0 : 1;
+  s.n_active = -1;
   p->active_dirty = true;
   return CALICO_OK;
 }
@@ -1349,6 +1352,7 @@ int32_t calico_mark_outliers(calico_problem* p, int32_t sid, double threshold, i
   HIP_TRY(p, hipMemcpyAsync(&marked, p->d_counter.p, sizeof(int), hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(p, hipStreamSynchronize(p->stream));
   for (int64_t i = 0; i < s.n(); ++i) s.active[size_t(i)] = act[size_t(s.sorted_pos[size_t(i)] - s.sorted_begin)];
+  s.n_active = -1;
   if (n_marked) *n_marked = marked;
   return CALICO_OK;
 }
