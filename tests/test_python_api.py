@@ -284,3 +284,83 @@ def test_camera_calibration_with_outlier_tagging():
     assert summary.num_residual_blocks == len(measurements) - len(corrupted)
     assert summary.final_cost < 1e-6
     np.testing.assert_allclose(camera.GetIntrinsics(), truth, rtol=0, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_toy_stereo_camera_and_imu_calibration_python():
+    """batch_optimizer_test.cpp:32-213 (ToyStereoCameraAndImuCalibration) through the Python surface: perfect
+    measurements from Project(), perturbed start, every sensor parameter recovered to 1e-7."""
+    stamps, poses = _poses()
+    times = [float(t) for t in stamps]
+    trajectory = calico.Trajectory()
+    trajectory.FitSpline(poses)
+    chart = calico.RigidBody()
+    chart.model_definition = {i: p for i, p in enumerate(syn.planar_points())}
+    chart.world_pose_is_constant = True
+    chart.model_definition_is_constant = True
+    world = calico.WorldModel()
+    world.AddRigidBody(chart)
+
+    def pose(axis, angle_deg, t):
+        axis = np.asarray(axis, float) / np.linalg.norm(axis)
+        half = 0.5 * np.deg2rad(angle_deg)
+        p = calico.Pose3d()
+        p.rotation = [np.cos(half), *(np.sin(half) * axis)]
+        p.translation = t
+        return p
+
+    true_cam = np.array([785, 640, 400, -3.149e-1, 1.069e-1, 1.616e-4, 1.141e-4, -1.853e-2])
+    true_imu = np.array([1.3, 0.01, -0.01, 0.01])
+    ex_right = pose([0.68, -0.21, 0.57], 2.0, 0.05 * np.array([0.6, -0.33, 0.54]))
+    ex_gyro = pose([-0.44, 0.11, -0.05], 2.0, [0, 0, 0])
+    ex_acc = pose([0.26, -0.27, 0.9], 2.0, [0, 0, 0])
+    truth = {}
+    specs = [("left", calico.Camera, calico.CameraIntrinsicsModel.kOpenCv5, true_cam, calico.Pose3d(), 0.0),
+             ("right", calico.Camera, calico.CameraIntrinsicsModel.kOpenCv5, true_cam, ex_right, 0.01),
+             ("gyro", calico.Gyroscope, calico.GyroscopeIntrinsicsModel.kGyroscopeScaleAndBias, true_imu, ex_gyro, 0.02),
+             ("acc", calico.Accelerometer, calico.AccelerometerIntrinsicsModel.kAccelerometerScaleAndBias, true_imu, ex_acc, 0.02)]
+    optimizer = calico.BatchOptimizer()
+    sensors = {}
+    for name, cls, model, intrinsics, extrinsics, latency in specs:
+        true_sensor = cls()
+        assert true_sensor.SetModel(model).ok()
+        true_sensor.SetIntrinsics(intrinsics)
+        true_sensor.SetExtrinsics(extrinsics)
+        assert true_sensor.SetLatency(latency).ok()
+        measurements = true_sensor.Project(times, trajectory, world)
+        assert len(measurements) > 0
+        sensor = cls()
+        sensor.SetName(name)
+        assert sensor.SetModel(model).ok()
+        init = 1.01 * intrinsics
+        if cls is calico.Camera:
+            init[3:] = 0.0
+        sensor.SetIntrinsics(init)
+        init_ext = calico.Pose3d(extrinsics)
+        if name == "right":
+            init_ext.translation = extrinsics.translation + 0.01 * np.array([0.3, -0.8, 0.5])
+        if name == "acc":
+            init_ext.translation = extrinsics.translation + 0.05 * np.array([-0.2, 0.7, 0.4])
+        sensor.SetExtrinsics(init_ext)
+        sensor.EnableIntrinsicsEstimation(True)
+        sensor.EnableExtrinsicsEstimation(name != "left")
+        sensor.EnableLatencyEstimation(name != "left")
+        assert sensor.AddMeasurements(measurements).ok()
+        optimizer.AddSensor(sensor)
+        sensors[name] = sensor
+        truth[name] = (intrinsics, extrinsics, latency)
+    optimizer.AddTrajectory(trajectory)
+    optimizer.AddWorldModel(world)
+    options = calico.DefaultSolverOptions()
+    options.minimizer_progress_to_stdout = False
+    options.max_num_iterations = 100
+    summary = optimizer.Optimize(options)
+    assert summary.IsSolutionUsable() and summary.final_cost < 1e-7
+    for name, sensor in sensors.items():
+        intrinsics, extrinsics, latency = truth[name]
+        np.testing.assert_allclose(sensor.GetIntrinsics(), intrinsics, rtol=0, atol=1e-7)
+        got = sensor.GetExtrinsics()
+        assert min(np.abs(got.rotation - extrinsics.rotation).max(), np.abs(got.rotation + extrinsics.rotation).max()) < 1e-7
+        if name != "gyro":     # the gyroscope's lever arm is unobservable (zero Jacobian): it keeps its start value
+            np.testing.assert_allclose(got.translation, extrinsics.translation, rtol=0, atol=1e-7)
+        assert abs(sensor.GetLatency() - latency) < 1e-7
