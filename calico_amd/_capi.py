@@ -120,7 +120,7 @@ ABI_SYMBOLS = [
     "get_iterations", "get_residuals", "get_inlier_mask",
     "num_effective_parameters", "evaluate", "problem_set_allreduce", "problem_set_shard",
     "problem_set_stream", "get_phase_time", "set_phase_timing", "project",
-    "problem_set_outlier_mask", "mark_outliers", "fit_spline",
+    "problem_set_outlier_mask", "mark_outliers", "fit_spline", "residual_heatmap",
 ]
 
 
@@ -165,6 +165,7 @@ class CApi:
             g("project", C.c_int32, [P, C.c_int32, D, C.POINTER(C.c_uint8)])
             g("problem_set_outlier_mask", C.c_int32, [P, C.c_int32, C.POINTER(C.c_uint8)])
             g("mark_outliers", C.c_int32, [P, C.c_int32, C.c_double, C.POINTER(C.c_int64)])
+            g("residual_heatmap", C.c_int32, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, D, C.POINTER(C.c_int64)])
             g("fit_spline", C.c_int32, [C.c_int32, C.c_int32, C.c_int32, D, D, C.c_int64, D, D, D])
             g("set_phase_timing", C.c_int32, [P, C.c_int32])
 
@@ -293,6 +294,14 @@ class Problem:
         n = C.c_int64(0)
         self._check(self.api.mark_outliers(self.h, sensor, float(threshold), C.byref(n)))
         return n.value
+
+    def residual_heatmap(self, sensor, image_width, image_height, num_rows=8, num_cols=12):
+        """Binned RMSE and feature count of a camera's residuals (utils.py:12-50), reduced on the device."""
+        rmse = np.zeros((num_rows, num_cols))
+        count = np.zeros((num_rows, num_cols), dtype=np.int64)
+        self._check(self.api.residual_heatmap(self.h, sensor, int(image_width), int(image_height), int(num_rows), int(num_cols),
+                                              _dp(rmse), count.ctypes.data_as(C.POINTER(C.c_int64))))
+        return rmse, count
 
     def inlier_mask(self, sensor, n, threshold):
         mask = np.zeros(n, dtype=np.uint8)

@@ -35,6 +35,9 @@ void launch_eval(const EvalArgs& a, bool jac, hipStream_t stream);
 void launch_eval_frames(const EvalArgs& a, hipStream_t stream);
 void launch_eval_jacobian(const EvalArgs& a, hipStream_t stream);
 void launch_expand_cells(const EvalArgs& a, hipStream_t stream);
+void launch_residual_heatmap(const double* res, const uint8_t* valid, const uint8_t* active, const double* px, const double* py,
+                             int begin, int end, int width, int height, int num_rows, int num_cols, double* rmse, long long* count,
+                             hipStream_t s);
 void launch_mark_outliers(const double* res, const uint8_t* valid, uint8_t* active, int begin, int end, int dim,
                           double threshold, int* n_marked, hipStream_t s);
 hipError_t configure_eval_kernels(size_t max_lds_bytes);
@@ -1354,6 +1357,37 @@ int32_t calico_mark_outliers(calico_problem* p, int32_t sid, double threshold, i
   for (int64_t i = 0; i < s.n(); ++i) s.active[size_t(i)] = act[size_t(s.sorted_pos[size_t(i)] - s.sorted_begin)];
   s.n_active = -1;
   if (n_marked) *n_marked = marked;
+  return CALICO_OK;
+}
+
+int32_t calico_residual_heatmap(calico_problem* p, int32_t sid, int32_t image_width, int32_t image_height, int32_t num_rows,
+                                int32_t num_cols, double* rmse_out, int64_t* count_out) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  if (sid < 0 || sid >= int(p->sensors.size())) return p->set_error(CALICO_INVALID_ARGUMENT, "bad sensor id");
+  if (p->sensors[size_t(sid)].kind != CALICO_SENSOR_CAMERA) return p->set_error(CALICO_INVALID_ARGUMENT, "not a camera");
+  if (image_width <= 0 || image_height <= 0 || num_rows <= 0 || num_cols <= 0 || !rmse_out || !count_out)
+    return p->set_error(CALICO_INVALID_ARGUMENT, "bad heat-map dimensions");
+  int rc = finalize(p);
+  if (rc != CALICO_OK) return rc;
+  HIP_TRY(p, hipSetDevice(p->device));
+  rc = upload_x(p);
+  if (rc != CALICO_OK) return rc;
+  const HSensor& s = p->sensors[size_t(sid)];
+  {
+    EvalArgs ea = make_eval_args(p, p->d_x.p, 0, true);   // residuals without the loss function (camera.cpp:70-80)
+    ea.items = p->d_items_all.p; ea.n_items = p->n_items_all;
+    launch_eval(ea, false, p->stream);
+  }
+  const size_t nb = size_t(num_rows) * num_cols;
+  DevBuf<double> d_rmse; DevBuf<long long> d_cnt;
+  HIP_TRY(p, d_rmse.alloc(nb)); HIP_TRY(p, d_cnt.alloc(nb));
+  launch_residual_heatmap(p->d_res.p, p->d_valid.p, p->d_active.p, p->d_m0.p, p->d_m1.p, int(std::min(s.sorted_begin, s.sorted_end)),
+                          int(s.sorted_end), image_width, image_height, num_rows, num_cols, d_rmse.p, d_cnt.p, p->stream);
+  std::vector<long long> cnt(nb);
+  HIP_TRY(p, hipMemcpyAsync(rmse_out, d_rmse.p, nb * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(p, hipMemcpyAsync(cnt.data(), d_cnt.p, nb * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(p, hipStreamSynchronize(p->stream));
+  for (size_t i = 0; i < nb; ++i) count_out[i] = int64_t(cnt[i]);
   return CALICO_OK;
 }
 

@@ -1166,6 +1166,41 @@ __global__ void mark_outliers_kernel(const double* __restrict__ res, const uint8
   const bool inlier = valid[q] && sqrt(sq) <= threshold;
   if (!inlier) { active[q] = 0; atomicAdd(n_marked, 1); }
 }
+// Residual statistics per image region: one workgroup per bin walks the sensor's observations (sorted order
+// [begin, end)) in a fixed thread-strided order and reduces in a fixed tree -- deterministic, no atomics.
+__global__ __launch_bounds__(256) void residual_heatmap_kernel(const double* __restrict__ res, const uint8_t* __restrict__ valid,
+                                                               const uint8_t* __restrict__ active, const double* __restrict__ px,
+                                                               const double* __restrict__ py, int begin, int end, double inv_w,
+                                                               double inv_h, int num_rows, int num_cols, double* rmse,
+                                                               long long* count) {
+  __shared__ double s_sq[256];
+  __shared__ long long s_n[256];
+  const int bin = blockIdx.x, brow = bin / num_cols, bcol = bin % num_cols, tid = threadIdx.x;
+  double sq = 0.0;
+  long long n = 0;
+  for (int o = begin + tid; o < end; o += 256) {
+    if ((active && !active[o]) || !valid[o]) continue;
+    int c = int(floor(px[o] * inv_w * num_cols)), r = int(floor(py[o] * inv_h * num_rows));
+    c = max(min(c, num_cols - 1), 0); r = max(min(r, num_rows - 1), 0);
+    if (r != brow || c != bcol) continue;
+    const double r0 = res[size_t(o) * 3], r1 = res[size_t(o) * 3 + 1];
+    sq += r0 * r0 + r1 * r1; n += 1;
+  }
+  s_sq[tid] = sq; s_n[tid] = n;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) { s_sq[tid] += s_sq[tid + off]; s_n[tid] += s_n[tid + off]; }
+    __syncthreads();
+  }
+  if (tid == 0) { count[bin] = s_n[0]; rmse[bin] = sqrt(s_sq[0] / double(s_n[0])); }   // 0/0 = NaN for an empty bin
+}
+void launch_residual_heatmap(const double* res, const uint8_t* valid, const uint8_t* active, const double* px, const double* py,
+                             int begin, int end, int width, int height, int num_rows, int num_cols, double* rmse, long long* count,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(residual_heatmap_kernel, dim3(num_rows * num_cols), dim3(256), 0, s, res, valid, active, px, py, begin, end,
+                     1.0 / width, 1.0 / height, num_rows, num_cols, rmse, count);
+}
+
 void launch_mark_outliers(const double* res, const uint8_t* valid, uint8_t* active, int begin, int end, int dim,
                           double threshold, int* n_marked, hipStream_t s) {
   if (end > begin) hipLaunchKernelGGL(mark_outliers_kernel, dim3((end - begin + 255) / 256), dim3(256), 0, s, res, valid, active, begin, end, dim, threshold, n_marked);

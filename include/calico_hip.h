@@ -238,6 +238,13 @@ int32_t calico_problem_set_outlier_mask(calico_problem* p, int32_t sensor, const
  * estimates without the loss function, every still-untagged observation of `sensor` with ||r|| > threshold (or that
  * cannot be evaluated) is tagged. *n_marked = number of observations tagged by this call. Follow with calico_solve. */
 int32_t calico_mark_outliers(calico_problem* p, int32_t sensor, double threshold, int64_t* n_marked);
+/* Residual statistics of a camera on the device (utils.py:12-50 ComputeRmseHeatmapAndFeatureCount, the notebooks'
+ * per-region RMSE / feature count): the image (image_width x image_height pixels) is divided into num_rows x num_cols
+ * bins by the measured pixel; rmse_out[row * num_cols + col] = sqrt(sum ||r||^2 / count) over the untagged
+ * observations of the bin (residuals at the current estimates without the loss function, NaN for an empty bin like
+ * the reference's 0/0), count_out the number of observations. Fixed-order reductions: results are reproducible. */
+int32_t calico_residual_heatmap(calico_problem* p, int32_t sensor, int32_t image_width, int32_t image_height,
+                                int32_t num_rows, int32_t num_cols, double* rmse_out, int64_t* count_out);
 
 /* Sensor::Project for the registered observations (camera.cpp:155-208, gyroscope.cpp:56-82,
  * accelerometer.cpp:76-123): the model's prediction -- pixel (2) or IMU reading (3) per observation, in insertion

@@ -132,3 +132,33 @@ def test_outlier_tagging_loop_on_device(hip, oracle):
     for i in cams:
         g.problem.set_outlier_mask(g.sensor_ids[i], None)
     assert g.problem.solve(o).num_residual_blocks == sg1.num_residual_blocks
+
+
+def test_residual_heatmap_on_device(hip):
+    """utils.py:12-50 on the device: binned RMSE / feature counts equal the host-side restatement on the residuals the
+    same problem hands back; tagged observations are left out."""
+    from calico_amd import calico
+    scene = syn.make_scene(2, 1, False, cam_rate=10.0, duration=3.0, segment_duration=3.0 / 23.9, pixel_noise=0.5, seed=9)
+    built = syn.build_problem(hip, scene)
+    P = built.problem
+    sid, sensor = built.sensor_ids[1], scene.sensors[1]
+    mask = np.zeros(sensor.n, np.uint8)
+    mask[::7] = 1                                   # tag every seventh observation
+    P.set_outlier_mask(sid, mask)
+    rmse, count = P.residual_heatmap(sid, 1280, 800, 8, 12)
+    res, valid = P.residuals(sid, sensor.n, 2, check=False)
+    pairs = []
+    for i in range(sensor.n):
+        if mask[i] or not valid[i]:
+            continue
+        m = calico.CameraMeasurement()
+        m.pixel = sensor.meas[i]
+        pairs.append((m, res[i]))
+    _, ref_rmse, ref_count = calico.ComputeRmseHeatmapAndFeatureCount(pairs, 1280, 800, 8, 12)
+    assert np.array_equal(count, ref_count.astype(np.int64))
+    filled = ref_count > 0
+    assert filled.sum() > 20
+    np.testing.assert_allclose(rmse[filled], ref_rmse[filled], rtol=1e-12)
+    assert np.isnan(rmse[~filled]).all()
+    again, _ = P.residual_heatmap(sid, 1280, 800, 8, 12)
+    assert np.array_equal(again[filled], rmse[filled])          # fixed-order reduction
