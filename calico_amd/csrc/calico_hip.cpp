@@ -1157,7 +1157,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
     for (int b = 0; b < batch; ++b) {
       // (speculative, single rank) the bookkeeping of the step accepted in the previous iteration of this batch rides
       // in the prepare kernel of this one; the last iteration of a batch gets a stand-alone post_eval below
-      const bool ride = spec && !multi && b > 0;
+      const bool ride = spec && async && b > 0;
       p->timer.begin(2, s);
       launch_solve(sa, o, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, p->dense_in_lds, s, ride, p->d_log.p, kLogCap,
                    opt->jacobi_scaling);
@@ -1172,7 +1172,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
         p->timer.begin(4, s);
         launch_control(p->d_state.p, o, p->d_R2.p, p->d_x.p, p->d_xc.p, p->n_amb, p->d_log.p, kLogCap, nullptr, 0, p->d_R.p,
                        p->r_size, s, /*commit_by_copy=*/multi && async);
-        if (multi || b == batch - 1)
+        if (!async || b == batch - 1)
           launch_post_eval(sa, p->d_x.p, p->d_blocks.p, n_blocks, o, p->d_log.p, kLogCap, 0, opt->jacobi_scaling, s);
         p->timer.end(s);
         if (!async) {

@@ -216,7 +216,11 @@ __global__ __launch_bounds__(256) void prepare_kernel(SolveArgs a, LmOptionsDev 
                                                       int jacobi_scaling) {
   const LmState* st = a.st;
   if (st->terminated) return;
-  if (with_post && blockIdx.x == gridDim.x - 1) { post_eval_body(a, x, blocks, n_blocks, o, log, log_cap, 0, jacobi_scaling); return; }
+  if (with_post && blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x == 0 && a.st->commit_pending) a.st->commit_pending = 0;   // see commit_kernel (several ranks)
+    post_eval_body(a, x, blocks, n_blocks, o, log, log_cap, 0, jacobi_scaling);
+    return;
+  }
   const size_t n_prep_blocks = gridDim.x - (with_post ? 1 : 0);
   use_current_R(a);
   const int n_s = a.n_s(), W = a.W(), m = a.m, mc = a.mc, m1 = a.m + 1;
