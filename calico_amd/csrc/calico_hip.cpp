@@ -1153,8 +1153,22 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   const bool multi_async_ok = [] { const char* e = std::getenv("CALICO_MULTIRANK_ASYNC"); return !e || std::atoi(e) != 0; }();
   const bool async = !multi || (spec && multi_async_ok);
   const int batch = async ? std::max(1, opt->sync_every) : 1;
+  int batch_now = batch;
   while (!streaming && !p->h_state->terminated) {
-    for (int b = 0; b < batch; ++b) {
+    // The iterations enqueued behind a terminated solve are wasted (with several ranks each still carries a real
+    // all-reduce), so the batch shrinks when the cost changes of the last two successful steps predict convergence
+    // by the function tolerance within fewer iterations: linear convergence, ratio r -> log(tol / change) / log(r).
+    batch_now = batch;
+    {
+      const LmState& hs = *p->h_state;
+      const double tol = opt->function_tolerance * hs.x_cost;
+      if (batch > 1 && hs.last_cost_change > 0.0 && hs.prev_cost_change > hs.last_cost_change && tol > 0.0) {
+        const double r = hs.last_cost_change / hs.prev_cost_change;
+        const double left = hs.last_cost_change <= tol ? 0.0 : std::ceil(std::log(tol / hs.last_cost_change) / std::log(r));
+        batch_now = int(std::max(1.0, std::min(double(batch), left + 1.0)));
+      }
+    }
+    for (int b = 0; b < batch_now; ++b) {
       // (speculative, single rank) the bookkeeping of the step accepted in the previous iteration of this batch rides
       // in the prepare kernel of this one; the last iteration of a batch gets a stand-alone post_eval below
       const bool ride = spec && async && b > 0;
@@ -1172,7 +1186,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
         p->timer.begin(4, s);
         launch_control(p->d_state.p, o, p->d_R2.p, p->d_x.p, p->d_xc.p, p->n_amb, p->d_log.p, kLogCap, nullptr, 0, p->d_R.p,
                        p->r_size, s, /*commit_by_copy=*/multi && async);
-        if (!async || b == batch - 1)
+        if (!async || b == batch_now - 1)
           launch_post_eval(sa, p->d_x.p, p->d_blocks.p, n_blocks, o, p->d_log.p, kLogCap, 0, opt->jacobi_scaling, s);
         p->timer.end(s);
         if (!async) {

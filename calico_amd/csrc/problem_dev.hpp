@@ -100,6 +100,8 @@ struct LmState {
   double x_cost, candidate_cost, model_cost_change;
   double x_norm, cand_norm, step_norm, gradient_max_norm, gradient_norm;
   double relative_decrease, cost_change;
+  double prev_cost_change;  // cost change of the successful step before the last one (the host sizes its batches with the ratio)
+  double last_cost_change;  // cost change of the last successful step
   double initial_cost, min_cost;
   int iteration;
   int need_jacobian;      // the last step was accepted: re-evaluate J at x

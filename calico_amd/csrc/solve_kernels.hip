@@ -1606,6 +1606,7 @@ DEVI void control_body(LmState* st, const LmOptionsDev& o, double* R2, double* x
           if (st->relative_decrease > o.min_relative_decrease) {
             s_accept = 1;
             st->step_successful = 1;
+            st->prev_cost_change = st->last_cost_change; st->last_cost_change = st->cost_change;
             st->need_jacobian = 1;
             // the buffer evaluated at the candidate becomes R(x): by a pointer swap, or (several ranks: the host hands
             // the collective a fixed address, so the candidate is always evaluated into buffer 1) by commit_kernel
