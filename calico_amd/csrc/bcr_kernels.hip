@@ -1,0 +1,865 @@
+// bcr_kernels.hip — tree solver for the arrowhead normal equations on gfx950.
+//
+// Same system as solve_kernels.hip (what the reference hands to Ceres' DENSE_SCHUR, batch_optimizer.cpp:10-17,72-73):
+//   [ B  E ] [y_s]   [g_s]      B: band over the spline control points (half bandwidth 6k-1),
+//   [ Eᵀ C ] [y_c] = [g_c]      E: dense border (calibration columns), C: dense corner,
+// with the Levenberg–Marquardt damping and Ceres' Jacobi scaling folded into the diagonal. The sequential band
+// factorisation (band_cholesky_kernel: n_cp/2 dependent steps) is replaced by nested dissection in time:
+//   * control points are grouped into superblocks of 5 (30 rows padded to 32); for spline order k <= 6 the band is
+//     block TRIDIAGONAL in superblocks, bordered by the calibration columns and the right-hand side (F);
+//   * level 0 eliminates chains of q consecutive superblocks between kept separators, every further level every other
+//     surviving separator, all chains of a level side by side on different CUs (one launch per level); the last survivor
+//     (the root) joins the calibration blocks in the dense reduced system, which reduced_solve_panel_kernel factors;
+//   * eliminating superblock e with neighbours a (left separator) and n (next of the chain / right separator):
+//       D_e = L Lᵀ,  [Z^A | Z^B | Z^F] = L⁻¹ [T(e,a) | T(n,e)ᵀ | F_e],
+//       D_n -= Z^BᵀZ^B, T(n,a) -= Z^BᵀZ^A, F_n -= Z^BᵀZ^F, D_a -= Z^AᵀZ^A, F_a -= Z^AᵀZ^F, C -= Z^FᵀZ^F (one SYRK at the end);
+//     a separator receives the contributions of the chains on either side in separate slots and adds them up in a
+//     fixed order => bitwise reproducible, no atomics;
+//   * back-substitution runs down the tree, y_e = L⁻ᵀ (L⁻¹g_e - Z^F y_c - Z^A y_a - Z^B y_n), and every node updates the
+//     candidate point of its own control points.
+// The dependent chain is (q + log2(n_cp / 5q)) block factorisations instead of n_cp / 2 band steps.
+// The 32x32 factorisation (+ inverse, via 32 identity rows riding as extra rows) is two in-wave 16-column panels
+// (panel_factor) and one MFMA tile update; everything else is v_mfma_f64_16x16x4_f64 tile products PᵀQ out of LDS.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "problem_dev.hpp"
+#include "solve_dev.hpp"
+
+namespace cal {
+
+namespace {
+constexpr int BP = kBcrBP;              // 32
+constexpr int BB = BP * BP;             // 1024
+constexpr int DLD = 33;                 // row stride of the augmented diagonal block [64][33]: rows 0..31 D, rows 32..63 identity -> L⁻ᵀ
+constexpr int XLD = 2 * BP + kBcrFS + 1;  // row stride of X = [A | B | F slice] (80 columns)
+constexpr int CA = 0, CB = BP, CF = 2 * BP;   // column offsets inside X / Z
+constexpr int kLevelThreads = 512;
+}  // namespace
+
+// acc (+/-)= Σ_k P[k][pc0 + i] · Q[k][qc0 + j], k in [k0, k1): one 16x16 tile of PᵀQ on the matrix cores; P, Q row-major in LDS.
+// Result layout: column j = lane & 15, row i = (lane >> 4) + 4·reg.
+// All operands are read before the first MFMA is issued (one LDS round trip per tile, not one per k-step).
+template <bool NEG, int NK>
+DEVI f64x4 atb_tile_n(const double* P, int ldp, int pc0, const double* Q, int ldq, int qc0, f64x4 acc, int lane) {
+  const int l16 = lane & 15, lk = lane >> 4;
+  const double* pp = P + lk * ldp + pc0 + l16;
+  const double* qq = Q + lk * ldq + qc0 + l16;
+  double av[NK], bv[NK];
+#pragma unroll
+  for (int u = 0; u < NK; ++u) { av[u] = pp[4 * u * ldp]; bv[u] = qq[4 * u * ldq]; }
+#pragma unroll
+  for (int u = 0; u < NK; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -av[u] : av[u], bv[u], acc, 0, 0, 0);
+  return acc;
+}
+template <bool NEG>
+DEVI f64x4 atb_tile(const double* P, int ldp, int pc0, const double* Q, int ldq, int qc0, int k0, int k1, f64x4 acc, int lane) {
+  // k0 is always 0 here; k1 is 16 (upper-triangular operand, first row tile) or 32
+  return k1 - k0 == 16 ? atb_tile_n<NEG, 4>(P, ldp, pc0, Q, ldq, qc0, acc, lane) : atb_tile_n<NEG, 8>(P, ldp, pc0, Q, ldq, qc0, acc, lane);
+}
+
+// ---------------------------------------------------------------------------
+// Entries of the damped system in superblock coordinates, straight from the reduce buffer R(x) (what prepare_kernel
+// stages for the banded solver). Loads are unconditional (indices clamped), the structure is applied by selects.
+// ---------------------------------------------------------------------------
+struct FromR {
+  const SolveArgs& a;
+  const LmOptionsDev& o;
+  double radius;
+  static constexpr int RB = 6 * kBcrCps;   // real rows of a superblock
+  // tangent row of (superblock I, local row r); -1: padding, beyond the trajectory, or an unobserved control point
+  DEVI int trow(int I, int r) const {
+    const int t = RB * I + r;
+    const bool ok = r < RB && t < a.n_s();
+    return (ok && a.cp_active[(ok ? t : 0) / 6]) ? t : -1;
+  }
+  // H(tr, tc) inside the band, any order; 0 outside the band or when either index is -1
+  DEVI double band(int tr, int tc) const {
+    const int hi = max(tr, tc), lo = min(tr, tc);
+    const int lo_c = max(lo, 0);
+    const int ic = lo_c / 6, cc = lo_c % 6, ir = max(hi, 0) / 6, rr = max(hi, 0) % 6;
+    const int d = ir - ic;
+    const bool ok = lo >= 0 && d < a.k;
+    const double v = a.R[a.off_B() + (size_t(ic) * a.k + (ok ? d : 0)) * 36 + cc * 6 + rr];
+    return ok ? v : 0.0;
+  }
+  DEVI double damping(double v, int t) const {
+    const double s = a.scale[t];
+    return fmin(fmax(v * s * s, o.min_lm_diagonal), o.max_lm_diagonal) / (radius * s * s);
+  }
+  // D(I)(r, c), damped; identity on padding / unobserved rows. `file`: this thread owns dadd of the row.
+  DEVI double diag_block(int I, int r, int c, bool file) const {
+    const int tr = trow(I, r), tc = trow(I, c);
+    double v = band(tr, tc);
+    if (r == c) {
+      const int t = RB * I + r;
+      const double d = damping(v, max(tr, 0));
+      if (tr < 0) { v = 1.0; if (file && r < RB && t < a.n_s()) a.dadd[t] = 0.0; }
+      else { v += d; if (file) a.dadd[tr] = d; }
+    }
+    return v;
+  }
+  // H(superblock In row r, superblock Ic column c), In = Ic + 1
+  DEVI double coupling(int In, int r, int Ic, int c) const { return band(trow(In, r), trow(Ic, c)); }
+  // border row: calibration columns, right-hand side in column mc, zero padding
+  DEVI double border(int I, int r, int j) const {
+    const int tr = trow(I, r), t = max(tr, 0);
+    const int jc = min(j, a.mc);
+    const double e = a.R[j < a.mc ? a.off_E() + size_t(t) * a.mc + jc : a.off_g() + t];
+    return (tr >= 0 && j <= a.mc) ? e : 0.0;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// One level of the elimination tree. Workgroup (node, role): role 0 owns the spine (it files L⁻ᵀ, Z^A, Z^B, the
+// separators' diagonal updates and the fill between them), role s >= 1 the border columns [16(s-1), 16s) (Z^F and the
+// separators' border updates). Every role repeats the chain's factorisations (same instructions, same inputs =>
+// identical factors), which costs no time and no communication. Extra workgroups behind the nodes add last level's
+// pending updates to the separators that survive this level, too.
+// ---------------------------------------------------------------------------
+// FROM_R (level 0): the chain blocks come straight from the reduce buffer R(x) with the damping applied on the fly (no
+// staging pass); the extra workgroups initialise D and F of the level's separators from R, and the last of them does
+// the bookkeeping of the step just accepted when `with_post` is set (post_eval_body: it only reads R(x) and x).
+template <bool FROM_R>
+__global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, BcrArgs b, int node0, int n_nodes, int nfs, int level,
+                                                                   int keep0, int n_keep, LmOptionsDev o, int with_post,
+                                                                   const double* __restrict__ x, const BlockDev* __restrict__ blocks,
+                                                                   int n_blocks, IterLog* log, int log_cap, int jacobi_scaling) {
+  LmState* st = a.st;
+  const int terminated = st->terminated;     // tested after the first loads are on their way (they are harmless)
+  const double radius = st->radius;
+  if (FROM_R) {
+    if (with_post && blockIdx.x == gridDim.x - 1) {
+      if (terminated) return;
+      if (threadIdx.x == 0 && a.st->commit_pending) a.st->commit_pending = 0;   // see commit_kernel (several ranks)
+      if (threadIdx.x < 256) post_eval_body(a, x, blocks, n_blocks, o, log, log_cap, 0, jacobi_scaling);
+      return;
+    }
+    use_current_R(a);
+  }
+  const FromR fr = {a, o, radius};
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = 1 + nfs, bid = blockIdx.x;
+  const int m1p = b.m1p, par = level & 1;
+  const size_t NB = size_t(b.N);
+  const size_t fblk = size_t(BP) * m1p;
+  double* const pendD_w = b.pendD + size_t(par) * NB * 2 * BB;
+  double* const pendF_w = b.pendF + size_t(par) * NB * 2 * fblk;
+  const double* const pendD_r = b.pendD + size_t(par ^ 1) * NB * 2 * BB;
+  const double* const pendF_r = b.pendF + size_t(par ^ 1) * NB * 2 * fblk;
+  const double* const Gr = b.G + size_t(par) * NB * BB;
+  double* const Gw = b.G + size_t(par ^ 1) * NB * BB;
+  if (bid >= n_nodes * per) {
+    if (terminated) return;
+    // surviving separators that are not eliminated at this level: D += pending, F += pending (in place; nobody else
+    // reads them in this launch). At level 0 they are initialised from R(x) instead.
+    const size_t aw = size_t(bid - n_nodes * per), naw = size_t(gridDim.x - n_nodes * per - (FROM_R && with_post ? 1 : 0));
+    const size_t per_blk = size_t(BB) + fblk;
+    for (size_t e = aw * kLevelThreads + tid; e < size_t(n_keep) * per_blk; e += naw * kLevelThreads) {
+      const int kb = int(e / per_blk);
+      const size_t rem = e % per_blk;
+      const int blk = b.keep[2 * (keep0 + kb)], mask = b.keep[2 * (keep0 + kb) + 1];
+      if (FROM_R) {
+        if (rem < size_t(BB)) b.D[size_t(blk) * BB + rem] = fr.diag_block(blk, int(rem) >> 5, int(rem) & 31, true);
+        else { const size_t q = rem - BB; b.F[size_t(blk) * fblk + q] = fr.border(blk, int(q / m1p), int(q % m1p)); }
+        continue;
+      }
+      if (rem < size_t(BB)) {
+        double v = b.D[size_t(blk) * BB + rem];
+        if (mask & 1) v += pendD_r[(size_t(blk) * 2 + 0) * BB + rem];
+        if (mask & 2) v += pendD_r[(size_t(blk) * 2 + 1) * BB + rem];
+        b.D[size_t(blk) * BB + rem] = v;
+      } else {
+        const size_t q = rem - BB;
+        double v = b.F[size_t(blk) * fblk + q];
+        if (mask & 1) v += pendF_r[(size_t(blk) * 2 + 0) * fblk + q];
+        if (mask & 2) v += pendF_r[(size_t(blk) * 2 + 1) * fblk + q];
+        b.F[size_t(blk) * fblk + q] = v;
+      }
+    }
+    return;
+  }
+  const BcrNodeDev* __restrict__ ndp = b.nodes + node0 + bid / per;
+  const int role = bid % per;
+  const int f0 = (role - 1) * kBcrFS;        // first border column of this role (role >= 1)
+  const int q = ndp->q, left = ndp->left, right = ndp->right, blk0 = ndp->blk0, pend_mask = ndp->pend;
+  extern __shared__ double lds[];
+  double* const Daug = lds;                        // [2][64·DLD]
+  double* const Xb = Daug + 2 * 64 * DLD;          // [2][32·XLD]
+  double* const Zb = Xb + 2 * BP * XLD;            // [32·XLD]
+  double* const dinv = Zb + BP * XLD;              // [80]
+  double* const bcast = dinv + 80;                 // [128]
+  double* const dump = bcast + 128 + tid;          // [512]
+  const int l16 = lane & 15, lk = lane >> 4;
+  // ---- global -> registers -> LDS of one chain block. Loaders are waves 1..7 (448 threads: three entries each of D /
+  // B / A, two of the F slice); wave 0 goes straight to the factorisation, it is the critical path of every step. ----
+  constexpr int NL = kLevelThreads - 64, NU = 3;
+  const int lt = tid - 64;
+  struct Pre { double d[NU], bt[NU], at[NU], f[2]; };
+  // level 0: positions in R of this thread's entries for superblock 0 (the band is uniform in time: superblock I adds
+  // I·stride), and what does not depend on the superblock of their validity
+  constexpr int RB = 6 * kBcrCps;
+  int iD[NU], iB[NU];
+  bool okD[NU], okB[NU];
+  const int strideB = kBcrCps * a.k * 36;
+  if (FROM_R) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int e = min(max(lt, 0) + NL * u, BB - 1);
+      const int r = e >> 5, c = e & 31;
+      const int hi = max(r, c), lo = min(r, c);
+      const int dD = hi / 6 - lo / 6;
+      okD[u] = r < RB && c < RB && dD < a.k;
+      iD[u] = okD[u] ? ((lo / 6) * a.k + dD) * 36 + (lo % 6) * 6 + hi % 6 : 0;
+      const int dB = kBcrCps + r / 6 - c / 6;       // row r of the next superblock against column c of this one
+      okB[u] = r < RB && c < RB && dB < a.k;
+      iB[u] = okB[u] ? ((c / 6) * a.k + dB) * 36 + (c % 6) * 6 + r % 6 : 0;
+    }
+  }
+  auto fetch = [&](int i, Pre& pr) {
+    const int blk = blk0 + i, mask = pend_mask;
+    const bool has_next = (i + 1 < q) || right >= 0;
+    const bool has_a = (i == 0) && left >= 0;
+    const size_t lc = size_t(left > 0 ? left : 0);
+    if (FROM_R) {
+      // neighbours in the tree are neighbours in time at level 0 (next = blk + 1, left separator = blk - 1)
+      const int nreal = a.n_s() - RB * blk, nreal_n = nreal - RB;     // real rows of this superblock / of the next one
+      const double* RBnd = a.R + a.off_B() + size_t(blk) * strideB;
+      const double* RBndA = a.R + a.off_B() + size_t(max(blk - 1, 0)) * strideB;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int e = min(max(lt, 0) + NL * u, BB - 1);
+        const int r = e >> 5, c = e & 31;
+        bool act_r = true, act_c = true, act_rn = true, act_cl = true;
+        if (!b.all_active) {
+          const int n_cp = a.n_cp;
+          act_r = a.cp_active[min(kBcrCps * blk + r / 6, n_cp - 1)] != 0;
+          act_c = a.cp_active[min(kBcrCps * blk + c / 6, n_cp - 1)] != 0;
+          act_rn = a.cp_active[min(kBcrCps * (blk + 1) + r / 6, n_cp - 1)] != 0;
+          act_cl = a.cp_active[min(max(kBcrCps * (blk - 1) + c / 6, 0), n_cp - 1)] != 0;
+        }
+        const bool vD = okD[u] && r < nreal && c < nreal && act_r && act_c;
+        double v = RBnd[vD ? iD[u] : 0];
+        v = vD ? v : 0.0;
+        if (r == c) {
+          const int t = RB * blk + r;
+          const bool real_row = r < RB && r < nreal;
+          const double d = fr.damping(v, real_row ? t : 0);
+          if (vD) { v += d; if (role == 0) a.dadd[t] = d; }
+          else { v = 1.0; if (role == 0 && real_row) a.dadd[t] = 0.0; }
+        }
+        pr.d[u] = v;
+        const bool vB = okB[u] && has_next && r < nreal_n && act_rn && act_c;
+        const double g = RBnd[vB ? iB[u] : 0];
+        pr.bt[u] = vB ? g : 0.0;
+        const bool vA = okB[u] && has_a && r < nreal && act_r && act_cl;
+        const double ga = RBndA[vA ? iB[u] : 0];
+        pr.at[u] = vA ? ga : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = min(max(lt, 0) + NL * u, BP * kBcrFS - 1);
+        const int r = e >> 4, col = role > 0 ? f0 + (e & 15) : 0;
+        const int t = RB * blk + r;
+        bool act_r = true;
+        if (!b.all_active) act_r = a.cp_active[min(kBcrCps * blk + r / 6, a.n_cp - 1)] != 0;
+        const bool vF = role > 0 && r < RB && r < nreal && col <= a.mc && act_r;
+        const size_t idx = vF ? (col < a.mc ? a.off_E() + size_t(t) * a.mc + col : a.off_g() + t) : a.off_g();
+        const double f = a.R[idx];
+        pr.f[u] = vF ? f : 0.0;
+      }
+      return;
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int e = min(max(lt, 0) + NL * u, BB - 1);
+      const double v0 = b.D[size_t(blk) * BB + e];
+      const double v1 = pendD_r[(size_t(blk) * 2 + 0) * BB + e];
+      const double v2 = pendD_r[(size_t(blk) * 2 + 1) * BB + e];
+      pr.d[u] = (v0 + ((mask & 1) ? v1 : 0.0)) + ((mask & 2) ? v2 : 0.0);
+      const double g = Gr[size_t(blk) * BB + e];
+      pr.bt[u] = has_next ? g : 0.0;
+      const double ga = Gr[lc * BB + e];
+      pr.at[u] = has_a ? ga : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = min(max(lt, 0) + NL * u, BP * kBcrFS - 1);
+      const int r = e >> 4, j = e & 15;
+      const int col = role > 0 ? f0 + j : 0;
+      const size_t o2 = size_t(r) * m1p + col;
+      const double v0 = b.F[size_t(blk) * fblk + o2];
+      const double v1 = pendF_r[(size_t(blk) * 2 + 0) * fblk + o2];
+      const double v2 = pendF_r[(size_t(blk) * 2 + 1) * fblk + o2];
+      pr.f[u] = role > 0 ? (v0 + ((mask & 1) ? v1 : 0.0)) + ((mask & 2) ? v2 : 0.0) : 0.0;
+    }
+  };
+  auto commit = [&](int p, const Pre& pr) {
+    double* Dp = Daug + p * 64 * DLD;
+    double* Xp = Xb + p * BP * XLD;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int e = lt + NL * u;
+      if (e < BB) {
+        const int r = e >> 5, c = e & 31;
+        Dp[r * DLD + c] = pr.d[u];
+        Dp[(BP + r) * DLD + c] = r == c ? 1.0 : 0.0;
+        Xp[c * XLD + CB + r] = pr.bt[u];     // B[row of this block][next's dim] = G[next's dim][row]
+        Xp[r * XLD + CA + c] = pr.at[u];     // A[row of this block][left separator's dim] = G_left as stored
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = lt + NL * u;
+      if (e < BP * kBcrFS) Xp[(e >> 4) * XLD + CF + (e & 15)] = pr.f[u];
+    }
+  };
+  const bool dbg = a.debug && bid < 2 && lane == 0 && (wave == 0 || wave == 5);
+  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
+#define LTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
+  double pmin = 1.0;
+  // U_aa (role 0: waves 0..3, tile (wave >> 1, wave & 1)) or U_aF (border roles: waves 2, 3, row tile wave - 2)
+  f64x4 acc_a = {0.0, 0.0, 0.0, 0.0};
+  {
+    Pre pr;
+    if (wave != 0) fetch(0, pr);
+    if (terminated) return;
+    if (wave != 0) commit(0, pr);
+  }
+  __syncthreads();
+  LTICK(0)
+  // (the barriers of the step loop order LDS traffic only: __syncthreads() would also drain the global loads of the
+  //  next block, which are meant to stay in flight while this one is factored)
+  for (int i = 0; i < q; ++i) {
+    const int p = i & 1;
+    double* Dp = Daug + p * 64 * DLD;
+    double* Xp = Xb + p * BP * XLD;
+    double* Dn = Daug + (p ^ 1) * 64 * DLD;
+    double* Xn = Xb + (p ^ 1) * BP * XLD;
+    const bool last = i + 1 == q;
+    const int blk = blk0 + i;
+    Pre pr;
+    if (!last && wave != 0) fetch(i + 1, pr);            // in flight while the block is factored
+    // ---- D = L Lᵀ and L⁻ᵀ: two in-wave panels, one tile update between them ----
+    if (wave == 0) panel_factor<1, false>(Dp, DLD, dinv, bcast, 0, 63, 16, lane, &pmin);
+    lds_barrier();
+    LTICK(1)
+    if (wave < 3) update_tile(Dp, DLD, 63, 1 + wave, 1, 0, 1, lane, dump);
+    lds_barrier();
+    LTICK(2)
+    if (wave == 0) panel_factor<1, false>(Dp, DLD, dinv, bcast, 16, 63, 16, lane, &pmin);
+    else if (!last) commit(p ^ 1, pr);
+    lds_barrier();
+    LTICK(3)
+    // ---- Z = L⁻¹ X = MᵀX, M = L⁻ᵀ in rows 32..63 (upper triangular: row tile it needs k < 16(it+1)) ----
+    {
+      const double* M = Dp + BP * DLD;
+      auto zjob = [&](int jt, int it) {
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        acc = atb_tile<false>(M, DLD, 16 * it, Xp, XLD, 16 * jt, 0, 16 * (it + 1), acc, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Zb[(16 * it + lk + 4 * r) * XLD + 16 * jt + l16] = acc[r];
+      };
+      zjob(wave >> 1, wave & 1);
+      if (role > 0 && wave < 2) zjob(4, wave);
+    }
+    lds_barrier();
+    LTICK(4)
+    // ---- file what the back-substitution needs ----
+    if (role == 0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + kLevelThreads * u;
+        const int r = e >> 5, c = e & 31;
+        b.M[size_t(blk) * BB + e] = Dp[(BP + r) * DLD + c];
+        b.ZA[size_t(blk) * BB + e] = Zb[r * XLD + CA + c];
+        b.ZB[size_t(blk) * BB + e] = Zb[r * XLD + CB + c];
+      }
+    } else {
+      const int r = tid >> 4, j = tid & 15;
+      b.Y[size_t(blk) * fblk + size_t(r) * m1p + f0 + j] = Zb[r * XLD + CF + j];
+    }
+    // ---- Schur updates of the next block of the chain (in LDS) or of the right separator (pending slots) ----
+    const int it = (wave & 3) >> 1, jt = wave & 1;
+    const int row0 = 16 * it + lk, col0 = 16 * jt + l16;
+    if (!last) {
+      if (wave < 4) {          // next.D -= Z^BᵀZ^B
+        f64x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Dn[(row0 + 4 * r) * DLD + col0];
+        acc = atb_tile<true>(Zb, XLD, CB + 16 * it, Zb, XLD, CB + 16 * jt, 0, BP, acc, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Dn[(row0 + 4 * r) * DLD + col0] = acc[r];
+      } else {                 // next.A -= Z^BᵀZ^A (fill towards the left separator)
+        f64x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Xn[(row0 + 4 * r) * XLD + CA + col0];
+        acc = atb_tile<true>(Zb, XLD, CB + 16 * it, Zb, XLD, CA + 16 * jt, 0, BP, acc, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xn[(row0 + 4 * r) * XLD + CA + col0] = acc[r];
+      }
+      if (role > 0 && wave < 2) {   // next.F -= Z^BᵀZ^F
+        const int rw = 16 * wave + lk;
+        f64x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Xn[(rw + 4 * r) * XLD + CF + l16];
+        acc = atb_tile<true>(Zb, XLD, CB + 16 * wave, Zb, XLD, CF, 0, BP, acc, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xn[(rw + 4 * r) * XLD + CF + l16] = acc[r];
+      }
+    } else if (right >= 0) {
+      if (role == 0) {
+        if (wave < 4) {        // pending D of the right separator, from its left (side 0)
+          f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+          acc = atb_tile<true>(Zb, XLD, CB + 16 * it, Zb, XLD, CB + 16 * jt, 0, BP, acc, lane);
+          double* dst = pendD_w + (size_t(right) * 2 + 0) * BB;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[(row0 + 4 * r) * BP + col0] = acc[r];
+        } else if (left >= 0) {   // fill T(right, left): the left separator's coupling to its next survivor
+          f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+          acc = atb_tile<true>(Zb, XLD, CB + 16 * it, Zb, XLD, CA + 16 * jt, 0, BP, acc, lane);
+          double* dst = Gw + size_t(left) * BB;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[(row0 + 4 * r) * BP + col0] = acc[r];
+        }
+      } else if (wave < 2) {   // pending F of the right separator
+        const int rw = 16 * wave + lk;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        acc = atb_tile<true>(Zb, XLD, CB + 16 * wave, Zb, XLD, CF, 0, BP, acc, lane);
+        double* dst = pendF_w + (size_t(right) * 2 + 0) * fblk + f0 + l16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[size_t(rw + 4 * r) * m1p] = acc[r];
+      }
+    }
+    // ---- what the left separator collects over the chain ----
+    if (left >= 0) {
+      if (role == 0) {
+        if (wave < 4) acc_a = atb_tile<true>(Zb, XLD, CA + 16 * it, Zb, XLD, CA + 16 * jt, 0, BP, acc_a, lane);
+      } else if (wave == 2 || wave == 3) {
+        acc_a = atb_tile<true>(Zb, XLD, CA + 16 * (wave - 2), Zb, XLD, CF, 0, BP, acc_a, lane);
+      }
+    }
+    LTICK(5)
+    lds_barrier();
+    LTICK(6)
+  }
+  if (dbg) printf("bcr_level %d wg %d wave %d (q %d) cycles: load %lld | per step: panel0 %lld  tile %lld  panel1+commit %lld  Z %lld  stores+U %lld  barrier %lld\n",
+                  level, bid, wave, q, tph[0], tph[1] / q, tph[2] / q, tph[3] / q, tph[4] / q, tph[5] / q, tph[6] / q);
+#undef LTICK
+  if (left >= 0) {
+    if (role == 0) {
+      if (wave < 4) {
+        const int it = wave >> 1, jt = wave & 1;
+        double* dst = pendD_w + (size_t(left) * 2 + 1) * BB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(16 * it + lk + 4 * r) * BP + 16 * jt + l16] = acc_a[r];
+      }
+    } else if (wave == 2 || wave == 3) {
+      double* dst = pendF_w + (size_t(left) * 2 + 1) * fblk + f0 + l16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[size_t(16 * (wave - 2) + lk + 4 * r) * m1p] = acc_a[r];
+    }
+  }
+  if (role == 0 && wave == 0 && lane == 0 && !(pmin > 0.0)) st->chol_failed = 1;
+}
+
+// ---------------------------------------------------------------------------
+// Reduced system in its final indexing [calibration | root | right-hand side]: the calibration / right-hand-side part
+// is S - YᵀY over all eliminated rows (one 16x16 tile per workgroup and K-slice, on the matrix cores straight from
+// global memory, like schur_kernel), the root part comes from the root superblock (+ its pending updates).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bcr_schur_kernel(SolveArgs a, BcrArgs b, int ks, int n_tile_wg, LmOptionsDev o) {
+  const LmState* st = a.st;
+  if (st->terminated) return;
+  use_current_R(a);
+  const FromR fr = {a, o, st->radius};
+  const int mc = a.mc, m = a.m, m1 = a.m + 1, m1p = b.m1p, m1y = a.mc + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t msq = size_t(m1) * m1;
+  if (int(blockIdx.x) >= n_tile_wg) {
+    // root rows: Spart(mc + r, j) = F_root(r, j), Spart(mc + r, mc + r2) = D_root(r, r2), Spart(m, mc + r) = F_root(r, mc)
+    if (b.root < 0) return;
+    const int br = m - mc;
+    const size_t fblk = size_t(BP) * m1p;
+    const double* pD = b.pendD + size_t(b.root_par) * size_t(b.N) * 2 * BB;
+    const double* pF = b.pendF + size_t(b.root_par) * size_t(b.N) * 2 * fblk;
+    const int mask = b.root_pend;
+    const int nw = gridDim.x - n_tile_wg, w0 = blockIdx.x - n_tile_wg;
+    const int total = br * (m1y + br);
+    for (int e = w0 * 256 + tid; e < total; e += nw * 256) {
+      const int r = e / (m1y + br), j = e % (m1y + br);
+      double v; int fi, fc;
+      if (j < m1y) {
+        const size_t o = size_t(b.root) * fblk + size_t(r) * m1p + j;
+        v = b.F[o];
+        if (mask & 1) v += pF[(size_t(b.root) * 2 + 0) * fblk + size_t(r) * m1p + j];
+        if (mask & 2) v += pF[(size_t(b.root) * 2 + 1) * fblk + size_t(r) * m1p + j];
+        if (j < mc) { fi = mc + r; fc = j; } else { fi = m; fc = mc + r; }
+      } else {
+        const int r2 = j - m1y;
+        if (r2 > r) continue;
+        const size_t o = size_t(r) * BP + r2;
+        v = b.D[size_t(b.root) * BB + o];
+        if (mask & 1) v += pD[(size_t(b.root) * 2 + 0) * BB + o];
+        if (mask & 2) v += pD[(size_t(b.root) * 2 + 1) * BB + o];
+        fi = mc + r; fc = mc + r2;
+      }
+      a.Spart[size_t(fi) * m1 + fc] = v;
+      for (int k = 1; k < ks; ++k) a.Spart[size_t(k) * msq + size_t(fi) * m1 + fc] = 0.0;
+    }
+    return;
+  }
+  __shared__ double sacc[4][256];
+  const int n = b.N * BP;                       // rows of Y (padding and root rows are zero)
+  const int tile = blockIdx.x / ks, slice = blockIdx.x % ks;
+  int tr = 0, rem = tile;
+  while (rem > tr) { rem -= tr + 1; ++tr; }
+  const int tc = rem;
+  const int lc16 = lane & 15, lk = lane >> 4;
+  const int rows_per = ((n + ks - 1) / ks + 15) & ~15;
+  const int r_begin = slice * rows_per, r_end = min(n, r_begin + rows_per);
+  const int per_wave = (((r_end - r_begin + 3) / 4 + 3) / 4) * 4;
+  const int w_begin = r_begin + wave * per_wave, w_end = min(r_end, w_begin + per_wave);
+  const int ca = 16 * tr + lc16, cb = 16 * tc + lc16;      // columns of Y: always < m1p
+  const double* pa = b.Y + ca;
+  const double* pb = b.Y + cb;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = w_begin; k0 < w_end; k0 += 32) {
+    double va[8], vb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int row = k0 + 4 * u + lk;
+      const size_t ro = size_t(min(row, n - 1)) * m1p;
+      va[u] = pa[ro]; vb[u] = pb[ro];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double rm = k0 + 4 * u + lk < w_end ? 1.0 : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u] * rm, vb[u], acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sacc[wave][(lk + 4 * r) * 16 + lc16] = acc[r];
+  __syncthreads();
+  {
+    const int ti = tid >> 4, tj = tid & 15;
+    const int r = tr * 16 + ti, c = tc * 16 + tj;      // columns of Y
+    const double sum = ((sacc[0][tid] + sacc[1][tid]) + sacc[2][tid]) + sacc[3][tid];
+    if (r < m1y && c <= r) {
+      const int fi = r < mc ? r : m, fc = c < mc ? c : m;   // final index: the right-hand side sits behind the root rows
+      // corner of the damped system: C(r, c) (+ damping on the diagonal), right-hand side g_c in row m; (m, m) is unused
+      double s0 = 0.0;
+      if (slice == 0) {
+        if (r < mc) {
+          s0 = a.R[a.off_C() + size_t(r) * mc + c];
+          if (r == c) { const double d = fr.damping(s0, a.n_s() + r); a.dadd[a.n_s() + r] = d; s0 += d; }
+        } else if (c < mc) s0 = a.R[a.off_g() + a.n_s() + c];
+      }
+      a.Spart[size_t(slice) * msq + size_t(fi) * m1 + fc] = s0 - sum;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Back-substitution down the tree + update of the candidate point.
+// ---------------------------------------------------------------------------
+// Solution of a separator: the root's comes from the reduced solve (behind the calibration part of y), the others'
+// from the level above.
+DEVI const double* sep_solution(const SolveArgs& a, const BcrArgs& b, int blk) {
+  return blk == b.root ? a.y + a.n_s() + a.mc : b.ysol + size_t(blk) * BP;
+}
+
+// delta = -y ; candidate = Plus(x, delta) for the parameter blocks selected by the caller; partial sums of the model
+// cost change and of the step norms go to the node's slot. (delta / Plus as in update_body, solve_kernels.hip.)
+struct UpdSums { double mcc, sn, cn; int bad; };
+DEVI void update_block(const BlockDev B, const double* yb, const double* __restrict__ x, double* __restrict__ x_cand, UpdSums& s) {
+  const double* p = x + B.amb_off;
+  double* qv = x_cand + B.amb_off;
+  if (B.manifold == 1) {
+    const double d0 = -yb[0], d1 = -yb[1], d2 = -yb[2];
+    const double nd = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    double nx = p[0], ny = p[1], nz = p[2], nw = p[3];
+    if (nd > 0.0) {
+      const double sd = sin(nd) / nd, qw = cos(nd);
+      const double qx = sd * d0, qy = sd * d1, qz = sd * d2;
+      const double px = p[0], py = p[1], pz = p[2], pw = p[3];
+      nw = qw * pw - qx * px - qy * py - qz * pz;
+      nx = qw * px + qx * pw + qy * pz - qz * py;
+      ny = qw * py + qy * pw + qz * px - qx * pz;
+      nz = qw * pz + qz * pw + qx * py - qy * px;
+    }
+    qv[0] = nx; qv[1] = ny; qv[2] = nz; qv[3] = nw;
+    const double e[4] = {p[0] - nx, p[1] - ny, p[2] - nz, p[3] - nw};
+    s.sn += e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3];
+    s.cn += nx * nx + ny * ny + nz * nz + nw * nw;
+  } else {
+    for (int i = 0; i < B.size; ++i) {
+      const double v = p[i] - yb[i];
+      qv[i] = v; const double e = p[i] - v; s.sn += e * e; s.cn += v * v;
+    }
+  }
+}
+// fixed-order reduction of the per-thread sums of one workgroup into slot `slot`
+DEVI void file_update_sums(const UpdSums& s, double* sh /* [4][T] */, double* upd, int slot) {
+  const int tid = threadIdx.x, T = blockDim.x;
+  sh[tid] = s.mcc; sh[T + tid] = s.sn; sh[2 * T + tid] = s.cn; sh[3 * T + tid] = s.bad ? 1.0 : 0.0;
+  __syncthreads();
+  for (int off = T >> 1; off > 0; off >>= 1) {
+    if (tid < off) {
+      sh[tid] += sh[tid + off]; sh[T + tid] += sh[T + tid + off]; sh[2 * T + tid] += sh[2 * T + tid + off];
+      sh[3 * T + tid] += sh[3 * T + tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid < 4) upd[size_t(slot) * 4 + tid] = sh[T * tid];
+}
+
+// grid = n_nodes, and for the top level (the first launch after the reduced solve) + 1 workgroup that updates the
+// calibration blocks and the root's control points + N·32/8 workgroups that form L⁻¹g - Z^F y_c for the rows of every
+// superblock (b.zb), which the levels below read instead of sweeping the border rows again. Dynamic LDS:
+// bcr_back_lds_bytes.
+constexpr int kBackThreads = 512;
+__global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, BcrArgs b, int node0, int n_nodes, int top, int q_max,
+                                                                const double* __restrict__ x, double* __restrict__ x_cand,
+                                                                const BlockDev* __restrict__ blocks, int n_blocks) {
+  LmState* st = a.st;
+  const int terminated = st->terminated;     // tested after the loads are on their way
+  use_current_R(a);
+  extern __shared__ double lds[];
+  __shared__ double sh[4 * kBackThreads];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_s = a.n_s(), mc = a.mc, m1p = b.m1p;
+  const size_t fblk = size_t(BP) * m1p;
+  constexpr int RB = 6 * kBcrCps;
+  UpdSums s = {0.0, 0.0, 0.0, 0};
+  if (int(blockIdx.x) >= n_nodes && terminated) return;
+  if (int(blockIdx.x) > n_nodes) {
+    // z - Z^F y_c, one wave per row of Y
+    const int row = (int(blockIdx.x) - n_nodes - 1) * (kBackThreads / 64) + wave;
+    if (row >= b.N * BP) return;
+    const double* yrow = b.Y + size_t(row) * m1p;
+    const double* yc = a.y + n_s;
+    double part = 0.0;
+#pragma unroll 2
+    for (int j = lane; j < mc; j += 64) part += yrow[j] * yc[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (lane == 0) b.zb[row] = yrow[mc] - part;
+    return;
+  }
+  if (int(blockIdx.x) == n_nodes) {
+    // calibration blocks (their BlockDevs follow the control points') and the root's control points
+    for (int j = tid; j < mc; j += kBackThreads) {
+      const double yj = a.y[n_s + j];
+      if (!isfinite(yj)) s.bad = 1;
+      s.mcc += 0.5 * yj * (a.R[a.off_g() + n_s + j] + yj * a.dadd[n_s + j]);
+    }
+    for (int bi = tid; bi < n_blocks; bi += kBackThreads) {
+      const BlockDev B = blocks[bi];
+      if (B.tan_off < n_s) continue;
+      update_block(B, a.y + B.tan_off, x, x_cand, s);
+    }
+    if (b.root >= 0) {
+      const double* yr = a.y + n_s + mc;
+      if (tid < RB) {
+        const int t = RB * b.root + tid;
+        if (t < n_s) {
+          const double yj = yr[tid];
+          if (!isfinite(yj)) s.bad = 1;
+          s.mcc += 0.5 * yj * (a.R[a.off_g() + t] + yj * a.dadd[t]);
+          a.y[t] = yj;
+        }
+      }
+      if (tid < kBcrCps) {
+        const int cp = kBcrCps * b.root + tid;
+        const int bi = cp < a.n_cp ? b.cp_block[cp] : -1;
+        if (bi >= 0) update_block(blocks[bi], yr + 6 * tid, x, x_cand, s);
+      }
+    }
+    if (tid == 0) { st->rfill = st->rcur ^ 1; st->upd_parts = 0; }
+    file_update_sums(s, sh, b.upd, b.n_slots - 1);
+    return;
+  }
+  const BcrNodeDev* __restrict__ ndp = b.nodes + node0 + blockIdx.x;
+  const int q = ndp->q, nd_left = ndp->left, nd_right = ndp->right, nd_slot = ndp->slot, blk0 = ndp->blk0;
+  double* ZBs = lds;                                   // [q][32][33]
+  double* Ms = ZBs + size_t(q_max) * BP * DLD;         // [q][32][33]
+  double* tv = Ms + size_t(q_max) * BP * DLD;          // [8][32]
+  double* ya = tv + kBcrMaxChain * BP;                 // [32]
+  double* yn = ya + BP;                                // [32]  solution of the next block (right separator first)
+  double* wv = yn + BP;                                // [32]
+  double* yc = wv + BP;                                // [m1p]
+  double* ych = yc + m1p;                              // [q_max][32] the chain's solutions
+  // Everything the node needs is requested before anything is consumed -- the separators' solutions, Z^B and L⁻ᵀ of
+  // every block (to LDS), this thread's entries of Z^A and of L⁻¹g - Z^F y_c (sixteen threads per row), and what the
+  // update of the candidate point reads (gradient, damping, the control points' current values): a dependent global
+  // load costs about a microsecond here, the arithmetic next to nothing. Chain indices are clamped, not predicated,
+  // so that the loads stay unconditional.
+  double ysep, ycv;
+  {
+    const double* pl = nd_left >= 0 ? sep_solution(a, b, nd_left) : a.y;
+    const double* pr = nd_right >= 0 ? sep_solution(a, b, nd_right) : a.y;
+    const double vl = pl[tid & 31], vr = pr[tid & 31];
+    ysep = tid < BP ? (nd_left >= 0 ? vl : 0.0) : (nd_right >= 0 ? vr : 0.0);
+    ycv = a.y[n_s + min(tid, mc - 1 > 0 ? mc - 1 : 0)];
+  }
+  const int r16 = tid >> 4, sub = tid & 15;
+  double vz[kBcrMaxChain][2], vm[kBcrMaxChain][2], za[kBcrMaxChain][2], zt[kBcrMaxChain];
+#pragma unroll
+  for (int i = 0; i < kBcrMaxChain; ++i) {
+    const int blk = blk0 + min(i, q - 1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t g = size_t(blk) * BB + tid + kBackThreads * u;
+      vz[i][u] = b.ZB[g]; vm[i][u] = b.M[g];
+    }
+    const double* arow = b.ZA + size_t(blk) * BB + size_t(r16) * BP;
+    za[i][0] = arow[sub]; za[i][1] = arow[sub + 16];
+    zt[i] = top ? b.Y[size_t(blk) * fblk + size_t(r16) * m1p + mc] : b.zb[size_t(blk) * BP + r16];
+  }
+  // update stage: thread e < 32q owns row e of the chain (gradient, damping), thread e < 5q control point e
+  const int my_row_t = RB * (blk0 + (tid >> 5)) + (tid & 31);
+  const bool my_row_ok = tid < q * BP && (tid & 31) < RB && my_row_t < n_s;
+  const double my_g = a.R[a.off_g() + (my_row_ok ? my_row_t : 0)], my_dadd = a.dadd[my_row_ok ? my_row_t : 0];
+  const int my_cp = kBcrCps * blk0 + tid;     // the chain's control points are consecutive
+  const bool my_cp_in = tid < q * kBcrCps && my_cp < a.n_cp;
+  const int my_cp_c = my_cp_in ? my_cp : 0;
+  const int my_off = b.ctrl_off[my_cp_c];
+  const bool my_cp_ok = my_cp_in && (b.all_active || a.cp_active[my_cp_c] != 0);
+  double px[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) px[c] = x[my_off + c];
+  if (terminated) return;
+  if (tid < BP) ya[tid] = ysep; else if (tid < 2 * BP) yn[tid - BP] = ysep;
+  if (top) {
+    if (tid < m1p) yc[tid] = tid < mc ? ycv : 0.0;
+    for (int j = tid + kBackThreads; j < m1p; j += kBackThreads) yc[j] = j < mc ? a.y[n_s + j] : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < kBcrMaxChain; ++i) {
+    if (i < q) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + kBackThreads * u;
+        const int o = (i * BP + (e >> 5)) * DLD + (e & 31);
+        ZBs[o] = vz[i][u]; Ms[o] = vm[i][u];
+      }
+    }
+  }
+  __syncthreads();
+  // t_i = (L⁻¹g_i - Z^F y_c) - Z^A y_a : sixteen threads per row, fixed-shape reduction
+#pragma unroll
+  for (int i = 0; i < kBcrMaxChain; ++i) {
+    if (i < q) {
+      double part = nd_left >= 0 ? za[i][0] * ya[sub] + za[i][1] * ya[sub + 16] : 0.0;
+      if (top) {
+        const double* yrow = b.Y + size_t(blk0 + i) * fblk + size_t(r16) * m1p;
+        double yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) yv[u] = yrow[min(sub + 16 * u, m1p - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) part += sub + 16 * u < mc ? yv[u] * yc[sub + 16 * u] : 0.0;
+        for (int j = sub + 128; j < mc; j += 16) part += yrow[j] * yc[j];
+      }
+      part += __shfl_xor(part, 8, 64); part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 1, 64);
+      if (sub == 0) tv[i * BP + r16] = zt[i] - part;
+    }
+  }
+  __syncthreads();
+  // the chain, last block first: w = t_i - Z^B y_next ; y_i = L⁻ᵀ w (one wave, two lanes per row)
+  if (wave == 0) {
+    const int r = lane & 31, h = lane >> 5;
+    for (int i = q - 1; i >= 0; --i) {
+      const double* zb = ZBs + (i * BP + r) * DLD + 16 * h;
+      double wp = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) wp += zb[j] * yn[16 * h + j];
+      wp += __shfl_xor(wp, 32, 64);
+      const double w = tv[i * BP + r] - wp;
+      if (h == 0) wv[r] = w;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const double* mr = Ms + (i * BP + r) * DLD + 16 * h;
+      double yp = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) yp += mr[c] * wv[16 * h + c];
+      yp += __shfl_xor(yp, 32, 64);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (h == 0) { yn[r] = yp; ych[i * BP + r] = yp; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  }
+  __syncthreads();
+  // file the solutions, update the candidate point of the chain's control points (delta = -y, plain vector blocks)
+  if (tid < q * BP) {
+    const double yj = ych[tid];
+    b.ysol[size_t(blk0) * BP + tid] = yj;
+    if (my_row_ok) {
+      if (!isfinite(yj)) s.bad = 1;
+      s.mcc += 0.5 * yj * (my_g + yj * my_dadd);
+      a.y[my_row_t] = yj;
+    }
+  }
+  if (my_cp_ok) {
+    const double* yb = ych + (tid / kBcrCps) * BP + 6 * (tid % kBcrCps);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double v = px[c] - yb[c];
+      x_cand[my_off + c] = v;
+      const double e = px[c] - v;
+      s.sn += e * e; s.cn += v * v;
+    }
+  }
+  file_update_sums(s, sh, b.upd, nd_slot);
+}
+
+// ---- launch helpers ---------------------------------------------------------
+size_t bcr_level_lds_bytes() { return size_t(2 * 64 * DLD + 3 * BP * XLD + 80 + 128 + kLevelThreads) * sizeof(double); }
+size_t bcr_back_lds_bytes(int q_max, int m1p) {
+  return (size_t(2) * q_max * BP * DLD + kBcrMaxChain * BP + 3 * BP + m1p + size_t(q_max) * BP) * sizeof(double);
+}
+hipError_t configure_bcr_kernels(int q_max, int m1p) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bcr_level_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     int(bcr_level_lds_bytes()));
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bcr_level_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          int(bcr_level_lds_bytes()));
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&bcr_back_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             int(bcr_back_lds_bytes(q_max, m1p)));
+}
+
+void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, int level, int keep0, int n_keep, const LmOptionsDev& o,
+                      const double* x, const BlockDev* blocks, int n_blocks, bool with_post_eval, IterLog* log, int log_cap, int jacobi,
+                      hipStream_t s) {
+  const int nfs = (a.mc + 1 + kBcrFS - 1) / kBcrFS;
+  const int n_apply = n_keep > 0 ? std::min(64, std::max(1, n_keep * 4)) : 0;
+  if (level == 0) {
+    hipLaunchKernelGGL(bcr_level_kernel<true>, dim3(n_nodes * (1 + nfs) + n_apply + (with_post_eval ? 1 : 0)), dim3(kLevelThreads),
+                       bcr_level_lds_bytes(), s, a, b, node0, n_nodes, nfs, level, keep0, n_keep, o, with_post_eval ? 1 : 0, x, blocks, n_blocks,
+                       log, log_cap, jacobi);
+  } else {
+    hipLaunchKernelGGL(bcr_level_kernel<false>, dim3(n_nodes * (1 + nfs) + n_apply), dim3(kLevelThreads), bcr_level_lds_bytes(), s, a, b,
+                       node0, n_nodes, nfs, level, keep0, n_keep, o, 0, x, blocks, n_blocks, log, log_cap, jacobi);
+  }
+}
+void launch_bcr_schur(const SolveArgs& a, const BcrArgs& b, int ks, const LmOptionsDev& o, hipStream_t s) {
+  const int nt = (a.mc + 1 + 15) / 16;
+  const int n_tile_wg = nt * (nt + 1) / 2 * ks;
+  hipLaunchKernelGGL(bcr_schur_kernel, dim3(n_tile_wg + (b.root >= 0 ? 4 : 0)), dim3(256), 0, s, a, b, ks, n_tile_wg, o);
+}
+void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, bool top, int q_max, const double* x,
+                     double* x_cand, const BlockDev* blocks, int n_blocks, hipStream_t s) {
+  const int n_mv = (b.N * BP + kBackThreads / 64 - 1) / (kBackThreads / 64);
+  hipLaunchKernelGGL(bcr_back_kernel, dim3(n_nodes + (top ? 1 + n_mv : 0)), dim3(kBackThreads), bcr_back_lds_bytes(q_max, b.m1p), s, a, b,
+                     node0, n_nodes, top ? 1 : 0, q_max, x, x_cand, blocks, n_blocks);
+}
+
+}  // namespace cal

@@ -58,7 +58,18 @@ void launch_cost_reduce(const double* item_cost, int n_items, double* R2, const 
 void launch_control(LmState* st, const LmOptionsDev& o, double* R2, double* x, const double* x_cand, int n_amb,
                     IterLog* log, int log_cap, const double* item_cost, int n_items, const double* Rbase, size_t r_stride,
                     hipStream_t s, bool commit_by_copy = false, int* progress = nullptr, int seq = 0);
-void launch_init_state(LmState* st, double radius, double x_norm, hipStream_t s);
+void launch_init_state(LmState* st, double radius, double x_norm, hipStream_t s, const double* upd_ext = nullptr, int upd_ext_n = 0);
+size_t bcr_level_lds_bytes();
+size_t bcr_back_lds_bytes(int q_max, int m1p);
+hipError_t configure_bcr_kernels(int q_max, int m1p);
+void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, int level, int keep0, int n_keep, const LmOptionsDev& o,
+                      const double* x, const BlockDev* blocks, int n_blocks, bool with_post_eval, IterLog* log, int log_cap, int jacobi,
+                      hipStream_t s);
+void launch_bcr_schur(const SolveArgs& a, const BcrArgs& b, int ks, const LmOptionsDev& o, hipStream_t s);
+void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, bool with_calib, int q_max, const double* x,
+                     double* x_cand, const BlockDev* blocks, int n_blocks, hipStream_t s);
+void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipStream_t s);
+int reduced_schur_slices(const SolveArgs& a);
 
 }  // namespace cal
 
@@ -179,6 +190,17 @@ struct calico_problem {
   bool speculative = true;    // evaluate cost AND Jacobian at the candidate point in one pass (two reduce buffers)
   size_t r_size = 0;
   int sep_s = 0, sep_n = 0;   // separator control points of the nested-dissection split (sep_n = 0: none)
+  // tree solver (bcr_kernels.hip): elimination plan, level after level
+  struct BcrLevel { int node0, n_nodes, keep0, n_keep, q_max; };
+  bool use_bcr = false, bcr_all_active = false;
+  int bcr_N = 0, bcr_m1p = 16, bcr_root = -1, bcr_root_pend = 0, bcr_root_par = 0, bcr_br = 0, bcr_q_max = 1, bcr_slots = 1;
+  std::vector<BcrLevel> bcr_levels;
+  std::vector<BcrNodeDev> h_bcr_nodes;
+  std::vector<int> h_bcr_keep;
+  DevBuf<double> d_bD, d_bG, d_bF, d_bpD, d_bpF, d_bM, d_bZA, d_bZB, d_bY, d_bysol, d_bzb, d_bupd;
+  DevBuf<BcrNodeDev> d_bnodes;
+  DevBuf<int> d_bkeep, d_cp_block;
+  int border_extra() const { return use_bcr ? bcr_br : 6 * sep_n; }   // rows the band hands to the dense reduced solve
   int n_cp = 0, m = 0, n_amb = 0, n_eff = 0, n_items = 0, n_items_all = 0, lds_cols = 0, row_pad = kRowPad;
   int64_t n_obs = 0;
   size_t partial_doubles = 0;
@@ -252,11 +274,82 @@ SolveArgs make_solve_args(calico_problem* p) {
   SolveArgs a;
   a.R = p->d_R.p; a.r_stride = p->speculative ? p->r_size : 0; a.Lb = p->d_Lb.p; a.Linv = p->d_Linv.p; a.Y = p->d_Y.p; a.S = p->d_S.p; a.Spart = p->d_Spart.p;
   a.Swork = p->d_Swork.p; a.y = p->d_y.p; a.zbuf = p->d_zbuf.p; a.dadd = p->d_dadd.p;
-  a.scale = p->d_scale.p; a.cp_active = p->d_cp_active.p; a.st = p->d_state.p; a.n_cp = p->n_cp; a.k = p->order; a.mc = p->m; a.sep_s = p->sep_s; a.sep_n = p->sep_n; a.m = p->m + 6 * p->sep_n;
+  a.scale = p->d_scale.p; a.cp_active = p->d_cp_active.p; a.st = p->d_state.p; a.n_cp = p->n_cp; a.k = p->order; a.mc = p->m; a.sep_s = p->sep_s; a.sep_n = p->sep_n; a.m = p->m + p->border_extra();
   static const int dbg = std::getenv("CALICO_KERNEL_TIMING") ? std::atoi(std::getenv("CALICO_KERNEL_TIMING")) : 0;
   a.debug = dbg;
   a.progress = nullptr;
   return a;
+}
+
+BcrArgs make_bcr_args(calico_problem* p) {
+  BcrArgs b;
+  b.D = p->d_bD.p; b.G = p->d_bG.p; b.F = p->d_bF.p; b.pendD = p->d_bpD.p; b.pendF = p->d_bpF.p; b.M = p->d_bM.p; b.ZA = p->d_bZA.p;
+  b.ZB = p->d_bZB.p; b.Y = p->d_bY.p; b.ysol = p->d_bysol.p; b.zb = p->d_bzb.p; b.upd = p->d_bupd.p; b.nodes = p->d_bnodes.p; b.keep = p->d_bkeep.p;
+  b.cp_block = p->d_cp_block.p; b.ctrl_off = p->d_ctrl_off.p; b.all_active = p->bcr_all_active ? 1 : 0; b.pad0 = 0; b.N = p->bcr_N; b.m1p = p->bcr_m1p; b.root = p->bcr_root; b.root_pend = p->bcr_root_pend;
+  b.root_par = p->bcr_root_par; b.n_slots = p->bcr_slots;
+  return b;
+}
+
+// Elimination plan of the tree solver: level 0 eliminates chains of q consecutive superblocks between kept
+// separators, every further level every other survivor; the last survivor is the root (joins the dense solve).
+// q minimises (levels · launch + chain steps · factorisation) for the trajectory length at hand.
+void build_bcr_plan(calico_problem* p) {
+  const int N = (p->n_cp + kBcrCps - 1) / kBcrCps;
+  p->bcr_N = N;
+  auto levels_after = [](int n_sep) { int l = 0; while (n_sep > 1) { n_sep /= 2; ++l; } return l; };
+  int q = 1;
+  {
+    double best = 1e300;
+    for (int c = 1; c <= kBcrMaxChain; ++c) {
+      const int n_sep = N > c ? N / (c + 1) : 0;
+      const int L = 1 + levels_after(n_sep);
+      const double cost = 6.0 * L + 4.0 * (c + L - 1);
+      if (cost < best) { best = cost; q = c; }
+    }
+    if (const char* e = std::getenv("CALICO_BCR_LEAF")) q = std::max(1, std::min(kBcrMaxChain, std::atoi(e)));
+  }
+  p->bcr_levels.clear(); p->h_bcr_nodes.clear(); p->h_bcr_keep.clear();
+  std::vector<int> alive(static_cast<size_t>(N), 0), mask(static_cast<size_t>(N), 0);
+  for (int i = 0; i < N; ++i) alive[size_t(i)] = i;
+  int level = 0, q_max_all = 1;
+  while (!alive.empty() && (level == 0 || alive.size() > 1)) {
+    const int chain = level == 0 ? q : 1;
+    calico_problem::BcrLevel L;
+    L.node0 = int(p->h_bcr_nodes.size()); L.keep0 = int(p->h_bcr_keep.size() / 2); L.q_max = 1;
+    std::vector<int> kept, new_mask(size_t(N), 0);
+    const size_t n = alive.size();
+    size_t pos = 0;
+    // level 0 with N <= q: one chain, no separator. Otherwise: [chain of `chain`] [keep] [chain] [keep] ...
+    while (pos < n) {
+      BcrNodeDev nd = {};
+      nd.left = kept.empty() ? -1 : kept.back();
+      nd.q = 0;
+      nd.blk0 = alive[pos]; nd.pend = mask[size_t(alive[pos])];     // chains longer than one block only exist at level 0 (consecutive, no pending)
+      while (pos < n && nd.q < chain) { ++nd.q; ++pos; }
+      nd.right = pos < n ? alive[pos] : -1;
+      nd.slot = int(p->h_bcr_nodes.size());
+      L.q_max = std::max(L.q_max, nd.q);
+      if (nd.left >= 0) new_mask[size_t(nd.left)] |= 2;
+      if (nd.right >= 0) new_mask[size_t(nd.right)] |= 1;
+      p->h_bcr_nodes.push_back(nd);
+      if (pos < n) { kept.push_back(alive[pos]); ++pos; }
+    }
+    // separators that survive this level: level 0 initialises them from R(x), later levels add last level's pending updates
+    for (int kb : kept)
+      if (level == 0 || mask[size_t(kb)]) { p->h_bcr_keep.push_back(kb); p->h_bcr_keep.push_back(mask[size_t(kb)]); }
+    L.n_nodes = int(p->h_bcr_nodes.size()) - L.node0;
+    L.n_keep = int(p->h_bcr_keep.size() / 2) - L.keep0;
+    q_max_all = std::max(q_max_all, L.q_max);
+    p->bcr_levels.push_back(L);
+    alive = kept; mask = new_mask;
+    ++level;
+  }
+  p->bcr_root = alive.empty() ? -1 : alive[0];
+  p->bcr_root_pend = alive.empty() ? 0 : mask[size_t(alive[0])];
+  p->bcr_root_par = (level - 1) & 1;
+  p->bcr_br = alive.empty() ? 0 : 6 * kBcrCps;
+  p->bcr_q_max = q_max_all;
+  p->bcr_slots = int(p->h_bcr_nodes.size()) + 1;
 }
 
 EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool want_res) {
@@ -341,6 +434,20 @@ int finalize(calico_problem* p) {
     if (allowed && all_active && n_cp >= 6 * k && m + 6 * (k - 1) + 1 <= 1024) {
       p->sep_n = k - 1;
       p->sep_s = (n_cp - p->sep_n) / 2;
+    }
+  }
+  // Tree solver for spline orders up to 6 (superblocks of five control points are then block tridiagonal); it takes
+  // over the split of the band, so the single-separator variant above is switched off. CALICO_SOLVER=band keeps the
+  // sequential banded factorisation (A/B switch, and the path of higher spline orders).
+  {
+    const char* env = std::getenv("CALICO_SOLVER");
+    p->use_bcr = k <= 6 && !(env && std::string(env) == "band");
+    if (p->use_bcr) {
+      p->sep_s = 0; p->sep_n = 0;
+      p->bcr_all_active = true;
+      for (int i = 0; i < n_cp; ++i) p->bcr_all_active = p->bcr_all_active && cp_active[size_t(i)] != 0;
+      build_bcr_plan(p);
+      p->bcr_m1p = 16 * ((m + 1 + 15) / 16);
     }
   }
   const int NS = 6 * n_cp;
@@ -631,7 +738,7 @@ int finalize(calico_problem* p) {
     p->row_cell_chunk = std::min(p->row_cell_chunk, most);
   }
   // ---- gather lists ----
-  SolveArgs sa; sa.n_cp = n_cp; sa.k = k; sa.mc = m; sa.sep_s = p->sep_s; sa.sep_n = p->sep_n; sa.m = m + 6 * p->sep_n; sa.debug = 0; sa.progress = nullptr;
+  SolveArgs sa; sa.n_cp = n_cp; sa.k = k; sa.mc = m; sa.sep_s = p->sep_s; sa.sep_n = p->sep_n; sa.m = m + p->border_extra(); sa.debug = 0; sa.progress = nullptr;
   const size_t r_size = sa.r_size();
   if (r_size >= size_t(0x7fffffff)) return p->set_error(CALICO_UNIMPLEMENTED, "normal-equation buffer too large");
   struct Pair { int dst, src; };
@@ -721,11 +828,11 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_R.alloc(2 * r_size)); HIP_TRY(p, hipMemsetAsync(p->d_R.p, 0, 2 * r_size * sizeof(double), s));
   HIP_TRY(p, p->d_R2.alloc(2));
   const int NT = 6 * n_cp + m;
-  const int mw = m + 6 * p->sep_n;     // border width the solver kernels work with
+  const int mw = m + p->border_extra();     // border width the solver kernels work with
   HIP_TRY(p, p->d_Lb.alloc(size_t(NS) * 6 * k)); HIP_TRY(p, p->d_Linv.alloc(size_t(n_cp) * 36));
   HIP_TRY(p, p->d_Y.alloc(size_t(NS) * (mw + 1)));
   HIP_TRY(p, p->d_S.alloc(size_t(mw + 1) * (mw + 1)));
-  HIP_TRY(p, p->d_y.alloc(size_t(NT) + 6 * p->sep_n)); HIP_TRY(p, p->d_zbuf.alloc(size_t(NS) + 64)); HIP_TRY(p, p->d_dadd.alloc(NT)); HIP_TRY(p, p->d_scale.alloc(NT));
+  HIP_TRY(p, p->d_y.alloc(size_t(NT) + p->border_extra() + 64)); HIP_TRY(p, p->d_zbuf.alloc(size_t(NS) + 64)); HIP_TRY(p, p->d_dadd.alloc(NT)); HIP_TRY(p, p->d_scale.alloc(NT));
   HIP_TRY(p, p->d_res.alloc(size_t(n_obs) * 3)); HIP_TRY(p, p->d_valid.alloc(size_t(n_obs)));
   HIP_TRY(p, p->d_active.alloc(size_t(n_obs))); HIP_TRY(p, p->d_counter.alloc(1));
   p->active_dirty = true; p->xc_stale = true;
@@ -755,6 +862,25 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_Swork.alloc(std::max<size_t>(reduced_lds / sizeof(double) + 8, size_t(mw + 1) * 16 * 13 + 8)));
   sa = make_solve_args(p);
   HIP_TRY(p, configure_solve_kernels(band_lds, p->dense_in_lds ? reduced_lds : 0, back_lds));
+  if (p->use_bcr) {
+    const size_t N = size_t(p->bcr_N), bb = size_t(kBcrBP) * kBcrBP, fb = size_t(kBcrBP) * p->bcr_m1p;
+    HIP_TRY(p, p->d_bD.alloc(N * bb)); HIP_TRY(p, p->d_bG.alloc(2 * N * bb)); HIP_TRY(p, p->d_bF.alloc(N * fb));
+    HIP_TRY(p, p->d_bpD.alloc(4 * N * bb)); HIP_TRY(p, p->d_bpF.alloc(4 * N * fb));
+    HIP_TRY(p, p->d_bM.alloc(N * bb)); HIP_TRY(p, p->d_bZA.alloc(N * bb)); HIP_TRY(p, p->d_bZB.alloc(N * bb));
+    HIP_TRY(p, p->d_bY.alloc(N * fb)); HIP_TRY(p, p->d_bysol.alloc(N * kBcrBP)); HIP_TRY(p, p->d_bzb.alloc(N * kBcrBP)); HIP_TRY(p, p->d_bupd.alloc(size_t(p->bcr_slots) * 4));
+    HIP_TRY(p, hipMemsetAsync(p->d_bY.p, 0, N * fb * sizeof(double), s));       // rows of the root are never written
+    HIP_TRY(p, hipMemsetAsync(p->d_bG.p, 0, 2 * N * bb * sizeof(double), s));
+    HIP_TRY(p, hipMemsetAsync(p->d_bpD.p, 0, 4 * N * bb * sizeof(double), s)); HIP_TRY(p, hipMemsetAsync(p->d_bpF.p, 0, 4 * N * fb * sizeof(double), s));
+    HIP_TRY(p, hipMemsetAsync(p->d_bupd.p, 0, size_t(p->bcr_slots) * 4 * sizeof(double), s));
+    HIP_TRY(p, p->d_bnodes.upload(p->h_bcr_nodes, s)); HIP_TRY(p, p->d_bkeep.upload(p->h_bcr_keep, s));
+    std::vector<int> cp_block(size_t(n_cp), -1);
+    for (size_t bi = 0; bi < p->h_blocks.size(); ++bi)
+      if (p->h_blocks[bi].tan_off < NS) cp_block[size_t(p->h_blocks[bi].tan_off / 6)] = int(bi);
+    HIP_TRY(p, p->d_cp_block.upload(cp_block, s));
+    if (bcr_level_lds_bytes() > kMaxLds || bcr_back_lds_bytes(p->bcr_q_max, p->bcr_m1p) > kMaxLds)
+      return p->set_error(CALICO_UNIMPLEMENTED, "tree solver workspace exceeds the LDS");
+    HIP_TRY(p, configure_bcr_kernels(p->bcr_q_max, p->bcr_m1p));
+  }
   HIP_TRY(p, hipStreamSynchronize(s));
   p->dirty = false;
   return CALICO_OK;
@@ -824,6 +950,30 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, c
   p->timer.end(p->stream);
   if (!p->allreduce) return CALICO_OK;  // single rank: no exchange
   return do_allreduce(p, target, int64_t(p->r_size));
+}
+
+// One linear solve + update of the candidate point: tree solver or sequential banded factorisation.
+void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOptionsDev& o, bool with_post_eval, int jacobi) {
+  hipStream_t s = p->stream;
+  const int n_blocks = int(p->h_blocks.size());
+  if (!p->use_bcr) {
+    launch_solve(sa, o, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, p->dense_in_lds, s, with_post_eval, p->d_log.p, kLogCap, jacobi);
+    return;
+  }
+  const BcrArgs b = make_bcr_args(p);
+  const int L = int(p->bcr_levels.size());
+  for (int l = 0; l < L; ++l) {
+    const calico_problem::BcrLevel& lv = p->bcr_levels[size_t(l)];
+    launch_bcr_level(sa, b, lv.node0, lv.n_nodes, l, lv.keep0, lv.n_keep, o, p->d_x.p, p->d_blocks.p, n_blocks, l == 0 && with_post_eval,
+                     p->d_log.p, kLogCap, jacobi, s);
+  }
+  const int ks = reduced_schur_slices(sa);
+  launch_bcr_schur(sa, b, ks, o, s);
+  launch_reduced_solve(sa, p->dense_in_lds, ks, s);
+  for (int l = L - 1; l >= 0; --l) {
+    const calico_problem::BcrLevel& lv = p->bcr_levels[size_t(l)];
+    launch_bcr_back(sa, b, lv.node0, lv.n_nodes, l == L - 1, lv.q_max, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, s);
+  }
 }
 
 int read_state(calico_problem* p) {
@@ -1071,13 +1221,15 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   for (const BlockDev& b : p->h_blocks) for (int i = 0; i < b.size; ++i) xn += p->h_x[b.amb_off + i] * p->h_x[b.amb_off + i];
   hipStream_t s = p->stream;
   const auto t_loop = std::chrono::steady_clock::now();
-  launch_init_state(p->d_state.p, opt->initial_trust_region_radius, std::sqrt(xn), s);
+  const double* upd_ext = p->use_bcr ? p->d_bupd.p : nullptr;
+  const int upd_ext_n = p->use_bcr ? p->bcr_slots : 0;
+  launch_init_state(p->d_state.p, opt->initial_trust_region_radius, std::sqrt(xn), s, upd_ext, upd_ext_n);
   // what a hipEventRecord pair costs around a ~2 us kernel on this stream: lets the caller take the bracket
   // overhead out of the per-launch phase times (phase 5)
   if ((p->timer.mask >> 5) & 1) {
     for (int r = 0; r < 4; ++r) {
       p->timer.begin(5, s);
-      launch_init_state(p->d_state.p, opt->initial_trust_region_radius, std::sqrt(xn), s);
+      launch_init_state(p->d_state.p, opt->initial_trust_region_radius, std::sqrt(xn), s, upd_ext, upd_ext_n);
       p->timer.end(s);
     }
   }
@@ -1120,8 +1272,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
       }
       if (done) break;
       p->timer.begin(2, s);
-      launch_solve(sa, o, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, p->dense_in_lds, s, /*with_post_eval=*/enq > 0, p->d_log.p,
-                   kLogCap, opt->jacobi_scaling);
+      enqueue_linear_solve(p, sa, o, /*with_post_eval=*/enq > 0, opt->jacobi_scaling);
       p->timer.end(s);
       // the control stage rides in the last workgroup of the gather kernel
       ControlTail tail;
@@ -1173,8 +1324,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
       // in the prepare kernel of this one; the last iteration of a batch gets a stand-alone post_eval below
       const bool ride = spec && async && b > 0;
       p->timer.begin(2, s);
-      launch_solve(sa, o, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, p->dense_in_lds, s, ride, p->d_log.p, kLogCap,
-                   opt->jacobi_scaling);
+      enqueue_linear_solve(p, sa, o, ride, opt->jacobi_scaling);
       p->timer.end(s);
       if (spec) {
         // Speculative evaluation: cost AND Jacobian at the candidate point in one pass, into the reduce buffer that

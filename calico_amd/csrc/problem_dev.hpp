@@ -117,6 +117,11 @@ struct LmState {
   double upd_mcc[2], upd_sn[2], upd_cn[2];
   int upd_bad[2], upd_parts;
   int commit_pending;     // multi-rank speculative evaluation: the accepted candidate's buffer 1 is to be copied over buffer 0
+  // tree solver (bcr_kernels.hip): every node of the elimination tree leaves the partial sums of the update stage
+  // [model cost change, |step|^2, |candidate|^2, non-finite flag] in its own slot; the control stage adds them up in
+  // slot order (upd_parts == 0 selects this form)
+  const double* upd_ext;
+  int upd_ext_n, pad_ext;
 };
 
 struct LmOptionsDev {
@@ -199,6 +204,50 @@ struct SolveArgs {
   CAL_HD int border_tangent(int b) const { return b < mc ? n_s() + b : 6 * sep_s + (b - mc); }
   // where the solution of tangent index j sits in y: the separator part is solved with the border
   CAL_HD int y_index(int j) const { return in_sep(j) ? n_s() + mc + (j - 6 * sep_s) : j; }
+};
+
+// ---------------------------------------------------------------------------
+// Tree solver ("BCR": block cyclic reduction / nested dissection of the band, bcr_kernels.hip).
+// The control points are grouped into superblocks of kBcrCps = 5 (30 rows, padded to 32): with spline order k <= 6 a
+// superblock only couples to its two neighbours, so the band is block tridiagonal with a dense border (calibration
+// columns + right-hand side). Level 0 eliminates chains of q consecutive superblocks between kept separators, every
+// further level every other surviving separator; the last survivor (the root) joins the calibration blocks in the
+// dense reduced system. The dependent chain is O(q + log(n_cp)) block factorisations instead of n_cp / 2 band steps.
+// ---------------------------------------------------------------------------
+constexpr int kBcrCps = 5;        // control points per superblock
+constexpr int kBcrBP = 32;        // padded superblock size
+constexpr int kBcrMaxChain = 8;   // longest chain a node eliminates
+constexpr int kBcrFS = 16;        // border columns per workgroup of a node
+
+struct BcrNodeDev {
+  int q;                     // chain length: superblocks blk0, blk0 + 1, ..., eliminated left to right (q > 1 only at level 0)
+  int left, right;           // separator superblocks on either side (-1: none)
+  int slot;                  // the node's slot of update-stage partial sums
+  int blk0;                  // first superblock of the chain
+  int pend;                  // bit 0 / 1: the (single) superblock carries a pending update from the chain on its left / right (previous level)
+};
+
+struct BcrArgs {
+  double* D;                 // [N][32][32]   diagonal superblocks (damped), symmetric, full storage
+  double* G;                 // [2][N][32][32] coupling to the NEXT surviving superblock: G[b][r][c] = H(next row r, b column c); ping-pong by level
+  double* F;                 // [N][32][m1p]  border rows: calibration columns, right-hand side in column mc, zero padding
+  double* pendD;             // [2][N][2][32][32]   updates a chain leaves for its separators (to be ADDED), by level parity and side
+  double* pendF;             // [2][N][2][32][m1p]
+  double* M;                 // [N][32][32]   L^-T of every eliminated superblock (upper triangular)
+  double* ZA;                // [N][32][32]   L^-1 · coupling to the left separator
+  double* ZB;                // [N][32][32]   L^-1 · coupling to the next superblock of the chain / the right separator
+  double* Y;                 // [N][32][m1p]  L^-1 · border rows (column mc: L^-1 g); rows of the root stay zero
+  double* ysol;              // [N][32]       solution by superblock
+  double* zb;                // [N][32]       L^-1 g - Z^F y_c by superblock row (formed once per solve for the levels below the top)
+  double* upd;               // [n_slots][4]  update-stage partial sums
+  const BcrNodeDev* nodes;   // all levels, level after level
+  const int* keep;           // kept superblocks with pending updates to apply, level after level: [blk, mask] pairs
+  const int* cp_block;       // [n_cp] BlockDev index of a control point (-1: unobserved)
+  const int* ctrl_off;       // [n_cp] ambient offset of a control point (6 values, no manifold)
+  int all_active, pad0;      // every control point is observed (no activity look-ups)
+  int N, m1p;                // superblocks; padded border width (multiple of 16, >= mc + 1)
+  int root, root_pend, root_par;   // surviving superblock (-1: none), its pending mask and the parity of those slots
+  int n_slots;
 };
 
 }  // namespace cal

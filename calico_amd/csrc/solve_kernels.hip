@@ -17,30 +17,9 @@
 #include <cstdlib>
 
 #include "problem_dev.hpp"
-
-#ifndef CALICO_RSQRT_NEWTON_STEPS
-#define CALICO_RSQRT_NEWTON_STEPS 1
-#endif
+#include "solve_dev.hpp"
 
 namespace cal {
-
-#define DEVI __device__ __forceinline__
-
-// The reduce buffer that holds R(x): with speculative evaluation the Jacobian pass at the candidate point fills the
-// other one and the control kernel swaps them when the step is accepted.
-DEVI void use_current_R(SolveArgs& a) { if (a.r_stride && a.st->rcur) a.R += a.r_stride; }
-
-DEVI double band_entry(const SolveArgs& a, int row, int col) {  // H(row, col), row >= col, inside the band
-  const int ic = col / 6, cc = col % 6, ir = row / 6, rr = row % 6;
-  const int d = ir - ic;
-  if (d >= a.k) return 0.0;
-  return a.R[a.off_B() + (size_t(ic) * a.k + d) * 36 + cc * 6 + rr];
-}
-DEVI double diag_entry(const SolveArgs& a, int j) {
-  if (j < a.n_s()) return band_entry(a, j, j);
-  const int i = j - a.n_s();
-  return a.R[a.off_C() + size_t(i) * a.mc + i];
-}
 
 // ---------------------------------------------------------------------------
 // Gather: every entry of the reduce buffer is the sum of a fixed, host-built
@@ -119,81 +98,6 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
 // LM bookkeeping shared by the kernels below ([Ceres] trust_region_minimizer.cc
 // FinalizeIterationAndCheckIfMinimizerCanContinue).
 // ---------------------------------------------------------------------------
-DEVI void publish(int* word, int value) { __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-
-DEVI void log_and_finalize(LmState* st, const LmOptionsDev& o, IterLog* log, int log_cap) {
-  if (st->iteration > 0) { if (st->step_successful) st->num_successful++; else st->num_unsuccessful++; }
-  if (st->n_log < log_cap) {
-    IterLog& r = log[st->n_log++];
-    r.iteration = st->iteration; r.step_is_valid = st->step_valid; r.step_is_successful = st->step_successful; r.reserved = 0;
-    r.cost = st->step_successful || st->iteration == 0 ? st->x_cost : (st->step_valid ? st->candidate_cost : st->x_cost);
-    r.cost_change = st->cost_change; r.gradient_max_norm = st->gradient_max_norm; r.step_norm = st->step_norm;
-    r.relative_decrease = st->relative_decrease; r.trust_region_radius = st->radius;
-    if (r.cost < st->min_cost) st->min_cost = r.cost;
-  }
-  if (st->iteration >= o.max_num_iterations) { st->terminated = 1; st->termination_type = 1; st->termination_reason = 1; return; }
-  if (st->gradient_max_norm <= o.gradient_tolerance) { st->terminated = 1; st->termination_type = 0; st->termination_reason = 2; return; }
-  if (st->radius < o.min_radius) { st->terminated = 1; st->termination_type = 0; st->termination_reason = 3; return; }
-}
-
-// After a Jacobian evaluation at x: x_cost, gradient norms |x - Plus(x,-g)|,
-// Jacobi scaling at iteration 0, the iteration's log row.
-DEVI void post_eval_body(SolveArgs a, const double* __restrict__ x, const BlockDev* __restrict__ blocks, int n_blocks,
-                         const LmOptionsDev& o, IterLog* log, int log_cap, int first, int jacobi_scaling) {
-  LmState* st = a.st;
-  if (st->terminated || (!first && !st->need_jacobian)) return;
-  use_current_R(a);
-  __shared__ double s_max[256], s_sum[256];
-  const int tid = threadIdx.x;
-  const int NT = a.NT();
-  if (first) {
-    for (int j = tid; j < NT; j += 256) a.scale[j] = jacobi_scaling ? 1.0 / (1.0 + sqrt(diag_entry(a, j))) : 1.0;
-  }
-  double mx = 0.0, sm = 0.0;
-  for (int b = tid; b < n_blocks; b += 256) {
-    const BlockDev B = blocks[b];
-    const double* g = a.R + a.off_g() + B.tan_off;
-    if (B.manifold == 1) {
-      const double d0 = -g[0], d1 = -g[1], d2 = -g[2];
-      const double nd = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-      if (nd > 0.0) {
-        const double sd = sin(nd) / nd, cd = cos(nd);
-        const double qx = sd * d0, qy = sd * d1, qz = sd * d2, qw = cd;
-        const double* p = x + B.amb_off;  // x,y,z,w
-        const double px = p[0], py = p[1], pz = p[2], pw = p[3];
-        const double nw = qw * pw - qx * px - qy * py - qz * pz;
-        const double nx = qw * px + qx * pw + qy * pz - qz * py;
-        const double ny = qw * py + qy * pw + qz * px - qx * pz;
-        const double nz = qw * pz + qz * pw + qx * py - qy * px;
-        const double e[4] = {px - nx, py - ny, pz - nz, pw - nw};
-        for (int i = 0; i < 4; ++i) { mx = fmax(mx, fabs(e[i])); sm += e[i] * e[i]; }
-      }
-    } else {
-      for (int i = 0; i < B.size; ++i) { mx = fmax(mx, fabs(g[i])); sm += g[i] * g[i]; }
-    }
-  }
-  s_max[tid] = mx; s_sum[tid] = sm;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (tid < off) { s_max[tid] = fmax(s_max[tid], s_max[tid + off]); s_sum[tid] += s_sum[tid + off]; }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    st->x_cost = a.R[0];
-    st->n_jac_evals += 1;
-    st->gradient_max_norm = s_max[0];
-    st->gradient_norm = sqrt(s_sum[0]);
-    st->need_jacobian = 0;
-    if (a.R[1] > 0.0) {  // a residual block failed to evaluate at an accepted point
-      st->terminated = 1; st->termination_type = 2; st->termination_reason = first ? 10 : 11;
-    } else {
-      if (first) { st->initial_cost = st->x_cost; st->min_cost = st->x_cost; }
-      log_and_finalize(st, o, log, log_cap);
-    }
-    if (a.progress && st->terminated) publish(a.progress + 1, 1);   // the host stops enqueueing iterations
-  }
-}
-
 __global__ __launch_bounds__(256) void post_eval_kernel(SolveArgs a, const double* __restrict__ x,
                                                         const BlockDev* __restrict__ blocks, int n_blocks,
                                                         LmOptionsDev o, IterLog* log, int log_cap, int first,
@@ -282,29 +186,6 @@ __global__ __launch_bounds__(256) void prepare_kernel(SolveArgs a, LmOptionsDev 
   }
 }
 
-DEVI double readlane_f64(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-
-// 1/sqrt(d): hardware estimate (2^-24 relative, profiles/microbench/rsq_accuracy.hip) + Newton steps, no division and no
-// sqrt call. Two steps give 1 ulp; one step gives 4e-15 relative, which is what the factorisation chains use: a
-// Cholesky factor carries rounding errors of that order anyway (n·eps), and every pivot sits on a latency chain.
-DEVI double rsqrt_nr(double d) {
-  double r = __builtin_amdgcn_rsq(d);
-  const double h = 0.5 * d;
-  r = r * (1.5 - h * r * r);
-#if CALICO_RSQRT_NEWTON_STEPS > 1
-  r = r * (1.5 - h * r * r);
-#endif
-  return r;
-}
-
-// Workgroup barrier that orders LDS traffic only. __syncthreads() also drains vmcnt, which puts the full latency of
-// every in-flight global prefetch / write-back on the per-step critical path of the sequential sweeps.
-DEVI void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // Bordered band Cholesky, blocked by control point (6 columns). Workgroup b factors the band (redundantly)
 // together with border rows [b·16, (b+1)·16); the window of k block columns lives in an LDS ring.
 // Step J:  panel X = A(:, J) L_JJ⁻ᵀ  |barrier|  trailing update A -= X Xᵀ  |barrier|, with one job per wave:
@@ -321,7 +202,6 @@ DEVI void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "
 // offset and predicate is computed once per thread before the sweep (masked operands read a zero word, masked
 // results go to a dump word, both inside each ring slot), divergent branches are avoided, and blocks past the end of
 // the band are streamed in as zeros so that the short windows at the end need no special cases.
-typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int kSlotPad = 16;     // per ring slot: zero words [0, 8), dump words [8, 16)
 
 // Cholesky of a 6×6 block (lower, row-major 36) in every lane: L and the reciprocal diagonal. A non-positive or
@@ -846,94 +726,6 @@ __global__ __launch_bounds__(256) void reduced_solve_reg_kernel(SolveArgs a) {
                   tph[0] / (m > 0 ? m : 1), tph[1] / (m > 0 ? m : 1), tph[2] / (m > 0 ? m : 1), tph[3] / (m > 0 ? m : 1),
                   (long long)__builtin_readcyclecounter() - t_fact);
   if (tid == 0 && s_fail) st->chol_failed = 1;
-}
-
-// Factor one 16-column panel (columns j0..j0+15 of rows j0..m) inside ONE wave; lane l owns rows j0 + l (+ 64·r).
-// Column jj: pivot chain (readlane -> rsqrt -> scale), then only the update of column jj+1 that the next pivot needs
-// (its multiplier travels by readlane); the multipliers of the columns beyond go through a 64-double LDS buffer and
-// are applied one step later, as wave-uniform 16-byte reads, filling the next chain's latency. One wave issues a
-// VALU instruction every 4+ clocks, so the count matters: v_readlane costs two instructions (plus two copies, or an
-// SGPR spill) per multiplier and use, the LDS broadcast half an instruction. A bad pivot is not patched: it turns
-// the factor into NaN (caught by the update stage) and is reported through the running minimum *pmin.
-template <int R>
-DEVI void panel_factor(double* A, int LD, double* dinv, double* bcast, int j0, int m, int w, int lane, double* pmin) {
-  double av[R][16];
-  int row[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    row[r] = j0 + lane + 64 * r;
-    const double* src = A + min(row[r], m) * LD + j0;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) av[r][c] = src[c];
-  }
-  double lprev[R], rs_keep = 0.0;
-#pragma unroll
-  for (int r = 0; r < R; ++r) lprev[r] = 0.0;
-#pragma unroll
-  for (int jj = 0; jj < 16; ++jj) {
-    const double pv = readlane_f64(av[0][jj], jj);
-    *pmin = fmin(*pmin, jj < w ? pv : 1.0);
-    const double rs = rsqrt_nr(pv);
-    double l[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) { l[r] = av[r][jj] * rs; av[r][jj] = l[r]; }
-    double* bw = bcast + (jj & 1) * 64;
-    bw[lane] = l[0];                                   // lanes 0..15 hold L(j0 + c, jj)
-    if (jj + 1 < 16) {
-      double lc = readlane_f64(l[0], jj + 1);
-      asm volatile("" : "+v"(lc));                     // park it in a VGPR: as an SGPR pair it gets spilled between its uses
-#pragma unroll
-      for (int r = 0; r < R; ++r) av[r][jj + 1] -= l[r] * lc;
-    }
-    if (jj > 0) {
-      const double* br = bcast + ((jj - 1) & 1) * 64;  // written one step ago
-#pragma unroll
-      for (int c = jj + 1; c < 16; ++c) {
-        const double lc = br[c];
-#pragma unroll
-        for (int r = 0; r < R; ++r) av[r][c] -= lprev[r] * lc;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) lprev[r] = l[r];
-    rs_keep = lane == jj ? rs : rs_keep;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (lane < 16) dinv[j0 + lane] = rs_keep;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    if (row[r] <= m) {
-      double* dst = A + row[r] * LD + j0;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) dst[c] = av[r][c];
-    }
-  }
-}
-
-// One 16×16 tile of the reduced matrix, block row I / block column c (16-blocks): D(I, c) -= Σ_q L(I, q) L(c, q)ᵀ over
-// the factored panels q in [q0, q1), on the matrix cores. The tile is read and written once however many panels
-// contribute (left-looking); rows past m are clamped for the operands and go to a dump word for the result.
-DEVI void update_tile(double* A, int LD, int m, int I, int c, int q0, int q1, int lane, double* dump) {
-  const int lr = lane & 15, lk = lane >> 4;
-  const double* pa = A + min(16 * I + lr, m) * LD + lk;
-  const double* pb = A + min(16 * c + lr, m) * LD + lk;
-  double* pd[4];
-  f64x4 acc;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = 16 * I + lk + 4 * r;
-    pd[r] = row <= m ? A + row * LD + 16 * c + lr : dump;
-    acc[r] = *pd[r];
-  }
-  for (int q = q0; q < q1; ++q) {
-    double va[4], vb[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) { va[kk] = -pa[16 * q + 4 * kk]; vb[kk] = pb[16 * q + 4 * kk]; }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], acc, 0, 0, 0);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) *pd[r] = acc[r];
 }
 
 // Panel variant for m+1 <= 64·RPL: the augmented reduced matrix lives in LDS (row-major, odd stride) and is
@@ -1571,6 +1363,25 @@ DEVI void control_body(LmState* st, const LmOptionsDev& o, double* R2, double* x
     if (tid == 0) { R2[0] = s_a[0]; R2[1] = s_b[0]; }
     __syncthreads();
   }
+  if (st->upd_parts == 0 && st->upd_ext) {
+    // tree solver: one slot of partial sums per node, added up in slot order (fixed-shape reduction)
+    __shared__ double s_u[4][256];
+    double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
+    for (int i = tid; i < st->upd_ext_n; i += 256) {
+      u0 += st->upd_ext[4 * i]; u1 += st->upd_ext[4 * i + 1]; u2 += st->upd_ext[4 * i + 2]; u3 += st->upd_ext[4 * i + 3];
+    }
+    s_u[0][tid] = u0; s_u[1][tid] = u1; s_u[2][tid] = u2; s_u[3][tid] = u3;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (tid < off) { s_u[0][tid] += s_u[0][tid + off]; s_u[1][tid] += s_u[1][tid + off]; s_u[2][tid] += s_u[2][tid + off]; s_u[3][tid] += s_u[3][tid + off]; }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      st->upd_mcc[0] = s_u[0][0]; st->upd_sn[0] = s_u[1][0]; st->upd_cn[0] = s_u[2][0]; st->upd_bad[0] = s_u[3][0] > 0.0 ? 1 : 0;
+      st->upd_parts = 1;
+    }
+    __syncthreads();
+  }
   if (tid == 0) {
     s_accept = 0;
     finish_update(st, 0);
@@ -1648,8 +1459,9 @@ __global__ __launch_bounds__(256) void commit_kernel(const LmState* st, double* 
   for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256) R[i] = R[n + i];
 }
 
-__global__ void init_state_kernel(LmState* st, double radius, double x_norm) {
+__global__ void init_state_kernel(LmState* st, double radius, double x_norm, const double* upd_ext, int upd_ext_n) {
   LmState s = {};
+  s.upd_ext = upd_ext; s.upd_ext_n = upd_ext_n; s.upd_parts = 1;
   s.radius = radius; s.decrease_factor = 2.0; s.x_norm = x_norm; s.need_jacobian = 1; s.rfill = 1;
   s.min_cost = 1.7976931348623157e308;
   *st = s;
@@ -1703,20 +1515,20 @@ hipError_t configure_solve_kernels(size_t band_lds, size_t reduced_lds, size_t b
   }
   return hipSuccess;
 }
-void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, double* x_cand, const BlockDev* blocks,
-                  int n_blocks, bool reduced_in_lds, hipStream_t s, bool with_post_eval, IterLog* log, int log_cap, int jacobi) {
+static int reduced_blocked_from() {
+  static const int v = [] { const char* e = std::getenv("CALICO_REDUCED_BLOCKED_FROM"); return e ? std::atoi(e) : 129; }();
+  return v;
+}
+static bool reduced_is_blocked(const SolveArgs& a) {
   const int m1 = a.m + 1;
-  const size_t total = size_t(a.n_cp) * a.W() * 6 + size_t(a.n_s()) * m1 + size_t(m1) * m1;
-  const int pb = int((total + 255) / 256);
-  hipLaunchKernelGGL(prepare_kernel, dim3((pb < 2048 ? pb : 2048) + (with_post_eval ? 1 : 0)), dim3(256), 0, s, a, o, with_post_eval ? 1 : 0,
-                     x, blocks, n_blocks, log, log_cap, jacobi);
-  const int nwg = (m1 + kBorderSlice - 1) / kBorderSlice;
-  hipLaunchKernelGGL(band_cholesky_kernel, dim3(nwg, a.n_seg()), dim3(256), band_cholesky_lds_bytes(a), s, a, kBorderSlice);
-  const int nt = (m1 + 15) / 16;
-  static const int blocked_from = [] { const char* e = std::getenv("CALICO_REDUCED_BLOCKED_FROM"); return e ? std::atoi(e) : 129; }();
-  const bool blocked = m1 >= blocked_from && m1 > 128 && a.m <= 256 * kRBCols;
-  const int ks = (m1 <= 128 || blocked) ? kSchurSlices : 1;
-  hipLaunchKernelGGL(schur_kernel, dim3(nt * (nt + 1) / 2 * ks), dim3(256), 0, s, a, ks);
+  return m1 >= reduced_blocked_from() && m1 > 128 && a.m <= 256 * kRBCols;
+}
+// K-slices of the Schur complement the reduced solve adds up on load
+int reduced_schur_slices(const SolveArgs& a) { return (a.m + 1 <= 128 || reduced_is_blocked(a)) ? kSchurSlices : 1; }
+// Dense solve of the (m+1)x(m+1) augmented reduced system in a.Spart (ks K-slices) -> a.y[n_s ...]
+void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipStream_t s) {
+  const int m1 = a.m + 1;
+  const bool blocked = reduced_is_blocked(a);
   if (m1 <= 128) {
     const size_t lds = (size_t(m1) * ((16 * ((m1 + 15) / 16)) | 1) + m1 + 32 + 128 + 256) * sizeof(double);
     if (m1 <= 64) hipLaunchKernelGGL(reduced_solve_panel_kernel<1>, dim3(1), dim3(256), lds, s, a, 0, ks);
@@ -1753,6 +1565,20 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
     hipLaunchKernelGGL(reduced_solve_kernel, dim3(1), dim3(256), reduced_in_lds ? reduced_solve_lds_bytes(a) : 0, s, a,
                        reduced_in_lds ? 1 : 0);
   }
+}
+void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, double* x_cand, const BlockDev* blocks,
+                  int n_blocks, bool reduced_in_lds, hipStream_t s, bool with_post_eval, IterLog* log, int log_cap, int jacobi) {
+  const int m1 = a.m + 1;
+  const size_t total = size_t(a.n_cp) * a.W() * 6 + size_t(a.n_s()) * m1 + size_t(m1) * m1;
+  const int pb = int((total + 255) / 256);
+  hipLaunchKernelGGL(prepare_kernel, dim3((pb < 2048 ? pb : 2048) + (with_post_eval ? 1 : 0)), dim3(256), 0, s, a, o, with_post_eval ? 1 : 0,
+                     x, blocks, n_blocks, log, log_cap, jacobi);
+  const int nwg = (m1 + kBorderSlice - 1) / kBorderSlice;
+  hipLaunchKernelGGL(band_cholesky_kernel, dim3(nwg, a.n_seg()), dim3(256), band_cholesky_lds_bytes(a), s, a, kBorderSlice);
+  const int nt = (m1 + 15) / 16;
+  const int ks = reduced_schur_slices(a);
+  hipLaunchKernelGGL(schur_kernel, dim3(nt * (nt + 1) / 2 * ks), dim3(256), 0, s, a, ks);
+  launch_reduced_solve(a, reduced_in_lds, ks, s);
   hipLaunchKernelGGL(border_matvec_kernel, dim3((a.n_s() + 3) / 4), dim3(256), 0, s, a);
   {
     const size_t bl = band_backsolve_lds_bytes(a);
@@ -1779,8 +1605,8 @@ void launch_control(LmState* st, const LmOptionsDev& o, double* R2, double* x, c
     hipLaunchKernelGGL(commit_kernel, dim3(unsigned(std::min<size_t>(512, (r_stride + 255) / 256))), dim3(256), 0, s, st,
                        const_cast<double*>(Rbase), r_stride);
 }
-void launch_init_state(LmState* st, double radius, double x_norm, hipStream_t s) {
-  hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, s, st, radius, x_norm);
+void launch_init_state(LmState* st, double radius, double x_norm, hipStream_t s, const double* upd_ext, int upd_ext_n) {
+  hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, s, st, radius, x_norm, upd_ext, upd_ext_n);
 }
 
 }  // namespace cal

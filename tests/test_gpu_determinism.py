@@ -50,18 +50,27 @@ def test_repeated_solves_are_bit_identical(name):
 
 @pytest.mark.gpu
 def test_solver_variants_agree(monkeypatch):
-    """The nested-dissection split of the band and the speculative evaluation are pure re-orderings of the same
-    algorithm: with either switched off (development toggles, read when the problem is finalised) the solve must take
-    the same path -- same accept/reject sequence, estimates equal to rounding."""
+    """The tree solver (chains of any length at level 0), the sequential banded factorisation with and without its
+    nested-dissection split, and the speculative evaluation are pure re-orderings of the same algorithm: whichever is
+    selected (development toggles, read when the problem is finalised) the solve must take the same path -- same
+    accept/reject sequence, estimates equal to rounding."""
     api = helpers.hip_api()
-    scene = syn.make_scene(2, 1, True, 2, seed=4)      # 185 control points: the split is active by default
+    scene = syn.make_scene(2, 1, True, 2, seed=4)      # 185 control points: 37 superblocks, several tree levels
     results = {}
-    for split, spec in [("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")]:
+    for solver, leaf, split, spec in [("bcr", "", "1", "1"), ("bcr", "1", "1", "1"), ("bcr", "3", "1", "0"), ("bcr", "8", "1", "1"),
+                                      ("band", "", "1", "1"), ("band", "", "0", "1"), ("band", "", "1", "0"), ("band", "", "0", "0")]:
+        monkeypatch.setenv("CALICO_SOLVER", solver)
+        if leaf:
+            monkeypatch.setenv("CALICO_BCR_LEAF", leaf)
+        else:
+            monkeypatch.delenv("CALICO_BCR_LEAF", raising=False)
         monkeypatch.setenv("CALICO_BAND_SPLIT", split)
         monkeypatch.setenv("CALICO_SPECULATIVE", spec)
-        results[(split, spec)] = _solve_repeatedly(api, scene, repeats=1, max_iter=50)[0]
+        results[(solver, leaf, split, spec)] = _solve_repeatedly(api, scene, repeats=1, max_iter=50)[0]
     # the other development toggles (read per solve / per finalisation): blocking batches instead of the polled loop,
     # stand-alone control kernel, IMU items forming their own blocks, smaller IMU work items
+    monkeypatch.delenv("CALICO_SOLVER")
+    monkeypatch.delenv("CALICO_BCR_LEAF", raising=False)
     monkeypatch.setenv("CALICO_BAND_SPLIT", "1")
     monkeypatch.setenv("CALICO_SPECULATIVE", "1")
     for name, value in [("CALICO_STREAM_DEPTH", "0"), ("CALICO_FUSED_CONTROL", "0"), ("CALICO_ROW_CELLS", "0"),
@@ -69,7 +78,7 @@ def test_solver_variants_agree(monkeypatch):
         monkeypatch.setenv(name, value)
         results[(name, value)] = _solve_repeatedly(api, scene, repeats=1, max_iter=50)[0]
         monkeypatch.delenv(name)
-    ref = results[("0", "0")]
+    ref = results[("band", "", "0", "0")]
     assert ref[1] == _capi.CONVERGENCE
     for key, r in results.items():
         assert r[0] == ref[0] and r[1] == ref[1], key
