@@ -193,10 +193,11 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   double* const bcast = dinv + 80;                 // [128]
   double* const dump = bcast + 128 + tid;          // [512]
   const int l16 = lane & 15, lk = lane >> 4;
-  // ---- global -> registers -> LDS of one chain block. Loaders are waves 1..7 (448 threads: three entries each of D /
-  // B / A, two of the F slice); wave 0 goes straight to the factorisation, it is the critical path of every step. ----
-  constexpr int NL = kLevelThreads - 64, NU = 3;
-  const int lt = tid - 64;
+  // ---- global -> registers -> LDS of one chain block. Loaders are waves 1-3 and 5-7 (384 threads: three entries each
+  // of D / B / A, two of the F slice); wave 0 goes straight to the factorisation, it is the critical path of every step. ----
+  constexpr int NL = kLevelThreads - 128, NU = 3;
+  const bool loader = wave != 0 && wave != 4;    // wave 4 shares the panel wave's SIMD: it stays out of the way, too
+  const int lt = tid - 64 - (wave > 4 ? 64 : 0);
   struct Pre { double d[NU], bt[NU], at[NU], f[2]; };
   // level 0: positions in R of this thread's entries for superblock 0 (the band is uniform in time: superblock I adds
   // I·stride), and what does not depend on the superblock of their validity
@@ -324,9 +325,9 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   f64x4 acc_a = {0.0, 0.0, 0.0, 0.0};
   {
     Pre pr;
-    if (wave != 0) fetch(0, pr);
+    if (loader) fetch(0, pr);
     if (terminated) return;
-    if (wave != 0) commit(0, pr);
+    if (loader) commit(0, pr);
   }
   __syncthreads();
   LTICK(0)
@@ -341,16 +342,16 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     const bool last = i + 1 == q;
     const int blk = blk0 + i;
     Pre pr;
-    if (!last && wave != 0) fetch(i + 1, pr);            // in flight while the block is factored
+    if (!last && loader) fetch(i + 1, pr);            // in flight while the block is factored
     // ---- D = L Lᵀ and L⁻ᵀ: two in-wave panels, one tile update between them ----
-    if (wave == 0) panel_factor<1, false>(Dp, DLD, dinv, bcast, 0, 63, 16, lane, &pmin);
+    if (wave == 0) panel_factor<1, false, false>(Dp, DLD, dinv, bcast, 0, 63, 16, lane, &pmin);
     lds_barrier();
     LTICK(1)
     if (wave < 3) update_tile(Dp, DLD, 63, 1 + wave, 1, 0, 1, lane, dump);
     lds_barrier();
     LTICK(2)
-    if (wave == 0) panel_factor<1, false>(Dp, DLD, dinv, bcast, 16, 63, 16, lane, &pmin);
-    else if (!last) commit(p ^ 1, pr);
+    if (wave == 0) panel_factor<1, false, false>(Dp, DLD, dinv, bcast, 16, 63, 16, lane, &pmin);
+    else if (!last && loader) commit(p ^ 1, pr);
     lds_barrier();
     LTICK(3)
     // ---- Z = L⁻¹ X = MᵀX, M = L⁻ᵀ in rows 32..63 (upper triangular: row tile it needs k < 16(it+1)) ----
@@ -601,19 +602,23 @@ DEVI void update_block(const BlockDev B, const double* yb, const double* __restr
     }
   }
 }
-// fixed-order reduction of the per-thread sums of one workgroup into slot `slot`
-DEVI void file_update_sums(const UpdSums& s, double* sh /* [4][T] */, double* upd, int slot) {
-  const int tid = threadIdx.x, T = blockDim.x;
-  sh[tid] = s.mcc; sh[T + tid] = s.sn; sh[2 * T + tid] = s.cn; sh[3 * T + tid] = s.bad ? 1.0 : 0.0;
-  __syncthreads();
-  for (int off = T >> 1; off > 0; off >>= 1) {
-    if (tid < off) {
-      sh[tid] += sh[tid + off]; sh[T + tid] += sh[T + tid + off]; sh[2 * T + tid] += sh[2 * T + tid + off];
-      sh[3 * T + tid] += sh[3 * T + tid + off];
-    }
-    __syncthreads();
+// fixed-shape reduction of the per-thread sums of one workgroup into slot `slot`: shuffle tree inside every wave, then
+// one thread per quantity adds the waves up in order (one barrier instead of a log-depth LDS tree)
+DEVI void file_update_sums(const UpdSums& s, double* sh /* [4][waves] */, double* upd, int slot) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  double v[4] = {s.mcc, s.sn, s.cn, s.bad ? 1.0 : 0.0};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
   }
-  if (tid < 4) upd[size_t(slot) * 4 + tid] = sh[T * tid];
+  if (lane == 0) { sh[wave] = v[0]; sh[16 + wave] = v[1]; sh[32 + wave] = v[2]; sh[48 + wave] = v[3]; }
+  __syncthreads();
+  if (tid < 4) {
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += sh[16 * tid + w];
+    upd[size_t(slot) * 4 + tid] = t;
+  }
 }
 
 // grid = n_nodes, and for the top level (the first launch after the reduced solve) + 1 workgroup that updates the
@@ -621,6 +626,7 @@ DEVI void file_update_sums(const UpdSums& s, double* sh /* [4][T] */, double* up
 // superblock (b.zb), which the levels below read instead of sweeping the border rows again. Dynamic LDS:
 // bcr_back_lds_bytes.
 constexpr int kBackThreads = 512;
+template <int QM>     // longest chain of the level: bounds the unrolled load batches
 __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, BcrArgs b, int node0, int n_nodes, int top, int q_max,
                                                                 const double* __restrict__ x, double* __restrict__ x_cand,
                                                                 const BlockDev* __restrict__ blocks, int n_blocks) {
@@ -628,7 +634,7 @@ __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, Bcr
   const int terminated = st->terminated;     // tested after the loads are on their way
   use_current_R(a);
   extern __shared__ double lds[];
-  __shared__ double sh[4 * kBackThreads];
+  __shared__ double sh[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_s = a.n_s(), mc = a.mc, m1p = b.m1p;
   const size_t fblk = size_t(BP) * m1p;
@@ -697,6 +703,9 @@ __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, Bcr
   // update of the candidate point reads (gradient, damping, the control points' current values): a dependent global
   // load costs about a microsecond here, the arithmetic next to nothing. Chain indices are clamped, not predicated,
   // so that the loads stay unconditional.
+  const bool bdbg = a.debug && blockIdx.x == 0 && tid == 0;
+  long long bt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, btk = bdbg ? __builtin_readcyclecounter() : 0;
+#define BTICK(i) if (bdbg) { const long long t_ = __builtin_readcyclecounter(); bt[i] += t_ - btk; btk = t_; }
   double ysep, ycv;
   {
     const double* pl = nd_left >= 0 ? sep_solution(a, b, nd_left) : a.y;
@@ -706,9 +715,9 @@ __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, Bcr
     ycv = a.y[n_s + min(tid, mc - 1 > 0 ? mc - 1 : 0)];
   }
   const int r16 = tid >> 4, sub = tid & 15;
-  double vz[kBcrMaxChain][2], vm[kBcrMaxChain][2], za[kBcrMaxChain][2], zt[kBcrMaxChain];
+  double vz[QM][2], vm[QM][2], za[QM][2], zt[QM];
 #pragma unroll
-  for (int i = 0; i < kBcrMaxChain; ++i) {
+  for (int i = 0; i < QM; ++i) {
     const int blk = blk0 + min(i, q - 1);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -732,13 +741,14 @@ __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, Bcr
 #pragma unroll
   for (int c = 0; c < 6; ++c) px[c] = x[my_off + c];
   if (terminated) return;
+  BTICK(0)
   if (tid < BP) ya[tid] = ysep; else if (tid < 2 * BP) yn[tid - BP] = ysep;
   if (top) {
     if (tid < m1p) yc[tid] = tid < mc ? ycv : 0.0;
     for (int j = tid + kBackThreads; j < m1p; j += kBackThreads) yc[j] = j < mc ? a.y[n_s + j] : 0.0;
   }
 #pragma unroll
-  for (int i = 0; i < kBcrMaxChain; ++i) {
+  for (int i = 0; i < QM; ++i) {
     if (i < q) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -749,9 +759,10 @@ __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, Bcr
     }
   }
   __syncthreads();
+  BTICK(1)
   // t_i = (L⁻¹g_i - Z^F y_c) - Z^A y_a : sixteen threads per row, fixed-shape reduction
 #pragma unroll
-  for (int i = 0; i < kBcrMaxChain; ++i) {
+  for (int i = 0; i < QM; ++i) {
     if (i < q) {
       double part = nd_left >= 0 ? za[i][0] * ya[sub] + za[i][1] * ya[sub + 16] : 0.0;
       if (top) {
@@ -768,6 +779,7 @@ __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, Bcr
     }
   }
   __syncthreads();
+  BTICK(2)
   // the chain, last block first: w = t_i - Z^B y_next ; y_i = L⁻ᵀ w (one wave, two lanes per row)
   if (wave == 0) {
     const int r = lane & 31, h = lane >> 5;
@@ -796,7 +808,9 @@ __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, Bcr
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
   }
+  BTICK(3)
   __syncthreads();
+  BTICK(4)
   // file the solutions, update the candidate point of the chain's control points (delta = -y, plain vector blocks)
   if (tid < q * BP) {
     const double yj = ych[tid];
@@ -817,7 +831,12 @@ __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, Bcr
       s.sn += e * e; s.cn += v * v;
     }
   }
+  BTICK(5)
   file_update_sums(s, sh, b.upd, nd_slot);
+  BTICK(6)
+  if (bdbg) printf("bcr_back top %d (q %d) cycles: loads issued+arrived %lld  to LDS+barrier %lld  t-phase %lld  chain %lld  barrier %lld  outputs %lld  sums %lld\n",
+                   top, q, bt[0], bt[1], bt[2], bt[3], bt[4], bt[5], bt[6]);
+#undef BTICK
 }
 
 // ---- launch helpers ---------------------------------------------------------
@@ -832,8 +851,12 @@ hipError_t configure_bcr_kernels(int q_max, int m1p) {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bcr_level_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           int(bcr_level_lds_bytes()));
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&bcr_back_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             int(bcr_back_lds_bytes(q_max, m1p)));
+  for (const void* f : {reinterpret_cast<const void*>(&bcr_back_kernel<1>), reinterpret_cast<const void*>(&bcr_back_kernel<2>),
+                        reinterpret_cast<const void*>(&bcr_back_kernel<4>), reinterpret_cast<const void*>(&bcr_back_kernel<8>)}) {
+    e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(bcr_back_lds_bytes(q_max, m1p)));
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, int level, int keep0, int n_keep, const LmOptionsDev& o,
@@ -858,8 +881,11 @@ void launch_bcr_schur(const SolveArgs& a, const BcrArgs& b, int ks, const LmOpti
 void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, bool top, int q_max, const double* x,
                      double* x_cand, const BlockDev* blocks, int n_blocks, hipStream_t s) {
   const int n_mv = (b.N * BP + kBackThreads / 64 - 1) / (kBackThreads / 64);
-  hipLaunchKernelGGL(bcr_back_kernel, dim3(n_nodes + (top ? 1 + n_mv : 0)), dim3(kBackThreads), bcr_back_lds_bytes(q_max, b.m1p), s, a, b,
-                     node0, n_nodes, top ? 1 : 0, q_max, x, x_cand, blocks, n_blocks);
+  const dim3 grid(n_nodes + (top ? 1 + n_mv : 0)), block(kBackThreads);
+  const size_t lds = bcr_back_lds_bytes(q_max, b.m1p);
+#define LAUNCH_BACK(QM) hipLaunchKernelGGL(bcr_back_kernel<QM>, grid, block, lds, s, a, b, node0, n_nodes, top ? 1 : 0, q_max, x, x_cand, blocks, n_blocks)
+  if (q_max <= 1) LAUNCH_BACK(1); else if (q_max <= 2) LAUNCH_BACK(2); else if (q_max <= 4) LAUNCH_BACK(4); else LAUNCH_BACK(8);
+#undef LAUNCH_BACK
 }
 
 }  // namespace cal

@@ -134,16 +134,26 @@ DEVI void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "
 
 
 // Factor one 16-column panel (columns j0..j0+15 of rows j0..m) inside ONE wave; lane l owns rows j0 + l (+ 64·r).
-// Column jj: pivot chain (readlane -> rsqrt -> scale), then only the update of column jj+1 that the next pivot needs
-// (its multiplier travels by readlane); the multipliers of the columns beyond go through a 64-double LDS buffer and
-// are applied one step later, as wave-uniform 16-byte reads, filling the next chain's latency (columns jj+1 AND jj+2
-// get theirs by readlane, so that no pivot ever waits for the LDS round trip of the step before). One wave issues a
-// VALU instruction every 4+ clocks, so the count matters: v_readlane costs two instructions (plus two copies, or an
-// SGPR spill) per multiplier and use, the LDS broadcast half an instruction. A bad pivot is not patched: it turns
-// the factor into NaN (caught by the update stage) and is reported through the running minimum *pmin.
+// The latency chain runs through the diagonal only, and the diagonal entry of column jj+1 lives in lane jj+1, which
+// holds everything it takes: pivot(jj+1) = a(jj+1, jj+1) - L(jj+1, jj)², both factors its own. So every lane follows
+// its own would-be pivot `pown` (exact in the lane that matters), takes the reciprocal square root of it, and the
+// chain per column is  rsqrt (v_rsq_f64 + one Newton step) -> one v_readlane pair (the pivot lane's 1/sqrt, now wave
+// uniform) -> scale -> one FMA  ≈ 70 clocks (profiles/microbench/panel_latency.hip), with no second broadcast on it.
+// Off the chain: columns jj+1 and jj+2 take column jj's contribution at once (multipliers by v_readlane, so that the
+// diagonal entries two columns ahead are complete in time), the columns beyond one step later through a 64-double LDS
+// buffer, as wave-uniform 16-byte reads requested before the chain starts. One wave issues a VALU instruction every
+// 4+ clocks, so the count matters: v_readlane costs two instructions per multiplier, the LDS broadcast half an
+// instruction. A bad pivot is not patched: it turns the factor into NaN (caught by the update stage); with PMIN the
+// running minimum of the pivots is kept as well.
 // DINV: also file the reciprocal diagonal (the dense reduced solve's backward sweep reads it; the tree solver does not).
-template <int R, bool DINV = true>
-DEVI void panel_factor(double* A, int LD, double* dinv, double* bcast, int j0, int m, int w, int lane, double* pmin) {
+// PUB (R = 1): the wave is the LEAD of a pair. It publishes every finished column (64 multipliers), the pivot's
+// reciprocal square root and a progress word in `bcast` (kPanelPubDoubles doubles, laid out below), so that a second
+// wave (panel_follow) can take the rows from 64 on through the same factorisation a few hundred clocks behind it --
+// the lead then issues the instructions of 64 rows, not 128. `flag_base` makes the progress word monotonic over the
+// panels of one kernel.
+constexpr int kPanelPubL = 0, kPanelPubRs = 16 * 64, kPanelPubFlag = 16 * 64 + 16, kPanelPubDoubles = 16 * 64 + 16 + 2;
+template <int R, bool DINV = true, bool PMIN = true, bool PUB = false>
+DEVI void panel_factor(double* A, int LD, double* dinv, double* bcast, int j0, int m, int w, int lane, double* pmin, int flag_base = 0) {
   double av[R][16];
   int row[R];
 #pragma unroll
@@ -156,48 +166,53 @@ DEVI void panel_factor(double* A, int LD, double* dinv, double* bcast, int j0, i
   double lprev[R], rs_keep = 0.0;
 #pragma unroll
   for (int r = 0; r < R; ++r) lprev[r] = 0.0;
+  double pown = av[0][0];
 #pragma unroll
   for (int jj = 0; jj < 16; ++jj) {
     // multipliers of column jj-1 for the columns from jj+2 on (written one step ago): requested before the pivot
-    // chain starts, consumed after it -- the LDS latency never sits on the chain
+    // chain starts, consumed after it
     double lb[16];
     if (jj > 0) {
-      const double* br = bcast + ((jj - 1) & 1) * 64;
+      const double* br = PUB ? bcast + kPanelPubL + (jj - 1) * 64 : bcast + ((jj - 1) & 1) * 64;
 #pragma unroll
       for (int c = jj + 2; c < 16; ++c) lb[c] = br[c];
     }
-    const double pv = readlane_f64(av[0][jj], jj);
-    *pmin = fmin(*pmin, jj < w ? pv : 1.0);
-    const double rs = rsqrt_nr(pv);
+    const double rs_own = rsqrt_nr(pown);
+    const double rs = readlane_f64(rs_own, jj);
+    const double piv_own = pown;
     double l[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { l[r] = av[r][jj] * rs; av[r][jj] = l[r]; }
-    double* bw = bcast + (jj & 1) * 64;
+    if (jj + 1 < 16) pown = __builtin_fma(-l[0], l[0], av[0][jj + 1]);    // the next pivot, in the lane that owns it
+    double* bw = PUB ? bcast + kPanelPubL + jj * 64 : bcast + (jj & 1) * 64;
     bw[lane] = l[0];                                   // lanes 0..15 hold L(j0 + c, jj)
-    // columns jj+1 and jj+2 take column jj's contribution at once (multipliers by v_readlane): pivot jj+1 is then
-    // complete, and pivot jj+2 will only wait for column jj+1's readlane -- never for an LDS round trip
+    if (PUB) {
+      bcast[kPanelPubRs + jj] = rs;
+      *reinterpret_cast<volatile int*>(bcast + kPanelPubFlag) = flag_base + jj + 1;    // LDS operations of a wave complete in order
+    }
+    if (PMIN) *pmin = fmin(*pmin, jj < w ? readlane_f64(piv_own, jj) : 1.0);     // off the chain
     if (jj + 1 < 16) {
       double lc = readlane_f64(l[0], jj + 1);
       if (R > 1) asm volatile("" : "+v"(lc));          // park it in a VGPR: as an SGPR pair it gets spilled between its uses
 #pragma unroll
-      for (int r = 0; r < R; ++r) av[r][jj + 1] -= l[r] * lc;
+      for (int r = 0; r < R; ++r) av[r][jj + 1] = __builtin_fma(-l[r], lc, av[r][jj + 1]);
     }
     if (jj + 2 < 16) {
       double lc = readlane_f64(l[0], jj + 2);
       if (R > 1) asm volatile("" : "+v"(lc));
 #pragma unroll
-      for (int r = 0; r < R; ++r) av[r][jj + 2] -= l[r] * lc;
+      for (int r = 0; r < R; ++r) av[r][jj + 2] = __builtin_fma(-l[r], lc, av[r][jj + 2]);
     }
     if (jj > 0) {
 #pragma unroll
       for (int c = jj + 2; c < 16; ++c) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) av[r][c] -= lprev[r] * lb[c];
+        for (int r = 0; r < R; ++r) av[r][c] = __builtin_fma(-lprev[r], lb[c], av[r][c]);
       }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) lprev[r] = l[r];
-    if (DINV) rs_keep = lane == jj ? rs : rs_keep;
+    if (DINV) rs_keep = lane == jj ? rs_own : rs_keep;
     __builtin_amdgcn_sched_barrier(0);
   }
   if (DINV && lane < 16) dinv[j0 + lane] = rs_keep;
@@ -208,6 +223,35 @@ DEVI void panel_factor(double* A, int LD, double* dinv, double* bcast, int j0, i
 #pragma unroll
       for (int c = 0; c < 16; ++c) dst[c] = av[r][c];
     }
+  }
+}
+
+// The second wave of a panel pair: rows j0 + 64 + lane of the panel, factored behind the lead from what it publishes
+// (every multiplier a wave-uniform LDS read; no cross-lane traffic, no pivots of its own).
+DEVI void panel_follow(double* A, int LD, const double* pub, int j0, int m, int lane, int flag_base) {
+  const int row = j0 + 64 + lane;
+  double av[16];
+  const double* src = A + min(row, m) * LD + j0;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) av[c] = src[c];
+  const volatile int* flag = reinterpret_cast<const volatile int*>(pub + kPanelPubFlag);
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) {
+    while (*flag < flag_base + jj + 1) __builtin_amdgcn_s_sleep(1);
+    const double rs = pub[kPanelPubRs + jj];
+    const double* lp = pub + kPanelPubL + jj * 64;
+    double lc[16];
+#pragma unroll
+    for (int c = jj + 1; c < 16; ++c) lc[c] = lp[c];
+    const double l = av[jj] * rs;
+    av[jj] = l;
+#pragma unroll
+    for (int c = jj + 1; c < 16; ++c) av[c] = __builtin_fma(-l, lc[c], av[c]);
+  }
+  if (row <= m) {
+    double* dst = A + row * LD + j0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) dst[c] = av[c];
   }
 }
 

@@ -756,16 +756,16 @@ __global__ __launch_bounds__(256) void reduced_solve_panel_kernel(SolveArgs a, i
   double* dump = bcast + 128 + tid;             // [256] per-thread dump word
   __shared__ int s_fail;
   if (tid == 0) s_fail = 0;
-  // load the lower triangle, summing the K-slices of the Schur complement: wave w takes rows w, w+4, ..., four rows
+  // load the lower triangle, summing the K-slices of the Schur complement: wave w takes rows w, w+4, ..., sixteen rows
   // per pass with every load of the pass issued before the first LDS store (a single workgroup pulls this matrix in,
-  // so it is the number of loads in flight that matters)
+  // so it is the number of loads in flight that matters: a dependent round trip costs about a microsecond)
   {
     const size_t mm = size_t(M1) * M1;
     const double* src0 = a.Spart + size_t(t0) * M1 + t0;
-    for (int r0 = wave; r0 < m1; r0 += 16) {
-      double v[4][2];
+    for (int r0 = wave; r0 < m1; r0 += 64) {     // sixteen rows per wave and pass: two passes cover 128 rows
+      double v[16][2];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int r = min(r0 + 4 * u, m1 - 1);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256) void reduced_solve_panel_kernel(SolveArgs a, i
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int r = r0 + 4 * u;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
