@@ -121,6 +121,7 @@ ABI_SYMBOLS = [
     "num_effective_parameters", "evaluate", "problem_set_allreduce", "problem_set_shard",
     "problem_set_stream", "get_phase_time", "set_phase_timing", "project",
     "problem_set_outlier_mask", "mark_outliers", "fit_spline", "residual_heatmap",
+    "debug_lm_control_replay", "comm_get_unique_id", "comm_init_rccl", "problem_finalize",
 ]
 
 
@@ -168,6 +169,11 @@ class CApi:
             g("residual_heatmap", C.c_int32, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, D, C.POINTER(C.c_int64)])
             g("fit_spline", C.c_int32, [C.c_int32, C.c_int32, C.c_int32, D, D, C.c_int64, D, D, D])
             g("set_phase_timing", C.c_int32, [P, C.c_int32])
+            g("problem_finalize", C.c_int32, [P])
+            g("comm_get_unique_id", C.c_int32, [C.POINTER(C.c_uint8)])
+            g("comm_init_rccl", C.c_int32, [P, C.POINTER(C.c_uint8), C.c_int32, C.c_int32])
+            g("debug_lm_control_replay", C.c_int32,
+              [C.c_int32, C.c_int32, D, I, C.POINTER(SolverOptions), D, I, D])
 
     def _get(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)
@@ -179,6 +185,15 @@ class CApi:
         o = SolverOptions()
         self.default_solver_options(C.byref(o))
         return o
+
+
+def comm_unique_id(api):
+    """128-byte RCCL id drawn by rank 0, to be handed to every rank's Problem.comm_init_rccl."""
+    buf = (C.c_uint8 * 128)()
+    st = api.comm_get_unique_id(buf)
+    if st != OK:
+        raise CalicoError(st, "calico_comm_get_unique_id failed")
+    return bytes(buf)
 
 
 class Problem:
@@ -326,6 +341,14 @@ class Problem:
         cb = ALLREDUCE_FN(pyfunc)
         self._keep.append(cb)
         self._check(self.api.problem_set_allreduce(self.h, cb, None))
+
+    def finalize(self):
+        self._check(self.api.problem_finalize(self.h))
+
+    def comm_init_rccl(self, unique_id, rank, world_size):
+        """Native exchange: the handle creates its own RCCL communicator from the 128-byte id (see comm_unique_id)."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._check(self.api.comm_init_rccl(self.h, buf, int(rank), int(world_size)))
 
     def set_shard(self, rank, world_size):
         self._check(self.api.problem_set_shard(self.h, int(rank), int(world_size)))

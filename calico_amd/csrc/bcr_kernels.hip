@@ -711,7 +711,11 @@ __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, Bcr
     const double* pl = nd_left >= 0 ? sep_solution(a, b, nd_left) : a.y;
     const double* pr = nd_right >= 0 ? sep_solution(a, b, nd_right) : a.y;
     const double vl = pl[tid & 31], vr = pr[tid & 31];
-    ysep = tid < BP ? (nd_left >= 0 ? vl : 0.0) : (nd_right >= 0 ? vr : 0.0);
+    // the root's solution comes from the reduced solve, which knows its 30 real rows only: the two padding rows are 0,
+    // not whatever sits behind them in y (an uninitialised word there may be a NaN, and NaN times a zero column is NaN)
+    const bool pad = (tid & 31) >= RB;
+    ysep = tid < BP ? ((nd_left >= 0 && !(pad && nd_left == b.root)) ? vl : 0.0)
+                    : ((nd_right >= 0 && !(pad && nd_right == b.root)) ? vr : 0.0);
     ycv = a.y[n_s + min(tid, mc - 1 > 0 ? mc - 1 : 0)];
   }
   const int r16 = tid >> 4, sub = tid & 15;
@@ -742,6 +746,17 @@ __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, Bcr
   for (int c = 0; c < 6; ++c) px[c] = x[my_off + c];
   if (terminated) return;
   BTICK(0)
+  if (a.debug > 1) {     // development aid: which input of the node is not finite?
+    bool bz = false, bm = false, ba = false, bt = false;
+#pragma unroll
+    for (int i = 0; i < QM; ++i) {
+      if (i < q) { bz = bz || !isfinite(vz[i][0]) || !isfinite(vz[i][1]); bm = bm || !isfinite(vm[i][0]) || !isfinite(vm[i][1]);
+                   ba = ba || !isfinite(za[i][0]) || !isfinite(za[i][1]); bt = bt || !isfinite(zt[i]); }
+    }
+    if (bz || bm || ba || bt || (tid < 2 * BP && !isfinite(ysep)) || (top && tid < mc && !isfinite(ycv)))
+      printf("bcr_back top %d node %d (blk0 %d q %d left %d right %d) tid %d: ZB %d M %d ZA %d zt %d ysep %d ycv %d\n", top, int(blockIdx.x), blk0, q,
+             nd_left, nd_right, tid, int(bz), int(bm), int(ba), int(bt), int(tid < 2 * BP && !isfinite(ysep)), int(top && tid < mc && !isfinite(ycv)));
+  }
   if (tid < BP) ya[tid] = ysep; else if (tid < 2 * BP) yn[tid - BP] = ysep;
   if (top) {
     if (tid < m1p) yc[tid] = tid < mc ? ycv : 0.0;

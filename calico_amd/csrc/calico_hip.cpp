@@ -12,6 +12,7 @@
 //   calico_get_residuals -> cost-only kernel without the loss function.
 // There is no CPU compute path in this library.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -59,6 +60,8 @@ void launch_control(LmState* st, const LmOptionsDev& o, double* R2, double* x, c
                     IterLog* log, int log_cap, const double* item_cost, int n_items, const double* Rbase, size_t r_stride,
                     hipStream_t s, bool commit_by_copy = false, int* progress = nullptr, int seq = 0);
 void launch_init_state(LmState* st, double radius, double x_norm, hipStream_t s, const double* upd_ext = nullptr, int upd_ext_n = 0);
+void launch_debug_control_replay(LmState* st, const LmOptionsDev& o, const double* rho, const int* infinite, int n, double* R2,
+                                 double* radius_out, int* accepted_out, double* cost_out, IterLog* log, int log_cap, hipStream_t s);
 size_t bcr_level_lds_bytes();
 size_t bcr_back_lds_bytes(int q_max, int m1p);
 hipError_t configure_bcr_kernels(int q_max, int m1p);
@@ -184,6 +187,8 @@ struct calico_problem {
   bool dirty = true;
   calico_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
+  ncclComm_t comm = nullptr;      // native exchange: RCCL communicator owned by the handle (calico_comm_init_rccl)
+  bool has_exchange() const { return allreduce != nullptr || comm != nullptr; }
   int rank = 0, world = 1;
 
   // flattened problem
@@ -196,7 +201,7 @@ struct calico_problem {
   int bcr_N = 0, bcr_m1p = 16, bcr_root = -1, bcr_root_pend = 0, bcr_root_par = 0, bcr_br = 0, bcr_q_max = 1, bcr_slots = 1;
   std::vector<BcrLevel> bcr_levels;
   std::vector<BcrNodeDev> h_bcr_nodes;
-  std::vector<int> h_bcr_keep;
+  std::vector<int> h_bcr_keep, h_cp_block;
   DevBuf<double> d_bD, d_bG, d_bF, d_bpD, d_bpF, d_bM, d_bZA, d_bZB, d_bY, d_bysol, d_bzb, d_bupd;
   DevBuf<BcrNodeDev> d_bnodes;
   DevBuf<int> d_bkeep, d_cp_block;
@@ -873,10 +878,11 @@ int finalize(calico_problem* p) {
     HIP_TRY(p, hipMemsetAsync(p->d_bpD.p, 0, 4 * N * bb * sizeof(double), s)); HIP_TRY(p, hipMemsetAsync(p->d_bpF.p, 0, 4 * N * fb * sizeof(double), s));
     HIP_TRY(p, hipMemsetAsync(p->d_bupd.p, 0, size_t(p->bcr_slots) * 4 * sizeof(double), s));
     HIP_TRY(p, p->d_bnodes.upload(p->h_bcr_nodes, s)); HIP_TRY(p, p->d_bkeep.upload(p->h_bcr_keep, s));
-    std::vector<int> cp_block(size_t(n_cp), -1);
+    // (a member, not a local: the asynchronous upload reads it until the synchronisation at the end of finalize)
+    p->h_cp_block.assign(size_t(n_cp), -1);
     for (size_t bi = 0; bi < p->h_blocks.size(); ++bi)
-      if (p->h_blocks[bi].tan_off < NS) cp_block[size_t(p->h_blocks[bi].tan_off / 6)] = int(bi);
-    HIP_TRY(p, p->d_cp_block.upload(cp_block, s));
+      if (p->h_blocks[bi].tan_off < NS) p->h_cp_block[size_t(p->h_blocks[bi].tan_off / 6)] = int(bi);
+    HIP_TRY(p, p->d_cp_block.upload(p->h_cp_block, s));
     if (bcr_level_lds_bytes() > kMaxLds || bcr_back_lds_bytes(p->bcr_q_max, p->bcr_m1p) > kMaxLds)
       return p->set_error(CALICO_UNIMPLEMENTED, "tree solver workspace exceeds the LDS");
     HIP_TRY(p, configure_bcr_kernels(p->bcr_q_max, p->bcr_m1p));
@@ -911,6 +917,11 @@ int upload_x(calico_problem* p) {
 }
 
 int do_allreduce(calico_problem* p, double* buf, int64_t n) {
+  if (p->comm) {     // native: one in-place RCCL all-reduce on the handle's stream, no host code in between
+    const ncclResult_t r = ncclAllReduce(buf, buf, size_t(n), ncclDouble, ncclSum, p->comm, p->stream);
+    if (r != ncclSuccess) return p->set_error(CALICO_INTERNAL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    return CALICO_OK;
+  }
   if (!p->allreduce) return CALICO_OK;
   const int st = p->allreduce(p->allreduce_ctx, buf, n, p->stream);
   if (st != 0) return p->set_error(CALICO_INTERNAL, "all-reduce callback failed");
@@ -939,7 +950,7 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, c
   // the host knows which buffer is filled: multi-rank runs either read the state back every iteration or (batched)
   // always evaluate the candidate into buffer 1
   double* target = p->d_R.p + ((spec && p->h_state && !p->h_state->rcur) ? p->r_size : 0);
-  if (p->allreduce && p->world > 1) {
+  if (p->has_exchange() && p->world > 1) {
     // a rank's gather only writes the entries its own residual blocks contribute to; the others must enter the sum
     // as zeros, not as what the previous reduction left there
     HIP_TRY(p, hipMemsetAsync(target, 0, p->r_size * sizeof(double), p->stream));
@@ -948,7 +959,7 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, c
   launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->d_out_fat.p,
                 p->d_ptr_fat.p, p->d_idx_fat.p, p->n_fat, st, need_flag, spec ? p->r_size : 0, p->stream, tail);
   p->timer.end(p->stream);
-  if (!p->allreduce) return CALICO_OK;  // single rank: no exchange
+  if (!p->has_exchange()) return CALICO_OK;  // single rank: no exchange
   return do_allreduce(p, target, int64_t(p->r_size));
 }
 
@@ -973,6 +984,32 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
   for (int l = L - 1; l >= 0; --l) {
     const calico_problem::BcrLevel& lv = p->bcr_levels[size_t(l)];
     launch_bcr_back(sa, b, lv.node0, lv.n_nodes, l == L - 1, lv.q_max, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, s);
+  }
+  // development aid (CALICO_CHECK_FINITE=1): where does the first non-finite value of a solve sit?
+  static const bool check = std::getenv("CALICO_CHECK_FINITE") != nullptr;
+  if (check) {
+    (void)hipStreamSynchronize(s);
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) std::fprintf(stderr, "[calico] launch error after the tree solve: %s\n", hipGetErrorString(le));
+    auto scan = [&](const char* name, const double* d, size_t n) {
+      std::vector<double> h(n);
+      (void)hipMemcpy(h.data(), d, n * sizeof(double), hipMemcpyDeviceToHost);
+      size_t bad = 0, first = 0;
+      for (size_t i = 0; i < n; ++i) if (!std::isfinite(h[i])) { if (!bad) first = i; ++bad; }
+      if (bad) std::fprintf(stderr, "[calico] %s: %zu of %zu non-finite, first at %zu\n", name, bad, n, first);
+    };
+    const size_t N = size_t(p->bcr_N), bb = size_t(kBcrBP) * kBcrBP, fb = size_t(kBcrBP) * p->bcr_m1p, m1 = size_t(sa.m) + 1;
+    scan("R", p->d_R.p, 2 * p->r_size); scan("D", b.D, N * bb); scan("F", b.F, N * fb); scan("M", b.M, N * bb); scan("ZA", b.ZA, N * bb);
+    scan("ZB", b.ZB, N * bb); scan("Y", b.Y, N * fb); scan("Spart", sa.Spart, size_t(ks) * m1 * m1); scan("y", sa.y, size_t(sa.NT()) + p->border_extra());
+    scan("dadd", sa.dadd, size_t(sa.NT())); scan("scale", sa.scale, size_t(sa.NT()));
+    scan("zb", b.zb, N * kBcrBP); scan("ysol", b.ysol, N * kBcrBP); scan("x", p->d_x.p, size_t(p->n_amb)); scan("x_cand", p->d_xc.p, size_t(p->n_amb));
+    {
+      std::vector<double> h(N * kBcrBP);
+      (void)hipMemcpy(h.data(), b.ysol, h.size() * sizeof(double), hipMemcpyDeviceToHost);
+      std::string okb;
+      for (size_t I = 0; I < N; ++I) { bool ok = true; for (int r = 0; r < kBcrBP; ++r) ok = ok && std::isfinite(h[I * kBcrBP + r]); okb += ok ? '.' : 'X'; }
+      std::fprintf(stderr, "[calico] ysol by superblock (X = non-finite): %s  root %d levels %zu\n", okb.c_str(), p->bcr_root, p->bcr_levels.size());
+    }
   }
 }
 
@@ -1035,6 +1072,7 @@ int32_t calico_problem_create(calico_problem** out, int32_t device) {
 }
 
 void calico_problem_destroy(calico_problem* p) {
+  if (p && p->comm) { (void)hipSetDevice(p->device); (void)ncclCommDestroy(p->comm); p->comm = nullptr; }
   if (!p) return;
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
@@ -1203,6 +1241,8 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   if (!p || !opt || !sm) return CALICO_INVALID_ARGUMENT;
   const auto t_start = std::chrono::steady_clock::now();
   std::memset(sm, 0, sizeof(*sm));
+  if (p->world > 1 && !p->has_exchange())
+    return p->set_error(CALICO_FAILED_PRECONDITION, "calico_problem_set_shard(world > 1) needs an exchange: calico_comm_init_rccl or calico_problem_set_allreduce");
   int rc = finalize(p);
   if (rc != CALICO_OK) return rc;
   HIP_TRY(p, hipSetDevice(p->device));
@@ -1241,7 +1281,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   // batches of `sync_every` iterations and a blocking read-back per batch this takes the read-back gaps out of the
   // stream and leaves at most `depth` iterations of early-exit kernels behind a terminated solve.
   const int stream_depth = [] { const char* e = std::getenv("CALICO_STREAM_DEPTH"); return e ? std::atoi(e) : 2; }();
-  const bool streaming = p->speculative && p->allreduce == nullptr && stream_depth > 0 && p->h_progress != nullptr;
+  const bool streaming = p->speculative && !p->has_exchange() && stream_depth > 0 && p->h_progress != nullptr;
   if (streaming) {
     __atomic_store_n(p->h_progress, 0, __ATOMIC_RELEASE);
     __atomic_store_n(p->h_progress + 1, 0, __ATOMIC_RELEASE);
@@ -1256,18 +1296,24 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   const bool fused_control = [] { const char* e = std::getenv("CALICO_FUSED_CONTROL"); return !e || std::atoi(e) != 0; }();
   if (streaming) {
     int enq = 0;
-    const auto t_spin0 = std::chrono::steady_clock::now();
+    auto t_progress = std::chrono::steady_clock::now();     // when the device last reported a finished iteration
+    int last_seen = 0;
     int64_t spins = 0;
     for (;;) {
       bool done = false;
       for (;;) {
         if (__atomic_load_n(p->h_progress + 1, __ATOMIC_ACQUIRE)) { done = true; break; }
-        if (enq - __atomic_load_n(p->h_progress, __ATOMIC_ACQUIRE) < stream_depth) break;
+        const int seen = __atomic_load_n(p->h_progress, __ATOMIC_ACQUIRE);
+        if (seen != last_seen) { last_seen = seen; t_progress = std::chrono::steady_clock::now(); spins = 0; }
+        if (enq - seen < stream_depth) break;
+        __builtin_ia32_pause();
         if ((++spins & 0xfffff) == 0) {   // a device fault must not leave the host spinning
           const hipError_t qe = hipStreamQuery(s);
           if (qe != hipSuccess && qe != hipErrorNotReady) return p->set_error(CALICO_INTERNAL, hipGetErrorString(qe));
-          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_spin0).count() > 600.0)
+          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_progress).count() > 600.0) {
+            (void)hipStreamSynchronize(s);     // nothing of this solve stays behind on the stream
             return p->set_error(CALICO_INTERNAL, "solve loop: no progress from the device");
+          }
         }
       }
       if (done) break;
@@ -1300,7 +1346,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   // candidate is committed by a copy (commit_kernel) instead of the pointer swap. Without the speculative evaluation
   // a multi-rank run needs the host between the phases (the all-reduce must not run when the evaluation was skipped).
   const bool spec = p->speculative;
-  const bool multi = p->allreduce != nullptr;
+  const bool multi = p->has_exchange();
   const bool multi_async_ok = [] { const char* e = std::getenv("CALICO_MULTIRANK_ASYNC"); return !e || std::atoi(e) != 0; }();
   const bool async = !multi || (spec && multi_async_ok);
   const int batch = async ? std::max(1, opt->sync_every) : 1;
@@ -1352,7 +1398,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
         ea.st = p->d_state.p;
         launch_eval(ea, false, s);
       }
-      const bool fuse_cost = p->allreduce == nullptr;    // single rank: the cost sum rides in the control kernel
+      const bool fuse_cost = !p->has_exchange();    // single rank: the cost sum rides in the control kernel
       if (!fuse_cost) launch_cost_reduce(p->d_partials.p + p->partial_doubles, p->n_items, p->d_R2.p, p->d_state.p, s);
       p->timer.end(s);
       rc = do_allreduce(p, p->d_R2.p, 2);
@@ -1406,12 +1452,42 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   }
   sm->termination_type = st.termination_type;
   sm->num_successful_steps = st.num_successful; sm->num_unsuccessful_steps = st.num_unsuccessful;
-  sm->num_iterations = log.empty() ? 0 : log.back().iteration;
+  sm->num_iterations = st.last_logged_iteration;      // Summary::iterations.size() - 1; not read from the log buffer, which is capped at kLogCap rows
   sm->initial_cost = st.initial_cost;
   sm->final_cost = st.termination_type == CALICO_FAILURE ? 0.0 : std::min(st.initial_cost, st.min_cost);
   std::snprintf(sm->message, sizeof(sm->message), "%s", reason_message(st.termination_reason));
   sm->solve_time_in_seconds = t_solve;
   sm->total_time_in_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  return CALICO_OK;
+}
+
+int32_t calico_debug_lm_control_replay(int32_t device, int32_t n, const double* rho, const int32_t* infinite,
+                                       const calico_solver_options* opt, double* radius_out, int32_t* accepted_out,
+                                       double* cost_column_out) {
+  if (n <= 0 || n > kLogCap - 2 || !rho || !infinite || !opt || !radius_out || !accepted_out || !cost_column_out)
+    return CALICO_INVALID_ARGUMENT;
+  if (hipSetDevice(device) != hipSuccess) return CALICO_INTERNAL;
+  DevBuf<double> d_rho, d_R2, d_rad, d_cost;
+  DevBuf<int> d_inf, d_acc;
+  DevBuf<LmState> d_st;
+  DevBuf<IterLog> d_log;
+  std::vector<double> h_rho(rho, rho + n);
+  std::vector<int> h_inf(infinite, infinite + n);
+  if (d_rho.upload(h_rho, nullptr) != hipSuccess || d_inf.upload(h_inf, nullptr) != hipSuccess || d_R2.alloc(2) != hipSuccess ||
+      d_rad.alloc(size_t(n)) != hipSuccess || d_cost.alloc(size_t(n)) != hipSuccess || d_acc.alloc(size_t(n)) != hipSuccess ||
+      d_st.alloc(1) != hipSuccess || d_log.alloc(kLogCap) != hipSuccess)
+    return CALICO_INTERNAL;
+  LmOptionsDev o;
+  o.max_num_iterations = 1 << 30; o.max_num_consecutive_invalid_steps = opt->max_num_consecutive_invalid_steps;
+  o.function_tolerance = 0.0; o.gradient_tolerance = 0.0; o.parameter_tolerance = 0.0;     // the replay never converges
+  o.max_radius = opt->max_trust_region_radius; o.min_radius = opt->min_trust_region_radius;
+  o.min_relative_decrease = opt->min_relative_decrease; o.min_lm_diagonal = opt->min_lm_diagonal; o.max_lm_diagonal = opt->max_lm_diagonal;
+  launch_init_state(d_st.p, opt->initial_trust_region_radius, 1.0, nullptr);
+  launch_debug_control_replay(d_st.p, o, d_rho.p, d_inf.p, n, d_R2.p, d_rad.p, d_acc.p, d_cost.p, d_log.p, kLogCap, nullptr);
+  if (hipMemcpy(radius_out, d_rad.p, size_t(n) * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(accepted_out, d_acc.p, size_t(n) * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(cost_column_out, d_cost.p, size_t(n) * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+    return CALICO_INTERNAL;
   return CALICO_OK;
 }
 
@@ -1565,6 +1641,8 @@ int32_t calico_num_effective_parameters(calico_problem* p, int32_t* n_out) {
 
 int32_t calico_evaluate(calico_problem* p, double* cost, double* gradient, double* jtj) {
   if (!p) return CALICO_INVALID_ARGUMENT;
+  if (p->world > 1 && !p->has_exchange())
+    return p->set_error(CALICO_FAILED_PRECONDITION, "calico_problem_set_shard(world > 1) needs an exchange: calico_comm_init_rccl or calico_problem_set_allreduce");
   int rc = finalize(p);
   if (rc != CALICO_OK) return rc;
   HIP_TRY(p, hipSetDevice(p->device));
@@ -1600,6 +1678,35 @@ int32_t calico_evaluate(calico_problem* p, double* cost, double* gradient, doubl
 int32_t calico_problem_set_allreduce(calico_problem* p, calico_allreduce_fn fn, void* ctx) {
   if (!p) return CALICO_INVALID_ARGUMENT;
   p->allreduce = fn; p->allreduce_ctx = ctx;
+  return CALICO_OK;
+}
+
+int32_t calico_problem_finalize(calico_problem* p) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  const int rc = finalize(p);
+  if (rc != CALICO_OK) return rc;
+  return upload_x(p) == CALICO_OK && hipStreamSynchronize(p->stream) == hipSuccess ? CALICO_OK : CALICO_INTERNAL;
+}
+
+int32_t calico_comm_get_unique_id(uint8_t* id_out) {
+  if (!id_out) return CALICO_INVALID_ARGUMENT;
+  static_assert(sizeof(ncclUniqueId) == CALICO_COMM_ID_BYTES, "RCCL unique id size");
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return CALICO_INTERNAL;
+  std::memcpy(id_out, &id, sizeof(id));
+  return CALICO_OK;
+}
+
+int32_t calico_comm_init_rccl(calico_problem* p, const uint8_t* id, int32_t rank, int32_t world_size) {
+  if (!p || !id) return CALICO_INVALID_ARGUMENT;
+  if (world_size < 1 || rank < 0 || rank >= world_size) return p->set_error(CALICO_INVALID_ARGUMENT, "bad rank / world size");
+  HIP_TRY(p, hipSetDevice(p->device));
+  if (p->comm) { (void)ncclCommDestroy(p->comm); p->comm = nullptr; }
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  const ncclResult_t r = ncclCommInitRank(&p->comm, world_size, uid, rank);
+  if (r != ncclSuccess) { p->comm = nullptr; return p->set_error(CALICO_INTERNAL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+  p->rank = rank; p->world = world_size; p->dirty = true;
   return CALICO_OK;
 }
 

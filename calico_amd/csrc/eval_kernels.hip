@@ -1170,8 +1170,8 @@ __global__ void mark_outliers_kernel(const double* __restrict__ res, const uint8
 // [begin, end)) in a fixed thread-strided order and reduces in a fixed tree -- deterministic, no atomics.
 __global__ __launch_bounds__(256) void residual_heatmap_kernel(const double* __restrict__ res, const uint8_t* __restrict__ valid,
                                                                const uint8_t* __restrict__ active, const double* __restrict__ px,
-                                                               const double* __restrict__ py, int begin, int end, double inv_w,
-                                                               double inv_h, int num_rows, int num_cols, double* rmse,
+                                                               const double* __restrict__ py, int begin, int end, double img_w,
+                                                               double img_h, int num_rows, int num_cols, double* rmse,
                                                                long long* count) {
   __shared__ double s_sq[256];
   __shared__ long long s_n[256];
@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(256) void residual_heatmap_kernel(const double* __r
   long long n = 0;
   for (int o = begin + tid; o < end; o += 256) {
     if ((active && !active[o]) || !valid[o]) continue;
-    int c = int(floor(px[o] * inv_w * num_cols)), r = int(floor(py[o] * inv_h * num_rows));
+    int c = int(floor(px[o] / img_w * num_cols)), r = int(floor(py[o] / img_h * num_rows));   // operation order of utils.py:39-40
     c = max(min(c, num_cols - 1), 0); r = max(min(r, num_rows - 1), 0);
     if (r != brow || c != bcol) continue;
     const double r0 = res[size_t(o) * 3], r1 = res[size_t(o) * 3 + 1];
@@ -1198,7 +1198,7 @@ void launch_residual_heatmap(const double* res, const uint8_t* valid, const uint
                              int begin, int end, int width, int height, int num_rows, int num_cols, double* rmse, long long* count,
                              hipStream_t s) {
   hipLaunchKernelGGL(residual_heatmap_kernel, dim3(num_rows * num_cols), dim3(256), 0, s, res, valid, active, px, py, begin, end,
-                     1.0 / width, 1.0 / height, num_rows, num_cols, rmse, count);
+                     double(width), double(height), num_rows, num_cols, rmse, count);
 }
 
 void launch_mark_outliers(const double* res, const uint8_t* valid, uint8_t* active, int begin, int end, int dim,

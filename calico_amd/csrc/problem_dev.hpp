@@ -121,7 +121,8 @@ struct LmState {
   // [model cost change, |step|^2, |candidate|^2, non-finite flag] in its own slot; the control stage adds them up in
   // slot order (upd_parts == 0 selects this form)
   const double* upd_ext;
-  int upd_ext_n, pad_ext;
+  int upd_ext_n;
+  int last_logged_iteration;   // iteration number of the last row of the log, kept even when the log buffer is full
 };
 
 struct LmOptionsDev {

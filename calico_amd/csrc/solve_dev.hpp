@@ -37,13 +37,15 @@ DEVI void publish(int* word, int value) { __hip_atomic_store(word, value, __ATOM
 
 DEVI void log_and_finalize(LmState* st, const LmOptionsDev& o, IterLog* log, int log_cap) {
   if (st->iteration > 0) { if (st->step_successful) st->num_successful++; else st->num_unsuccessful++; }
+  const double row_cost = st->step_successful || st->iteration == 0 ? st->x_cost : (st->step_valid ? st->candidate_cost : st->x_cost);
+  if (row_cost < st->min_cost) st->min_cost = row_cost;       // whether or not the row still fits the log
+  st->last_logged_iteration = st->iteration;
   if (st->n_log < log_cap) {
     IterLog& r = log[st->n_log++];
     r.iteration = st->iteration; r.step_is_valid = st->step_valid; r.step_is_successful = st->step_successful; r.reserved = 0;
-    r.cost = st->step_successful || st->iteration == 0 ? st->x_cost : (st->step_valid ? st->candidate_cost : st->x_cost);
+    r.cost = row_cost;
     r.cost_change = st->cost_change; r.gradient_max_norm = st->gradient_max_norm; r.step_norm = st->step_norm;
     r.relative_decrease = st->relative_decrease; r.trust_region_radius = st->radius;
-    if (r.cost < st->min_cost) st->min_cost = r.cost;
   }
   if (st->iteration >= o.max_num_iterations) { st->terminated = 1; st->termination_type = 1; st->termination_reason = 1; return; }
   if (st->gradient_max_norm <= o.gradient_tolerance) { st->terminated = 1; st->termination_type = 0; st->termination_reason = 2; return; }

@@ -1459,6 +1459,36 @@ __global__ __launch_bounds__(256) void commit_kernel(const LmState* st, double* 
   for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256) R[i] = R[n + i];
 }
 
+// Test hook (calico_debug_lm_control_replay): the control stage driven by a given sequence of step qualities. Row i is
+// seeded as "x_cost = model cost change = 1, candidate cost = 1 - rho[i]" (or a candidate that could not be evaluated),
+// everything else -- radius, decrease factor, counters -- carries over from row to row as in a solve.
+__global__ __launch_bounds__(256) void debug_control_replay_kernel(LmState* st, LmOptionsDev o, const double* rho, const int* infinite,
+                                                                    int n, double* R2, double* radius_out, int* accepted_out,
+                                                                    double* cost_out, IterLog* log, int log_cap) {
+  for (int i = 0; i < n; ++i) {
+    if (threadIdx.x == 0) {
+      st->terminated = 0; st->x_cost = 1.0; st->x_norm = 1.0; st->chol_failed = 0;
+      st->upd_parts = 1; st->upd_mcc[0] = 1.0; st->upd_sn[0] = 1.0; st->upd_cn[0] = 1.0; st->upd_bad[0] = 0;
+      R2[0] = 1.0 - rho[i]; R2[1] = infinite[i] ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    control_body(st, o, R2, nullptr, nullptr, 0, log, log_cap, nullptr, 0, nullptr, 0, 0, nullptr, 0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      radius_out[i] = st->radius; accepted_out[i] = st->step_successful;
+      // accepted: the iteration's row is written after the re-evaluation at the new point (its cost is the candidate's);
+      // rejected: the control stage has just written the row
+      cost_out[i] = st->step_successful ? st->candidate_cost : log[st->n_log - 1].cost;
+    }
+    __syncthreads();
+  }
+}
+void launch_debug_control_replay(LmState* st, const LmOptionsDev& o, const double* rho, const int* infinite, int n, double* R2,
+                                 double* radius_out, int* accepted_out, double* cost_out, IterLog* log, int log_cap, hipStream_t s) {
+  hipLaunchKernelGGL(debug_control_replay_kernel, dim3(1), dim3(256), 0, s, st, o, rho, infinite, n, R2, radius_out, accepted_out, cost_out,
+                     log, log_cap);
+}
+
 __global__ void init_state_kernel(LmState* st, double radius, double x_norm, const double* upd_ext, int upd_ext_n) {
   LmState s = {};
   s.upd_ext = upd_ext; s.upd_ext_n = upd_ext_n; s.upd_parts = 1;

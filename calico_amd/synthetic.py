@@ -563,7 +563,7 @@ def _initial_intrinsics(kind, model, truth):
 def make_scene(n_cameras=1, camera_model=1, imu=False, imu_model=2, duration=None, cam_rate=None, imu_rate=None,
                knot_frequency=10.0, order=6, chart="plane", pixel_noise=0.0, gyro_noise=0.0, accel_noise=0.0,
                seed=0xCA11C0, robust=False, outlier_fraction=0.0, perturb=True, estimate_spline_from_truth=True,
-               max_cam_obs=None, segment_duration=0.75, repeats=1, free_chart_pose=False, free_points=False):
+               max_cam_obs=None, segment_duration=0.75, repeats=1, free_chart_pose=False, free_points=False, n_imus=1):
     """Synthetic rig problem in the style of ToyStereoCameraAndImuCalibration
     (batch_optimizer_test.cpp:32-213): camera 0 is the rig frame with free
     intrinsics; further cameras also estimate extrinsics + latency; the IMU
@@ -627,8 +627,11 @@ def make_scene(n_cameras=1, camera_model=1, imu=False, imu_model=2, duration=Non
         else:
             imu_times = np.arange(0.0, t_end + 1e-12, 1.0 / imu_rate)
         imu_times = imu_times[imu_times + max_lat <= last_valid]
-        for kind, nm, noise in ((_capi.SENSOR_GYROSCOPE, "gyro", gyro_noise),
-                                (_capi.SENSOR_ACCELEROMETER, "accel", accel_noise)):
+        imu_specs = []
+        for u in range(n_imus):      # one gyroscope + one accelerometer per IMU (each with its own mounting and intrinsics)
+            sfx = "" if u == 0 else str(u)
+            imu_specs += [(_capi.SENSOR_GYROSCOPE, "gyro" + sfx, gyro_noise), (_capi.SENSOR_ACCELEROMETER, "accel" + sfx, accel_noise)]
+        for kind, nm, noise in imu_specs:
             truth = _IMU_TRUE[imu_model].copy()
             q_true = quat_from_axis_angle(rand_unit() * (2.0 * np.pi / 180.0))
             lat_true = 0.02
@@ -680,8 +683,17 @@ def config_scene(index, seed=None):
         return make_scene(4, 1, True, 3, cam_rate=20.0, imu_rate=200.0, duration=8.7, chart="april", seed=sd,
                           pixel_noise=0.1, gyro_noise=1.7e-4 * np.sqrt(200.0), accel_noise=2e-3 * np.sqrt(200.0),
                           robust=True, segment_duration=8.7 / 23.9)
-    if index == 4:   # 8 cam + IMU, 500k blocks, 2% gross outliers
+    if index == 4:   # 8 cam + 2 IMU, 500k blocks, 2% gross outliers (to be tagged: SURVEY 8(d) row 5)
         return make_scene(8, 1, True, 3, cam_rate=20.0, imu_rate=200.0, duration=21.7, chart="april", seed=sd,
                           pixel_noise=0.1, gyro_noise=1.7e-4 * np.sqrt(200.0), accel_noise=2e-3 * np.sqrt(200.0),
-                          robust=True, outlier_fraction=0.02, repeats=2, segment_duration=21.7 / 47.9)
+                          robust=True, outlier_fraction=0.02, repeats=2, segment_duration=21.7 / 47.9, n_imus=2)
+    if index == 5:   # the north star at 50 Hz knots ("also report"): ~438 control points
+        return make_scene(4, 1, True, 3, cam_rate=20.0, imu_rate=200.0, duration=8.7, chart="april", seed=0xCA11C0 + 3,
+                          pixel_noise=0.1, gyro_noise=1.7e-4 * np.sqrt(200.0), accel_noise=2e-3 * np.sqrt(200.0),
+                          robust=True, segment_duration=8.7 / 23.9, knot_frequency=50.0)
+    if index == 6:   # the shape of the one run the reference publishes (demos/imu_camera_calibration.ipynb: EuRoC,
+        # one KannalaBrandt camera ~184k blocks, VectorNav gyro + accel ~14.4k each, ~1445 control points at 10 Hz knots)
+        return make_scene(1, 3, True, 3, cam_rate=8.87, imu_rate=100.0, duration=144.2, chart="april", seed=sd,
+                          pixel_noise=0.1, gyro_noise=1.7e-4 * np.sqrt(100.0), accel_noise=2e-3 * np.sqrt(100.0),
+                          robust=True, repeats=6, segment_duration=144.2 / (6 * 23.9))
     raise ValueError(index)

@@ -201,6 +201,12 @@ int32_t calico_problem_add_imu_residuals(calico_problem* p, int32_t sensor_id,
                                          int64_t n, const double* measurements,
                                          const double* stamps);
 
+/* Flatten the recorded blocks into the device-side problem now (cells, work items, gather lists, elimination plan;
+ * uploads) instead of inside the first calico_solve / calico_evaluate. What BatchOptimizer::Optimize does before
+ * ceres::Solve on every call (batch_optimizer.cpp:57-70: it rebuilds the ceres::Problem each time), made separately
+ * callable so that its cost can be measured (bench.py: config.setup_ms). */
+int32_t calico_problem_finalize(calico_problem* p);
+
 /* ---- solve ------------------------------------------------------------ */
 /* Replaces ceres::Solve (batch_optimizer.cpp:72-73): Levenberg–Marquardt
  * trust region on the flattened problem, entirely on the device. */
@@ -209,6 +215,17 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* options,
 /* Per-iteration table of the last solve; returns rows written via *n_out. */
 int32_t calico_get_iterations(calico_problem* p, calico_iteration* out,
                               int32_t max_rows, int32_t* n_out);
+
+/* Test hook, not part of the drop-in surface: the device's trust-region control stage (the accept / reject decision, the
+ * radius schedule and the iteration log of ceres::TrustRegionMinimizer as restated in solve_kernels.hip) driven by a
+ * given sequence of step qualities rho[i] (infinite[i] != 0: the candidate's cost could not be evaluated). Row i runs
+ * the same control kernel a solve runs, seeded with x_cost = model_cost_change = 1 and candidate cost 1 - rho[i];
+ * radius, decrease factor and counters carry over. Out: radius after the row, accepted flag, and the cost column the
+ * row shows. tests/test_ceres_log.py replays the iteration table the reference ships
+ * (demos/imu_camera_calibration.ipynb) through it. */
+int32_t calico_debug_lm_control_replay(int32_t device, int32_t n, const double* rho, const int32_t* infinite,
+                                       const calico_solver_options* options, double* radius_out, int32_t* accepted_out,
+                                       double* cost_column_out);
 
 /* Replaces Sensor::UpdateResiduals (camera.cpp:70-80, gyroscope.cpp:171-182,
  * accelerometer.cpp:58-69): sigma-weighted residuals WITHOUT the loss
@@ -279,6 +296,16 @@ int32_t calico_evaluate(calico_problem* p, double* cost, double* gradient,
  * n doubles in place at device address buf, ordered on HIP stream `stream`
  * (e.g. torch.distributed.all_reduce over RCCL). Without a callback the
  * handle is single-rank. */
+/* Native exchange (the production path): the handle owns an RCCL communicator and issues ncclAllReduce itself, on its
+ * own stream, between the kernels of an iteration -- no host code in the loop. Rank 0 draws the 128-byte id with
+ * calico_comm_get_unique_id and hands it to every rank by whatever means the application has (MPI, a file, a
+ * torch.distributed broadcast); every rank then calls calico_comm_init_rccl, which also selects its shard (like
+ * calico_problem_set_shard). One process per GPU; the communicator lives until the handle is destroyed.
+ * Replaces nothing in the reference (it is single-process); SURVEY.md 8(b),(e). */
+#define CALICO_COMM_ID_BYTES 128
+int32_t calico_comm_get_unique_id(uint8_t* id_out /* CALICO_COMM_ID_BYTES */);
+int32_t calico_comm_init_rccl(calico_problem* p, const uint8_t* id, int32_t rank, int32_t world_size);
+/* Host-side exchange (tests, exotic transports): a callback instead of the communicator. */
 typedef int32_t (*calico_allreduce_fn)(void* ctx, void* buf, int64_t n,
                                        void* stream);
 int32_t calico_problem_set_allreduce(calico_problem* p, calico_allreduce_fn fn,

@@ -38,6 +38,27 @@
 
 namespace oracle {
 
+// Trust-region control of [Ceres] TrustRegionMinimizer / LevenbergMarquardtStrategy: the radius after an accepted step
+// (StepAccepted: radius / max(1/3, 1 - (2 rho - 1)^3), capped), after a rejected one (StepRejected: radius /
+// decrease_factor, the factor doubling with every consecutive rejection and going back to 2 on acceptance), after an
+// invalid linear solve (StepIsInvalid: radius / 2, factor untouched), and the step quality rho -- the lowest double
+// when the candidate's cost could not be evaluated. Pinned by the iteration table the reference ships
+// (demos/imu_camera_calibration.ipynb; tests/test_ceres_log.py replays it through oracle_lm_control_replay).
+struct TrustRegionControl {
+  double radius, decrease_factor;
+  static double relative_decrease(double x_cost, double candidate_cost, double model_cost_change) {
+    return candidate_cost >= std::numeric_limits<double>::max() ? std::numeric_limits<double>::lowest()
+                                                                 : (x_cost - candidate_cost) / model_cost_change;
+  }
+  void step_accepted(double rho, double max_radius) {
+    radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3));
+    radius = std::min(max_radius, radius);
+    decrease_factor = 2.0;
+  }
+  void step_rejected() { radius = radius / decrease_factor; decrease_factor *= 2.0; }
+  void step_is_invalid() { radius *= 0.5; }
+};
+
 struct ParamBlock {
   std::vector<double> v;
   int size = 0;
@@ -569,7 +590,8 @@ static int Solve(Problem& P, const calico_solver_options& o, calico_summary* sm)
     PlusAll(P, x, ng.data(), &xp);
     ReducedDiffNorms(P, x, xp, gnorm, gmax);
   };
-  double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
+  TrustRegionControl tr{o.initial_trust_region_radius, 2.0};
+  double& radius = tr.radius;
   bool reuse_diagonal = false;
   std::vector<double> diagonal(n, 0.0);
   calico_iteration it{};
@@ -642,7 +664,7 @@ static int Solve(Problem& P, const calico_solver_options& o, calico_summary* sm)
         finish(CALICO_FAILURE, "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps.");
         break;
       }
-      radius *= 0.5; reuse_diagonal = true;  // LevenbergMarquardtStrategy::StepIsInvalid
+      tr.step_is_invalid(); reuse_diagonal = true;
       it.cost = x_cost; it.cost_change = 0; it.gradient_max_norm = prev_gmax; it.step_norm = 0; it.relative_decrease = 0;
       continue;
     }
@@ -665,9 +687,7 @@ static int Solve(Problem& P, const calico_solver_options& o, calico_summary* sm)
       finish(CALICO_CONVERGENCE, "Function tolerance reached."); break;
     }
     // IsStepSuccessful
-    it.relative_decrease = (candidate_cost >= std::numeric_limits<double>::max())
-                               ? std::numeric_limits<double>::lowest()
-                               : (x_cost - candidate_cost) / model_cost_change;
+    it.relative_decrease = TrustRegionControl::relative_decrease(x_cost, candidate_cost, model_cost_change);
     if (it.relative_decrease > o.min_relative_decrease) {
       // HandleSuccessfulStep
       x = cand; x_norm = ReducedNorm(P, x);
@@ -678,12 +698,10 @@ static int Solve(Problem& P, const calico_solver_options& o, calico_summary* sm)
       AccumulateJtJ(P, E, scale.data(), o.num_threads, &H);
       it.cost = x_cost; it.step_is_successful = 1;
       gradient_norms(&it.gradient_max_norm, &gnorm);
-      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
-      radius = std::min(o.max_trust_region_radius, radius);
-      decrease_factor = 2.0; reuse_diagonal = false;
+      tr.step_accepted(it.relative_decrease, o.max_trust_region_radius); reuse_diagonal = false;
     } else {
       it.step_is_successful = 0; it.cost = candidate_cost; it.gradient_max_norm = prev_gmax;
-      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+      tr.step_rejected(); reuse_diagonal = true;
     }
   }
   // write back the best point (monotonic steps: the last accepted x)
@@ -701,6 +719,25 @@ using oracle::Problem;
 extern "C" {
 
 int32_t oracle_problem_create(Problem** out) { *out = new Problem(); return CALICO_OK; }
+
+// Test hook: the trust-region control driven by a given sequence of step qualities. Row i: candidate cost =
+// x_cost - rho[i] * model_cost_change with x_cost = model_cost_change = 1, or "cannot be evaluated" when infinite[i];
+// out: radius after the row, whether the step was accepted, and what the cost column of the iteration log shows.
+int32_t oracle_lm_control_replay(int32_t n, const double* rho, const int32_t* infinite, double initial_radius,
+                                 double min_relative_decrease, double max_radius, double* radius_out,
+                                 int32_t* accepted_out, double* cost_column_out) {
+  oracle::TrustRegionControl tr{initial_radius, 2.0};
+  const double x_cost = 1.0, mcc = 1.0;
+  for (int32_t i = 0; i < n; ++i) {
+    const double candidate_cost = infinite[i] ? std::numeric_limits<double>::max() : x_cost - rho[i] * mcc;
+    const double r = oracle::TrustRegionControl::relative_decrease(x_cost, candidate_cost, mcc);
+    const bool ok = r > min_relative_decrease;
+    if (ok) tr.step_accepted(r, max_radius); else tr.step_rejected();
+    radius_out[i] = tr.radius; accepted_out[i] = ok ? 1 : 0;
+    cost_column_out[i] = candidate_cost;      // accepted: the new x_cost (= the candidate's); rejected: the candidate's cost
+  }
+  return CALICO_OK;
+}
 void oracle_problem_destroy(Problem* p) { delete p; }
 const char* oracle_last_error(const Problem* p) { return p->error.c_str(); }
 

@@ -6,7 +6,8 @@
    [cost | Jtr | JtJ] through the callback (device buffer -> host -> gloo all-reduce -> device buffer): both ranks must
    reach the estimates of the single-rank solve (1e-9 relative: the sum is associated differently), in the batched
    mode and in the one-iteration-per-round-trip mode (CALICO_MULTIRANK_ASYNC=0).
-On the 8-GPU node the same callback slot carries torch.distributed's RCCL all-reduce (bench.py)."""
+3. The native exchange (calico_comm_init_rccl: the handle's own RCCL communicator, what bench.py uses on several GPUs)
+   with a world of one rank; and the refusal of a sharded handle that has no exchange at all."""
 import os
 import sys
 
@@ -36,6 +37,43 @@ def _solve(P, api, sync_every):
     o.sync_every = sync_every
     s = P.solve(o)
     return s, [(i.iteration, i.step_is_successful, i.cost) for i in P.iterations()]
+
+
+def test_native_rccl_exchange_equals_plain_solve(hip):
+    """The production exchange: the handle owns an RCCL communicator (calico_comm_init_rccl) and all-reduces natively on
+    its own stream. With a world of one rank the all-reduce is the identity, so the solve must walk exactly the
+    iterations of the plain one, bit for bit -- through the real ncclAllReduce calls, no Python in the loop."""
+    from calico_amd import _capi, synthetic as syn
+    scene = _scene()
+    plain = syn.build_problem(hip, scene)
+    s0, it0 = _solve(plain.problem, hip, 8)
+    coll = syn.build_problem(hip, scene)
+    coll.problem.comm_init_rccl(_capi.comm_unique_id(hip), 0, 1)
+    s1, it1 = _solve(coll.problem, hip, 8)
+    assert s1.termination_type == s0.termination_type and s1.num_iterations == s0.num_iterations
+    assert it0 == it1            # same kernels on the same data: bit-identical costs
+    e0, _ = syn.read_back(plain, scene)
+    e1, _ = syn.read_back(coll, scene)
+    for a, b in zip(e0, e1):
+        assert np.array_equal(a["intrinsics"], b["intrinsics"])
+
+
+def test_shard_without_exchange_is_refused(hip):
+    """A rank of a larger world with no way to exchange would silently solve its own time window only
+    (ADVICE r1): solve and evaluate refuse instead."""
+    from calico_amd import _capi, synthetic as syn
+    built = syn.build_problem(hip, _scene())
+    built.problem.set_shard(0, 2)
+    o = hip.default_options()
+    o.minimizer_progress_to_stdout = 0
+    with pytest.raises(_capi.CalicoError) as e:
+        built.problem.solve(o)
+    assert e.value.code == _capi.FAILED_PRECONDITION
+    with pytest.raises(_capi.CalicoError) as e:
+        built.problem.evaluate()
+    assert e.value.code == _capi.FAILED_PRECONDITION
+    built.problem.set_shard(0, 1)       # back to a world of one: fine again
+    assert built.problem.solve(o).num_iterations > 0
 
 
 def test_collective_control_flow_equals_plain_solve(hip):
