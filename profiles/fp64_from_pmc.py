@@ -21,6 +21,24 @@ NAMES = ["SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYC
          "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"]
 
 
+def mangled_fragment(demangled):
+    """'void cal::bcr_level_kernel<true>(...)' -> 'bcr_level_kernelILb1EE': enough of the Itanium name to find the
+    kernel in the kernel-trace statistics (which carry mangled names)."""
+    d = demangled.strip().strip('"')
+    if d.startswith("void "):
+        d = d[5:]
+    head = d.split("(")[0]
+    base, targs = (head.split("<")[0], head.split("<")[1].rstrip(">")) if "<" in head else (head, "")
+    base = base.split("::")[-1]
+    frag = base
+    if targs:
+        frag += "I"
+        for a in [t.strip() for t in targs.split(",")]:
+            frag += "Lb%dE" % (1 if a == "true" else 0) if a in ("true", "false") else "Li%sE" % a
+        frag += "E"
+    return frag
+
+
 def main():
     pmc_csv, stats_csv, out_csv, out_json = sys.argv[1:5]
     per = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -42,8 +60,8 @@ def main():
         a = {n: avg(n) for n in NAMES}
         flops_valu = 64.0 * (2 * a["SQ_INSTS_VALU_FMA_F64"] + a["SQ_INSTS_VALU_ADD_F64"] + a["SQ_INSTS_VALU_MUL_F64"])
         flops_mfma = 512.0 * a["SQ_INSTS_VALU_MFMA_MOPS_F64"]
-        key = k.replace(".kd", "")
-        ns = dur.get(key) or next((v for n, v in dur.items() if n.startswith(key[:60])), None)
+        frag = mangled_fragment(k)
+        ns = next((v for n, v in dur.items() if frag in n), None)
         frac = ((flops_valu + flops_mfma) / (ns * 1e-9) / PEAK_FP64) if ns else None
         rows.append((k, ns, flops_valu, flops_mfma, frac,
                      a["SQ_VALU_MFMA_BUSY_CYCLES"] / a["SQ_BUSY_CYCLES"] if a["SQ_BUSY_CYCLES"] else None, len(keep)))

@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: two processes (gloo), each evaluating only its time window of the residual
+"""N > 1 path on CPU: 2, 4 and 8 processes (gloo), each evaluating only its time window of the residual
 blocks and all-reducing cost / gradient / JtJ, must walk the same LM iterations and reach the same
 estimates as one process. The sharding rule is the product's (calico_amd/csrc/shard.hpp); the
 collective plumbing (callback -> torch.distributed.all_reduce) is the one bench.py uses on RCCL."""
@@ -53,7 +53,9 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_solve_equals_single_rank():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_solve_equals_single_rank(world):
+    """2, 4 and 8 ranks on the product's partition (contiguous time windows balanced by block count)."""
     import torch.multiprocessing as mp
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -63,7 +65,7 @@ def test_two_rank_sharded_solve_equals_single_rank():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port + world, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
@@ -86,5 +88,6 @@ def test_two_rank_sharded_solve_equals_single_rank():
             assert np.allclose(a, b, rtol=1e-7, atol=1e-10)
         assert np.allclose(rctrl, ctrl, rtol=1e-7, atol=1e-9)
         assert [(a, b) for a, b, _ in rits] == [(a, b) for a, b, _ in its]
-    # both ranks hold bit-identical estimates (same all-reduced system, same arithmetic)
-    assert np.array_equal(results[0][4], results[1][4])
+    # all ranks hold bit-identical estimates (same all-reduced system, same arithmetic)
+    for r in results[1:]:
+        assert np.array_equal(results[0][4], r[4])
