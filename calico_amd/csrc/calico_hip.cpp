@@ -382,6 +382,15 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, hipSetDevice(p->device));
   const int n_cp = int(p->ctrl.size());
   p->n_cp = n_cp;
+  // CALICO_SETUP_TIMING=1: wall time of the sections of this function (development aid)
+  static const bool setup_timing = std::getenv("CALICO_SETUP_TIMING") != nullptr;
+  auto t_sec = std::chrono::steady_clock::now();
+  auto section = [&](const char* name) {
+    if (!setup_timing) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[calico] finalize %-28s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(t - t_sec).count());
+    t_sec = t;
+  };
   // ---- ambient offsets, used flags ----
   int off = 0;
   for (HBlock& b : p->blocks) { b.amb_off = off; off += b.size; b.used = false; b.tan = -1; b.eff = -1; }
@@ -456,6 +465,7 @@ int finalize(calico_problem* p) {
     }
   }
   const int NS = 6 * n_cp;
+  section("blocks / tangent order");
   // ---- layouts ----
   std::vector<SensorDev> sd(p->sensors.size());
   std::vector<LayoutDev> layouts;
@@ -503,6 +513,7 @@ int finalize(calico_problem* p) {
       layouts.push_back(L); layout_gmap.push_back(gmap);
     }
   }
+  section("layouts");
   // ---- sort observations by (layout, segment) and cut work items ----
   struct Key { int layout, seg, sensor; int64_t idx; double stamp; };
   std::vector<Key> keys;
@@ -742,6 +753,7 @@ int finalize(calico_problem* p) {
     for (const CellDev& c : p->h_cells) if (c.prim_off < 0) most = std::max(most, c.frame_count);
     p->row_cell_chunk = std::min(p->row_cell_chunk, most);
   }
+  section("sort + work items");
   // ---- gather lists ----
   SolveArgs sa; sa.n_cp = n_cp; sa.k = k; sa.mc = m; sa.sep_s = p->sep_s; sa.sep_n = p->sep_n; sa.m = m + p->border_extra(); sa.debug = 0; sa.progress = nullptr;
   const size_t r_size = sa.r_size();
@@ -785,24 +797,42 @@ int finalize(calico_problem* p) {
     pairs.push_back({0, int(poff) + 2 * itn});
     pairs.push_back({1, int(poff) + 2 * itn + 1});
   }
-  std::stable_sort(pairs.begin(), pairs.end(), [](const Pair& a, const Pair& b) { return a.dst < b.dst; });
+  // Group the pairs by output, keeping the order in which they were generated inside every group (the summation
+  // order of the device's gather, hence its rounding): a counting sort over the outputs -- linear, where a comparison
+  // sort of the ~10^6 pairs took most of the set-up time.
   std::vector<int> out_thin, idx_thin, out_fat, idx_fat;
   std::vector<int64_t> ptr_thin(1, 0), ptr_fat(1, 0);
-  for (size_t q = 0; q < pairs.size();) {
-    size_t e = q;
-    while (e < pairs.size() && pairs[e].dst == pairs[q].dst) ++e;
-    const bool fat = (e - q) > 48;
-    std::vector<int>& out = fat ? out_fat : out_thin;
-    std::vector<int>& idx = fat ? idx_fat : idx_thin;
-    std::vector<int64_t>& ptr = fat ? ptr_fat : ptr_thin;
-    out.push_back(pairs[q].dst);
-    for (size_t r = q; r < e; ++r) idx.push_back(pairs[r].src);
-    ptr.push_back(int64_t(idx.size()));
-    q = e;
+  {
+    std::vector<int64_t> start(r_size + 1, 0);
+    for (const Pair& pr : pairs) ++start[size_t(pr.dst) + 1];
+    for (size_t d = 0; d < r_size; ++d) start[d + 1] += start[d];
+    std::vector<int> sorted_src(pairs.size());
+    {
+      std::vector<int64_t> fill(start.begin(), start.end() - 1);
+      for (const Pair& pr : pairs) sorted_src[size_t(fill[size_t(pr.dst)]++)] = pr.src;
+    }
+    size_t n_thin_src = 0, n_fat_src = 0;
+    for (size_t d = 0; d < r_size; ++d) {
+      const int64_t c = start[d + 1] - start[d];
+      if (c > 48) n_fat_src += size_t(c); else n_thin_src += size_t(c);
+    }
+    idx_thin.reserve(n_thin_src); idx_fat.reserve(n_fat_src);
+    for (size_t d = 0; d < r_size; ++d) {
+      const int64_t q0 = start[d], q1 = start[d + 1];
+      if (q1 == q0) continue;
+      const bool fat = (q1 - q0) > 48;
+      std::vector<int>& out = fat ? out_fat : out_thin;
+      std::vector<int>& idx = fat ? idx_fat : idx_thin;
+      std::vector<int64_t>& ptr = fat ? ptr_fat : ptr_thin;
+      out.push_back(int(d));
+      idx.insert(idx.end(), sorted_src.begin() + q0, sorted_src.begin() + q1);
+      ptr.push_back(int64_t(idx.size()));
+    }
   }
   p->n_thin = int(out_thin.size()); p->n_fat = int(out_fat.size());
   // outputs 0 and 1 (cost, invalid count) head whichever list they are in: fat role = first workgroups of the gather
   p->gather_owner_block = (!out_fat.empty() && out_fat[0] == 0) ? 0 : int((out_fat.size() + 3) / 4);
+  section("gather lists");
   // ---- upload ----
   hipStream_t s = p->stream;
   p->h_x.assign(size_t(p->n_amb), 0.0);
@@ -854,6 +884,7 @@ int finalize(calico_problem* p) {
     HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_progress), 64, hipHostMallocMapped | hipHostMallocCoherent));   // fine-grained: the host polls it while kernels run
     HIP_TRY(p, hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_progress), p->h_progress, 0));
   }
+  section("uploads + allocations");
   // kernel attributes
   HIP_TRY(p, configure_eval_kernels(size_t(p->lds_cols) * p->row_pad * sizeof(double)));
   sa = make_solve_args(p);
@@ -888,6 +919,7 @@ int finalize(calico_problem* p) {
     HIP_TRY(p, configure_bcr_kernels(p->bcr_q_max, p->bcr_m1p));
   }
   HIP_TRY(p, hipStreamSynchronize(s));
+  section("kernel attributes + tree plan");
   p->dirty = false;
   return CALICO_OK;
 }
