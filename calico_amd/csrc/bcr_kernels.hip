@@ -564,6 +564,247 @@ __global__ __launch_bounds__(256) void bcr_schur_kernel(SolveArgs a, BcrArgs b, 
 }
 
 // ---------------------------------------------------------------------------
+// Dense reduced solve for m + 1 <= 128, by 32-column blocks: the same building blocks as a tree node -- D_jj = L Lᵀ with
+// L⁻ᵀ riding along as 32 identity rows (two in-wave 16-column panels on 64 rows, one lane per row), the rows below as
+// Z = A_ij L⁻ᵀ on the matrix cores, the trailing update as 16x16 MFMA tiles over all eight waves, and a
+// back-substitution that is four 32x32 matrix-vector products with the stored L⁻ᵀ instead of a 122-step chain.
+// (reduced_solve_panel_kernel factors 16-column panels over ALL rows in one wave, two rows per lane: 8 panels of
+// ≈4.9k clocks + 2.0k of column update each and a 17k backward sweep, 74k clocks; here the chain is 8 panels of ≈4k
+// on 64 rows and everything else is spread over the workgroup.)
+// The matrix lives in LDS (row stride 129: conflict-free column walks), the right-hand side as a separate row; L⁻ᵀ of
+// block j is kept in the (otherwise unused) strict upper triangle of the diagonal block, its diagonal in dinvm.
+// ---------------------------------------------------------------------------
+constexpr int kDenseThreads = 512;
+constexpr int DNL = 129;     // row stride of the dense matrix in LDS
+__global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveArgs a, int nsl) {
+  LmState* st = a.st;
+  const int terminated = st->terminated;
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, lk = lane >> 4;
+  const int m = a.m, M1 = a.m + 1, n = a.n_s();
+  const int nb = (m + BP - 1) / BP;              // 32-column blocks
+  const int mp = BP * nb;                        // padded size (identity beyond m)
+  double* A = lds;                               // [128][DNL]
+  double* gv = A + 128 * DNL;                    // [128] right-hand side row, forward-substituted in place (-> z)
+  double* Daug = gv + 128;                       // [64][DLD]
+  double* dinvm = Daug + 64 * DLD;               // [128] diagonal of L⁻ᵀ
+  double* yv = dinvm + 128;                      // [128] solution
+  double* pend = yv + 128;                       // [128] Σ_{later blocks} Lᵀ y
+  double* wv = pend + 128;                       // [32]
+  double* bcast = wv + 32;                       // [128]
+  double* dump = bcast + 128 + tid;              // [512]
+  // ---- load: lower triangle (K-slices summed), right-hand side = row m; identity beyond m ----
+  {
+    const size_t mm = size_t(M1) * M1;
+    // thread (wave w, lane): rows w, w+8, ...; columns lane, lane+64 -- sixteen rows in flight per pass
+    for (int r0 = wave; r0 < mp; r0 += 8 * 16) {
+      double v[16][2];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int r = min(r0 + 8 * u, m - 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int c = min(lane + 64 * h, r);
+          double acc = 0.0;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) acc += a.Spart[size_t(min(k, nsl - 1)) * mm + size_t(r) * M1 + c] * (k < nsl ? 1.0 : 0.0);
+          v[u][h] = acc;
+        }
+      }
+      if (terminated) return;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int r = r0 + 8 * u;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int c = lane + 64 * h;
+          if (r < mp && c <= r) A[r * DNL + c] = (r < m) ? v[u][h] : (r == c ? 1.0 : 0.0);
+        }
+      }
+    }
+    if (tid < 128) {
+      const int c = min(tid, m - 1);
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) acc += a.Spart[size_t(min(k, nsl - 1)) * mm + size_t(m) * M1 + c] * (k < nsl ? 1.0 : 0.0);
+      gv[tid] = tid < m ? acc : 0.0;
+      pend[tid] = 0.0;
+    }
+  }
+  if (terminated) return;
+  const bool dbg = a.debug && (tid == 0 || tid == 64 * 5);
+  long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
+#define DTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
+  __syncthreads();
+  DTICK(0)
+  double pmin = 1.0;
+  // 16x16 tile (I, c) of the trailing matrix minus the contribution of block jb's two panels, all sixteen operands
+  // read before the first MFMA
+  auto trail_tile = [&](int I, int c, int jb) {
+    const double* pa = A + (16 * I + l16) * DNL + 32 * jb + lk;
+    const double* pb = A + (16 * c + l16) * DNL + 32 * jb + lk;
+    double va[8], vb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { va[u] = -pa[4 * u]; vb[u] = pb[4 * u]; }
+    double* pd = A + (16 * I + lk) * DNL + 16 * c + l16;
+    f64x4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = pd[4 * r * DNL];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], vb[u], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pd[4 * r * DNL] = acc[r];
+  };
+  // the tiles behind block jb that the NEXT diagonal block does not need ("rest"), dealt to waves 1..7 in two
+  // batches that run beside the two panels of the next block's factorisation (look-ahead)
+  auto rest_batch = [&](int jb, int batch) {
+    const int t_first = 2 * (jb + 1), T = mp / 16 - t_first;
+    const int ntile = T * (T + 1) / 2;
+    // tile q of the row-major lower triangle: q = 0, 1, 2 are (0,0), (1,0), (1,1) -- the next diagonal block
+    const int per_wave = (ntile - 3 + 6) / 7, half = (per_wave + 1) / 2;
+    const int k0 = batch == 0 ? 0 : half, k1 = batch == 0 ? half : per_wave;
+    for (int k = k0; k < k1; ++k) {
+      const int q = 3 + (wave - 1) + 7 * k;
+      if (q >= ntile) break;
+      int I = 0, rem = q;
+      while (rem > I) { rem -= I + 1; ++I; }
+      trail_tile(t_first + I, t_first + rem, jb);
+    }
+  };
+  // diagonal block (lower part, zeros above) + identity rows into the panel buffer
+  auto stage_diag = [&](int jb) {
+    const int c0 = BP * jb;
+#pragma unroll
+    for (int u = 0; u < BB / kDenseThreads; ++u) {
+      const int e = tid + kDenseThreads * u;
+      const int r = e >> 5, c = e & 31;
+      const double v = A[(c0 + r) * DNL + c0 + min(c, r)];
+      Daug[r * DLD + c] = c <= r ? v : 0.0;
+      Daug[(BP + r) * DLD + c] = r == c ? 1.0 : 0.0;
+    }
+  };
+  stage_diag(0);
+  for (int jb = 0; jb < nb; ++jb) {
+    const int c0 = BP * jb;
+    lds_barrier();
+    DTICK(1)
+    if (wave == 0) panel_factor<1, false, false>(Daug, DLD, dinvm, bcast, 0, 63, 16, lane, &pmin);
+    else if (jb > 0) rest_batch(jb - 1, 0);
+    lds_barrier();
+    DTICK(2)
+    if (wave < 3) update_tile(Daug, DLD, 63, 1 + wave, 1, 0, 1, lane, dump);
+    lds_barrier();
+    DTICK(3)
+    if (wave == 0) panel_factor<1, false, false>(Daug, DLD, dinvm, bcast, 16, 63, 16, lane, &pmin);
+    else if (jb > 0) rest_batch(jb - 1, 1);
+    lds_barrier();
+    DTICK(4)
+    const double* Mj = Daug + BP * DLD;           // L⁻ᵀ of this block (upper triangular)
+    // ---- rows below: Z = X·M on the matrix cores, one wave per 16-row tile (both column tiles, then written in
+    //      place); wave 7: the right-hand side row, z = g·M ----
+    const int t_first = 2 * (jb + 1), t_end = mp / 16;
+    for (int t = t_first + wave; wave < 7 && t < t_end; t += 7) {
+      const double* X = A + (16 * t + l16) * DNL + c0 + lk;
+      double xv[8], m0[4], m1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv[u] = X[4 * u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) m0[u] = Mj[(4 * u + lk) * DLD + l16];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m1[u] = Mj[(4 * u + lk) * DLD + 16 + l16];
+      f64x4 z0 = {0.0, 0.0, 0.0, 0.0}, z1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) z0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u], m0[u], z0, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) z1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u], m1[u], z1, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* dst = A + (16 * t + lk + 4 * r) * DNL + c0 + l16;
+        dst[0] = z0[r]; dst[16] = z1[r];
+      }
+    }
+    if (wave == 7 && lane < BP) {      // z = g·M, M upper triangular: fixed trip count, masked (a lane-dependent loop serialises)
+      double zc = 0.0;
+#pragma unroll
+      for (int r = 0; r < BP; ++r) zc += (r <= lane ? gv[c0 + r] : 0.0) * Mj[r * DLD + lane];
+      wv[lane] = zc;
+    }
+    lds_barrier();
+    DTICK(5)
+    if (tid < BP) gv[c0 + tid] = wv[tid];
+    // L (lower) back into the matrix, L⁻ᵀ (strict upper) beside it, its diagonal apart: the backward sweep reads them
+#pragma unroll
+    for (int u = 0; u < BB / kDenseThreads; ++u) {
+      const int e = tid + kDenseThreads * u;
+      const int r = e >> 5, c = e & 31;
+      const double lv = Daug[r * DLD + c], mv = Mj[r * DLD + c];
+      A[(c0 + r) * DNL + c0 + c] = c <= r ? lv : mv;
+      if (r == c) dinvm[c0 + r] = mv;
+    }
+    // right-hand side of the rows below: g_p -= Z_p · z
+    if (tid >= 256 && tid < 256 + mp - c0 - BP) {
+      const int prow = c0 + BP + (tid - 256);
+      const double* zr = A + prow * DNL + c0;
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < BP; ++c) acc += zr[c] * wv[c];
+      gv[prow] -= acc;
+    }
+    // the three tiles of the next diagonal block first (waves 0..2): the factorisation of block jb+1 only waits for
+    // these; the rest of the trailing update runs beside its panels
+    if (jb + 1 < nb && wave < 3) trail_tile(t_first + (wave > 0 ? 1 : 0), t_first + (wave > 1 ? 1 : 0), jb);
+    lds_barrier();
+    DTICK(6)
+    if (jb + 1 < nb) stage_diag(jb + 1);
+  }
+  lds_barrier();
+  // ---- backward: y_j = L_jj⁻ᵀ (z_j - pend_j), pend_k += L_jkᵀ y_j for the blocks before ----
+  for (int jb = nb - 1; jb >= 0; --jb) {
+    const int c0 = BP * jb;
+    if (tid < BP) wv[tid] = gv[c0 + tid] - pend[c0 + tid];
+    lds_barrier();
+    if (tid < 8 * BP) {                      // eight threads per row, four columns each; fixed-shape reduction
+      const int r = tid >> 3, part = tid & 7;
+      const double* mr = A + (c0 + r) * DNL + c0;
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = 4 * part + u;
+        const double mv = c == r ? dinvm[c0 + r] : mr[c];
+        acc += (c >= r ? mv : 0.0) * wv[c];
+      }
+      acc += __shfl_xor(acc, 4, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 1, 64);
+      if (part == 0) yv[c0 + r] = acc;
+    }
+    lds_barrier();
+    if (tid < 4 * c0) {                      // four threads per earlier column, eight rows each
+      const int col = tid >> 2, part = tid & 3;
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int r = 8 * part + u; acc += A[(c0 + r) * DNL + col] * yv[c0 + r]; }
+      acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 1, 64);
+      if (part == 0) pend[col] += acc;
+    }
+    lds_barrier();
+  }
+  DTICK(7)
+  if (dbg) printf("dense_block_solve wave %d cycles: load %lld | stage %lld  panel0 (rest tiles beside it) %lld  tile %lld  panel1 (rest tiles) %lld  Z %lld  file+rhs+next diagonal %lld | backward %lld\n",
+                  wave, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7]);
+#undef DTICK
+  if (tid < m) a.y[n + tid] = yv[tid];
+  if (wave == 0 && lane == 0 && !(pmin > 0.0)) st->chol_failed = 1;
+}
+size_t dense_block_solve_lds_bytes() { return size_t(128 * DNL + 128 + 64 * DLD + 128 * 3 + 32 + 128 + kDenseThreads) * sizeof(double); }
+hipError_t configure_dense_block_solve() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_block_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             int(dense_block_solve_lds_bytes()));
+}
+void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s) {
+  hipLaunchKernelGGL(dense_block_solve_kernel, dim3(1), dim3(kDenseThreads), dense_block_solve_lds_bytes(), s, a, ks);
+}
+
+// ---------------------------------------------------------------------------
 // Back-substitution down the tree + update of the candidate point.
 // ---------------------------------------------------------------------------
 // Solution of a separator: the root's comes from the reduced solve (behind the calibration part of y), the others'

@@ -65,6 +65,8 @@ void launch_debug_control_replay(LmState* st, const LmOptionsDev& o, const doubl
 size_t bcr_level_lds_bytes();
 size_t bcr_back_lds_bytes(int q_max, int m1p);
 hipError_t configure_bcr_kernels(int q_max, int m1p);
+hipError_t configure_dense_block_solve();
+size_t dense_block_solve_lds_bytes();
 void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, int level, int keep0, int n_keep, const LmOptionsDev& o,
                       const double* x, const BlockDev* blocks, int n_blocks, bool with_post_eval, IterLog* log, int log_cap, int jacobi,
                       hipStream_t s);
@@ -898,6 +900,7 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_Swork.alloc(std::max<size_t>(reduced_lds / sizeof(double) + 8, size_t(mw + 1) * 16 * 13 + 8)));
   sa = make_solve_args(p);
   HIP_TRY(p, configure_solve_kernels(band_lds, p->dense_in_lds ? reduced_lds : 0, back_lds));
+  HIP_TRY(p, configure_dense_block_solve());
   if (p->use_bcr) {
     const size_t N = size_t(p->bcr_N), bb = size_t(kBcrBP) * kBcrBP, fb = size_t(kBcrBP) * p->bcr_m1p;
     HIP_TRY(p, p->d_bD.alloc(N * bb)); HIP_TRY(p, p->d_bG.alloc(2 * N * bb)); HIP_TRY(p, p->d_bF.alloc(N * fb));

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 
 #include "problem_dev.hpp"
 #include "solve_dev.hpp"
@@ -1556,9 +1557,13 @@ static bool reduced_is_blocked(const SolveArgs& a) {
 // K-slices of the Schur complement the reduced solve adds up on load
 int reduced_schur_slices(const SolveArgs& a) { return (a.m + 1 <= 128 || reduced_is_blocked(a)) ? kSchurSlices : 1; }
 // Dense solve of the (m+1)x(m+1) augmented reduced system in a.Spart (ks K-slices) -> a.y[n_s ...]
+void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s);     // bcr_kernels.hip
 void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipStream_t s) {
   const int m1 = a.m + 1;
   const bool blocked = reduced_is_blocked(a);
+  // CALICO_DENSE=panel keeps the 16-column panel kernel for the in-LDS case (A/B switch)
+  static const bool use_block = [] { const char* e = std::getenv("CALICO_DENSE"); return !(e && std::string(e) == "panel"); }();
+  if (m1 <= 128 && a.m >= 1 && use_block && ks <= 2) { launch_dense_block_solve(a, ks, s); return; }
   if (m1 <= 128) {
     const size_t lds = (size_t(m1) * ((16 * ((m1 + 15) / 16)) | 1) + m1 + 32 + 128 + 256) * sizeof(double);
     if (m1 <= 64) hipLaunchKernelGGL(reduced_solve_panel_kernel<1>, dim3(1), dim3(256), lds, s, a, 0, ks);
