@@ -564,6 +564,324 @@ __global__ __launch_bounds__(256) void bcr_schur_kernel(SolveArgs a, BcrArgs b, 
 }
 
 // ---------------------------------------------------------------------------
+// Back-substitution down the tree + update of the candidate point.
+// ---------------------------------------------------------------------------
+// Solution of a separator: the root's comes from the reduced solve (behind the calibration part of y), the others'
+// from the level above.
+DEVI const double* sep_solution(const SolveArgs& a, const BcrArgs& b, int blk) {
+  return blk == b.root ? a.y + a.n_s() + a.mc : b.ysol + size_t(blk) * BP;
+}
+
+// delta = -y ; candidate = Plus(x, delta) for the parameter blocks selected by the caller; partial sums of the model
+// cost change and of the step norms go to the node's slot. (delta / Plus as in update_body, solve_kernels.hip.)
+struct UpdSums { double mcc, sn, cn; int bad; };
+DEVI void update_block(const BlockDev B, const double* yb, const double* __restrict__ x, double* __restrict__ x_cand, UpdSums& s) {
+  const double* p = x + B.amb_off;
+  double* qv = x_cand + B.amb_off;
+  if (B.manifold == 1) {
+    const double d0 = -yb[0], d1 = -yb[1], d2 = -yb[2];
+    const double nd = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    double nx = p[0], ny = p[1], nz = p[2], nw = p[3];
+    if (nd > 0.0) {
+      const double sd = sin(nd) / nd, qw = cos(nd);
+      const double qx = sd * d0, qy = sd * d1, qz = sd * d2;
+      const double px = p[0], py = p[1], pz = p[2], pw = p[3];
+      nw = qw * pw - qx * px - qy * py - qz * pz;
+      nx = qw * px + qx * pw + qy * pz - qz * py;
+      ny = qw * py + qy * pw + qz * px - qx * pz;
+      nz = qw * pz + qz * pw + qx * py - qy * px;
+    }
+    qv[0] = nx; qv[1] = ny; qv[2] = nz; qv[3] = nw;
+    const double e[4] = {p[0] - nx, p[1] - ny, p[2] - nz, p[3] - nw};
+    s.sn += e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3];
+    s.cn += nx * nx + ny * ny + nz * nz + nw * nw;
+  } else {
+    for (int i = 0; i < B.size; ++i) {
+      const double v = p[i] - yb[i];
+      qv[i] = v; const double e = p[i] - v; s.sn += e * e; s.cn += v * v;
+    }
+  }
+}
+// fixed-shape reduction of the per-thread sums of one workgroup into slot `slot`: shuffle tree inside every wave, then
+// one thread per quantity adds the waves up in order (one barrier instead of a log-depth LDS tree)
+DEVI void file_update_sums(const UpdSums& s, double* sh /* [4][waves] */, double* upd, int slot) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  double v[4] = {s.mcc, s.sn, s.cn, s.bad ? 1.0 : 0.0};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+  }
+  if (lane == 0) { sh[wave] = v[0]; sh[16 + wave] = v[1]; sh[32 + wave] = v[2]; sh[48 + wave] = v[3]; }
+  __syncthreads();
+  if (tid < 4) {
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += sh[16 * tid + w];
+    upd[size_t(slot) * 4 + tid] = t;
+  }
+}
+
+// grid = n_nodes, and for the top level (the first launch after the reduced solve) + 1 workgroup that updates the
+// calibration blocks and the root's control points + N·32/8 workgroups that form L⁻¹g - Z^F y_c for the rows of every
+// superblock (b.zb), which the levels below read instead of sweeping the border rows again. Dynamic LDS:
+// bcr_back_lds_bytes.
+constexpr int kBackThreads = 512;
+// Update of the calibration blocks (their BlockDevs follow the control points') and of the root's control points,
+// whose solution comes from the reduced solve; one workgroup of kBackThreads threads.
+DEVI void back_calib(const SolveArgs& a, const BcrArgs& b, const double* __restrict__ x, double* __restrict__ x_cand,
+                     const BlockDev* __restrict__ blocks, int n_blocks, double* sh) {
+  LmState* st = a.st;
+  const int tid = threadIdx.x;
+  const int n_s = a.n_s(), mc = a.mc;
+  constexpr int RB = 6 * kBcrCps;
+  UpdSums s = {0.0, 0.0, 0.0, 0};
+  {
+    // calibration blocks (their BlockDevs follow the control points') and the root's control points
+    for (int j = tid; j < mc; j += kBackThreads) {
+      const double yj = a.y[n_s + j];
+      if (!isfinite(yj)) s.bad = 1;
+      s.mcc += 0.5 * yj * (a.R[a.off_g() + n_s + j] + yj * a.dadd[n_s + j]);
+    }
+    for (int bi = tid; bi < n_blocks; bi += kBackThreads) {
+      const BlockDev B = blocks[bi];
+      if (B.tan_off < n_s) continue;
+      update_block(B, a.y + B.tan_off, x, x_cand, s);
+    }
+    if (b.root >= 0) {
+      const double* yr = a.y + n_s + mc;
+      if (tid < RB) {
+        const int t = RB * b.root + tid;
+        if (t < n_s) {
+          const double yj = yr[tid];
+          if (!isfinite(yj)) s.bad = 1;
+          s.mcc += 0.5 * yj * (a.R[a.off_g() + t] + yj * a.dadd[t]);
+          a.y[t] = yj;
+        }
+      }
+      if (tid < kBcrCps) {
+        const int cp = kBcrCps * b.root + tid;
+        const int bi = cp < a.n_cp ? b.cp_block[cp] : -1;
+        if (bi >= 0) update_block(blocks[bi], yr + 6 * tid, x, x_cand, s);
+      }
+    }
+    if (tid == 0) { st->rfill = st->rcur ^ 1; st->upd_parts = 0; }
+    file_update_sums(s, sh, b.upd, b.n_slots - 1);
+  }
+}
+
+// One node of the tree: back-substitution of its chain and update of the candidate point of its control points; one
+// workgroup of kBackThreads threads. `top`: the node forms L⁻¹g - Z^F y_c itself (sweeping its border rows) instead of
+// reading b.zb. QM bounds the unrolled load batches (longest chain of the level).
+template <int QM>
+DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __restrict__ ndp, int top, int q_max, int terminated,
+                    bool dbg_first, const double* __restrict__ x, double* __restrict__ x_cand, double* lds, double* sh) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_s = a.n_s(), mc = a.mc, m1p = b.m1p;
+  const size_t fblk = size_t(BP) * m1p;
+  constexpr int RB = 6 * kBcrCps;
+  UpdSums s = {0.0, 0.0, 0.0, 0};
+  const int q = ndp->q, nd_left = ndp->left, nd_right = ndp->right, nd_slot = ndp->slot, blk0 = ndp->blk0;
+  double* ZBs = lds;                                   // [q][32][33]
+  double* Ms = ZBs + size_t(q_max) * BP * DLD;         // [q][32][33]
+  double* tv = Ms + size_t(q_max) * BP * DLD;          // [8][32]
+  double* ya = tv + kBcrMaxChain * BP;                 // [32]
+  double* yn = ya + BP;                                // [32]  solution of the next block (right separator first)
+  double* wv = yn + BP;                                // [32]
+  double* yc = wv + BP;                                // [m1p]
+  double* ych = yc + m1p;                              // [q_max][32] the chain's solutions
+  // Everything the node needs is requested before anything is consumed -- the separators' solutions, Z^B and L⁻ᵀ of
+  // every block (to LDS), this thread's entries of Z^A and of L⁻¹g - Z^F y_c (sixteen threads per row), and what the
+  // update of the candidate point reads (gradient, damping, the control points' current values): a dependent global
+  // load costs about a microsecond here, the arithmetic next to nothing. Chain indices are clamped, not predicated,
+  // so that the loads stay unconditional.
+  const bool bdbg = a.debug && dbg_first && tid == 0;
+  long long bt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, btk = bdbg ? __builtin_readcyclecounter() : 0;
+#define BTICK(i) if (bdbg) { const long long t_ = __builtin_readcyclecounter(); bt[i] += t_ - btk; btk = t_; }
+  double ysep, ycv;
+  {
+    const double* pl = nd_left >= 0 ? sep_solution(a, b, nd_left) : a.y;
+    const double* pr = nd_right >= 0 ? sep_solution(a, b, nd_right) : a.y;
+    const double vl = pl[tid & 31], vr = pr[tid & 31];
+    // the root's solution comes from the reduced solve, which knows its 30 real rows only: the two padding rows are 0,
+    // not whatever sits behind them in y (an uninitialised word there may be a NaN, and NaN times a zero column is NaN)
+    const bool pad = (tid & 31) >= RB;
+    ysep = tid < BP ? ((nd_left >= 0 && !(pad && nd_left == b.root)) ? vl : 0.0)
+                    : ((nd_right >= 0 && !(pad && nd_right == b.root)) ? vr : 0.0);
+    ycv = a.y[n_s + min(tid, mc - 1 > 0 ? mc - 1 : 0)];
+  }
+  const int r16 = tid >> 4, sub = tid & 15;
+  double vz[QM][2], vm[QM][2], za[QM][2], zt[QM], yv[QM][8];
+#pragma unroll
+  for (int i = 0; i < QM; ++i) {
+    const int blk = blk0 + min(i, q - 1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t g = size_t(blk) * BB + tid + kBackThreads * u;
+      vz[i][u] = b.ZB[g]; vm[i][u] = b.M[g];
+    }
+    const double* arow = b.ZA + size_t(blk) * BB + size_t(r16) * BP;
+    za[i][0] = arow[sub]; za[i][1] = arow[sub + 16];
+    const double* yrow = b.Y + size_t(blk) * fblk + size_t(r16) * m1p;
+    zt[i] = top ? yrow[mc] : b.zb[size_t(blk) * BP + r16];
+    if (top) {       // this thread's share of the border row (the first 128 calibration columns)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) yv[i][u] = yrow[min(sub + 16 * u, m1p - 1)];
+    }
+  }
+  // update stage: thread e < 32q owns row e of the chain (gradient, damping), thread e < 5q control point e
+  const int my_row_t = RB * (blk0 + (tid >> 5)) + (tid & 31);
+  const bool my_row_ok = tid < q * BP && (tid & 31) < RB && my_row_t < n_s;
+  const double my_g = a.R[a.off_g() + (my_row_ok ? my_row_t : 0)], my_dadd = a.dadd[my_row_ok ? my_row_t : 0];
+  const int my_cp = kBcrCps * blk0 + tid;     // the chain's control points are consecutive
+  const bool my_cp_in = tid < q * kBcrCps && my_cp < a.n_cp;
+  const int my_cp_c = my_cp_in ? my_cp : 0;
+  const int my_off = b.ctrl_off[my_cp_c];
+  const bool my_cp_ok = my_cp_in && (b.all_active || a.cp_active[my_cp_c] != 0);
+  double px[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) px[c] = x[my_off + c];
+  if (terminated) return;
+  BTICK(0)
+  if (a.debug > 1) {     // development aid: which input of the node is not finite?
+    bool bz = false, bm = false, ba = false, bt = false;
+#pragma unroll
+    for (int i = 0; i < QM; ++i) {
+      if (i < q) { bz = bz || !isfinite(vz[i][0]) || !isfinite(vz[i][1]); bm = bm || !isfinite(vm[i][0]) || !isfinite(vm[i][1]);
+                   ba = ba || !isfinite(za[i][0]) || !isfinite(za[i][1]); bt = bt || !isfinite(zt[i]); }
+    }
+    if (bz || bm || ba || bt || (tid < 2 * BP && !isfinite(ysep)) || (top && tid < mc && !isfinite(ycv)))
+      printf("bcr_back top %d node %d (blk0 %d q %d left %d right %d) tid %d: ZB %d M %d ZA %d zt %d ysep %d ycv %d\n", top, int(blockIdx.x), blk0, q,
+             nd_left, nd_right, tid, int(bz), int(bm), int(ba), int(bt), int(tid < 2 * BP && !isfinite(ysep)), int(top && tid < mc && !isfinite(ycv)));
+  }
+  if (tid < BP) ya[tid] = ysep; else if (tid < 2 * BP) yn[tid - BP] = ysep;
+  if (top) {
+    if (tid < m1p) yc[tid] = tid < mc ? ycv : 0.0;
+    for (int j = tid + kBackThreads; j < m1p; j += kBackThreads) yc[j] = j < mc ? a.y[n_s + j] : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < QM; ++i) {
+    if (i < q) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + kBackThreads * u;
+        const int o = (i * BP + (e >> 5)) * DLD + (e & 31);
+        ZBs[o] = vz[i][u]; Ms[o] = vm[i][u];
+      }
+    }
+  }
+  __syncthreads();
+  BTICK(1)
+  // t_i = (L⁻¹g_i - Z^F y_c) - Z^A y_a : sixteen threads per row, fixed-shape reduction
+#pragma unroll
+  for (int i = 0; i < QM; ++i) {
+    if (i < q) {
+      double part = nd_left >= 0 ? za[i][0] * ya[sub] + za[i][1] * ya[sub + 16] : 0.0;
+      if (top) {
+        const double* yrow = b.Y + size_t(blk0 + i) * fblk + size_t(r16) * m1p;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) part += sub + 16 * u < mc ? yv[i][u] * yc[sub + 16 * u] : 0.0;
+        for (int j = sub + 128; j < mc; j += 16) part += yrow[j] * yc[j];
+      }
+      part += __shfl_xor(part, 8, 64); part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 1, 64);
+      if (sub == 0) tv[i * BP + r16] = zt[i] - part;
+    }
+  }
+  __syncthreads();
+  BTICK(2)
+  // the chain, last block first: w = t_i - Z^B y_next ; y_i = L⁻ᵀ w (one wave, two lanes per row)
+  if (wave == 0) {
+    const int r = lane & 31, h = lane >> 5;
+    for (int i = q - 1; i >= 0; --i) {
+      const double* zb = ZBs + (i * BP + r) * DLD + 16 * h;
+      double wp = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) wp += zb[j] * yn[16 * h + j];
+      wp += __shfl_xor(wp, 32, 64);
+      const double w = tv[i * BP + r] - wp;
+      if (h == 0) wv[r] = w;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const double* mr = Ms + (i * BP + r) * DLD + 16 * h;
+      double yp = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) yp += mr[c] * wv[16 * h + c];
+      yp += __shfl_xor(yp, 32, 64);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (h == 0) { yn[r] = yp; ych[i * BP + r] = yp; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  }
+  BTICK(3)
+  __syncthreads();
+  BTICK(4)
+  // file the solutions, update the candidate point of the chain's control points (delta = -y, plain vector blocks)
+  if (tid < q * BP) {
+    const double yj = ych[tid];
+    b.ysol[size_t(blk0) * BP + tid] = yj;
+    if (my_row_ok) {
+      if (!isfinite(yj)) s.bad = 1;
+      s.mcc += 0.5 * yj * (my_g + yj * my_dadd);
+      a.y[my_row_t] = yj;
+    }
+  }
+  if (my_cp_ok) {
+    const double* yb = ych + (tid / kBcrCps) * BP + 6 * (tid % kBcrCps);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double v = px[c] - yb[c];
+      x_cand[my_off + c] = v;
+      const double e = px[c] - v;
+      s.sn += e * e; s.cn += v * v;
+    }
+  }
+  BTICK(5)
+  file_update_sums(s, sh, b.upd, nd_slot);
+  BTICK(6)
+  if (bdbg) printf("bcr_back top %d (q %d) cycles: loads issued+arrived %lld  to LDS+barrier %lld  t-phase %lld  chain %lld  barrier %lld  outputs %lld  sums %lld\n",
+                   top, q, bt[0], bt[1], bt[2], bt[3], bt[4], bt[5], bt[6]);
+#undef BTICK
+}
+
+// grid = n_nodes; with `extras` (the first launch after the reduced solve when that kernel does not take the top
+// level along) + 1 workgroup for back_calib + N·32/8 workgroups that form L⁻¹g - Z^F y_c for the rows of every
+// superblock (b.zb), which nodes launched with top = 0 read instead of sweeping the border rows again.
+template <int QM>     // longest chain of the level
+__global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, BcrArgs b, int node0, int n_nodes, int top, int extras, int q_max,
+                                                                const double* __restrict__ x, double* __restrict__ x_cand,
+                                                                const BlockDev* __restrict__ blocks, int n_blocks) {
+  LmState* st = a.st;
+  const int terminated = st->terminated;     // tested after the loads are on their way
+  use_current_R(a);
+  extern __shared__ double lds[];
+  __shared__ double sh[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_s = a.n_s(), mc = a.mc, m1p = b.m1p;
+  if (int(blockIdx.x) >= n_nodes && terminated) return;
+  if (int(blockIdx.x) > n_nodes) {
+    // z - Z^F y_c, one wave per row of Y
+    const int row = (int(blockIdx.x) - n_nodes - 1) * (kBackThreads / 64) + wave;
+    if (row >= b.N * BP) return;
+    const double* yrow = b.Y + size_t(row) * m1p;
+    const double* yc = a.y + n_s;
+    double part = 0.0;
+#pragma unroll 2
+    for (int j = lane; j < mc; j += 64) part += yrow[j] * yc[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (lane == 0) b.zb[row] = yrow[mc] - part;
+    return;
+  }
+  if (int(blockIdx.x) == n_nodes) { back_calib(a, b, x, x_cand, blocks, n_blocks, sh); return; }
+  (void)extras;
+  back_node<QM>(a, b, b.nodes + node0 + blockIdx.x, top, q_max, terminated, blockIdx.x == 0, x, x_cand, lds, sh);
+}
+
+// ---------------------------------------------------------------------------
 // Dense reduced solve for m + 1 <= 128, by 32-column blocks: the same building blocks as a tree node -- D_jj = L Lᵀ with
 // L⁻ᵀ riding along as 32 identity rows (two in-wave 16-column panels on 64 rows, one lane per row), the rows below as
 // Z = A_ij L⁻ᵀ on the matrix cores, the trailing update as 16x16 MFMA tiles over all eight waves, and a
@@ -576,6 +894,9 @@ __global__ __launch_bounds__(256) void bcr_schur_kernel(SolveArgs a, BcrArgs b, 
 // ---------------------------------------------------------------------------
 constexpr int kDenseThreads = 512;
 constexpr int DNL = 129;     // row stride of the dense matrix in LDS
+// (Taking the top level of the tree along in this workgroup -- back_calib + back_node for its one to three nodes -- was
+//  tried and lost: two nodes one after the other cost 12 us of dependent loads here against the 7 us of a launch that
+//  runs them side by side, and the levels below then sweep their own border rows.)
 __global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveArgs a, int nsl) {
   LmState* st = a.st;
   const int terminated = st->terminated;
@@ -804,297 +1125,6 @@ void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s) {
   hipLaunchKernelGGL(dense_block_solve_kernel, dim3(1), dim3(kDenseThreads), dense_block_solve_lds_bytes(), s, a, ks);
 }
 
-// ---------------------------------------------------------------------------
-// Back-substitution down the tree + update of the candidate point.
-// ---------------------------------------------------------------------------
-// Solution of a separator: the root's comes from the reduced solve (behind the calibration part of y), the others'
-// from the level above.
-DEVI const double* sep_solution(const SolveArgs& a, const BcrArgs& b, int blk) {
-  return blk == b.root ? a.y + a.n_s() + a.mc : b.ysol + size_t(blk) * BP;
-}
-
-// delta = -y ; candidate = Plus(x, delta) for the parameter blocks selected by the caller; partial sums of the model
-// cost change and of the step norms go to the node's slot. (delta / Plus as in update_body, solve_kernels.hip.)
-struct UpdSums { double mcc, sn, cn; int bad; };
-DEVI void update_block(const BlockDev B, const double* yb, const double* __restrict__ x, double* __restrict__ x_cand, UpdSums& s) {
-  const double* p = x + B.amb_off;
-  double* qv = x_cand + B.amb_off;
-  if (B.manifold == 1) {
-    const double d0 = -yb[0], d1 = -yb[1], d2 = -yb[2];
-    const double nd = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-    double nx = p[0], ny = p[1], nz = p[2], nw = p[3];
-    if (nd > 0.0) {
-      const double sd = sin(nd) / nd, qw = cos(nd);
-      const double qx = sd * d0, qy = sd * d1, qz = sd * d2;
-      const double px = p[0], py = p[1], pz = p[2], pw = p[3];
-      nw = qw * pw - qx * px - qy * py - qz * pz;
-      nx = qw * px + qx * pw + qy * pz - qz * py;
-      ny = qw * py + qy * pw + qz * px - qx * pz;
-      nz = qw * pz + qz * pw + qx * py - qy * px;
-    }
-    qv[0] = nx; qv[1] = ny; qv[2] = nz; qv[3] = nw;
-    const double e[4] = {p[0] - nx, p[1] - ny, p[2] - nz, p[3] - nw};
-    s.sn += e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3];
-    s.cn += nx * nx + ny * ny + nz * nz + nw * nw;
-  } else {
-    for (int i = 0; i < B.size; ++i) {
-      const double v = p[i] - yb[i];
-      qv[i] = v; const double e = p[i] - v; s.sn += e * e; s.cn += v * v;
-    }
-  }
-}
-// fixed-shape reduction of the per-thread sums of one workgroup into slot `slot`: shuffle tree inside every wave, then
-// one thread per quantity adds the waves up in order (one barrier instead of a log-depth LDS tree)
-DEVI void file_update_sums(const UpdSums& s, double* sh /* [4][waves] */, double* upd, int slot) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  double v[4] = {s.mcc, s.sn, s.cn, s.bad ? 1.0 : 0.0};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
-  }
-  if (lane == 0) { sh[wave] = v[0]; sh[16 + wave] = v[1]; sh[32 + wave] = v[2]; sh[48 + wave] = v[3]; }
-  __syncthreads();
-  if (tid < 4) {
-    double t = 0.0;
-    for (int w = 0; w < nw; ++w) t += sh[16 * tid + w];
-    upd[size_t(slot) * 4 + tid] = t;
-  }
-}
-
-// grid = n_nodes, and for the top level (the first launch after the reduced solve) + 1 workgroup that updates the
-// calibration blocks and the root's control points + N·32/8 workgroups that form L⁻¹g - Z^F y_c for the rows of every
-// superblock (b.zb), which the levels below read instead of sweeping the border rows again. Dynamic LDS:
-// bcr_back_lds_bytes.
-constexpr int kBackThreads = 512;
-template <int QM>     // longest chain of the level: bounds the unrolled load batches
-__global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, BcrArgs b, int node0, int n_nodes, int top, int q_max,
-                                                                const double* __restrict__ x, double* __restrict__ x_cand,
-                                                                const BlockDev* __restrict__ blocks, int n_blocks) {
-  LmState* st = a.st;
-  const int terminated = st->terminated;     // tested after the loads are on their way
-  use_current_R(a);
-  extern __shared__ double lds[];
-  __shared__ double sh[64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n_s = a.n_s(), mc = a.mc, m1p = b.m1p;
-  const size_t fblk = size_t(BP) * m1p;
-  constexpr int RB = 6 * kBcrCps;
-  UpdSums s = {0.0, 0.0, 0.0, 0};
-  if (int(blockIdx.x) >= n_nodes && terminated) return;
-  if (int(blockIdx.x) > n_nodes) {
-    // z - Z^F y_c, one wave per row of Y
-    const int row = (int(blockIdx.x) - n_nodes - 1) * (kBackThreads / 64) + wave;
-    if (row >= b.N * BP) return;
-    const double* yrow = b.Y + size_t(row) * m1p;
-    const double* yc = a.y + n_s;
-    double part = 0.0;
-#pragma unroll 2
-    for (int j = lane; j < mc; j += 64) part += yrow[j] * yc[j];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    if (lane == 0) b.zb[row] = yrow[mc] - part;
-    return;
-  }
-  if (int(blockIdx.x) == n_nodes) {
-    // calibration blocks (their BlockDevs follow the control points') and the root's control points
-    for (int j = tid; j < mc; j += kBackThreads) {
-      const double yj = a.y[n_s + j];
-      if (!isfinite(yj)) s.bad = 1;
-      s.mcc += 0.5 * yj * (a.R[a.off_g() + n_s + j] + yj * a.dadd[n_s + j]);
-    }
-    for (int bi = tid; bi < n_blocks; bi += kBackThreads) {
-      const BlockDev B = blocks[bi];
-      if (B.tan_off < n_s) continue;
-      update_block(B, a.y + B.tan_off, x, x_cand, s);
-    }
-    if (b.root >= 0) {
-      const double* yr = a.y + n_s + mc;
-      if (tid < RB) {
-        const int t = RB * b.root + tid;
-        if (t < n_s) {
-          const double yj = yr[tid];
-          if (!isfinite(yj)) s.bad = 1;
-          s.mcc += 0.5 * yj * (a.R[a.off_g() + t] + yj * a.dadd[t]);
-          a.y[t] = yj;
-        }
-      }
-      if (tid < kBcrCps) {
-        const int cp = kBcrCps * b.root + tid;
-        const int bi = cp < a.n_cp ? b.cp_block[cp] : -1;
-        if (bi >= 0) update_block(blocks[bi], yr + 6 * tid, x, x_cand, s);
-      }
-    }
-    if (tid == 0) { st->rfill = st->rcur ^ 1; st->upd_parts = 0; }
-    file_update_sums(s, sh, b.upd, b.n_slots - 1);
-    return;
-  }
-  const BcrNodeDev* __restrict__ ndp = b.nodes + node0 + blockIdx.x;
-  const int q = ndp->q, nd_left = ndp->left, nd_right = ndp->right, nd_slot = ndp->slot, blk0 = ndp->blk0;
-  double* ZBs = lds;                                   // [q][32][33]
-  double* Ms = ZBs + size_t(q_max) * BP * DLD;         // [q][32][33]
-  double* tv = Ms + size_t(q_max) * BP * DLD;          // [8][32]
-  double* ya = tv + kBcrMaxChain * BP;                 // [32]
-  double* yn = ya + BP;                                // [32]  solution of the next block (right separator first)
-  double* wv = yn + BP;                                // [32]
-  double* yc = wv + BP;                                // [m1p]
-  double* ych = yc + m1p;                              // [q_max][32] the chain's solutions
-  // Everything the node needs is requested before anything is consumed -- the separators' solutions, Z^B and L⁻ᵀ of
-  // every block (to LDS), this thread's entries of Z^A and of L⁻¹g - Z^F y_c (sixteen threads per row), and what the
-  // update of the candidate point reads (gradient, damping, the control points' current values): a dependent global
-  // load costs about a microsecond here, the arithmetic next to nothing. Chain indices are clamped, not predicated,
-  // so that the loads stay unconditional.
-  const bool bdbg = a.debug && blockIdx.x == 0 && tid == 0;
-  long long bt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, btk = bdbg ? __builtin_readcyclecounter() : 0;
-#define BTICK(i) if (bdbg) { const long long t_ = __builtin_readcyclecounter(); bt[i] += t_ - btk; btk = t_; }
-  double ysep, ycv;
-  {
-    const double* pl = nd_left >= 0 ? sep_solution(a, b, nd_left) : a.y;
-    const double* pr = nd_right >= 0 ? sep_solution(a, b, nd_right) : a.y;
-    const double vl = pl[tid & 31], vr = pr[tid & 31];
-    // the root's solution comes from the reduced solve, which knows its 30 real rows only: the two padding rows are 0,
-    // not whatever sits behind them in y (an uninitialised word there may be a NaN, and NaN times a zero column is NaN)
-    const bool pad = (tid & 31) >= RB;
-    ysep = tid < BP ? ((nd_left >= 0 && !(pad && nd_left == b.root)) ? vl : 0.0)
-                    : ((nd_right >= 0 && !(pad && nd_right == b.root)) ? vr : 0.0);
-    ycv = a.y[n_s + min(tid, mc - 1 > 0 ? mc - 1 : 0)];
-  }
-  const int r16 = tid >> 4, sub = tid & 15;
-  double vz[QM][2], vm[QM][2], za[QM][2], zt[QM];
-#pragma unroll
-  for (int i = 0; i < QM; ++i) {
-    const int blk = blk0 + min(i, q - 1);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const size_t g = size_t(blk) * BB + tid + kBackThreads * u;
-      vz[i][u] = b.ZB[g]; vm[i][u] = b.M[g];
-    }
-    const double* arow = b.ZA + size_t(blk) * BB + size_t(r16) * BP;
-    za[i][0] = arow[sub]; za[i][1] = arow[sub + 16];
-    zt[i] = top ? b.Y[size_t(blk) * fblk + size_t(r16) * m1p + mc] : b.zb[size_t(blk) * BP + r16];
-  }
-  // update stage: thread e < 32q owns row e of the chain (gradient, damping), thread e < 5q control point e
-  const int my_row_t = RB * (blk0 + (tid >> 5)) + (tid & 31);
-  const bool my_row_ok = tid < q * BP && (tid & 31) < RB && my_row_t < n_s;
-  const double my_g = a.R[a.off_g() + (my_row_ok ? my_row_t : 0)], my_dadd = a.dadd[my_row_ok ? my_row_t : 0];
-  const int my_cp = kBcrCps * blk0 + tid;     // the chain's control points are consecutive
-  const bool my_cp_in = tid < q * kBcrCps && my_cp < a.n_cp;
-  const int my_cp_c = my_cp_in ? my_cp : 0;
-  const int my_off = b.ctrl_off[my_cp_c];
-  const bool my_cp_ok = my_cp_in && (b.all_active || a.cp_active[my_cp_c] != 0);
-  double px[6];
-#pragma unroll
-  for (int c = 0; c < 6; ++c) px[c] = x[my_off + c];
-  if (terminated) return;
-  BTICK(0)
-  if (a.debug > 1) {     // development aid: which input of the node is not finite?
-    bool bz = false, bm = false, ba = false, bt = false;
-#pragma unroll
-    for (int i = 0; i < QM; ++i) {
-      if (i < q) { bz = bz || !isfinite(vz[i][0]) || !isfinite(vz[i][1]); bm = bm || !isfinite(vm[i][0]) || !isfinite(vm[i][1]);
-                   ba = ba || !isfinite(za[i][0]) || !isfinite(za[i][1]); bt = bt || !isfinite(zt[i]); }
-    }
-    if (bz || bm || ba || bt || (tid < 2 * BP && !isfinite(ysep)) || (top && tid < mc && !isfinite(ycv)))
-      printf("bcr_back top %d node %d (blk0 %d q %d left %d right %d) tid %d: ZB %d M %d ZA %d zt %d ysep %d ycv %d\n", top, int(blockIdx.x), blk0, q,
-             nd_left, nd_right, tid, int(bz), int(bm), int(ba), int(bt), int(tid < 2 * BP && !isfinite(ysep)), int(top && tid < mc && !isfinite(ycv)));
-  }
-  if (tid < BP) ya[tid] = ysep; else if (tid < 2 * BP) yn[tid - BP] = ysep;
-  if (top) {
-    if (tid < m1p) yc[tid] = tid < mc ? ycv : 0.0;
-    for (int j = tid + kBackThreads; j < m1p; j += kBackThreads) yc[j] = j < mc ? a.y[n_s + j] : 0.0;
-  }
-#pragma unroll
-  for (int i = 0; i < QM; ++i) {
-    if (i < q) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int e = tid + kBackThreads * u;
-        const int o = (i * BP + (e >> 5)) * DLD + (e & 31);
-        ZBs[o] = vz[i][u]; Ms[o] = vm[i][u];
-      }
-    }
-  }
-  __syncthreads();
-  BTICK(1)
-  // t_i = (L⁻¹g_i - Z^F y_c) - Z^A y_a : sixteen threads per row, fixed-shape reduction
-#pragma unroll
-  for (int i = 0; i < QM; ++i) {
-    if (i < q) {
-      double part = nd_left >= 0 ? za[i][0] * ya[sub] + za[i][1] * ya[sub + 16] : 0.0;
-      if (top) {
-        const double* yrow = b.Y + size_t(blk0 + i) * fblk + size_t(r16) * m1p;
-        double yv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) yv[u] = yrow[min(sub + 16 * u, m1p - 1)];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) part += sub + 16 * u < mc ? yv[u] * yc[sub + 16 * u] : 0.0;
-        for (int j = sub + 128; j < mc; j += 16) part += yrow[j] * yc[j];
-      }
-      part += __shfl_xor(part, 8, 64); part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 1, 64);
-      if (sub == 0) tv[i * BP + r16] = zt[i] - part;
-    }
-  }
-  __syncthreads();
-  BTICK(2)
-  // the chain, last block first: w = t_i - Z^B y_next ; y_i = L⁻ᵀ w (one wave, two lanes per row)
-  if (wave == 0) {
-    const int r = lane & 31, h = lane >> 5;
-    for (int i = q - 1; i >= 0; --i) {
-      const double* zb = ZBs + (i * BP + r) * DLD + 16 * h;
-      double wp = 0.0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) wp += zb[j] * yn[16 * h + j];
-      wp += __shfl_xor(wp, 32, 64);
-      const double w = tv[i * BP + r] - wp;
-      if (h == 0) wv[r] = w;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      const double* mr = Ms + (i * BP + r) * DLD + 16 * h;
-      double yp = 0.0;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) yp += mr[c] * wv[16 * h + c];
-      yp += __shfl_xor(yp, 32, 64);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      if (h == 0) { yn[r] = yp; ych[i * BP + r] = yp; }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-  }
-  BTICK(3)
-  __syncthreads();
-  BTICK(4)
-  // file the solutions, update the candidate point of the chain's control points (delta = -y, plain vector blocks)
-  if (tid < q * BP) {
-    const double yj = ych[tid];
-    b.ysol[size_t(blk0) * BP + tid] = yj;
-    if (my_row_ok) {
-      if (!isfinite(yj)) s.bad = 1;
-      s.mcc += 0.5 * yj * (my_g + yj * my_dadd);
-      a.y[my_row_t] = yj;
-    }
-  }
-  if (my_cp_ok) {
-    const double* yb = ych + (tid / kBcrCps) * BP + 6 * (tid % kBcrCps);
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const double v = px[c] - yb[c];
-      x_cand[my_off + c] = v;
-      const double e = px[c] - v;
-      s.sn += e * e; s.cn += v * v;
-    }
-  }
-  BTICK(5)
-  file_update_sums(s, sh, b.upd, nd_slot);
-  BTICK(6)
-  if (bdbg) printf("bcr_back top %d (q %d) cycles: loads issued+arrived %lld  to LDS+barrier %lld  t-phase %lld  chain %lld  barrier %lld  outputs %lld  sums %lld\n",
-                   top, q, bt[0], bt[1], bt[2], bt[3], bt[4], bt[5], bt[6]);
-#undef BTICK
-}
-
 // ---- launch helpers ---------------------------------------------------------
 size_t bcr_level_lds_bytes() { return size_t(2 * 64 * DLD + 3 * BP * XLD + 80 + 128 + kLevelThreads) * sizeof(double); }
 size_t bcr_back_lds_bytes(int q_max, int m1p) {
@@ -1134,12 +1164,12 @@ void launch_bcr_schur(const SolveArgs& a, const BcrArgs& b, int ks, const LmOpti
   const int n_tile_wg = nt * (nt + 1) / 2 * ks;
   hipLaunchKernelGGL(bcr_schur_kernel, dim3(n_tile_wg + (b.root >= 0 ? 4 : 0)), dim3(256), 0, s, a, b, ks, n_tile_wg, o);
 }
-void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, bool top, int q_max, const double* x,
+void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, bool top, bool extras, int q_max, const double* x,
                      double* x_cand, const BlockDev* blocks, int n_blocks, hipStream_t s) {
   const int n_mv = (b.N * BP + kBackThreads / 64 - 1) / (kBackThreads / 64);
-  const dim3 grid(n_nodes + (top ? 1 + n_mv : 0)), block(kBackThreads);
+  const dim3 grid(n_nodes + (extras ? 1 + n_mv : 0)), block(kBackThreads);
   const size_t lds = bcr_back_lds_bytes(q_max, b.m1p);
-#define LAUNCH_BACK(QM) hipLaunchKernelGGL(bcr_back_kernel<QM>, grid, block, lds, s, a, b, node0, n_nodes, top ? 1 : 0, q_max, x, x_cand, blocks, n_blocks)
+#define LAUNCH_BACK(QM) hipLaunchKernelGGL(bcr_back_kernel<QM>, grid, block, lds, s, a, b, node0, n_nodes, top ? 1 : 0, extras ? 1 : 0, q_max, x, x_cand, blocks, n_blocks)
   if (q_max <= 1) LAUNCH_BACK(1); else if (q_max <= 2) LAUNCH_BACK(2); else if (q_max <= 4) LAUNCH_BACK(4); else LAUNCH_BACK(8);
 #undef LAUNCH_BACK
 }

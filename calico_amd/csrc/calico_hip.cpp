@@ -71,8 +71,9 @@ void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nod
                       const double* x, const BlockDev* blocks, int n_blocks, bool with_post_eval, IterLog* log, int log_cap, int jacobi,
                       hipStream_t s);
 void launch_bcr_schur(const SolveArgs& a, const BcrArgs& b, int ks, const LmOptionsDev& o, hipStream_t s);
-void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, bool with_calib, int q_max, const double* x,
+void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, bool top, bool extras, int q_max, const double* x,
                      double* x_cand, const BlockDev* blocks, int n_blocks, hipStream_t s);
+
 void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipStream_t s);
 int reduced_schur_slices(const SolveArgs& a);
 
@@ -1018,7 +1019,7 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
   launch_reduced_solve(sa, p->dense_in_lds, ks, s);
   for (int l = L - 1; l >= 0; --l) {
     const calico_problem::BcrLevel& lv = p->bcr_levels[size_t(l)];
-    launch_bcr_back(sa, b, lv.node0, lv.n_nodes, l == L - 1, lv.q_max, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, s);
+    launch_bcr_back(sa, b, lv.node0, lv.n_nodes, l == L - 1, l == L - 1, lv.q_max, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, s);
   }
   // development aid (CALICO_CHECK_FINITE=1): where does the first non-finite value of a solve sit?
   static const bool check = std::getenv("CALICO_CHECK_FINITE") != nullptr;
