@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""What happens between two solves: kernels, DMA copies and idle gaps from the end of one solve's last working kernel to
+the next solve's first level kernel.  python profiles/solve_boundary_gaps.py <rocprofv3 rocpd .db>"""
+import sqlite3
+import sys
+
+
+def main():
+    c = sqlite3.connect(sys.argv[1])
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if "kernel_dispatch" in t][0]
+    ks = [t for t in tabs if "kernel_symbol" in t][0]
+    rows = [(s, e, n) for n, s, e in c.execute("select s.kernel_name, d.start, d.end from %s d join %s s on d.kernel_id = s.id" % (kd, ks))]
+    mc = [t for t in tabs if "memory_copy" in t]
+    if mc:
+        cols = [r[1] for r in c.execute("pragma table_info(%s)" % mc[0])]
+        if "start" in cols and "end" in cols:
+            rows += [(s, e, "<memory copy>") for s, e in c.execute("select start, end from %s" % mc[0])]
+    rows.sort()
+    # a solve starts with init_state_kernel
+    starts = [i for i, r in enumerate(rows) if "init_state" in r[2]]
+    if len(starts) < 4:
+        raise SystemExit("not enough solves in the trace")
+    i0 = starts[len(starts) // 2]
+    # walk back to the last kernel of the previous solve that did work (> 6 us)
+    j = i0 - 1
+    while j > 0 and (rows[j][1] - rows[j][0]) < 6000:
+        j -= 1
+    t0 = rows[j][1]
+    k = i0
+    while "bcr_level_kernelILb1" not in rows[k][2] and "band_cholesky" not in rows[k][2] and k < len(rows) - 1:
+        k += 1
+    prev = t0
+    print("from the end of the previous solve's last working kernel to the first linear solve of the next:")
+    for s, e, n in rows[j + 1:k + 1]:
+        print("  +%8.2f us  gap %7.2f  dur %7.2f  %s" % ((s - t0) / 1e3, (s - prev) / 1e3, (e - s) / 1e3, n.split("(")[0][:60]))
+        prev = e
+    print("total %.2f us" % ((rows[k][0] - t0) / 1e3))
+
+
+if __name__ == "__main__":
+    main()
