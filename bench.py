@@ -104,6 +104,9 @@ def main():
                     help="exercise the sharding + all-reduce path even with one rank (validation)")
     ap.add_argument("--repeats", type=int, default=0,
                     help="timed samples of --steps iterations each (default: 25 when --steps <= 50, else 5); the median is reported")
+    ap.add_argument("--poor-start", type=float, default=0.0,
+                    help="move the start away from the truth: focal lengths x (1 + F/100), translations + F cm, control "
+                         "points + F mrad / F mm of noise (context runs: many rejected steps); 0 = the reference test's perturbation")
     ap.add_argument("--tagging-passes", type=int, default=0,
                     help="outlier tagging loop (configs[4]): solve, tag |r| > 3 on the device, re-solve, N times; reported, untimed")
     args = ap.parse_args()
@@ -151,6 +154,17 @@ def main():
         init += [(sb["intrinsics"], s.intrinsics.copy()), (sb["t"], s.t.copy()), (sb["q"], s.q.copy()),
                  (sb["latency"], np.array([s.latency]))]
 
+    if args.poor_start > 0:
+        rng = np.random.default_rng(1234)
+        F = args.poor_start
+        init = [(int(b), scene.ctrl[i] + 1e-3 * F * rng.standard_normal(6))
+                for i, b in enumerate(built.ctrl_blocks)]
+        for s_, sb in zip(scene.sensors, built.sensor_blocks):
+            intr = s_.intrinsics.copy()
+            if s_.kind == _capi.SENSOR_CAMERA:
+                intr[0] *= 1.0 + F / 100.0
+            init += [(sb["intrinsics"], intr), (sb["t"], s_.t + 0.01 * F * rng.uniform(-1, 1, 3)), (sb["q"], s_.q.copy()),
+                     (sb["latency"], np.array([s_.latency]))]
     init_ids = np.array([b for b, _ in init], np.int32)
     init_vals = np.concatenate([np.asarray(v, float).ravel() for _, v in init])
 
@@ -189,7 +203,7 @@ def main():
             # (convergence within Ceres' default 50 iterations is demanded of the benchmark workload; the context
             #  configurations -- 50 Hz knots, the EuRoC shape -- are weakly constrained and take longer)
             if not (s.num_successful_steps > 0 and s.final_cost < s.initial_cost) or \
-                    (args.config <= 4 and opts.max_num_iterations >= 50 and s.termination_type != _capi.CONVERGENCE):
+                    (args.config <= 4 and args.poor_start == 0 and opts.max_num_iterations >= 50 and s.termination_type != _capi.CONVERGENCE):
                 raise RuntimeError("solve did not behave (%g -> %g, %d successful steps, termination %d): %s" % (
                     s.initial_cost, s.final_cost, s.num_successful_steps, s.termination_type, s.message.decode()))
             done += s.num_iterations
@@ -317,6 +331,8 @@ def main():
                 "residual_blocks_evaluated_per_s": n_blocks * max(jac, cost) / elapsed,
                 "parallelism": "obs-shard x%d + native RCCL all-reduce(JtJ,Jtr,cost)" % world if world > 1 else "single GPU",
                 "host_loop": "non-blocking: device-published progress, two iterations enqueued ahead" if world == 1 and not args.force_collective else "batches of %d iterations per host read-back" % args.sync_every,
+                "poor_start": args.poor_start,
+                "successful_steps_last_solve": last.num_successful_steps, "unsuccessful_steps_last_solve": last.num_unsuccessful_steps,
                 "linear_solver": os.environ.get("CALICO_SOLVER", "tree (block cyclic reduction over 5-control-point superblocks)"),
                 "setup_ms": setup_ms,
                 "setup_ms_add_calls": setup_add_ms,        # of which: the add_* calls through the C ABI (python + ctypes here)

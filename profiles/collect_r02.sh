@@ -31,4 +31,6 @@ CALICO_SOLVER=band timeout 600 python $REPO/bench.py --config 5 --steps 100 --wa
 timeout 300 python $REPO/bench.py --force-collective --no-cpu-baseline --repeats 5 2>/dev/null | tail -1 > $OUT/r02_collective_1gpu.json
 # 6. speculative evaluation under rejections: configs[4] (2 % gross outliers) and a poor start
 for sp in 1 0; do CALICO_SPECULATIVE=$sp timeout 600 python $REPO/bench.py --config 4 --steps 100 --warmup 20 --repeats 3 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/r02_config4_speculative$sp.json; done
+# the same A/B from a deliberately poor start (control points + 100 mrad / 100 mm of noise, focal lengths x2): ~30 % rejected steps
+for sp in 1 0; do CALICO_SPECULATIVE=$sp timeout 300 python $REPO/bench.py --poor-start 100 --steps 100 --warmup 20 --repeats 3 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/r02_poor_start_speculative$sp.json; done
 ls -la $OUT
