@@ -186,11 +186,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_solves(n, phases=range(6)):
-        """n LM iterations over whole solves; returns counters and the HIP-event phase times (of `phases`)."""
+    def timed_solves(n):
+        """n LM iterations over whole solves; returns the counters (phase times: read_phases, after the closing barrier)."""
         done = jac = cost = solves = 0
-        phase_ms = [0.0] * 7
-        phase_n = [0] * 7
         last = None
         while done < n:
             reset()
@@ -211,14 +209,17 @@ def main():
             cost += s.num_cost_evaluations
             solves += 1
             last = s
-            for i in phases:  # the timers restart at every solve
-                ms, cnt = P.phase_time(i)
-                phase_ms[i] += ms
-                phase_n[i] += cnt
-            ms, cnt = P.phase_time(0 | 0x100)   # Jacobian launches that did work (not the early exits after termination)
-            phase_ms[6] += ms
-            phase_n[6] += cnt
-        return done, jac, cost, solves, last, phase_ms, phase_n
+        return done, jac, cost, solves, last
+
+    def read_phases(phases=range(6)):
+        """HIP-event phase times accumulated since the last set_phase_timing (waits for the stream: a solve returns as soon
+        as the device reports its end, the early-exit kernels of the iterations enqueued ahead drain afterwards)."""
+        phase_ms = [0.0] * 7
+        phase_n = [0] * 7
+        for i in phases:
+            phase_ms[i], phase_n[i] = P.phase_time(i)
+        phase_ms[6], phase_n[6] = P.phase_time(0 | 0x100)   # Jacobian launches that did work (not the early exits after termination)
+        return phase_ms, phase_n
 
     # Optimize() end to end on a fresh handle: the reference rebuilds its ceres::Problem on every call
     # (batch_optimizer.cpp:57-70), so flattening + upload (setup) and the copy-back of estimates and residuals
@@ -245,19 +246,21 @@ def main():
 
     # warmup: all phases bracketed by HIP events -> per-phase breakdown (reported, untimed)
     P.set_phase_timing(0x3f)   # all phases + the bracket calibration (phase 5)
-    _, _, _, _, _, wu_ms, wu_n = timed_solves(max(1, args.warmup))
+    timed_solves(max(1, args.warmup))
+    wu_ms, wu_n = read_phases()
     # timed region: only the dominant kernel (phase 0) carries events, and only every 16th of its launches -- an event
     # pair costs ~6 us of stream time on either side of the kernel. The K-step sample is a few milliseconds long, so it is
     # repeated and the MEDIAN sample is the one reported (box-to-box and run-to-run spread is several per cent).
-    P.set_phase_timing(0x01 | (16 << 8))
     repeats = args.repeats if args.repeats > 0 else (25 if args.steps <= 50 else 5)
     samples = []
     for _ in range(repeats):
+        P.set_phase_timing(0x01 | (16 << 8))             # (restarts the accumulated phase times)
         barrier()
         t0 = time.perf_counter()
-        rec = timed_solves(args.steps, phases=(0,))      # only the Jacobian kernel carries events in the timed region
+        rec = timed_solves(args.steps)
         barrier()
         elapsed = time.perf_counter() - t0
+        rec = rec + read_phases((0,))                    # only the Jacobian kernel carries events in the timed region
         if dist is not None:
             t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

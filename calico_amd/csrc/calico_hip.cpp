@@ -60,6 +60,8 @@ void launch_control(LmState* st, const LmOptionsDev& o, double* R2, double* x, c
                     IterLog* log, int log_cap, const double* item_cost, int n_items, const double* Rbase, size_t r_stride,
                     hipStream_t s, bool commit_by_copy = false, int* progress = nullptr, int seq = 0);
 void launch_init_state(LmState* st, double radius, double x_norm, hipStream_t s, const double* upd_ext = nullptr, int upd_ext_n = 0);
+void launch_begin_solve(LmState* st, double radius, double x_norm, const double* upd_ext, int upd_ext_n, const ResultSink& sink, double* x,
+                        double* x_cand, const double* h_x, int n_amb, hipStream_t s);
 void launch_publish_results(const LmState* st, const IterLog* log, int log_rows, const double* x, int n_amb, LmState* h_state,
                             IterLog* h_log, double* h_x, hipStream_t s);
 void launch_seed_x(double* x, const double* h_x, int n_amb, hipStream_t s);
@@ -227,6 +229,7 @@ struct calico_problem {
   int n_thin = 0, n_fat = 0;
   bool dense_in_lds = true;
 
+  DevBuf<unsigned long long> d_wave_log;   // CALICO_KERNEL_TIMING=3
   DevBuf<double> d_x, d_xc, d_knots, d_basis, d_m0, d_m1, d_m2, d_stamp, d_partials, d_R, d_R2, d_Lb, d_Linv, d_Y, d_S, d_Spart, d_Swork, d_zbuf, d_y,
       d_dadd, d_scale, d_res;
   DevBuf<int> d_ctrl_off, d_point_off, d_out_thin, d_idx_thin, d_out_fat, d_idx_fat;
@@ -246,7 +249,8 @@ struct calico_problem {
   DevBuf<LmState> d_state;
   DevBuf<IterLog> d_log;
   LmState* h_state = nullptr;  // pinned
-  int* h_progress = nullptr;   // pinned, device-visible: [iterations the control kernel is through with, terminated]
+  int* h_progress = nullptr;   // pinned, device-visible: [epoch << 20 | iterations the control kernel is through with, epoch of the terminated solve]
+  int solve_epoch = 0;         // number of the streaming solve under way (1 .. 2047, wraps)
   int* d_progress = nullptr;
   double* h_xpin = nullptr;    // pinned staging for the parameter vector (upload at the start of a call, download at its end)
   size_t h_xpin_n = 0;
@@ -373,7 +377,7 @@ EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool
   a.partials = p->d_partials.p; a.item_cost = p->d_partials.p + p->partial_doubles;
   a.res_out = want_res ? p->d_res.p : nullptr; a.valid_out = want_res ? p->d_valid.p : nullptr;
   a.order = p->order; a.n_items = p->n_items; a.lds_cols = p->lds_cols; a.row_pad = p->row_pad; a.n_cells = int(p->h_cells.size()); a.cells = p->d_cells.p; a.prim_tab = p->d_prim_tab.p;
-  a.cell_chunk = p->cell_chunk; a.cell_rec_max = p->cell_rec_max; a.project = 0; a.row_cell_chunk = p->row_cell_chunk; a.frame_lds_doubles = p->frame_lds_doubles; a.pad5 = 0; a.active = p->d_active.p; a.apply_loss = apply_loss;
+  a.cell_chunk = p->cell_chunk; a.cell_rec_max = p->cell_rec_max; a.project = 0; a.row_cell_chunk = p->row_cell_chunk; a.frame_lds_doubles = p->frame_lds_doubles; a.pad5 = 0; a.wave_log = p->d_wave_log.p; a.active = p->d_active.p; a.apply_loss = apply_loss;
   a.st = nullptr; a.need_flag = 0; a.cost_index_base = 0;
   a.fitems = p->d_fitems.p; a.n_fitems = p->n_fitems;
   return a;
@@ -860,6 +864,7 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_out_fat.upload(out_fat, s)); HIP_TRY(p, p->d_idx_fat.upload(idx_fat, s));
   HIP_TRY(p, p->d_ptr_fat.upload(ptr_fat, s));
   HIP_TRY(p, p->d_partials.alloc(comp_base + comp_off + row_store));
+  if (std::getenv("CALICO_KERNEL_TIMING") && std::atoi(std::getenv("CALICO_KERNEL_TIMING")) >= 3) HIP_TRY(p, p->d_wave_log.alloc(2 * size_t(p->n_jac_items + p->n_fitems)));
   HIP_TRY(p, p->d_cells.upload(p->h_cells, s)); HIP_TRY(p, p->d_prim_tab.upload(prim_tab, s));
   p->r_size = r_size;
   {
@@ -878,12 +883,14 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_active.alloc(size_t(n_obs))); HIP_TRY(p, p->d_counter.alloc(1));
   p->active_dirty = true; p->xc_stale = true;
   HIP_TRY(p, p->d_state.alloc(1)); HIP_TRY(p, p->d_log.alloc(kLogCap));
-  if (!p->h_state) HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LmState)));
-  if (!p->h_log) HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_log), size_t(kLogCap) * sizeof(IterLog)));
+  // fine-grained (coherent): the terminating stage of a solve writes its results here and the host reads them while
+  // later kernels are still on the stream
+  if (!p->h_state) HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LmState), hipHostMallocMapped | hipHostMallocCoherent));
+  if (!p->h_log) HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_log), size_t(kLogCap) * sizeof(IterLog), hipHostMallocMapped | hipHostMallocCoherent));
   if (p->h_xpin_n < size_t(p->n_amb)) {
     if (p->h_xpin) (void)hipHostFree(p->h_xpin);
     p->h_xpin = nullptr; p->h_xpin_n = 0;
-    HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_xpin), std::max<size_t>(1, size_t(p->n_amb)) * sizeof(double)));
+    HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_xpin), std::max<size_t>(1, size_t(p->n_amb)) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     p->h_xpin_n = size_t(p->n_amb);
   }
   if (!p->h_progress) {
@@ -931,7 +938,7 @@ int finalize(calico_problem* p) {
   return CALICO_OK;
 }
 
-int upload_x(calico_problem* p) {
+int upload_x(calico_problem* p, bool seed = true) {
   if (p->active_dirty) {   // outlier tags, in the sorted order of the device arrays
     std::vector<uint8_t> act(size_t(std::max<int64_t>(p->n_obs, 1)), 1);
     for (const HSensor& s : p->sensors)
@@ -944,6 +951,7 @@ int upload_x(calico_problem* p) {
   // through the pinned staging buffer: a true asynchronous DMA (every API call ends with a stream synchronisation, so
   // the buffer is never rewritten while a transfer is pending)
   std::copy(p->h_x.begin(), p->h_x.end(), p->h_xpin);
+  if (!seed) return CALICO_OK;   // calico_solve: the kernel that resets the LM state reads the staging buffer
   launch_seed_x(p->d_x.p, p->h_xpin, int(p->h_x.size()), p->stream);      // the kernel reads the pinned buffer: no DMA copy (~13 us) on the stream
   // d_xc needs no upload: every parameter block, constant ones included, is rewritten by the update kernel... except
   // the constant blocks, which the update never touches -- so it is seeded once per finalisation (below) and whenever
@@ -1279,17 +1287,21 @@ int32_t calico_problem_add_imu_residuals(calico_problem* p, int32_t sid, int64_t
 int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico_summary* sm) {
   if (!p || !opt || !sm) return CALICO_INVALID_ARGUMENT;
   const auto t_start = std::chrono::steady_clock::now();
+  // CALICO_SOLVE_TIMING=1: host time of the sections of this call and since the previous call returned (development aid)
+  static const bool solve_timing = std::getenv("CALICO_SOLVE_TIMING") != nullptr;
+  static std::chrono::steady_clock::time_point t_last_return = t_start;
+  double t_mark[6] = {0, 0, 0, 0, 0, 0};
+  auto mark = [&](int i) { if (solve_timing) t_mark[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count(); };
   std::memset(sm, 0, sizeof(*sm));
   if (p->world > 1 && !p->has_exchange())
     return p->set_error(CALICO_FAILED_PRECONDITION, "calico_problem_set_shard(world > 1) needs an exchange: calico_comm_init_rccl or calico_problem_set_allreduce");
   int rc = finalize(p);
   if (rc != CALICO_OK) return rc;
   HIP_TRY(p, hipSetDevice(p->device));
-  rc = upload_x(p);
+  rc = upload_x(p, /*seed=*/false);
   if (rc != CALICO_OK) return rc;
   fill_counts(p, sm);
   p->iterations.clear();
-  p->timer.reset();
   LmOptionsDev o;
   o.max_num_iterations = opt->max_num_iterations; o.max_num_consecutive_invalid_steps = opt->max_num_consecutive_invalid_steps;
   o.function_tolerance = opt->function_tolerance; o.gradient_tolerance = opt->gradient_tolerance;
@@ -1302,7 +1314,22 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   const auto t_loop = std::chrono::steady_clock::now();
   const double* upd_ext = p->use_bcr ? p->d_bupd.p : nullptr;
   const int upd_ext_n = p->use_bcr ? p->bcr_slots : 0;
-  launch_init_state(p->d_state.p, opt->initial_trust_region_radius, std::sqrt(xn), s, upd_ext, upd_ext_n);
+  // Single rank, speculative evaluation: the host never blocks inside the solve. The control kernel publishes the
+  // number of the iteration it has finished with (and post_eval / control the termination flag) in host-mapped
+  // memory; the host keeps `depth` iterations enqueued ahead of that and stops when the flag goes up. Compared with
+  // batches of `sync_every` iterations and a blocking read-back per batch this takes the read-back gaps out of the
+  // stream and leaves at most `depth` iterations of early-exit kernels behind a terminated solve. The stage that
+  // terminates the solve writes the results (state, log, parameters) into pinned host memory itself, so the call
+  // returns as soon as the flag is up: the early-exit kernels drain while the caller prepares its next call.
+  const int stream_depth = [] { const char* e = std::getenv("CALICO_STREAM_DEPTH"); return e ? std::atoi(e) : 2; }();
+  const bool streaming = p->speculative && !p->has_exchange() && stream_depth > 0 && p->h_progress != nullptr;
+  const int log_rows = std::min(kLogCap, std::max(0, opt->max_num_iterations) + 2);
+  ResultSink sink = {};
+  if (streaming) {
+    p->solve_epoch = p->solve_epoch % 2047 + 1;
+    sink.state = p->h_state; sink.log = p->h_log; sink.x = p->h_xpin; sink.src_log = p->d_log.p; sink.src_x = p->d_x.p;
+    sink.rows = log_rows; sink.n_amb = int(p->h_x.size()); sink.epoch = p->solve_epoch;
+  }
   // what a hipEventRecord pair costs around a ~2 us kernel on this stream: lets the caller take the bracket
   // overhead out of the per-launch phase times (phase 5)
   if ((p->timer.mask >> 5) & 1) {
@@ -1312,20 +1339,15 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
       p->timer.end(s);
     }
   }
+  mark(0);
+  launch_begin_solve(p->d_state.p, opt->initial_trust_region_radius, std::sqrt(xn), upd_ext, upd_ext_n, sink, p->d_x.p,
+                     p->xc_stale ? p->d_xc.p : nullptr, p->h_xpin, int(p->h_x.size()), s);
+  p->xc_stale = false;
+  mark(1);
   SolveArgs sa = make_solve_args(p);
   const int n_blocks = int(p->h_blocks.size());
-  // Single rank, speculative evaluation: the host never blocks inside the solve. The control kernel publishes the
-  // number of the iteration it has finished with (and post_eval / control the termination flag) in host-mapped
-  // memory; the host keeps `depth` iterations enqueued ahead of that and stops when the flag goes up. Compared with
-  // batches of `sync_every` iterations and a blocking read-back per batch this takes the read-back gaps out of the
-  // stream and leaves at most `depth` iterations of early-exit kernels behind a terminated solve.
-  const int stream_depth = [] { const char* e = std::getenv("CALICO_STREAM_DEPTH"); return e ? std::atoi(e) : 2; }();
-  const bool streaming = p->speculative && !p->has_exchange() && stream_depth > 0 && p->h_progress != nullptr;
-  if (streaming) {
-    __atomic_store_n(p->h_progress, 0, __ATOMIC_RELEASE);
-    __atomic_store_n(p->h_progress + 1, 0, __ATOMIC_RELEASE);
-    sa.progress = p->d_progress;
-  }
+  if (streaming) sa.progress = p->d_progress;
+  const int epoch = p->solve_epoch;
   // iteration 0
   rc = enqueue_jacobian_eval(p, nullptr, 0);
   if (rc != CALICO_OK) return rc;
@@ -1333,6 +1355,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   launch_post_eval(sa, p->d_x.p, p->d_blocks.p, int(p->h_blocks.size()), o, p->d_log.p, kLogCap, 1, opt->jacobi_scaling, s);
   p->timer.end(s);
   const bool fused_control = [] { const char* e = std::getenv("CALICO_FUSED_CONTROL"); return !e || std::atoi(e) != 0; }();
+  mark(2);
   if (streaming) {
     int enq = 0;
     auto t_progress = std::chrono::steady_clock::now();     // when the device last reported a finished iteration
@@ -1341,8 +1364,9 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
     for (;;) {
       bool done = false;
       for (;;) {
-        if (__atomic_load_n(p->h_progress + 1, __ATOMIC_ACQUIRE)) { done = true; break; }
-        const int seen = __atomic_load_n(p->h_progress, __ATOMIC_ACQUIRE);
+        if (__atomic_load_n(p->h_progress + 1, __ATOMIC_ACQUIRE) == epoch) { done = true; break; }
+        const int word = __atomic_load_n(p->h_progress, __ATOMIC_ACQUIRE);
+        const int seen = (word >> 20) == epoch ? (word & 0xfffff) : 0;    // words of another epoch: early-exit kernels of the previous solve
         if (seen != last_seen) { last_seen = seen; t_progress = std::chrono::steady_clock::now(); spins = 0; }
         if (enq - seen < stream_depth) break;
         __builtin_ia32_pause();
@@ -1461,12 +1485,13 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
     if (rc != CALICO_OK) return rc;
   }
   // results: final state, iteration log and parameters come back in one go (pinned buffers, one synchronisation)
-  const int log_rows = std::min(kLogCap, std::max(0, opt->max_num_iterations) + 2);
   // one small kernel writes them into the pinned host buffers (three DMA copies cost ~13 us of stream time each). R(x)
   // may sit in either reduce buffer afterwards: nobody reads it (every entry point that needs it evaluates first).
-  launch_publish_results(p->d_state.p, p->d_log.p, log_rows, p->d_x.p, int(p->h_x.size()), p->h_state, p->h_log, p->h_xpin, s);
-  HIP_TRY(p, hipStreamSynchronize(s));
-  p->timer.resolve();
+  // (streaming loop: the terminating stage has written them already, and nothing is waited for; event brackets of the
+  //  phase timer are resolved when somebody asks for the times)
+  mark(3);
+  if (!streaming) launch_publish_results(p->d_state.p, p->d_log.p, log_rows, p->d_x.p, int(p->h_x.size()), p->h_state, p->h_log, p->h_xpin, s);
+  if (!streaming) HIP_TRY(p, hipStreamSynchronize(s));
   sm->num_jacobian_evaluations = p->h_state->n_jac_evals;
   sm->num_cost_evaluations = p->h_state->n_cost_evals;
   const double t_solve = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
@@ -1486,6 +1511,12 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
                   r.step_norm, r.relative_decrease, r.trust_region_radius);
     }
   }
+  if (p->d_wave_log.p && p->d_wave_log.n > 1) {   // development aid: the last Jacobian launch of the solve, workgroup by workgroup
+    std::vector<unsigned long long> wl(p->d_wave_log.n);
+    HIP_TRY(p, hipMemcpy(wl.data(), p->d_wave_log.p, wl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i + 1 < wl.size(); i += 2)
+      std::fprintf(stderr, "WAVE %zu %s t0 %llu t1 %llu\n", i / 2, int(i / 2) < p->n_jac_items ? "item" : "frame", wl[i], wl[i + 1]);
+  }
   sm->termination_type = st.termination_type;
   sm->num_successful_steps = st.num_successful; sm->num_unsuccessful_steps = st.num_unsuccessful;
   sm->num_iterations = st.last_logged_iteration;      // Summary::iterations.size() - 1; not read from the log buffer, which is capped at kLogCap rows
@@ -1494,6 +1525,13 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   std::snprintf(sm->message, sizeof(sm->message), "%s", reason_message(st.termination_reason));
   sm->solve_time_in_seconds = t_solve;
   sm->total_time_in_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  if (solve_timing) {
+    mark(4);
+    std::fprintf(stderr, "solve host us: since last return %.1f | prep %.1f | begin launch %.1f | first evaluation enqueued %.1f | loop %.1f | results %.1f\n",
+                 std::chrono::duration<double, std::micro>(t_start - t_last_return).count(), t_mark[0], t_mark[1] - t_mark[0],
+                 t_mark[2] - t_mark[1], t_mark[3] - t_mark[2], t_mark[4] - t_mark[3]);
+    t_last_return = std::chrono::steady_clock::now();
+  }
   return CALICO_OK;
 }
 
@@ -1764,6 +1802,9 @@ int32_t calico_problem_set_stream(calico_problem* p, void* stream) {
 
 int32_t calico_set_phase_timing(calico_problem* p, int32_t mask) {
   if (!p) return CALICO_INVALID_ARGUMENT;
+  // the phase times accumulate from this call on, over as many solves as follow
+  if (!p->timer.pending.empty()) { (void)hipSetDevice(p->device); (void)hipStreamSynchronize(p->stream); p->timer.resolve(); }
+  p->timer.reset();
   p->timer.mask = mask & 0xff;
   p->timer.every = std::max(1, (mask >> 8) & 0xff);
   return CALICO_OK;
@@ -1773,6 +1814,11 @@ int32_t calico_get_phase_time(calico_problem* p, int32_t phase, double* ms, int6
   const bool working = (phase & 0x100) != 0;
   phase &= 0xff;
   if (!p || phase < 0 || phase >= kNumPhases) return CALICO_INVALID_ARGUMENT;
+  if (!p->timer.pending.empty()) {   // brackets still on the stream (a solve returns without waiting for it to drain)
+    HIP_TRY(p, hipSetDevice(p->device));
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    p->timer.resolve();
+  }
   if (ms) *ms = working ? p->timer.ms_working[phase] : p->timer.ms[phase];
   if (launches) *launches = working ? p->timer.count_working[phase] : p->timer.count[phase];
   return CALICO_OK;

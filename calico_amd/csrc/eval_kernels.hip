@@ -1005,10 +1005,9 @@ __global__ __launch_bounds__(64) void eval_jacobian_kernel(EvalArgs a) {
   const unsigned long long t0 = a.debug >= 3 ? __builtin_amdgcn_s_memrealtime() : 0;
   if (int(blockIdx.x) < a.n_items) eval_items_body<true, 6>(a, blockIdx.x, lds);
   else eval_frames_body(a, blockIdx.x - a.n_items, lds);
-  if (a.debug >= 3 && threadIdx.x == 0) {   // CALICO_KERNEL_TIMING=3: placement and life span of every wave (100 MHz clock)
+  if (a.debug >= 3 && a.wave_log && threadIdx.x == 0) {   // CALICO_KERNEL_TIMING=3: life span of every wave (100 MHz clock)
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
-    const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);
-    printf("WAVE %d %s t0 %llu t1 %llu hw %08x xcc %08x\n", int(blockIdx.x), int(blockIdx.x) < a.n_items ? "item" : "frame", t0, t1, hw, xcc);
+    if (t1 - t0 > 200) { a.wave_log[2 * blockIdx.x] = t0; a.wave_log[2 * blockIdx.x + 1] = t1; }   // not the early exits after termination
   }
 }
 

@@ -92,6 +92,18 @@ struct EvalArgs {
                                  // model); work items per LDS pass of a row cell
   const uint8_t* active; // per observation (sorted order): 0 = tagged as outlier, left out; nullptr = all in
   int frame_lds_doubles, pad5;   // LDS of a frame workgroup for the widest frame layout of the problem (0: worst case)
+  unsigned long long* wave_log;  // CALICO_KERNEL_TIMING=3: [start, end] of every workgroup of the Jacobian launch (100 MHz clock)
+};
+
+// Where the stage that terminates a solve leaves its results for the host (pinned, host-mapped memory: final state,
+// iteration log, parameter vector), and the solve's number: the progress words the host polls carry it, so that the
+// early-exit kernels a terminated solve leaves behind on the stream cannot be mistaken for the next solve's.
+struct IterLog;
+struct LmState;
+struct ResultSink {
+  LmState* state; IterLog* log; double* x;   // host side (nullptr: results are fetched by publish_results_kernel)
+  const IterLog* src_log; const double* src_x;
+  int rows, n_amb, epoch, pad;
 };
 
 // LM state kept on the device; the control kernel is its only writer.
@@ -123,6 +135,8 @@ struct LmState {
   const double* upd_ext;
   int upd_ext_n;
   int last_logged_iteration;   // iteration number of the last row of the log, kept even when the log buffer is full
+  int published;               // the results went to `sink` (once per solve)
+  ResultSink sink;
 };
 
 struct LmOptionsDev {

@@ -35,6 +35,27 @@ DEVI double diag_entry(const SolveArgs& a, int j) {
 
 DEVI void publish(int* word, int value) { __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
+// Progress words of the streaming solve loop (host-mapped): [epoch << 20 | iterations the control stage is through with,
+// epoch of the solve that has terminated].
+DEVI void publish_progress(int* progress, const LmState* st, int seq) {
+  if (st->terminated) publish(progress + 1, st->sink.epoch);
+  publish(progress, (st->sink.epoch << 20) | seq);
+}
+// Results of a solve straight into host-visible pinned memory, by the stage that terminates it: a few kilobytes written
+// over the fabric by one workgroup; the host returns as soon as it sees the terminated word, without waiting for the
+// early-exit kernels of the iterations enqueued ahead. Call with all `nt` threads, between two barriers, after
+// `terminated` was set; the caller publishes the progress words afterwards.
+DEVI void publish_results_block(LmState* st, int tid, int nt) {
+  const ResultSink k = st->sink;
+  if (!k.state || st->published) return;
+  const int n_state = int(sizeof(LmState) / sizeof(int)), n_row = int(sizeof(IterLog) / sizeof(int));
+  const int rows = min(max(st->n_log, 0), k.rows);
+  for (int i = tid; i < rows * n_row; i += nt) reinterpret_cast<int*>(k.log)[i] = reinterpret_cast<const int*>(k.src_log)[i];
+  for (int i = tid; i < k.n_amb; i += nt) k.x[i] = k.src_x[i];
+  for (int i = tid; i < n_state; i += nt) reinterpret_cast<int*>(k.state)[i] = reinterpret_cast<const int*>(st)[i];
+  __threadfence_system();
+}
+
 DEVI void log_and_finalize(LmState* st, const LmOptionsDev& o, IterLog* log, int log_cap) {
   if (st->iteration > 0) { if (st->step_successful) st->num_successful++; else st->num_unsuccessful++; }
   const double row_cost = st->step_successful || st->iteration == 0 ? st->x_cost : (st->step_valid ? st->candidate_cost : st->x_cost);
@@ -106,7 +127,12 @@ DEVI void post_eval_body(SolveArgs a, const double* __restrict__ x, const BlockD
       if (first) { st->initial_cost = st->x_cost; st->min_cost = st->x_cost; }
       log_and_finalize(st, o, log, log_cap);
     }
-    if (a.progress && st->terminated) publish(a.progress + 1, 1);   // the host stops enqueueing iterations
+  }
+  __syncthreads();
+  if (st->terminated) {   // (uniform) the host stops enqueueing iterations and reads the results
+    publish_results_block(st, tid, 256);
+    __syncthreads();
+    if (tid == 0) { st->published = 1; if (a.progress) publish(a.progress + 1, st->sink.epoch); }
   }
 }
 

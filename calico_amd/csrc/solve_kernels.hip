@@ -42,9 +42,7 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
                                                      const int* __restrict__ idx_fat, int n_fat, int nb_fat,
                                                      const LmState* st, int need_flag, size_t other_stride, ControlTail tail) {
   if (st && (st->terminated || (need_flag && !st->need_jacobian))) {
-    if (tail.enabled && tail.progress && st->terminated && blockIdx.x == 0 && threadIdx.x == 0) {
-      publish(tail.progress + 1, 1); publish(tail.progress, tail.seq);
-    }
+    if (tail.enabled && tail.progress && st->terminated && blockIdx.x == 0 && threadIdx.x == 0) publish_progress(tail.progress, st, tail.seq);
     return;
   }
   if (other_stride && st && st->rfill) R += other_stride;     // speculative: fill the buffer that does NOT hold R(x)
@@ -1344,7 +1342,7 @@ DEVI void control_body(LmState* st, const LmOptionsDev& o, double* R2, double* x
                        int no_swap, int* progress, int seq) {
   const int tid = threadIdx.x;
   if (st->terminated) {
-    if (progress && tid == 0) { publish(progress + 1, 1); publish(progress, seq); }
+    if (progress && tid == 0) publish_progress(progress, st, seq);
     return;
   }
   __shared__ int s_accept;
@@ -1442,7 +1440,13 @@ DEVI void control_body(LmState* st, const LmOptionsDev& o, double* R2, double* x
   if (s_accept) {
     for (int i = tid; i < n_amb; i += 256) x[i] = x_cand[i];
   }
-  if (progress && tid == 0) { if (st->terminated) publish(progress + 1, 1); publish(progress, seq); }
+  if (st->terminated) {   // (uniform)
+    __syncthreads();
+    publish_results_block(st, tid, 256);
+    __syncthreads();
+    if (tid == 0) st->published = 1;
+  }
+  if (progress && tid == 0) publish_progress(progress, st, seq);
 }
 __global__ __launch_bounds__(256) void lm_control_kernel(LmState* st, LmOptionsDev o, double* R2, double* x,
                                                          const double* x_cand, int n_amb, IterLog* log, int log_cap,
@@ -1512,6 +1516,29 @@ __global__ __launch_bounds__(256) void seed_x_kernel(double* x, const double* h_
 }
 void launch_seed_x(double* x, const double* h_x, int n_amb, hipStream_t s) {
   hipLaunchKernelGGL(seed_x_kernel, dim3(4), dim3(256), 0, s, x, h_x, n_amb);
+}
+
+// Start of a solve in one launch: the parameter vector from the pinned staging buffer into x (and into the candidate
+// buffer when a constant block may have changed: the update stage never writes those) and the LM state reset.
+__global__ __launch_bounds__(256) void begin_solve_kernel(LmState* st, double radius, double x_norm, const double* upd_ext, int upd_ext_n,
+                                                          ResultSink sink, double* x, double* x_cand, const double* h_x, int n_amb) {
+  for (int i = threadIdx.x + blockIdx.x * 256; i < n_amb; i += 256 * gridDim.x) {
+    const double v = h_x[i];
+    x[i] = v;
+    if (x_cand) x_cand[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    LmState s = {};
+    s.upd_ext = upd_ext; s.upd_ext_n = upd_ext_n; s.upd_parts = 1;
+    s.radius = radius; s.decrease_factor = 2.0; s.x_norm = x_norm; s.need_jacobian = 1; s.rfill = 1;
+    s.min_cost = 1.7976931348623157e308;
+    s.sink = sink;
+    *st = s;
+  }
+}
+void launch_begin_solve(LmState* st, double radius, double x_norm, const double* upd_ext, int upd_ext_n, const ResultSink& sink, double* x,
+                        double* x_cand, const double* h_x, int n_amb, hipStream_t s) {
+  hipLaunchKernelGGL(begin_solve_kernel, dim3(4), dim3(256), 0, s, st, radius, x_norm, upd_ext, upd_ext_n, sink, x, x_cand, h_x, n_amb);
 }
 
 __global__ void init_state_kernel(LmState* st, double radius, double x_norm, const double* upd_ext, int upd_ext_n) {

@@ -322,8 +322,11 @@ int32_t calico_problem_set_shard(calico_problem* p, int32_t rank,
 int32_t calico_problem_set_stream(calico_problem* p, void* stream);
 
 /* ---- timing ----------------------------------------------------------- */
-/* HIP-event timings of the last solve, milliseconds summed over launches,
- * and launch counts, for the named phase: 0 jacobian evaluation (residual +
+/* HIP-event timings accumulated since the last calico_set_phase_timing call (over
+ * as many solves as followed it), milliseconds summed over launches, and launch
+ * counts, for the named phase (the call waits for the stream when brackets are
+ * still pending: calico_solve itself returns as soon as the device reports the
+ * end of the solve): 0 jacobian evaluation (residual +
  * Jacobian + JᵀJ partials), 1 reduction of partials, 2 linear solve,
  * 3 cost-only evaluation, 4 LM control + update, 5 calibration: the same
  * event bracket around a trivial (~2 us) kernel, i.e. the overhead contained
@@ -335,7 +338,8 @@ int32_t calico_get_phase_time(calico_problem* p, int32_t phase, double* ms,
                               int64_t* launches);
 /* Which phases are bracketed by HIP events (bits 0..5: bit i = phase i; default: none) and, in bits 8..15, a sampling
  * interval N: only every N-th launch of a phase is bracketed (0 or 1: every launch). An event pair costs about 6 us of
- * stream time, so a throughput measurement brackets a sample of the launches, not all of them. */
+ * stream time, so a throughput measurement brackets a sample of the launches, not all of them. The call resets the
+ * accumulated times. */
 int32_t calico_set_phase_timing(calico_problem* p, int32_t mask);
 
 #ifdef __cplusplus
