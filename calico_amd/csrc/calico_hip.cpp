@@ -45,7 +45,7 @@ hipError_t configure_eval_kernels(size_t max_lds_bytes);
 
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
                    int n_thin, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
-                   const LmState* st, int need_flag, size_t other_stride, hipStream_t s, const ControlTail* tail = nullptr);
+                   const double* cost_src, int n_cost, const LmState* st, int need_flag, size_t other_stride, hipStream_t s, const ControlTail* tail = nullptr);
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s);
 size_t band_cholesky_lds_bytes(const SolveArgs& a);
@@ -803,10 +803,8 @@ int finalize(calico_problem* p) {
       }
     }
   }
-  for (int itn = 0; itn < p->n_fitems + p->n_jac_items; ++itn) {   // cost / invalid count: one slot pair per frame and item
-    pairs.push_back({0, int(poff) + 2 * itn});
-    pairs.push_back({1, int(poff) + 2 * itn + 1});
-  }
+  // (outputs 0 and 1 -- cost and invalid count -- are summed by the gather's first workgroup straight from the slot pairs
+  //  of the frames and work items behind the partial blocks: no index list)
   // Group the pairs by output, keeping the order in which they were generated inside every group (the summation
   // order of the device's gather, hence its rounding): a counting sort over the outputs -- linear, where a comparison
   // sort of the ~10^6 pairs took most of the set-up time.
@@ -840,8 +838,7 @@ int finalize(calico_problem* p) {
     }
   }
   p->n_thin = int(out_thin.size()); p->n_fat = int(out_fat.size());
-  // outputs 0 and 1 (cost, invalid count) head whichever list they are in: fat role = first workgroups of the gather
-  p->gather_owner_block = (!out_fat.empty() && out_fat[0] == 0) ? 0 : int((out_fat.size() + 3) / 4);
+  p->gather_owner_block = 0;
   section("gather lists");
   // ---- upload ----
   hipStream_t s = p->stream;
@@ -1004,7 +1001,8 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, c
   }
   launch_expand_cells(ea, p->stream);                     // compact frame records -> one expanded block per cell
   launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->d_out_fat.p,
-                p->d_ptr_fat.p, p->d_idx_fat.p, p->n_fat, st, need_flag, spec ? p->r_size : 0, p->stream, tail);
+                p->d_ptr_fat.p, p->d_idx_fat.p, p->n_fat, p->d_partials.p + p->partial_doubles, p->n_fitems + p->n_jac_items, st, need_flag,
+                spec ? p->r_size : 0, p->stream, tail);
   p->timer.end(p->stream);
   if (!p->has_exchange()) return CALICO_OK;  // single rank: no exchange
   return do_allreduce(p, target, int64_t(p->r_size));

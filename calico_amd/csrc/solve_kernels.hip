@@ -30,9 +30,14 @@ namespace cal {
 // One launch, two roles by workgroup: the first nb_fat workgroups take the fat outputs (> 48 sources, one wave
 // each, the long ones first), the others the thin outputs (eight lanes each, strided over the sources); both end in
 // a fixed-shape shuffle tree.
+// What the control stage reads, requested before the workgroup's share of the gather so that the loads are back when
+// the decision is due: the LM state (a working copy in LDS -- the scalar chain of the decision then runs on LDS instead
+// of one global round trip per field), the tree solver's partial sums and the first candidate values of this thread.
+struct ControlStage { double u0, u1, u2, u3; double xc[4]; const double* c01; };   // c01: the gather's outputs 0 and 1 (candidate cost, invalid count) in LDS
+DEVI void control_prefetch(const LmState* st, const double* x_cand, int n_amb, LmState* s_st, ControlStage& pf);
 DEVI void control_body(LmState* st, const LmOptionsDev& o, double* R2, double* x, const double* x_cand, int n_amb, IterLog* log,
                        int log_cap, const double* __restrict__ item_cost, int n_items, const double* Rbase, size_t r_stride,
-                       int no_swap, int* progress, int seq);
+                       int no_swap, int* progress, int seq, LmState* s_st, const ControlStage* staged = nullptr);
 DEVI void publish(int* word, int value);
 // `tail`: the LM control stage rides in the workgroup that finishes last (see ControlTail).
 __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, const double* __restrict__ src,
@@ -40,16 +45,52 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
                                                      const int* __restrict__ idx_thin, int n_thin,
                                                      const int* __restrict__ out_fat, const int64_t* __restrict__ ptr_fat,
                                                      const int* __restrict__ idx_fat, int n_fat, int nb_fat,
+                                                     const double* __restrict__ cost_src, int n_cost,
                                                      const LmState* st, int need_flag, size_t other_stride, ControlTail tail) {
   if (st && (st->terminated || (need_flag && !st->need_jacobian))) {
     if (tail.enabled && tail.progress && st->terminated && blockIdx.x == 0 && threadIdx.x == 0) publish_progress(tail.progress, st, tail.seq);
     return;
   }
+  __shared__ LmState s_st;
+  __shared__ double s_c01[2];
+  ControlStage pf;
+  // Workgroup 0 sums the cost / invalid-count slots of the frames and work items (contiguous, interleaved [cost, invalid]:
+  // no index list, one round trip with all 256 threads) into outputs 0 and 1 -- the longest sums of the launch -- and,
+  // with `tail`, goes on to the LM control stage while the other workgroups assemble the normal equations.
+  const bool owner = blockIdx.x == 0;
+  if (owner && tail.enabled) { control_prefetch(st, tail.x_cand, tail.n_amb, &s_st, pf); pf.c01 = s_c01; }
   if (other_stride && st && st->rfill) R += other_stride;     // speculative: fill the buffer that does NOT hold R(x)
+  if (owner) {
+    const int tid = threadIdx.x;
+    double c = 0.0, v = 0.0;
+    for (int i = tid; i < n_cost; i += 256 * 4) {
+      double cc[4], vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int j = min(i + 256 * u, n_cost - 1); cc[u] = cost_src[2 * j]; vv[u] = cost_src[2 * j + 1]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (i + 256 * u < n_cost) { c += cc[u]; v += vv[u]; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off, 64); v += __shfl_xor(v, off, 64); }
+    __shared__ double s_w[2][4];
+    if ((tid & 63) == 0) { s_w[0][tid >> 6] = c; s_w[1][tid >> 6] = v; }
+    __syncthreads();
+    if (tid == 0) {
+      const double ct = ((s_w[0][0] + s_w[0][1]) + s_w[0][2]) + s_w[0][3], vt = ((s_w[1][0] + s_w[1][1]) + s_w[1][2]) + s_w[1][3];
+      R[0] = ct; R[1] = vt; s_c01[0] = ct; s_c01[1] = vt;
+    }
+    if (tail.enabled) {
+      __syncthreads();
+      control_body(const_cast<LmState*>(st), tail.o, nullptr, tail.x, tail.x_cand, tail.n_amb, tail.log, tail.log_cap, nullptr, 0,
+                   tail.Rbase, tail.r_stride, 0, tail.progress, tail.seq, &s_st, &pf);
+    }
+    return;
+  }
+  const int bid = int(blockIdx.x) - 1;
   // Both roles issue all index loads of a lane first and all value loads second: two memory round trips per output
   // instead of one dependent pair per source.
-  if (int(blockIdx.x) < nb_fat) {
-    const int wave_raw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (bid < nb_fat) {
+    const int wave_raw = (bid * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     const bool live = wave_raw < n_fat;
     const int wave = live ? wave_raw : n_fat - 1;
@@ -69,7 +110,7 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (live && lane == 0) R[out_fat[wave]] = s;
   } else {
-    const int gid = (blockIdx.x - nb_fat) * blockDim.x + threadIdx.x;
+    const int gid = (bid - nb_fat) * blockDim.x + threadIdx.x;
     const int o = gid >> 3, sub = gid & 7;
     const bool live = o < n_thin;
     const int oc = live ? o : n_thin - 1;
@@ -85,11 +126,6 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
     for (int u = 0; u < 6; ++u) s += q0 + sub + 8 * u < q1 ? v[u] : 0.0;
     s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
     if (live && sub == 0) R[out_thin[o]] = s;
-  }
-  if (tail.enabled && int(blockIdx.x) == tail.owner_block) {
-    __syncthreads();      // outputs 0 and 1 were written by this workgroup
-    control_body(const_cast<LmState*>(st), tail.o, nullptr, tail.x, tail.x_cand, tail.n_amb, tail.log, tail.log_cap, nullptr, 0,
-                 tail.Rbase, tail.r_stride, 0, tail.progress, tail.seq);
   }
 }
 
@@ -1337,10 +1373,29 @@ __global__ __launch_bounds__(256) void cost_reduce_kernel(const double* __restri
 // [Ceres] TrustRegionMinimizer: tolerance tests, step acceptance, radius update.
 // item_cost != nullptr: single-rank path, the reduction of the per-item [cost, invalid] pairs is done here instead
 // of in a separate cost_reduce_kernel launch (with several ranks the sum goes through the all-reduce in between).
-DEVI void control_body(LmState* st, const LmOptionsDev& o, double* R2, double* x, const double* x_cand, int n_amb, IterLog* log,
-                       int log_cap, const double* __restrict__ item_cost, int n_items, const double* Rbase, size_t r_stride,
-                       int no_swap, int* progress, int seq) {
+DEVI void control_prefetch(const LmState* st, const double* x_cand, int n_amb, LmState* s_st, ControlStage& pf) {
   const int tid = threadIdx.x;
+  constexpr int n_int = int(sizeof(LmState) / sizeof(int));
+  for (int i = tid; i < n_int; i += 256) reinterpret_cast<int*>(s_st)[i] = reinterpret_cast<const int*>(st)[i];
+  pf.u0 = pf.u1 = pf.u2 = pf.u3 = 0.0; pf.c01 = nullptr;
+  const double* upd = st->upd_ext;
+  if (upd) {
+    const int n = st->upd_ext_n;
+    for (int i = tid; i < n; i += 256) { pf.u0 += upd[4 * i]; pf.u1 += upd[4 * i + 1]; pf.u2 += upd[4 * i + 2]; pf.u3 += upd[4 * i + 3]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pf.xc[k] = (x_cand && n_amb > 0) ? x_cand[min(tid + 256 * k, n_amb - 1)] : 0.0;
+}
+
+// `st_g`: the state in global memory; the stage works on the copy `st` in LDS and writes it back at the end.
+DEVI void control_body(LmState* st_g, const LmOptionsDev& o, double* R2, double* x, const double* x_cand, int n_amb, IterLog* log,
+                       int log_cap, const double* __restrict__ item_cost, int n_items, const double* Rbase, size_t r_stride,
+                       int no_swap, int* progress, int seq, LmState* st, const ControlStage* staged) {
+  const int tid = threadIdx.x;
+  ControlStage pf;
+  if (staged) pf = *staged;
+  else { control_prefetch(st_g, x_cand, n_amb, st, pf); }
+  __syncthreads();        // the copy of the state is complete
   if (st->terminated) {
     if (progress && tid == 0) publish_progress(progress, st, seq);
     return;
@@ -1364,19 +1419,18 @@ DEVI void control_body(LmState* st, const LmOptionsDev& o, double* R2, double* x
   }
   if (st->upd_parts == 0 && st->upd_ext) {
     // tree solver: one slot of partial sums per node, added up in slot order (fixed-shape reduction)
-    __shared__ double s_u[4][256];
-    double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
-    for (int i = tid; i < st->upd_ext_n; i += 256) {
-      u0 += st->upd_ext[4 * i]; u1 += st->upd_ext[4 * i + 1]; u2 += st->upd_ext[4 * i + 2]; u3 += st->upd_ext[4 * i + 3];
+    // (a fixed-shape reduction: shuffle tree inside every wave, then the four waves in order)
+    __shared__ double s_u[4][4];
+    double u0 = pf.u0, u1 = pf.u1, u2 = pf.u2, u3 = pf.u3;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      u0 += __shfl_xor(u0, off, 64); u1 += __shfl_xor(u1, off, 64); u2 += __shfl_xor(u2, off, 64); u3 += __shfl_xor(u3, off, 64);
     }
-    s_u[0][tid] = u0; s_u[1][tid] = u1; s_u[2][tid] = u2; s_u[3][tid] = u3;
+    if ((tid & 63) == 0) { s_u[0][tid >> 6] = u0; s_u[1][tid >> 6] = u1; s_u[2][tid >> 6] = u2; s_u[3][tid >> 6] = u3; }
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if (tid < off) { s_u[0][tid] += s_u[0][tid + off]; s_u[1][tid] += s_u[1][tid + off]; s_u[2][tid] += s_u[2][tid + off]; s_u[3][tid] += s_u[3][tid + off]; }
-      __syncthreads();
-    }
     if (tid == 0) {
-      st->upd_mcc[0] = s_u[0][0]; st->upd_sn[0] = s_u[1][0]; st->upd_cn[0] = s_u[2][0]; st->upd_bad[0] = s_u[3][0] > 0.0 ? 1 : 0;
+      st->upd_mcc[0] = ((s_u[0][0] + s_u[0][1]) + s_u[0][2]) + s_u[0][3]; st->upd_sn[0] = ((s_u[1][0] + s_u[1][1]) + s_u[1][2]) + s_u[1][3];
+      st->upd_cn[0] = ((s_u[2][0] + s_u[2][1]) + s_u[2][2]) + s_u[2][3]; st->upd_bad[0] = ((s_u[3][0] + s_u[3][1]) + s_u[3][2]) + s_u[3][3] > 0.0 ? 1 : 0;
       st->upd_parts = 1;
     }
     __syncthreads();
@@ -1400,9 +1454,10 @@ DEVI void control_body(LmState* st, const LmOptionsDev& o, double* R2, double* x
       }
     } else {
       st->num_consecutive_invalid = 0;
-      const double candidate_cost = (R2[1] > 0.0) ? 1.7976931348623157e308 : R2[0];
+      const double ev_cost = pf.c01 ? pf.c01[0] : R2[0], ev_invalid = pf.c01 ? pf.c01[1] : R2[1];
+      const double candidate_cost = (ev_invalid > 0.0) ? 1.7976931348623157e308 : ev_cost;
       st->candidate_cost = candidate_cost;
-      st->invalid_eval = R2[1] > 0.0;
+      st->invalid_eval = ev_invalid > 0.0;
       if (st->step_norm <= o.parameter_tolerance * (st->x_norm + o.parameter_tolerance)) {
         st->terminated = 1; st->termination_type = 0; st->termination_reason = 4;  // parameter tolerance
       } else {
@@ -1437,14 +1492,20 @@ DEVI void control_body(LmState* st, const LmOptionsDev& o, double* R2, double* x
     }
   }
   __syncthreads();
+  {   // the working copy back into global memory (this workgroup is the state's only writer in this launch)
+    constexpr int n_int = int(sizeof(LmState) / sizeof(int));
+    for (int i = tid; i < n_int; i += 256) reinterpret_cast<int*>(st_g)[i] = reinterpret_cast<const int*>(st)[i];
+  }
   if (s_accept) {
-    for (int i = tid; i < n_amb; i += 256) x[i] = x_cand[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (tid + 256 * k < n_amb) x[tid + 256 * k] = pf.xc[k];
+    for (int i = tid + 1024; i < n_amb; i += 256) x[i] = x_cand[i];
   }
   if (st->terminated) {   // (uniform)
     __syncthreads();
-    publish_results_block(st, tid, 256);
+    publish_results_block(st_g, tid, 256);
     __syncthreads();
-    if (tid == 0) st->published = 1;
+    if (tid == 0) st_g->published = 1;
   }
   if (progress && tid == 0) publish_progress(progress, st, seq);
 }
@@ -1453,7 +1514,8 @@ __global__ __launch_bounds__(256) void lm_control_kernel(LmState* st, LmOptionsD
                                                          const double* __restrict__ item_cost, int n_items,
                                                          const double* Rbase, size_t r_stride, int no_swap, int* progress,
                                                          int seq) {
-  control_body(st, o, R2, x, x_cand, n_amb, log, log_cap, item_cost, n_items, Rbase, r_stride, no_swap, progress, seq);
+  __shared__ LmState s_st;
+  control_body(st, o, R2, x, x_cand, n_amb, log, log_cap, item_cost, n_items, Rbase, r_stride, no_swap, progress, seq, &s_st);
 }
 
 // Several ranks, speculative evaluation: copy the accepted candidate's reduce buffer (1) over R(x) (0). The flag is
@@ -1470,6 +1532,7 @@ __global__ __launch_bounds__(256) void commit_kernel(const LmState* st, double* 
 __global__ __launch_bounds__(256) void debug_control_replay_kernel(LmState* st, LmOptionsDev o, const double* rho, const int* infinite,
                                                                     int n, double* R2, double* radius_out, int* accepted_out,
                                                                     double* cost_out, IterLog* log, int log_cap) {
+  __shared__ LmState s_st;
   for (int i = 0; i < n; ++i) {
     if (threadIdx.x == 0) {
       st->terminated = 0; st->x_cost = 1.0; st->x_norm = 1.0; st->chol_failed = 0;
@@ -1477,7 +1540,7 @@ __global__ __launch_bounds__(256) void debug_control_replay_kernel(LmState* st, 
       R2[0] = 1.0 - rho[i]; R2[1] = infinite[i] ? 1.0 : 0.0;
     }
     __syncthreads();
-    control_body(st, o, R2, nullptr, nullptr, 0, log, log_cap, nullptr, 0, nullptr, 0, 0, nullptr, 0);
+    control_body(st, o, R2, nullptr, nullptr, 0, log, log_cap, nullptr, 0, nullptr, 0, 0, nullptr, 0, &s_st);
     __syncthreads();
     if (threadIdx.x == 0) {
       radius_out[i] = st->radius; accepted_out[i] = st->step_successful;
@@ -1552,13 +1615,14 @@ __global__ void init_state_kernel(LmState* st, double radius, double x_norm, con
 // ---- launch helpers ---------------------------------------------------------
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
                    int n_thin, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
+                   const double* cost_src, int n_cost,
                    const LmState* st, int need_flag, size_t other_stride, hipStream_t s, const ControlTail* tail) {
   const int nb_thin = (n_thin + 31) / 32, nb_fat = (n_fat + 3) / 4;
   ControlTail t;
   if (tail) t = *tail; else { t = ControlTail(); t.enabled = 0; }
-  if (nb_thin + nb_fat > 0)
-    hipLaunchKernelGGL(gather_kernel, dim3(nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin,
-                       out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, st, need_flag, other_stride, t);
+  // workgroup 0: cost / invalid count (+ control stage), then the fat outputs, then the thin ones
+  hipLaunchKernelGGL(gather_kernel, dim3(1 + nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin,
+                     out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, cost_src, n_cost, st, need_flag, other_stride, t);
 }
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s) {
