@@ -39,6 +39,8 @@ void launch_expand_cells(const EvalArgs& a, hipStream_t stream);
 void launch_residual_heatmap(const double* res, const uint8_t* valid, const uint8_t* active, const double* px, const double* py,
                              int begin, int end, int width, int height, int num_rows, int num_cols, double* rmse, long long* count,
                              hipStream_t s);
+void launch_inlier_mask(const double* res, uint8_t* valid_then_mask, const uint8_t* active, int begin, int end, int dim, double threshold,
+                        hipStream_t s);
 void launch_mark_outliers(const double* res, const uint8_t* valid, uint8_t* active, int begin, int end, int dim,
                           double threshold, int* n_marked, hipStream_t s);
 hipError_t configure_eval_kernels(size_t max_lds_bytes);
@@ -50,7 +52,7 @@ void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* block
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s);
 size_t band_cholesky_lds_bytes(const SolveArgs& a);
 size_t reduced_solve_lds_bytes(const SolveArgs& a);
-size_t frame_lds_doubles(int P1, int n1);
+size_t frame_lds_doubles(int Ps, int P1e, int n1);
 size_t band_backsolve_lds_bytes(const SolveArgs& a);
 hipError_t configure_solve_kernels(size_t band_lds, size_t reduced_lds, size_t back_lds);
 void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, double* x_cand, const BlockDev* blocks,
@@ -663,7 +665,8 @@ int finalize(calico_problem* p) {
       const LayoutDev& L = layouts[size_t(f.layout)];
       const HSensor& hs = p->sensors[size_t(L.sensor)];
       const int P1 = 7 + (L.c_intr >= 0 ? hs.K : 0) + 3 * (L.c_q >= 0) + 3 * (L.c_t >= 0) + 3 * (L.c_bq >= 0) + 3 * (L.c_bt >= 0);
-      p->frame_lds_doubles = std::max(p->frame_lds_doubles, int(frame_lds_doubles(P1, L.ncols + 1)));
+      const int Ps = 7 + (L.c_intr >= 0 ? hs.K : 0) + 3 * (L.c_bq >= 0);     // staged (small) prim columns: eval_kernels.hip
+      p->frame_lds_doubles = std::max(p->frame_lds_doubles, int(frame_lds_doubles(Ps, P1, L.ncols + 1)));
     }
     f.partial_off += int64_t(comp_base);
     p->cell_rec_max = std::max(p->cell_rec_max, int(frame_rec(layouts[size_t(f.layout)])));
@@ -1618,17 +1621,26 @@ int32_t calico_project(calico_problem* p, int32_t sid, double* out, uint8_t* val
 int32_t calico_get_inlier_mask(calico_problem* p, int32_t sid, double threshold, uint8_t* mask) {
   if (!p) return CALICO_INVALID_ARGUMENT;
   if (sid < 0 || sid >= int(p->sensors.size()) || !mask) return p->set_error(CALICO_INVALID_ARGUMENT, "bad sensor id");
+  int rc = finalize(p);
+  if (rc != CALICO_OK) return rc;
+  HIP_TRY(p, hipSetDevice(p->device));
+  rc = upload_x(p);
+  if (rc != CALICO_OK) return rc;
   const HSensor& s = p->sensors[sid];
-  const int dim = s.dim();
-  std::vector<double> r(size_t(s.n()) * dim);
-  std::vector<uint8_t> v(size_t(s.n()));
-  const int rc = calico_get_residuals(p, sid, r.data(), v.data());
-  if (rc != CALICO_OK && rc != CALICO_INTERNAL) return rc;
-  for (int64_t i = 0; i < s.n(); ++i) {
-    double sq = 0;
-    for (int c = 0; c < dim; ++c) sq += r[i * dim + c] * r[i * dim + c];
-    mask[i] = (s.active[size_t(i)] && v[size_t(i)] && std::sqrt(sq) <= threshold) ? 1 : 0;
+  if (s.n() == 0) return CALICO_OK;
+  {
+    EvalArgs ea = make_eval_args(p, p->d_x.p, 0, true);   // residuals without the loss function (camera.cpp:70-80)
+    ea.items = p->d_items_all.p; ea.n_items = p->n_items_all;
+    launch_eval(ea, false, p->stream);
   }
+  // the test runs on the device; one byte per observation comes back (a block that failed to evaluate, or one tagged
+  // as an outlier, is no inlier)
+  launch_inlier_mask(p->d_res.p, p->d_valid.p, p->d_active.p, int(s.sorted_begin), int(s.sorted_end), s.dim(), threshold, p->stream);
+  const int64_t nrange = std::max<int64_t>(0, s.sorted_end - s.sorted_begin);
+  std::vector<uint8_t> m(size_t(std::max<int64_t>(nrange, 1)));
+  if (nrange > 0) HIP_TRY(p, hipMemcpyAsync(m.data(), p->d_valid.p + s.sorted_begin, size_t(nrange), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(p, hipStreamSynchronize(p->stream));
+  for (int64_t i = 0; i < s.n(); ++i) mask[i] = m[size_t(s.sorted_pos[size_t(i)] - s.sorted_begin)];
   return CALICO_OK;
 }
 

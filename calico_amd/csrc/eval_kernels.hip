@@ -687,14 +687,20 @@ DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds) {
 // Camera frames (spline order 6). One wave per frame.
 //
 // All residual blocks of a frame share the pose p(t), its derivative and the
-// spline weights w, so their Jacobian rows are  J = J_prim · T  with
-//   J_prim = d r / d [p(6) | intrinsics | q | t | body q | body t]   (per block)
-//   T      = blockdiag(w ⊗ I6 for the 36 control-point columns, -pdot for the latency column, I)
-// The wave stages J_prim rows (≤ 30 columns instead of ≤ 74) in LDS, forms the small
-// M = [J_prim r]ᵀ[J_prim r] with 2×2 register tiles over all blocks of the frame, and expands
-// TᵀMT once per frame into the item's (c+1)×(c+1) partial block — same output layout as the
-// generic kernel, ~5× fewer FMAs and LDS reads, and every per-frame quantity (spline
-// evaluation, Rodrigues terms, rotation products) is computed once per wave, not per block.
+// spline weights w, and every Jacobian column of a block is a frame-constant linear
+// combination of a few block-level columns (camera_cost_functor.h:71-147 by hand):
+//   T = -(1/σ)√ρ' · D · R_rcᵀ   (2×3, D = d pixel / d x_c),   Y = T [y]×,   Z = T R_rw [R_wm x_m]×
+//   pose: rotation Y·J_l(φ), position -T·R_rw;  camera extrinsics: q 2Y - 2T[t_rc]×, t -T;
+//   body: q -2Z, t T·R_rw        (y: the point in the rig frame; Z only when the body pose is free)
+// The wave stages only the SMALL prim columns [Y | T | (Z) | intrinsics | r] in LDS -- 15 for an
+// 8-parameter camera with free extrinsics instead of 21: one 16-wide MFMA tile instead of three --
+// and forms M_s = [..]ᵀ[..] over all blocks of the frame on the matrix cores. Once per frame,
+// M = Bᵀ M_s B (B has at most three entries per column) is the block over the prim columns
+//   [pose 6 | intrinsics | q | t | body q | body t | r],
+// the latency row/column is -pdotᵀM, and M_ext with the expansion coefficients (spline weight of a
+// column's control point) is the frame's compact record; T_frameᵀ M T_frame is expanded once per CELL.
+// Every per-frame quantity (spline evaluation, Rodrigues terms, rotation products) is computed once
+// per wave, not per block.
 // ---------------------------------------------------------------------------
 constexpr int kMaxPrim = 32;   // 6 + 11 + 3 + 3 + 3 + 3 + r = 30, padded to two 16-wide MFMA tiles
 constexpr int kFramePad = 132; // row stride of a staged prim column: ≡ 4 (mod 32) spreads the MFMA operand read over all banks
@@ -717,6 +723,18 @@ DEV PrimMap prim_map(const LayoutDev& L, const SensorDev& S) {
   m.PE = m.PT + 1;               // M_ext = [[M, Qᵀ], [Q, qq]]
   return m;
 }
+// Small prim columns (what is staged): [Y 3 | T 3 | Z 3 (body rotation free) | intrinsics | residual]
+struct SmallMap { int z, k, r, P, PT; };
+DEV SmallMap small_map(const LayoutDev& L, const SensorDev& S) {
+  SmallMap m;
+  int pc = 6;
+  m.z = L.c_bq >= 0 ? pc : -1; if (L.c_bq >= 0) pc += 3;
+  m.k = L.c_intr >= 0 ? pc : -1; if (L.c_intr >= 0) pc += S.K;
+  m.r = pc;
+  m.P = pc + 1;
+  m.PT = (m.P + 15) & ~15;
+  return m;
+}
 // prim column of local column lc of the layout (spline columns: the pose component)
 DEV int prim_of_col(const LayoutDev& L, const SensorDev& S, const PrimMap& pm, int lc) {
   if (lc < 36) return lc % 6;
@@ -730,10 +748,9 @@ DEV int prim_of_col(const LayoutDev& L, const SensorDev& S, const PrimMap& pm, i
 }
 
 template <int MODEL>
-DEV bool frame_camera_block(const SensorDev& S, const LayoutDev& L, const double* intr, const M3& R_rc, const M3& R_rw,
-                            const M3& R_wm, const M3& Jl, const M3& G, V3 t_rc, V3 t_wm, V3 t_wr, double px, double py,
-                            const double* xm, int apply_loss, double* Jp, int row0, int pc_intr, int pc_q, int pc_t,
-                            int pc_bq, int pc_bt, int pc_r, double* cost) {
+DEV bool frame_camera_block(const SensorDev& S, const double* intr, const M3& R_rc, const M3& R_rw, const M3& R_wm, V3 t_rc, V3 t_wm,
+                            V3 t_wr, double px, double py, const double* xm, int apply_loss, double* Jp, int row0, int pc_z,
+                            int pc_k, int pc_r, double* cost) {
   const V3 Rx = mul(R_wm, mk(xm[0], xm[1], xm[2]));
   const V3 y = mul(R_rw, (Rx + t_wm) - t_wr);
   const V3 z = y - t_rc;
@@ -748,57 +765,34 @@ DEV bool frame_camera_block(const SensorDev& S, const LayoutDev& L, const double
   const double fac = -S.info * ls;
   auto put = [&](int col, int r, double v) { Jp[col * kFramePad + row0 + r] = v; };
   put(pc_r, 0, r0 * ls); put(pc_r, 1, r1 * ls);
-  double DRt[2][3], DG[2][3];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
+    double T[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) DRt[r][j] = fac * (D[r][0] * R_rc.m[j][0] + D[r][1] * R_rc.m[j][1] + D[r][2] * R_rc.m[j][2]);
+    for (int j = 0; j < 3; ++j) T[j] = fac * (D[r][0] * R_rc.m[j][0] + D[r][1] * R_rc.m[j][1] + D[r][2] * R_rc.m[j][2]);
+    put(0, r, T[1] * y.z - T[2] * y.y); put(1, r, T[2] * y.x - T[0] * y.z); put(2, r, T[0] * y.y - T[1] * y.x);   // Y = T [y]×
+    put(3, r, T[0]); put(4, r, T[1]); put(5, r, T[2]);
+    if (pc_z >= 0) {   // Z = (T R_rw) [R_wm x_m]×
+      double G[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) DG[r][j] = fac * (D[r][0] * G.m[0][j] + D[r][1] * G.m[1][j] + D[r][2] * G.m[2][j]);
+      for (int j = 0; j < 3; ++j) G[j] = T[0] * R_rw.m[0][j] + T[1] * R_rw.m[1][j] + T[2] * R_rw.m[2][j];
+      put(pc_z, r, G[1] * Rx.z - G[2] * Rx.y); put(pc_z + 1, r, G[2] * Rx.x - G[0] * Rx.z); put(pc_z + 2, r, G[0] * Rx.y - G[1] * Rx.x);
+    }
   }
-  const M3 Sy = skew(y);
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    double T1[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) T1[j] = DRt[r][0] * Sy.m[0][j] + DRt[r][1] * Sy.m[1][j] + DRt[r][2] * Sy.m[2][j];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) put(j, r, T1[0] * Jl.m[0][j] + T1[1] * Jl.m[1][j] + T1[2] * Jl.m[2][j]);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) put(3 + j, r, -DG[r][j]);
-  }
-  if (pc_intr >= 0) {
+  if (pc_k >= 0) {
     constexpr int K = CamK<MODEL>::K;
 #pragma unroll
-    for (int j = 0; j < K; ++j) { put(pc_intr + j, 0, fac * dK[0][j]); put(pc_intr + j, 1, fac * dK[1][j]); }
-  }
-  if (pc_q >= 0) {
-    const M3 Sz = skew(z);
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) put(pc_q + j, r, 2.0 * (DRt[r][0] * Sz.m[0][j] + DRt[r][1] * Sz.m[1][j] + DRt[r][2] * Sz.m[2][j]));
-  }
-  if (pc_t >= 0) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) put(pc_t + j, r, -DRt[r][j]);
-  }
-  if (pc_bq >= 0) {
-    const M3 Sx = skew(Rx);
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) put(pc_bq + j, r, -2.0 * (DG[r][0] * Sx.m[0][j] + DG[r][1] * Sx.m[1][j] + DG[r][2] * Sx.m[2][j]));
-  }
-  if (pc_bt >= 0) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) put(pc_bt + j, r, DG[r][j]);
+    for (int j = 0; j < K; ++j) { put(pc_k + j, 0, fac * dK[0][j]); put(pc_k + j, 1, fac * dK[1][j]); }
   }
   return true;
+}
+
+
+// LDS of a frame workgroup (doubles): area A = the staged rows [Ps][kFramePad], later M_s, N and the column lists of B;
+// then M_ext [PE][PE]; then the expansion coefficients [n1].
+DEV int frame_area_a(int Ps, int PTs, int P1e) {
+  const int after = PTs * PTs + ((Ps * P1e + 1) & ~1) + ((3 * P1e + 1) & ~1) + ((3 * P1e + 1) / 2 + 1);
+  return (max(Ps * kFramePad, after) + 1) & ~1;
 }
 
 DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
@@ -812,16 +806,19 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   const SensorDev& S = a.sensors[L.sensor];
   constexpr int K = 6;
   const PrimMap pm = prim_map(L, S);
+  const SmallMap sm = small_map(L, S);
   const int Kin = S.K;
-  const int pc_intr = pm.intr, pc_q = pm.q, pc_t = pm.t, pc_bq = pm.bq, pc_bt = pm.bt, pc_r = pm.r;
-  const int P1 = pm.P1, PT = pm.PT, PE = pm.PE;
+  const int P1e = pm.P1, PT = pm.PT, PE = pm.PE;
+  const int Ps = sm.P, PTs = sm.PT;
   const int ncols = L.ncols, n1 = ncols + 1;
-  // LDS: the staged rows of the P1 prim columns; M_ext takes their place once the products are in the accumulators;
-  // the expansion coefficients behind both. Sized by the layout, not by the worst case: at 43 KB per workgroup only
-  // three fit a CU and the launch ran in two rounds.
-  double* Jp = lds;                                  // [P1][kFramePad]   staged rows, column-major
-  double* Me = lds;                                  // [PE][PE]          (after the last MFMA)
-  double* coef = lds + max(P1 * kFramePad, PE * PE); // [n1] column c of the item = coef[c] · prim column prim[c]
+  const int SA = frame_area_a(Ps, PTs, P1e);
+  double* Jp = lds;                                  // [Ps][kFramePad]   staged rows, column-major
+  double* Ms = lds;                                  // [PTs][PTs]        (after the last MFMA)
+  double* Nmat = Ms + PTs * PTs;                     // [Ps][P1e]         M_s B
+  double* bco = Nmat + ((Ps * P1e + 1) & ~1);        // [P1e][3]          column lists of B: coefficients ...
+  int* bsrc = reinterpret_cast<int*>(bco + ((3 * P1e + 1) & ~1));   // [P1e][3]   ... and small prim columns
+  double* Me = lds + SA;                             // [PE][PE]
+  double* coef = Me + ((PE * PE + 1) & ~1);          // [n1] column c of the item = coef[c] · prim column prim[c]
   // ---- per-frame quantities (every lane computes the same values) ----
   const int ki = it.seg + K - 1;
   const double* Mb = a.basis + size_t(it.seg) * K * K;
@@ -844,11 +841,6 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   const V3 phi = mk(-p[0], -p[1], -p[2]);
   const M3 R_rw = rotmat(angle_axis_to_quat(phi));
   const M3 Jl = rod_J_matrix(rodrigues<double>(phi.x, phi.y, phi.z, false));
-  M3 G;
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) G.m[i][j] = R_rc.m[0][i] * R_rw.m[0][j] + R_rc.m[1][i] * R_rw.m[1][j] + R_rc.m[2][i] * R_rw.m[2][j];
   const double* intr = a.x + S.intr_off;
   // observation of this lane in the first batch (clamped: loads stay unconditional), fetched ahead of use
   auto obs_index = [&](int b0) { return it.obs_begin + min(b0 + lane, it.obs_count - 1); };
@@ -866,15 +858,15 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
     }
     coef[lc] = cf;
   }
-  // ---- blocks -> staged rows -> M = [J_prim r]ᵀ[J_prim r] on the matrix cores ----
+  // ---- blocks -> staged rows -> M_s = [small prim columns]ᵀ[..] on the matrix cores ----
   // v_mfma_f64_16x16x4_f64: A[i][k] and B[k][j] of the product JᵀJ are the SAME staged value
   // Jp[col = 16t + (lane & 15)][row = r0 + (lane >> 4)], so one LDS read feeds both operands.
   const int lc16 = lane & 15, lk = lane >> 4;
-  const bool two = PT > 16;
+  const bool two = PTs > 16;
   f64x4 acc00 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
-  const bool col0_ok = lc16 < P1, col1_ok = 16 + lc16 < P1;
-  const double* op0 = Jp + min(lc16, P1 - 1) * kFramePad + lk;        // columns past P1 - 1 are masked below
-  const double* op1 = Jp + min(16 + lc16, P1 - 1) * kFramePad + lk;
+  const bool col0_ok = lc16 < Ps, col1_ok = 16 + lc16 < Ps;
+  const double* op0 = Jp + min(lc16, Ps - 1) * kFramePad + lk;        // columns past Ps - 1 are masked below
+  const double* op1 = Jp + min(16 + lc16, Ps - 1) * kFramePad + lk;
   double cost = 0.0, n_bad = 0.0;
   FTICK(0)
   for (int b0 = 0; b0 < it.obs_count; b0 += 64) {
@@ -891,24 +883,24 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
     }
     const bool on = lane < nb && (!a.active || a.active[it.obs_begin + b0 + lane] != 0);   // not tagged as an outlier
     if (lane < nb && !on) {
-      for (int c = 0; c < P1; ++c) { Jp[c * kFramePad + 2 * lane] = 0.0; Jp[c * kFramePad + 2 * lane + 1] = 0.0; }
+      for (int c = 0; c < Ps; ++c) { Jp[c * kFramePad + 2 * lane] = 0.0; Jp[c * kFramePad + 2 * lane + 1] = 0.0; }
     }
     if (on) {
       double c1 = 0.0;
       bool ok;
       switch (S.model) {
-        case 1: ok = frame_camera_block<1>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
-        case 2: ok = frame_camera_block<2>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
-        case 3: ok = frame_camera_block<3>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
-        case 4: ok = frame_camera_block<4>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
-        case 5: ok = frame_camera_block<5>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
-        case 6: ok = frame_camera_block<6>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
-        default: ok = frame_camera_block<7>(S, L, intr, R_rc, R_rw, R_wm, Jl, G, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, pc_intr, pc_q, pc_t, pc_bq, pc_bt, pc_r, &c1); break;
+        case 1: ok = frame_camera_block<1>(S, intr, R_rc, R_rw, R_wm, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, sm.z, sm.k, sm.r, &c1); break;
+        case 2: ok = frame_camera_block<2>(S, intr, R_rc, R_rw, R_wm, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, sm.z, sm.k, sm.r, &c1); break;
+        case 3: ok = frame_camera_block<3>(S, intr, R_rc, R_rw, R_wm, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, sm.z, sm.k, sm.r, &c1); break;
+        case 4: ok = frame_camera_block<4>(S, intr, R_rc, R_rw, R_wm, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, sm.z, sm.k, sm.r, &c1); break;
+        case 5: ok = frame_camera_block<5>(S, intr, R_rc, R_rw, R_wm, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, sm.z, sm.k, sm.r, &c1); break;
+        case 6: ok = frame_camera_block<6>(S, intr, R_rc, R_rw, R_wm, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, sm.z, sm.k, sm.r, &c1); break;
+        default: ok = frame_camera_block<7>(S, intr, R_rc, R_rw, R_wm, t_rc, t_wm, t_wr, px, py, xm, a.apply_loss, Jp, 2 * lane, sm.z, sm.k, sm.r, &c1); break;
       }
       if (ok) cost += c1;
       else {   // an invalid block contributes nothing: zero its two rows
         n_bad += 1.0;
-        for (int c = 0; c < P1; ++c) { Jp[c * kFramePad + 2 * lane] = 0.0; Jp[c * kFramePad + 2 * lane + 1] = 0.0; }
+        for (int c = 0; c < Ps; ++c) { Jp[c * kFramePad + 2 * lane] = 0.0; Jp[c * kFramePad + 2 * lane + 1] = 0.0; }
       }
     }
     __syncthreads();
@@ -934,7 +926,7 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             const bool rok = 32 * g + 4 * u + lk < nrows;
-            const double x0 = rok ? v0[u] : 0.0;                   // columns 0..15 always exist when PT = 32
+            const double x0 = rok ? v0[u] : 0.0;                   // columns 0..15 always exist when PTs = 32
             const double x1 = (col1_ok && rok) ? v1[u] : 0.0;
             acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc00, 0, 0, 0);
             acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, acc10, 0, 0, 0);
@@ -948,23 +940,59 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   const double item_cost = wave_sum(cost);
   const double n_invalid = wave_sum(n_bad);
   if (lane == 0) { a.item_cost[2 * fidx] = item_cost; a.item_cost[2 * fidx + 1] = n_invalid; }
-  // ---- M to LDS (full symmetric; C/D layout: col = lane & 15, row = (lane >> 4) + 4·reg), latency row Q ----
+  // ---- M_s to LDS (full symmetric; C/D layout: col = lane & 15, row = (lane >> 4) + 4·reg) ----
+  __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = lk + 4 * r;
-    Me[row * PE + lc16] = acc00[r];
+    Ms[row * PTs + lc16] = acc00[r];
     if (two) {
-      Me[(16 + row) * PE + lc16] = acc10[r];
-      Me[lc16 * PE + 16 + row] = acc10[r];
-      Me[(16 + row) * PE + 16 + lc16] = acc11[r];
+      Ms[(16 + row) * PTs + lc16] = acc10[r];
+      Ms[lc16 * PTs + 16 + row] = acc10[r];
+      Ms[(16 + row) * PTs + 16 + lc16] = acc11[r];
     }
   }
+  // ---- M = Bᵀ M_s B over the prim columns [pose 6 | intrinsics | q | t | body q | body t | r] ----
+  if (lane < P1e) {   // column `lane` of B: M-column = Σ_u co[u] · (small prim column src[u])
+    const int j = lane;
+    int s0 = 0, s1 = 0, s2 = 0;
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    if (j < 3) { s0 = 0; s1 = 1; s2 = 2; c0 = Jl.m[0][j]; c1 = Jl.m[1][j]; c2 = Jl.m[2][j]; }          // rotation: Y·J_l
+    else if (j < 6) { s0 = 3; s1 = 4; s2 = 5; c0 = -R_rw.m[0][j - 3]; c1 = -R_rw.m[1][j - 3]; c2 = -R_rw.m[2][j - 3]; }   // position: -T·R_rw
+    else if (pm.intr >= 0 && j >= pm.intr && j < pm.intr + Kin) { s0 = sm.k + (j - pm.intr); c0 = 1.0; }
+    else if (pm.q >= 0 && j >= pm.q && j < pm.q + 3) {                    // camera q: 2Y - 2T[t_rc]×
+      const int c = j - pm.q, ka = (c + 1) % 3, kb = (c + 2) % 3;
+      s0 = c; c0 = 2.0; s1 = 3 + ka; c1 = -2.0 * comp(t_rc, kb); s2 = 3 + kb; c2 = 2.0 * comp(t_rc, ka);
+    }
+    else if (pm.t >= 0 && j >= pm.t && j < pm.t + 3) { s0 = 3 + (j - pm.t); c0 = -1.0; }                 // camera t: -T
+    else if (pm.bq >= 0 && j >= pm.bq && j < pm.bq + 3) { s0 = sm.z + (j - pm.bq); c0 = -2.0; }         // body q: -2Z
+    else if (pm.bt >= 0 && j >= pm.bt && j < pm.bt + 3) { const int c = j - pm.bt; s0 = 3; s1 = 4; s2 = 5; c0 = R_rw.m[0][c]; c1 = R_rw.m[1][c]; c2 = R_rw.m[2][c]; }
+    else { s0 = sm.r; c0 = 1.0; }
+    bsrc[3 * j] = s0; bsrc[3 * j + 1] = s1; bsrc[3 * j + 2] = s2;
+    bco[3 * j] = c0; bco[3 * j + 1] = c1; bco[3 * j + 2] = c2;
+  }
   __syncthreads();
-  if (lane < PT) {
-    double s = 0.0;
+  for (int idx = lane; idx < Ps * P1e; idx += 64) {                  // N = M_s B
+    const int ar = idx / P1e, j = idx - ar * P1e;
+    double sN = 0.0;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) s -= pd[c] * Me[c * PE + lane];
-    Me[PT * PE + lane] = s; Me[lane * PE + PT] = s;
+    for (int u = 0; u < 3; ++u) sN += bco[3 * j + u] * Ms[ar * PTs + bsrc[3 * j + u]];
+    Nmat[idx] = sN;
+  }
+  __syncthreads();
+  for (int idx = lane; idx < P1e * P1e; idx += 64) {                 // M = Bᵀ N
+    const int i = idx / P1e, j = idx - i * P1e;
+    double sM = 0.0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) sM += bco[3 * i + u] * Nmat[bsrc[3 * i + u] * P1e + j];
+    Me[i * PE + j] = sM;
+  }
+  __syncthreads();
+  if (lane < P1e) {                                                  // latency: dp/dlat = -pdot
+    double sQ = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) sQ -= pd[c] * Me[c * PE + lane];
+    Me[PT * PE + lane] = sQ; Me[lane * PE + PT] = sQ;
   }
   __syncthreads();
   if (lane == 0) {
@@ -976,14 +1004,15 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   __syncthreads();
   FTICK(4)
   // ---- compact record: M_ext (PE×PE) then coef (n1). The expansion TᵀMT -- out(i, j) = coef_i coef_j M_ext(prim_i, prim_j)
-  //      -- is done once per CELL by expand_cells_kernel over all its frames. ----
+  //      -- is done once per CELL by expand_cells_kernel over all its frames. Only prim rows / columns < P1e and the
+  //      latency row / column PT are read there; the others are written as they lie. ----
   double* out = a.partials + it.partial_off;
   const int nme = PE * PE;
   for (int i = lane; i < nme; i += 64) out[i] = Me[i];
   for (int i = lane; i < n1; i += 64) out[nme + i] = coef[i];
   FTICK(5)
-  if (dbg) printf("eval_frames cycles (frame of %d blocks, %d prim cols): frame-constants %lld  barrier %lld  blocks %lld  M-mfma %lld  M-to-lds %lld  record %lld\n",
-                  it.obs_count, P1, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
+  if (dbg) printf("eval_frames cycles (frame of %d blocks, %d small / %d prim cols): frame-constants %lld  barrier %lld  blocks %lld  M-mfma %lld  M-to-lds %lld  record %lld\n",
+                  it.obs_count, Ps, P1e, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
 #undef FTICK
 }
 
@@ -1165,6 +1194,20 @@ __global__ void mark_outliers_kernel(const double* __restrict__ res, const uint8
   const bool inlier = valid[q] && sqrt(sq) <= threshold;
   if (!inlier) { active[q] = 0; atomicAdd(n_marked, 1); }
 }
+// Inlier test of the residual pairs on the device (sensor_base.h GetMeasurementResidualPairs + the notebooks'
+// `norm <= tau` filter): the mask replaces the validity byte of every observation in [begin, end) (sorted order).
+__global__ void inlier_mask_kernel(const double* __restrict__ res, uint8_t* valid_then_mask, const uint8_t* __restrict__ active,
+                                   int begin, int end, int dim, double threshold) {
+  const int q = begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= end) return;
+  double sq = 0.0;
+  for (int c = 0; c < dim; ++c) sq += res[size_t(q) * 3 + c] * res[size_t(q) * 3 + c];
+  valid_then_mask[q] = (active[q] && valid_then_mask[q] && sqrt(sq) <= threshold) ? 1 : 0;
+}
+void launch_inlier_mask(const double* res, uint8_t* valid_then_mask, const uint8_t* active, int begin, int end, int dim, double threshold,
+                        hipStream_t s) {
+  if (end > begin) hipLaunchKernelGGL(inlier_mask_kernel, dim3((end - begin + 255) / 256), dim3(256), 0, s, res, valid_then_mask, active, begin, end, dim, threshold);
+}
 // Residual statistics per image region: one workgroup per bin walks the sensor's observations (sorted order
 // [begin, end)) in a fixed thread-strided order and reduces in a fixed tree -- deterministic, no atomics.
 __global__ __launch_bounds__(256) void residual_heatmap_kernel(const double* __restrict__ res, const uint8_t* __restrict__ valid,
@@ -1205,12 +1248,15 @@ void launch_mark_outliers(const double* res, const uint8_t* valid, uint8_t* acti
   if (end > begin) hipLaunchKernelGGL(mark_outliers_kernel, dim3((end - begin + 255) / 256), dim3(256), 0, s, res, valid, active, begin, end, dim, threshold, n_marked);
 }
 
-size_t frame_lds_bytes() { return (size_t(kMaxPrim) * kFramePad + size_t(kMaxPrim + 1) * (kMaxPrim + 1) + kMaxLocalCols + kMaxLocalCols / 2) * sizeof(double); }
-// LDS doubles of a frame workgroup whose layout has P1 prim columns (residual included) and n1 local columns
-size_t frame_lds_doubles(int P1, int n1) {
-  const int PE = ((P1 + 15) & ~15) + 1;
-  return size_t(std::max(P1 * kFramePad, PE * PE)) + size_t(n1) + 16;
+// LDS doubles of a frame workgroup whose layout has Ps small prim columns, P1e prim columns (residual included both) and
+// n1 local columns; the worst case over all layouts the frame kernel takes (P1e <= 31, Ps <= 25)
+size_t frame_lds_doubles(int Ps, int P1e, int n1) {
+  const int PTs = (Ps + 15) & ~15, PE = ((P1e + 15) & ~15) + 1;
+  const int after = PTs * PTs + ((Ps * P1e + 1) & ~1) + ((3 * P1e + 1) & ~1) + ((3 * P1e + 1) / 2 + 1);
+  const int SA = (std::max(Ps * kFramePad, after) + 1) & ~1;
+  return size_t(SA) + size_t((PE * PE + 1) & ~1) + size_t(n1) + 16;
 }
+size_t frame_lds_bytes() { return frame_lds_doubles(25, 31, kMaxLocalCols) * sizeof(double); }
 static size_t frame_launch_bytes(const EvalArgs& a) {
   return a.frame_lds_doubles > 0 ? size_t(a.frame_lds_doubles) * sizeof(double) : frame_lds_bytes();
 }

@@ -307,18 +307,17 @@ inline void SetPoseConstantInProblem(Problem& problem, Pose3d& pose) {
 // ---------------------------------------------------------------------------
 class BSpline6 {
  public:
-  /// The least-squares solve behind FitToData, with calico_fit_spline's arguments after `device`. It is
-  /// calico_fit_spline on device 0 and the library has no host fallback; the hook exists so that the host-only
-  /// unit test can run the surrounding logic on a machine without a GPU by installing a checker-backed solver.
+#ifdef CALICO_TEST_HOOKS
+  /// Test builds only (-DCALICO_TEST_HOOKS, tests/cpp): the least-squares solve behind FitToData can be replaced, so
+  /// that the host-only unit test runs the surrounding logic on a machine without a GPU with a checker-backed solver.
+  /// A product build calls calico_fit_spline on device 0 -- the library has no host fallback.
   using FitSolver = int32_t (*)(int32_t order, int32_t n_knots, const double* knots, const double* basis, int64_t n,
                                 const double* stamps, const double* data6, double* ctrl_out);
   static FitSolver& fit_solver() {
-    static FitSolver solver = [](int32_t order, int32_t n_knots, const double* knots, const double* basis, int64_t n,
-                                 const double* stamps, const double* data6, double* ctrl_out) -> int32_t {
-      return calico_fit_spline(0, order, n_knots, knots, basis, n, stamps, data6, ctrl_out);
-    };
+    static FitSolver solver = nullptr;
     return solver;
   }
+#endif
   int GetSplineOrder() const { return order_; }
   const std::vector<double>& knots() const { return knots_; }
   const std::vector<double>& valid_knots() const { return valid_knots_; }
@@ -364,7 +363,12 @@ class BSpline6 {
     const int ncp = nk - order, nd = int(time.size());
     std::vector<double> flat(size_t(nd) * 6), ctrl(size_t(ncp) * 6);
     for (int j = 0; j < nd; ++j) for (int c = 0; c < 6; ++c) flat[size_t(j) * 6 + c] = data[size_t(j)][size_t(c)];
-    const int32_t rc = fit_solver()(order, nk, knots_.data(), basis_.data(), nd, time.data(), flat.data(), ctrl.data());
+#ifdef CALICO_TEST_HOOKS
+    const int32_t rc = fit_solver() ? fit_solver()(order, nk, knots_.data(), basis_.data(), nd, time.data(), flat.data(), ctrl.data())
+                                    : calico_fit_spline(0, order, nk, knots_.data(), basis_.data(), nd, time.data(), flat.data(), ctrl.data());
+#else
+    const int32_t rc = calico_fit_spline(0, order, nk, knots_.data(), basis_.data(), nd, time.data(), flat.data(), ctrl.data());
+#endif
     if (rc == CALICO_INVALID_ARGUMENT) return InvalidArgumentError("spline fit: stamps must be sorted and inside the knot range");
     if (rc != CALICO_OK) return InternalError("spline fit failed on the device");
     ctrl_.assign(size_t(ncp), {});

@@ -18,7 +18,7 @@ def _build():
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
     libdir = os.path.join(helpers.ROOT, "calico_amd")
     oradir = os.path.join(helpers.ROOT, "oracle")  # only --host-only uses it (spline fit without a GPU)
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wno-unknown-pragmas", "-I", os.path.join(helpers.ROOT, "include"),
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wno-unknown-pragmas", "-DCALICO_TEST_HOOKS", "-I", os.path.join(helpers.ROOT, "include"),
                            SRC, "-o", EXE, "-L", libdir, "-lcalico_hip", "-Wl,-rpath," + libdir,
                            "-L", oradir, "-lcalico_oracle", "-Wl,-rpath," + oradir])
 

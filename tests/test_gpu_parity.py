@@ -206,4 +206,5 @@ def test_project_matches_measurements_and_gives_zero_residuals(hip):
         assert valid.all()
         assert np.all(r == 0.0)
     cost, _, _ = built2.problem.evaluate()
-    assert cost == 0.0
+    # (the residual + Jacobian kernel contracts its multiply-adds differently from the residual-only one: rounding level)
+    assert cost < 1e-18
