@@ -547,7 +547,7 @@ int finalize(calico_problem* p) {
   std::vector<double> m0(n_obs), m1(n_obs), m2(n_obs), st(n_obs);
   std::vector<int> point_off(n_obs, 0);
   p->h_items.clear(); p->h_items_all.clear();
-  const int imu_chunk_items = [] { const char* e = std::getenv("CALICO_IMU_CHUNK"); return e ? std::max(1, std::min(40, std::atoi(e))) : 24; }();
+  const int imu_chunk_items = [] { const char* e = std::getenv("CALICO_IMU_CHUNK"); return e ? std::max(1, std::min(21, std::atoi(e))) : 21; }();   // (the Jacobian kernel gives an IMU block three lanes)
   int max_cols = 0;
   for (int64_t q = 0; q < n_obs;) {
     int64_t e = q;

@@ -139,11 +139,30 @@ DEV void dsincos(D3 a, D3* s, D3* c) {
   s->v = sv; s->d0 = a.d0 * cv; s->d1 = a.d1 * cv; s->d2 = a.d2 * cv;
   c->v = cv; c->d0 = -a.d0 * sv; c->d1 = -a.d1 * sv; c->d2 = -a.d2 * sv;
 }
+// One-direction forward dual: the IMU Jacobians deal the three φ-directions of an observation to three lanes, each
+// lane differentiates along its own direction with the same operation sequence D3 uses per component.
+struct D1 { double v, d; };
+DEV D1 mk1(double v) { D1 r; r.v = v; r.d = 0.0; return r; }
+DEV D1 operator+(D1 a, D1 b) { D1 r; r.v = a.v + b.v; r.d = a.d + b.d; return r; }
+DEV D1 operator-(D1 a, D1 b) { D1 r; r.v = a.v - b.v; r.d = a.d - b.d; return r; }
+DEV D1 operator-(D1 a) { D1 r; r.v = -a.v; r.d = -a.d; return r; }
+DEV D1 operator*(D1 a, D1 b) { D1 r; r.v = a.v * b.v; r.d = a.v * b.d + a.d * b.v; return r; }
+DEV D1 operator*(double s, D1 a) { D1 r; r.v = s * a.v; r.d = s * a.d; return r; }
+DEV D1 operator/(D1 a, D1 b) { const double inv = 1.0 / b.v; D1 r; r.v = a.v * inv; r.d = (a.d - r.v * b.d) * inv; return r; }
+DEV D1 dsqrt(D1 a) { D1 r; r.v = sqrt(a.v); const double k = 0.5 / r.v; r.d = a.d * k; return r; }
+DEV void dsincos(D1 a, D1* s, D1* c) {
+  double sv, cv;
+  dsincos(a.v, &sv, &cv);
+  s->v = sv; s->d = a.d * cv;
+  c->v = cv; c->d = -a.d * sv;
+}
 DEV double val(double a) { return a; }
 DEV double val(D3 a) { return a.v; }
+DEV double val(D1 a) { return a.v; }
 template <class T> DEV T lit(double v);
 template <> DEV double lit<double>(double v) { return v; }
 template <> DEV D3 lit<D3>(double v) { return mkd(v); }
+template <> DEV D1 lit<D1>(double v) { return mk1(v); }
 
 // geometry.h:35-50
 template <class T> DEV T small_sin(T th) {
@@ -196,6 +215,12 @@ template <class T> DEV Rodrigues<T> rodrigues(T px, T py, T pz, bool want_hessia
 }
 // the plain-double coefficients of a dual evaluation (same phi): saves recomputing the trigonometry
 DEV Rodrigues<double> rod_value(const Rodrigues<D3>& R) {
+  Rodrigues<double> r;
+  r.hx = R.hx.v; r.hy = R.hy.v; r.hz = R.hz.v; r.a = R.a.v; r.b = R.b.v;
+  r.c0 = R.c0.v; r.c1 = R.c1.v; r.c2 = R.c2.v; r.c3 = R.c3.v; r.zero = R.zero;
+  return r;
+}
+DEV Rodrigues<double> rod_value(const Rodrigues<D1>& R) {
   Rodrigues<double> r;
   r.hx = R.hx.v; r.hy = R.hy.v; r.hz = R.hz.v; r.a = R.a.v; r.b = R.b.v;
   r.c0 = R.c0.v; r.c1 = R.c1.v; r.c2 = R.c2.v; r.c3 = R.c3.v; r.zero = R.zero;

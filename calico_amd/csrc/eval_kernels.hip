@@ -206,23 +206,35 @@ DEV bool camera_dispatch(const ItemCtx& c, double px, double py, double stamp, c
 // ---------------------------------------------------------------------------
 // IMU kinematics shared by the gyroscope and accelerometer blocks.
 // ---------------------------------------------------------------------------
-// omega = J(phi)·phid and W = d omega / d phi (via D3 over phi).
-DEV void omega_and_dphi(V3 phi, V3 phid, V3* omega, double Wm[3][3], Rodrigues<double>* Rv) {
-  D3 px = mkd(phi.x), py = mkd(phi.y), pz = mkd(phi.z);
-  px.d0 = 1.0; py.d1 = 1.0; pz.d2 = 1.0;
-  const Rodrigues<D3> R = rodrigues<D3>(px, py, pz, false);
+// The Jacobian rows of an IMU block are formed by THREE lanes (`jl` = 0, 1, 2 = lane of the observation's triple): all
+// of them evaluate the residual, lane jl differentiates along φ_jl and files the columns of every 3-wide group that
+// belong to component jl -- the single-lane chain these blocks were is the longest of the Jacobian launch.
+// Element [q][jl] of a 3×3 matrix every lane of the triple holds
+DEV double col_of(const M3& A, int q, int jl) { return jl == 0 ? A.m[q][0] : (jl == 1 ? A.m[q][1] : A.m[q][2]); }
+DEV double col_of(const double A[3][3], int q, int jl) { return jl == 0 ? A[q][0] : (jl == 1 ? A[q][1] : A[q][2]); }
+DEV double pick(const double v[6], int off, int jl) { return jl == 0 ? v[off] : (jl == 1 ? v[off + 1] : v[off + 2]); }
+// sum over the triple, in lane order (the latency column: Σ over the three pose components), valid in lane 0 of the triple
+DEV double triple_sum(double t, int jl) {
+  const int base = int(threadIdx.x & 63) - jl;
+  const double t1 = __shfl(t, base + 1, 64), t2 = __shfl(t, base + 2, 64);
+  return (t + t1) + t2;
+}
+
+// omega = J(phi)·phid and column jl of W = d omega / d phi (dual number along φ_jl).
+DEV void omega_and_dphi_col(V3 phi, V3 phid, int jl, V3* omega, double Wcol[3], Rodrigues<double>* Rv) {
+  D1 px = mk1(phi.x), py = mk1(phi.y), pz = mk1(phi.z);
+  px.d = jl == 0 ? 1.0 : 0.0; py.d = jl == 1 ? 1.0 : 0.0; pz.d = jl == 2 ? 1.0 : 0.0;
+  const Rodrigues<D1> R = rodrigues<D1>(px, py, pz, false);
   *Rv = rod_value(R);
-  D3 ox, oy, oz;
-  rod_J_apply<D3>(R, mkd(phid.x), mkd(phid.y), mkd(phid.z), &ox, &oy, &oz);
+  D1 ox, oy, oz;
+  rod_J_apply<D1>(R, mk1(phid.x), mk1(phid.y), mk1(phid.z), &ox, &oy, &oz);
   *omega = mk(ox.v, oy.v, oz.v);
-  Wm[0][0] = ox.d0; Wm[0][1] = ox.d1; Wm[0][2] = ox.d2;
-  Wm[1][0] = oy.d0; Wm[1][1] = oy.d1; Wm[1][2] = oy.d2;
-  Wm[2][0] = oz.d0; Wm[2][1] = oz.d1; Wm[2][2] = oz.d2;
+  Wcol[0] = ox.d; Wcol[1] = oy.d; Wcol[2] = oz.d;
 }
 
 template <bool JAC, int KT>
 DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], const RowSink& sink, double* cost,
-                    int apply_loss) {
+                    int apply_loss, int jl) {
   const SensorDev& S = *c.s;
   const LayoutDev& L = *c.L;
   const double* intr = c.x + S.intr_off;
@@ -236,11 +248,11 @@ DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], cons
   const V3 phi = mk(-P[0][0], -P[0][1], -P[0][2]);
   const V3 phid = mk(-P[1][0], -P[1][1], -P[1][2]);
   V3 omega;
-  double Wm[3][3];
+  double Wcol[3] = {0.0, 0.0, 0.0};
   M3 Jl;
   if constexpr (JAC) {
     Rodrigues<double> Rv;
-    omega_and_dphi(phi, phid, &omega, Wm, &Rv);
+    omega_and_dphi_col(phi, phid, jl, &omega, Wcol, &Rv);
     Jl = rod_J_matrix(Rv);
   } else {
     const Rodrigues<double> R = rodrigues<double>(phi.x, phi.y, phi.z, false);
@@ -264,62 +276,50 @@ DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], cons
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) B[i][j] = -fac * (Mw[i][0] * R_rg.m[j][0] + Mw[i][1] * R_rg.m[j][1] + Mw[i][2] * R_rg.m[j][2]);
-    // A0 = dr/dp_r = B·W·(-1); A1 = dr/dpdot_r = B·J·(-1)
-    double A0[3][3], A1[3][3];
+    // column jl of A0 = dr/dp_r = B·W·(-1) and of A1 = dr/dpdot_r = B·J·(-1)
+    double A0c[3], A1c[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        A0[i][j] = -(B[i][0] * Wm[0][j] + B[i][1] * Wm[1][j] + B[i][2] * Wm[2][j]);
-        A1[i][j] = -(B[i][0] * Jl.m[0][j] + B[i][1] * Jl.m[1][j] + B[i][2] * Jl.m[2][j]);
-      }
+    for (int i = 0; i < 3; ++i) {
+      A0c[i] = -(B[i][0] * Wcol[0] + B[i][1] * Wcol[1] + B[i][2] * Wcol[2]);
+      A1c[i] = -(B[i][0] * col_of(Jl, 0, jl) + B[i][1] * col_of(Jl, 1, jl) + B[i][2] * col_of(Jl, 2, jl));
+    }
 #pragma unroll
     for (int i = 0; i < kMaxOrder; ++i) {
       if (i >= (KT > 0 ? KT : c.k)) continue;
       const double w0 = W[0][i], w1 = W[1][i];
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int rr = 0; rr < 3; ++rr) {
-          sink.put(6 * i + a, rr, w0 * A0[rr][a] + w1 * A1[rr][a]);
-          sink.put(6 * i + 3 + a, rr, 0.0);
-        }
+      for (int rr = 0; rr < 3; ++rr) {
+        sink.put(6 * i + jl, rr, w0 * A0c[rr] + w1 * A1c[rr]);
+        sink.put(6 * i + 3 + jl, rr, 0.0);
+      }
     }
     if (L.c_intr >= 0) {
       const int K = imu_num_params(S.model);
 #pragma unroll
       for (int j = 0; j < kMaxIntr; ++j) {
-        if (j >= K) continue;
+        if (j >= K || j % 3 != jl) continue;
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr) sink.put(L.c_intr + j, rr, fac * dK[rr][j]);
       }
     }
     if (L.c_q >= 0) {  // d og / d delta = -2 R_rgᵀ [omega]×
       const M3 So = skew(omega);
-      double RtS[3][3];
+      double RtSc[3];   // column jl of R_rgᵀ [omega]×
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) RtS[i][j] = R_rg.m[0][i] * So.m[0][j] + R_rg.m[1][i] * So.m[1][j] + R_rg.m[2][i] * So.m[2][j];
+      for (int i = 0; i < 3; ++i) RtSc[i] = R_rg.m[0][i] * col_of(So, 0, jl) + R_rg.m[1][i] * col_of(So, 1, jl) + R_rg.m[2][i] * col_of(So, 2, jl);
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-          sink.put(L.c_q + j, rr, -2.0 * fac * (Mw[rr][0] * RtS[0][j] + Mw[rr][1] * RtS[1][j] + Mw[rr][2] * RtS[2][j]));
+        sink.put(L.c_q + jl, rr, -2.0 * fac * (Mw[rr][0] * RtSc[0] + Mw[rr][1] * RtSc[1] + Mw[rr][2] * RtSc[2]));
     }
     if (L.c_t >= 0) {  // the translation extrinsic has zero derivative (gyroscope_cost_functor.h:94-114)
 #pragma unroll
-      for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) sink.put(L.c_t + j, rr, 0.0);
+      for (int rr = 0; rr < 3; ++rr) sink.put(L.c_t + jl, rr, 0.0);
     }
     if (L.c_lat >= 0) {
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr) {
-        double s = 0.0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) s += A0[rr][a] * P[1][a] + A1[rr][a] * P[ND - 1][a];
-        sink.put(L.c_lat, rr, -s);
+        const double s = triple_sum(A0c[rr] * pick(P[1], 0, jl) + A1c[rr] * pick(P[ND - 1], 0, jl), jl);
+        if (jl == 0) sink.put(L.c_lat, rr, -s);
       }
     }
   }
@@ -328,7 +328,7 @@ DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], cons
 
 template <bool JAC, int KT>
 DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], const RowSink& sink, double* cost,
-                     int apply_loss) {
+                     int apply_loss, int jl) {
   const SensorDev& S = *c.s;
   const LayoutDev& L = *c.L;
   const double* intr = c.x + S.intr_off;
@@ -349,27 +349,28 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
   const V3 aw = mk(P[2][3], P[2][4], P[2][5]);
   const M3 R_rw = rotmat(angle_axis_to_quat(phi));
   V3 omega, alpha;
-  double dw_dphi[3][3], da_dphi[3][3];
+  double dw_col[3] = {0.0, 0.0, 0.0}, da_col[3] = {0.0, 0.0, 0.0};   // column jl of d omega / d phi, d alpha / d phi
+  double Hphid_row[3] = {0.0, 0.0, 0.0};                              // row jl of H(phi)·phid
   Rodrigues<double> Rd;   // the coefficients at phi as plain doubles (Jacobian path)
   Rd.zero = true;
   if constexpr (JAC) {
-    D3 px = mkd(phi.x), py = mkd(phi.y), pz = mkd(phi.z);
-    px.d0 = 1.0; py.d1 = 1.0; pz.d2 = 1.0;
-    const Rodrigues<D3> R = rodrigues<D3>(px, py, pz, true);
+    D1 px = mk1(phi.x), py = mk1(phi.y), pz = mk1(phi.z);
+    px.d = jl == 0 ? 1.0 : 0.0; py.d = jl == 1 ? 1.0 : 0.0; pz.d = jl == 2 ? 1.0 : 0.0;
+    const Rodrigues<D1> R = rodrigues<D1>(px, py, pz, true);
     Rd = rod_value(R);
-    D3 o[3], jdd[3], Hv[3][3];
-    rod_J_apply<D3>(R, mkd(phid.x), mkd(phid.y), mkd(phid.z), &o[0], &o[1], &o[2]);
-    rod_J_apply<D3>(R, mkd(phidd.x), mkd(phidd.y), mkd(phidd.z), &jdd[0], &jdd[1], &jdd[2]);
-    rod_H_apply<D3>(R, mkd(phid.x), mkd(phid.y), mkd(phid.z), Hv);
-    D3 al[3];
+    D1 o[3], jdd[3], Hv[3][3];
+    rod_J_apply<D1>(R, mk1(phid.x), mk1(phid.y), mk1(phid.z), &o[0], &o[1], &o[2]);
+    rod_J_apply<D1>(R, mk1(phidd.x), mk1(phidd.y), mk1(phidd.z), &jdd[0], &jdd[1], &jdd[2]);
+    rod_H_apply<D1>(R, mk1(phid.x), mk1(phid.y), mk1(phid.z), Hv);
+    D1 al[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) al[j] = phid.x * Hv[0][j] + phid.y * Hv[1][j] + phid.z * Hv[2][j] + jdd[j];
     omega = mk(o[0].v, o[1].v, o[2].v);
     alpha = mk(al[0].v, al[1].v, al[2].v);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      dw_dphi[j][0] = o[j].d0; dw_dphi[j][1] = o[j].d1; dw_dphi[j][2] = o[j].d2;
-      da_dphi[j][0] = al[j].d0; da_dphi[j][1] = al[j].d1; da_dphi[j][2] = al[j].d2;
+      dw_col[j] = o[j].d; da_col[j] = al[j].d;
+      Hphid_row[j] = jl == 0 ? Hv[0][j].v : (jl == 1 ? Hv[1][j].v : Hv[2][j].v);
     }
   } else {
     const Rodrigues<double> R = rodrigues<double>(phi.x, phi.y, phi.z, true);
@@ -411,75 +412,56 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
 #pragma unroll
       for (int j = 0; j < 3; ++j)
         dbdw[i][j] = (i == j ? ot : 0.0) + comp(omega, i) * comp(t, j) - 2.0 * comp(t, i) * comp(omega, j);
-    // explicit Hessian slices for d alpha / d phid:  H[i][j][l] = (H_i e_l)_j
+    // column jl of d alpha / d phid: with H[i][j][l] = (H_i e_l)_j it is Σ_i (H[i][j][jl] + H[jl][j][i]) phid_i; the first
+    // sum needs the slice of this lane's direction, the second is row jl of H·phid (already there)
     const M3 Jl = rod_J_matrix(Rd);
-    double Hm[3][3][3];
+    double Hs[3][3];
+    rod_H_apply<double>(Rd, jl == 0 ? 1.0 : 0.0, jl == 1 ? 1.0 : 0.0, jl == 2 ? 1.0 : 0.0, Hs);
+    double dad_col[3];
 #pragma unroll
-    for (int l = 0; l < 3; ++l) {
-      double Hv[3][3];
-      rod_H_apply<double>(Rd, l == 0 ? 1.0 : 0.0, l == 1 ? 1.0 : 0.0, l == 2 ? 1.0 : 0.0, Hv);
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) Hm[i][j][l] = Hv[i][j];
-    }
-    double da_dphid[3][3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int l = 0; l < 3; ++l) {
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) s += Hm[i][j][l] * comp(phid, i) + Hm[l][j][i] * comp(phid, i);
-        da_dphid[j][l] = s;
-      }
-    // db/dphi = -[rag]× J_l + dbdw·dw_dphi + St·da_dphi
+    for (int j = 0; j < 3; ++j) dad_col[j] = (Hs[0][j] * phid.x + Hs[1][j] * phid.y + Hs[2][j] * phid.z) + Hphid_row[j];
+    // column jl of db/dphi = -[rag]× J_l + dbdw·dw_dphi + St·da_dphi, of db/dphid and of db/dphidd
     const M3 Sr = skew(rag);
-    double db_dphi[3][3], db_dphid[3][3], db_dphidd[3][3];
+    double dbc[3], dbdc[3], dbddc[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3; ++i) {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        double s = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int q2 = 0; q2 < 3; ++q2) {
-          s += -Sr.m[i][q2] * Jl.m[q2][j] + dbdw[i][q2] * dw_dphi[q2][j] + St.m[i][q2] * da_dphi[q2][j];
-          s1 += dbdw[i][q2] * Jl.m[q2][j] + St.m[i][q2] * da_dphid[q2][j];
-          s2 += St.m[i][q2] * Jl.m[q2][j];
-        }
-        db_dphi[i][j] = s; db_dphid[i][j] = s1; db_dphidd[i][j] = s2;
+      for (int q2 = 0; q2 < 3; ++q2) {
+        const double jq = col_of(Jl, q2, jl);
+        s0 += -Sr.m[i][q2] * jq + dbdw[i][q2] * dw_col[q2] + St.m[i][q2] * da_col[q2];
+        s1 += dbdw[i][q2] * jq + St.m[i][q2] * dad_col[q2];
+        s2 += St.m[i][q2] * jq;
       }
-    // A0 = dr/dp_r, A1 = dr/dpdot_r, A2r = dr/dpddot_r (phi = -p_r), A2t = dr/dpddot_t = Bm·R_rw
-    double A0[3][3], A1[3][3], A2r[3][3], A2t[3][3];
+      dbc[i] = s0; dbdc[i] = s1; dbddc[i] = s2;
+    }
+    // column jl of A0 = dr/dp_r, A1 = dr/dpdot_r, A2r = dr/dpddot_r (phi = -p_r), A2t = dr/dpddot_t = Bm·R_rw
+    double A0c[3], A1c[3], A2rc[3], A2tc[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3; ++i) {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-        for (int q2 = 0; q2 < 3; ++q2) {
-          s0 += Bm[i][q2] * db_dphi[q2][j]; s1 += Bm[i][q2] * db_dphid[q2][j];
-          s2 += Bm[i][q2] * db_dphidd[q2][j]; s3 += Bm[i][q2] * R_rw.m[q2][j];
-        }
-        A0[i][j] = -s0; A1[i][j] = -s1; A2r[i][j] = -s2; A2t[i][j] = s3;
+      for (int q2 = 0; q2 < 3; ++q2) {
+        s0 += Bm[i][q2] * dbc[q2]; s1 += Bm[i][q2] * dbdc[q2];
+        s2 += Bm[i][q2] * dbddc[q2]; s3 += Bm[i][q2] * col_of(R_rw, q2, jl);
       }
+      A0c[i] = -s0; A1c[i] = -s1; A2rc[i] = -s2; A2tc[i] = s3;
+    }
 #pragma unroll
     for (int i = 0; i < kMaxOrder; ++i) {
       if (i >= (KT > 0 ? KT : c.k)) continue;
       const double w0 = W[0][i], w1 = W[1][i], w2 = W[2][i];
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int rr = 0; rr < 3; ++rr) {
-          sink.put(6 * i + a, rr, w0 * A0[rr][a] + w1 * A1[rr][a] + w2 * A2r[rr][a]);
-          sink.put(6 * i + 3 + a, rr, w2 * A2t[rr][a]);
-        }
+      for (int rr = 0; rr < 3; ++rr) {
+        sink.put(6 * i + jl, rr, w0 * A0c[rr] + w1 * A1c[rr] + w2 * A2rc[rr]);
+        sink.put(6 * i + 3 + jl, rr, w2 * A2tc[rr]);
+      }
     }
     if (L.c_intr >= 0) {
       const int K = imu_num_params(S.model);
 #pragma unroll
       for (int j = 0; j < kMaxIntr; ++j) {
-        if (j >= K) continue;
+        if (j >= K || j % 3 != jl) continue;
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr) sink.put(L.c_intr + j, rr, fac * dK[rr][j]);
       }
@@ -488,38 +470,31 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
       const M3 Sb = skew(b);
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-          sink.put(L.c_q + j, rr, 2.0 * (Bm[rr][0] * Sb.m[0][j] + Bm[rr][1] * Sb.m[1][j] + Bm[rr][2] * Sb.m[2][j]));
+        sink.put(L.c_q + jl, rr, 2.0 * (Bm[rr][0] * col_of(Sb, 0, jl) + Bm[rr][1] * col_of(Sb, 1, jl) + Bm[rr][2] * col_of(Sb, 2, jl)));
     }
     if (L.c_t >= 0) {  // db/dt = [omega]×[omega]× - [alpha]×
       const M3 So = skew(omega), Sa = skew(alpha);
       const M3 So2 = mul(So, So);
 #pragma unroll
-      for (int rr = 0; rr < 3; ++rr)
+      for (int rr = 0; rr < 3; ++rr) {
+        double s = 0.0;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          double s = 0.0;
-#pragma unroll
-          for (int q2 = 0; q2 < 3; ++q2) s += Bm[rr][q2] * (So2.m[q2][j] - Sa.m[q2][j]);
-          sink.put(L.c_t + j, rr, s);
-        }
+        for (int q2 = 0; q2 < 3; ++q2) s += Bm[rr][q2] * (col_of(So2, q2, jl) - col_of(Sa, q2, jl));
+        sink.put(L.c_t + jl, rr, s);
+      }
     }
     if (L.c_lat >= 0) {
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr) {
-        double s = 0.0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-          s += A0[rr][a] * P[1][a] + A1[rr][a] * P[2][a] + A2r[rr][a] * P[ND - 1][a] + A2t[rr][a] * P[ND - 1][3 + a];
-        sink.put(L.c_lat, rr, -s);
+        const double t = A0c[rr] * pick(P[1], 0, jl) + A1c[rr] * pick(P[2], 0, jl) + A2rc[rr] * pick(P[ND - 1], 0, jl) +
+                         A2tc[rr] * pick(P[ND - 1], 3, jl);
+        const double s = triple_sum(t, jl);
+        if (jl == 0) sink.put(L.c_lat, rr, -s);
       }
     }
     if (L.c_grav >= 0) {  // db/dg = -R_rw
 #pragma unroll
-      for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) sink.put(L.c_grav + j, rr, -A2t[rr][j]);
+      for (int rr = 0; rr < 3; ++rr) sink.put(L.c_grav + jl, rr, -A2tc[rr]);
     }
   }
   return true;
@@ -608,38 +583,41 @@ DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds) {
   // (no zeroing of the staging area: every active lane writes all columns of its rows, and stage B masks the
   //  rows / columns beyond the item)
   ITICK(0)
-  const bool active = lane < it.obs_count;
-  const int o = it.obs_begin + lane;
+  // IMU Jacobian rows: three lanes per observation (see gyro_block); everything else: one lane per observation
+  const bool triple = JAC && S.kind != 0;
+  const int ol = triple ? lane / 3 : lane, jl = triple ? lane - 3 * ol : 0;
+  const bool active = ol < it.obs_count;
+  const int o = it.obs_begin + ol;
   // observations tagged as outliers (camera.cpp:121-124: skipped by AddResidualsToProblem) stay in the arrays but
   // contribute nothing: zero rows, zero cost, not an evaluation failure
   const bool on = active && (!a.active || a.active[o] != 0);
   double res[3] = {0.0, 0.0, 0.0};
   double cost = 0.0;
   bool ok = true;
-  RowSink sink; sink.J = lds; sink.row0 = dim * lane; sink.pad = row_pad;
+  RowSink sink; sink.J = lds; sink.row0 = dim * ol; sink.pad = row_pad;
   if (on) {
     const double st = a.stamp[o];
     const double z0 = a.project ? 0.0 : a.m0[o], z1 = a.project ? 0.0 : a.m1[o], z2 = a.project ? 0.0 : a.m2[o];
     if (S.kind == 0) {
       ok = camera_dispatch<JAC, KT>(c, z0, z1, st, a.x + a.point_off[o], res, sink, &cost, a.apply_loss);
     } else if (S.kind == 1) {
-      ok = gyro_block<JAC, KT>(c, mk(z0, z1, z2), st, res, sink, &cost, a.apply_loss);
+      ok = gyro_block<JAC, KT>(c, mk(z0, z1, z2), st, res, sink, &cost, a.apply_loss, jl);
     } else {
-      ok = accel_block<JAC, KT>(c, mk(z0, z1, z2), st, res, sink, &cost, a.apply_loss);
+      ok = accel_block<JAC, KT>(c, mk(z0, z1, z2), st, res, sink, &cost, a.apply_loss, jl);
     }
     if (!ok) { cost = 0.0; res[0] = res[1] = res[2] = 0.0; }
   }
-  if (active && a.res_out) {
+  if (active && jl == 0 && a.res_out) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) if (r < dim) a.res_out[size_t(o) * 3 + r] = res[r];
     a.valid_out[o] = (on && ok) ? 1 : 0;
   }
   ITICK(1)
-  const double item_cost = wave_sum(cost);
-  const double n_invalid = wave_sum((on && !ok) ? 1.0 : 0.0);
+  const double item_cost = wave_sum(jl == 0 ? cost : 0.0);
+  const double n_invalid = wave_sum((on && !ok && jl == 0) ? 1.0 : 0.0);
   if (lane == 0) { a.item_cost[2 * (a.cost_index_base + item_id)] = item_cost; a.item_cost[2 * (a.cost_index_base + item_id) + 1] = n_invalid; }
   if constexpr (JAC) {
-    if (active) {
+    if (active && jl == 0) {
       if (!ok || !on) {  // drop the block: zero its rows
         for (int col = 0; col < ncols; ++col)
           for (int r = 0; r < dim; ++r) sink.put(col, r, 0.0);
