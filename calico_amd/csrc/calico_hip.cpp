@@ -849,6 +849,18 @@ int finalize(calico_problem* p) {
   for (const HBlock& b : p->blocks) std::copy(b.v.begin(), b.v.end(), p->h_x.begin() + b.amb_off);
   std::vector<int> ctrl_off(n_cp);
   for (int i = 0; i < n_cp; ++i) ctrl_off[i] = p->blocks[p->ctrl[i]].amb_off;
+  {
+    // every work item / frame carries copies of its layout, its sensor and the offsets of its control points
+    auto fill = [&](auto& it) {
+      it.L = layouts[size_t(it.layout)];
+      it.S = sd[size_t(it.L.sensor)];
+      for (int i = 0; i < 8; ++i) it.ctrl_off[i] = (i < k && it.seg + i < n_cp) ? ctrl_off[size_t(it.seg + i)] : 0;
+    };
+    for (ItemDev& it : p->h_items) fill(it);
+    for (ItemDev& it : p->h_items_all) fill(it);
+    for (ItemDev& it : p->h_jac_items) fill(it);
+    for (FrameItemDev& it : p->h_fitems) fill(it);
+  }
   HIP_TRY(p, p->d_x.upload(p->h_x, s)); HIP_TRY(p, p->d_xc.upload(p->h_x, s));
   HIP_TRY(p, p->d_knots.upload(p->knots, s)); HIP_TRY(p, p->d_basis.upload(p->basis, s));
   HIP_TRY(p, p->d_ctrl_off.upload(ctrl_off, s));

@@ -564,15 +564,16 @@ DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds) {
   const bool dbg = JAC && a.debug && (item_id == 3 || item_id == a.n_items - 2) && lane == 0;
   long long tph[4] = {0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define ITICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
-  const ItemDev it = a.items[item_id];
-  const LayoutDev& L = a.layouts[it.layout];
-  const SensorDev& S = a.sensors[L.sensor];
+  const ItemDev* ip = a.items + item_id;
+  const ItemDev it = *ip;
+  const LayoutDev& L = ip->L;       // (copies inside the item record: one hop instead of item -> layout -> sensor)
+  const SensorDev& S = ip->S;
   ItemCtx c;
   c.s = &S; c.L = &L; c.k = a.order; c.x = a.x; c.info = a.project ? -1.0 : S.info;
   const int ki = it.seg + a.order - 1;
   c.knot0 = a.knots[ki]; c.knot1 = a.knots[ki + 1];
   c.M = a.basis + size_t(it.seg) * a.order * a.order;
-  c.ctrl_off = a.ctrl_off + it.seg;
+  c.ctrl_off = ip->ctrl_off;
   const int dim = (S.kind == 0) ? 2 : 3;
   // The IMU blocks are the longest single-lane chains of the launch (accelerometer ≈ 45k clocks): where such a wave
   // shares a SIMD with a camera wave it gets the issue slots first, the launch ends when the last of them does.
@@ -779,9 +780,10 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   const bool dbg = a.debug && fidx == 7 && lane == 0;
   long long tph[6] = {0, 0, 0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define FTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
-  const FrameItemDev it = a.fitems[fidx];
-  const LayoutDev& L = a.layouts[it.layout];
-  const SensorDev& S = a.sensors[L.sensor];
+  const FrameItemDev* ip = a.fitems + fidx;
+  const FrameItemDev it = *ip;
+  const LayoutDev& L = ip->L;       // (copies inside the frame record: one hop instead of frame -> layout -> sensor)
+  const SensorDev& S = ip->S;
   constexpr int K = 6;
   const PrimMap pm = prim_map(L, S);
   const SmallMap sm = small_map(L, S);
@@ -806,7 +808,7 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   double p[6] = {0, 0, 0, 0, 0, 0}, pd[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    const double* cp = a.x + a.ctrl_off[it.seg + i];
+    const double* cp = a.x + ip->ctrl_off[i];
 #pragma unroll
     for (int c = 0; c < 6; ++c) { p[c] += W[0][i] * cp[c]; pd[c] += W[1][i] * cp[c]; }
   }

@@ -42,6 +42,11 @@ struct ItemDev {
   int64_t partial_off;  // offset (doubles) of this item's partial block
   int64_t rows_off;     // >= 0: the item files its staged rows [J r] here instead (lds_cols × row_pad doubles, column-major)
                         // and the cell kernel forms [J r]ᵀ[J r] of the whole cell; -1: the item forms its own block
+  // copies of what the wave would otherwise reach through item -> layout -> sensor and item -> segment -> control points:
+  // every dependent global load costs about a microsecond at the head of a latency chain
+  LayoutDev L;
+  SensorDev S;
+  int ctrl_off[8];      // ambient offsets of the segment's control points (spline order <= 8)
 };
 
 // A camera frame: residual blocks of one cell that also share the time stamp, hence the pose,
@@ -50,6 +55,9 @@ struct FrameItemDev {
   int layout, seg, obs_begin, obs_count;
   double stamp;
   int64_t partial_off;   // offset (doubles) of the frame's COMPACT record: M_ext (PE×PE) then coef (ncols+1)
+  LayoutDev L;           // copies, as in ItemDev
+  SensorDev S;
+  int ctrl_off[8];
 };
 
 // All frames of one cell = (layout, segment): the cell kernel expands and sums their compact records
