@@ -13,6 +13,7 @@ rm -rf /tmp/prof_kt; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_k
 python $REPO/profiles/summarize_rocpd.py /tmp/prof_kt/*.db $OUT/r02_kernel_stats.csv
 python $REPO/profiles/timeline_gaps.py /tmp/prof_kt/*.db > $OUT/r02_timeline_gaps.txt
 python $REPO/profiles/iteration_trace.py /tmp/prof_kt/*.db bcr_level_kernelILb1 > $OUT/r02_iteration_trace.txt
+python $REPO/profiles/solve_boundary_gaps.py /tmp/prof_kt/*.db > $OUT/r02_solve_boundary.txt
 # 3. HBM traffic: one PMC pass per counter
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c; timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o pmc -- python $REPO/bench.py --no-cpu-baseline --steps 16 --warmup 2 --repeats 1 > /dev/null 2>&1

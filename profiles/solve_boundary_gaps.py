@@ -17,8 +17,8 @@ def main():
         if "start" in cols and "end" in cols:
             rows += [(s, e, "<memory copy>") for s, e in c.execute("select start, end from %s" % mc[0])]
     rows.sort()
-    # a solve starts with init_state_kernel
-    starts = [i for i, r in enumerate(rows) if "init_state" in r[2]]
+    # a solve starts with begin_solve_kernel (round 1 / early round 2: init_state_kernel)
+    starts = [i for i, r in enumerate(rows) if "begin_solve" in r[2]] or [i for i, r in enumerate(rows) if "init_state" in r[2]]
     if len(starts) < 4:
         raise SystemExit("not enough solves in the trace")
     i0 = starts[len(starts) // 2]
