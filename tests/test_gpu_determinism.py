@@ -85,3 +85,61 @@ def test_solver_variants_agree(monkeypatch):
         # noise-free toy problem: the cost goes to ~0, so late iterates only agree in absolute terms
         np.testing.assert_allclose(r[2], ref[2], rtol=1e-6, atol=1e-5, err_msg=str(key))
         np.testing.assert_allclose(r[3], ref[3], rtol=1e-6, atol=1e-9, err_msg=str(key))   # the north star's tolerance
+
+
+@pytest.mark.gpu
+def test_back_to_back_solves_behind_leftover_kernels():
+    """calico_solve returns as soon as the device reports the end of the solve; the early-exit kernels of the iterations
+    enqueued ahead are still on the stream when the next call starts. Solves of different lengths, restarts, residual
+    read-backs and evaluations issued back to back must each give what the same call gives on an idle stream (the
+    progress words carry the solve's number, the results are written by the terminating stage itself)."""
+    api = helpers.hip_api()
+    scene = syn.make_scene(3, 1, True, 3, cam_rate=10.0, imu_rate=100.0, duration=2.0, chart="april", seed=21,
+                           pixel_noise=0.1, gyro_noise=1e-3, accel_noise=1e-2, robust=True, segment_duration=0.2)
+    built = syn.build_problem(api, scene, device=0)
+    P = built.problem
+    init = [(int(b), scene.ctrl[i].copy()) for i, b in enumerate(built.ctrl_blocks)]
+    for s, sb in zip(scene.sensors, built.sensor_blocks):
+        init += [(sb["intrinsics"], s.intrinsics.copy()), (sb["t"], s.t.copy()), (sb["q"], s.q.copy()),
+                 (sb["latency"], np.array([s.latency]))]
+    ids = np.array([b for b, _ in init], np.int32)
+    sizes = [int(np.asarray(v).size) for _, v in init]
+    vals = np.concatenate([np.asarray(v, float).ravel() for _, v in init])
+    o = api.default_options()
+    o.minimizer_progress_to_stdout = 0
+
+    def run(max_iter, restart=True):
+        if restart:
+            P.set_param_blocks(ids, vals)
+        o.max_num_iterations = max_iter
+        s = P.solve(o)
+        x = np.concatenate([np.asarray(P.get_param_block(int(b), n), float).ravel() for b, n in zip(ids, sizes)])
+        return (s.num_iterations, s.termination_type, s.final_cost, tuple(float(i.cost) for i in P.iterations()), x)
+
+    # references: every length once, with the stream drained before and after (calico_evaluate ends with a
+    # synchronisation of the handle's stream)
+    ref = {}
+    for k in (0, 1, 2, 5, 30):
+        P.evaluate()
+        ref[k] = run(k)
+        P.evaluate()
+    # now back to back, in an order that puts short solves right behind long ones and vice versa
+    order = [30, 0, 1, 30, 2, 1, 0, 5, 30, 5, 2, 2, 30, 1] * 3
+    for k in order:
+        got = run(k)
+        assert got[0] == ref[k][0] and got[1] == ref[k][1]
+        assert got[2] == ref[k][2] and got[3] == ref[k][3], "solve of %d iterations differs behind left-over kernels" % k
+        assert np.array_equal(got[4], ref[k][4])
+    # a continued solve (no restart) and calls of other kinds right behind a solve
+    a = run(3)
+    b = run(27, restart=False)
+    assert b[2] <= a[2]
+    r0, valid = P.residuals(built.sensor_ids[0], scene.sensors[0].n, scene.sensors[0].dim)
+    cost, _, _ = P.evaluate()
+    assert valid.all() and np.isfinite(r0).all()
+    assert abs(cost - b[2]) <= 1e-9 * abs(b[2])
+    # the epoch of the progress words wraps at 2047: cross it
+    for _ in range(2100):
+        got = run(1)
+        assert got[0] == ref[1][0] and got[2] == ref[1][2]
+    assert run(30)[3] == ref[30][3]
