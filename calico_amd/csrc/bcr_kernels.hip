@@ -1045,11 +1045,19 @@ __global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveA
         dst[0] = z0[r]; dst[16] = z1[r];
       }
     }
-    if (wave == 7 && lane < BP) {      // z = g·M, M upper triangular: fixed trip count, masked (a lane-dependent loop serialises)
-      double zc = 0.0;
+    if (wave == 7) {      // z = g·M, M upper triangular: lane (h, c) = (lane >> 5, lane & 31) sums rows 16h .. 16h+15 of column c
+      // in four interleaved partial sums (a single 32-term chain with its LDS reads in between took longer than the
+      // tile jobs beside it); fixed trip count, masked (a lane-dependent loop serialises)
+      const int c = lane & 31, h = lane >> 5;
+      double g16[16], mv[16];
 #pragma unroll
-      for (int r = 0; r < BP; ++r) zc += (r <= lane ? gv[c0 + r] : 0.0) * Mj[r * DLD + lane];
-      wv[lane] = zc;
+      for (int u = 0; u < 16; ++u) { g16[u] = gv[c0 + 16 * h + u]; mv[u] = Mj[(16 * h + u) * DLD + c]; }
+      double z4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < 16; ++u) z4[u & 3] += (16 * h + u <= c ? g16[u] : 0.0) * mv[u];
+      double zc = (z4[0] + z4[1]) + (z4[2] + z4[3]);
+      zc += __shfl_xor(zc, 32, 64);
+      if (h == 0) wv[c] = zc;
     }
     lds_barrier();
     DTICK(5)
@@ -1067,10 +1075,10 @@ __global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveA
     if (tid >= 256 && tid < 256 + mp - c0 - BP) {
       const int prow = c0 + BP + (tid - 256);
       const double* zr = A + prow * DNL + c0;
-      double acc = 0.0;
+      double a4[4] = {0.0, 0.0, 0.0, 0.0};      // four interleaved partial sums: no 32-term dependent chain
 #pragma unroll
-      for (int c = 0; c < BP; ++c) acc += zr[c] * wv[c];
-      gv[prow] -= acc;
+      for (int c = 0; c < BP; ++c) a4[c & 3] += zr[c] * wv[c];
+      gv[prow] -= (a4[0] + a4[1]) + (a4[2] + a4[3]);
     }
     // the three tiles of the next diagonal block first (waves 0..2): the factorisation of block jb+1 only waits for
     // these; the rest of the trailing update runs beside its panels
