@@ -141,7 +141,18 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   }
   const FromR fr = {a, o, radius};
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = 1 + nfs, bid = blockIdx.x;
+  // Workgroup -> (node, role), XCD-aware: workgroup p runs on XCD p % 8, each XCD has its own L2, and all roles of a node
+  // read the same spine blocks -- so node c takes the workgroups p = (c % 8) + 8·slot: one L2 serves its roles. The
+  // first 8·slots workgroups are (node, role) pairs (those of nodes that do not exist return), the others are the
+  // extra workgroups below.
+  const int per = 1 + nfs;
+  const int main_span = 8 * ((n_nodes + 7) / 8) * per;
+  const int pcol = int(blockIdx.x) & 7, pslot = int(blockIdx.x) >> 3;
+  const int node_l = (pslot / per) * 8 + pcol;
+  const bool extra_wg = int(blockIdx.x) >= main_span;
+  if (!extra_wg && node_l >= n_nodes) return;
+  const int bid = extra_wg ? n_nodes * per + (int(blockIdx.x) - main_span) : node_l * per + pslot % per;
+  const int grid_l = n_nodes * per + (int(gridDim.x) - main_span);      // logical grid: nodes × roles, then the extras
   const int m1p = b.m1p, par = level & 1;
   const size_t NB = size_t(b.N);
   const size_t fblk = size_t(BP) * m1p;
@@ -155,7 +166,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     if (terminated) return;
     // surviving separators that are not eliminated at this level: D += pending, F += pending (in place; nobody else
     // reads them in this launch). At level 0 they are initialised from R(x) instead.
-    const size_t aw = size_t(bid - n_nodes * per), naw = size_t(gridDim.x - n_nodes * per - (FROM_R && with_post ? 1 : 0));
+    const size_t aw = size_t(bid - n_nodes * per), naw = size_t(grid_l - n_nodes * per - (FROM_R && with_post ? 1 : 0));
     const size_t per_blk = size_t(BB) + fblk;
     for (size_t e = aw * kLevelThreads + tid; e < size_t(n_keep) * per_blk; e += naw * kLevelThreads) {
       const int kb = int(e / per_blk);
@@ -1158,12 +1169,13 @@ void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nod
                       hipStream_t s) {
   const int nfs = (a.mc + 1 + kBcrFS - 1) / kBcrFS;
   const int n_apply = n_keep > 0 ? std::min(64, std::max(1, n_keep * 4)) : 0;
+  const int main_span = 8 * ((n_nodes + 7) / 8) * (1 + nfs);      // (node, role) workgroups laid out by XCD: see the kernel
   if (level == 0) {
-    hipLaunchKernelGGL(bcr_level_kernel<true>, dim3(n_nodes * (1 + nfs) + n_apply + (with_post_eval ? 1 : 0)), dim3(kLevelThreads),
+    hipLaunchKernelGGL(bcr_level_kernel<true>, dim3(main_span + n_apply + (with_post_eval ? 1 : 0)), dim3(kLevelThreads),
                        bcr_level_lds_bytes(), s, a, b, node0, n_nodes, nfs, level, keep0, n_keep, o, with_post_eval ? 1 : 0, x, blocks, n_blocks,
                        log, log_cap, jacobi);
   } else {
-    hipLaunchKernelGGL(bcr_level_kernel<false>, dim3(n_nodes * (1 + nfs) + n_apply), dim3(kLevelThreads), bcr_level_lds_bytes(), s, a, b,
+    hipLaunchKernelGGL(bcr_level_kernel<false>, dim3(main_span + n_apply), dim3(kLevelThreads), bcr_level_lds_bytes(), s, a, b,
                        node0, n_nodes, nfs, level, keep0, n_keep, o, 0, x, blocks, n_blocks, log, log_cap, jacobi);
   }
 }
