@@ -1381,7 +1381,12 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
         const int word = __atomic_load_n(p->h_progress, __ATOMIC_ACQUIRE);
         const int seen = (word >> 20) == epoch ? (word & 0xfffff) : 0;    // words of another epoch: early-exit kernels of the previous solve
         if (seen != last_seen) { last_seen = seen; t_progress = std::chrono::steady_clock::now(); spins = 0; }
-        if (enq - seen < stream_depth) break;
+        if (enq - seen < stream_depth) {
+          // the device raises the termination word BEFORE the iteration count: having seen the count move, look at the
+          // flag once more, or one solve in two enqueues a whole iteration of early-exit kernels for nothing
+          if (__atomic_load_n(p->h_progress + 1, __ATOMIC_ACQUIRE) == epoch) done = true;
+          break;
+        }
         __builtin_ia32_pause();
         if ((++spins & 0xfffff) == 0) {   // a device fault must not leave the host spinning
           const hipError_t qe = hipStreamQuery(s);
