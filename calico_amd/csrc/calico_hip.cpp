@@ -1374,6 +1374,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
     auto t_progress = std::chrono::steady_clock::now();     // when the device last reported a finished iteration
     int last_seen = 0;
     int64_t spins = 0;
+    bool budget_spent = false;
     for (;;) {
       bool done = false;
       for (;;) {
@@ -1381,7 +1382,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
         const int word = __atomic_load_n(p->h_progress, __ATOMIC_ACQUIRE);
         const int seen = (word >> 20) == epoch ? (word & 0xfffff) : 0;    // words of another epoch: early-exit kernels of the previous solve
         if (seen != last_seen) { last_seen = seen; t_progress = std::chrono::steady_clock::now(); spins = 0; }
-        if (enq - seen < stream_depth) {
+        if (!budget_spent && enq - seen < stream_depth) {
           // the device raises the termination word BEFORE the iteration count: having seen the count move, look at the
           // flag once more, or one solve in two enqueues a whole iteration of early-exit kernels for nothing
           if (__atomic_load_n(p->h_progress + 1, __ATOMIC_ACQUIRE) == epoch) done = true;
@@ -1398,6 +1399,13 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
         }
       }
       if (done) break;
+      if (enq >= std::max(0, opt->max_num_iterations)) {
+        // the iteration budget is enqueued: all that can still be due is the bookkeeping of the last step, should it be
+        // accepted (it ends the solve by the iteration count) -- one kernel instead of an iteration of early exits
+        launch_post_eval(sa, p->d_x.p, p->d_blocks.p, n_blocks, o, p->d_log.p, kLogCap, 0, opt->jacobi_scaling, s);
+        budget_spent = true;
+        continue;
+      }
       p->timer.begin(2, s);
       enqueue_linear_solve(p, sa, o, /*with_post_eval=*/enq > 0, opt->jacobi_scaling);
       p->timer.end(s);
