@@ -174,14 +174,8 @@ DEVI void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "
 // instruction. A bad pivot is not patched: it turns the factor into NaN (caught by the update stage); with PMIN the
 // running minimum of the pivots is kept as well.
 // DINV: also file the reciprocal diagonal (the dense reduced solve's backward sweep reads it; the tree solver does not).
-// PUB (R = 1): the wave is the LEAD of a pair. It publishes every finished column (64 multipliers), the pivot's
-// reciprocal square root and a progress word in `bcast` (kPanelPubDoubles doubles, laid out below), so that a second
-// wave (panel_follow) can take the rows from 64 on through the same factorisation a few hundred clocks behind it --
-// the lead then issues the instructions of 64 rows, not 128. `flag_base` makes the progress word monotonic over the
-// panels of one kernel.
-constexpr int kPanelPubL = 0, kPanelPubRs = 16 * 64, kPanelPubFlag = 16 * 64 + 16, kPanelPubDoubles = 16 * 64 + 16 + 2;
-template <int R, bool DINV = true, bool PMIN = true, bool PUB = false>
-DEVI void panel_factor(double* A, int LD, double* dinv, double* bcast, int j0, int m, int w, int lane, double* pmin, int flag_base = 0) {
+template <int R, bool DINV = true, bool PMIN = true>
+DEVI void panel_factor(double* A, int LD, double* dinv, double* bcast, int j0, int m, int w, int lane, double* pmin) {
   double av[R][16];
   int row[R];
 #pragma unroll
@@ -201,7 +195,7 @@ DEVI void panel_factor(double* A, int LD, double* dinv, double* bcast, int j0, i
     // chain starts, consumed after it
     double lb[16];
     if (jj > 0) {
-      const double* br = PUB ? bcast + kPanelPubL + (jj - 1) * 64 : bcast + ((jj - 1) & 1) * 64;
+      const double* br = bcast + ((jj - 1) & 1) * 64;
 #pragma unroll
       for (int c = jj + 2; c < 16; ++c) lb[c] = br[c];
     }
@@ -212,12 +206,8 @@ DEVI void panel_factor(double* A, int LD, double* dinv, double* bcast, int j0, i
 #pragma unroll
     for (int r = 0; r < R; ++r) { l[r] = av[r][jj] * rs; av[r][jj] = l[r]; }
     if (jj + 1 < 16) pown = __builtin_fma(-l[0], l[0], av[0][jj + 1]);    // the next pivot, in the lane that owns it
-    double* bw = PUB ? bcast + kPanelPubL + jj * 64 : bcast + (jj & 1) * 64;
+    double* bw = bcast + (jj & 1) * 64;
     bw[lane] = l[0];                                   // lanes 0..15 hold L(j0 + c, jj)
-    if (PUB) {
-      bcast[kPanelPubRs + jj] = rs;
-      *reinterpret_cast<volatile int*>(bcast + kPanelPubFlag) = flag_base + jj + 1;    // LDS operations of a wave complete in order
-    }
     if (PMIN) *pmin = fmin(*pmin, jj < w ? readlane_f64(piv_own, jj) : 1.0);     // off the chain
     if (jj + 1 < 16) {
       double lc = readlane_f64(l[0], jj + 1);
@@ -251,35 +241,6 @@ DEVI void panel_factor(double* A, int LD, double* dinv, double* bcast, int j0, i
 #pragma unroll
       for (int c = 0; c < 16; ++c) dst[c] = av[r][c];
     }
-  }
-}
-
-// The second wave of a panel pair: rows j0 + 64 + lane of the panel, factored behind the lead from what it publishes
-// (every multiplier a wave-uniform LDS read; no cross-lane traffic, no pivots of its own).
-DEVI void panel_follow(double* A, int LD, const double* pub, int j0, int m, int lane, int flag_base) {
-  const int row = j0 + 64 + lane;
-  double av[16];
-  const double* src = A + min(row, m) * LD + j0;
-#pragma unroll
-  for (int c = 0; c < 16; ++c) av[c] = src[c];
-  const volatile int* flag = reinterpret_cast<const volatile int*>(pub + kPanelPubFlag);
-#pragma unroll
-  for (int jj = 0; jj < 16; ++jj) {
-    while (*flag < flag_base + jj + 1) __builtin_amdgcn_s_sleep(1);
-    const double rs = pub[kPanelPubRs + jj];
-    const double* lp = pub + kPanelPubL + jj * 64;
-    double lc[16];
-#pragma unroll
-    for (int c = jj + 1; c < 16; ++c) lc[c] = lp[c];
-    const double l = av[jj] * rs;
-    av[jj] = l;
-#pragma unroll
-    for (int c = jj + 1; c < 16; ++c) av[c] = __builtin_fma(-l, lc[c], av[c]);
-  }
-  if (row <= m) {
-    double* dst = A + row * LD + j0;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) dst[c] = av[c];
   }
 }
 
