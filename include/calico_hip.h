@@ -209,7 +209,11 @@ int32_t calico_problem_finalize(calico_problem* p);
 
 /* ---- solve ------------------------------------------------------------ */
 /* Replaces ceres::Solve (batch_optimizer.cpp:72-73): Levenberg–Marquardt
- * trust region on the flattened problem, entirely on the device. */
+ * trust region on the flattened problem, entirely on the device. On return the
+ * summary, the iteration table and the parameter values are complete; a few
+ * kernels of iterations enqueued ahead of the device (they exit at once) may
+ * still be draining on the handle's stream -- later calls on the handle are
+ * ordered behind them. */
 int32_t calico_solve(calico_problem* p, const calico_solver_options* options,
                      calico_summary* summary);
 /* Per-iteration table of the last solve; returns rows written via *n_out. */
