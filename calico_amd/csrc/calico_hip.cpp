@@ -582,7 +582,7 @@ int finalize(calico_problem* p) {
   auto frame_rec = [&](const LayoutDev& L) -> size_t {
     const HSensor& hs = p->sensors[size_t(L.sensor)];
     const int P1 = 7 + (L.c_intr >= 0 ? hs.K : 0) + 3 * (L.c_q >= 0) + 3 * (L.c_t >= 0) + 3 * (L.c_bq >= 0) + 3 * (L.c_bt >= 0);
-    const int PE = ((P1 + 15) & ~15) + 1;
+    const int PE = P1 + 1;     // prim columns + the latency row / column
     return size_t(PE) * PE + size_t(L.ncols + 1);
   };
   {
@@ -692,7 +692,7 @@ int finalize(calico_problem* p) {
       const int p_t = pc; if (L.c_t >= 0) pc += 3;
       const int p_bq = pc; if (L.c_bq >= 0) pc += 3;
       const int p_bt = pc; if (L.c_bt >= 0) pc += 3;
-      const int p_r = pc, PT = (pc + 1 + 15) & ~15;
+      const int p_r = pc, PT = pc + 1;     // latency row / column right behind the prim columns
       if (tab_off[size_t(c.layout)] < 0) {
         tab_off[size_t(c.layout)] = int(prim_tab.size());
         std::vector<int> prim;

@@ -698,7 +698,7 @@ DEV PrimMap prim_map(const LayoutDev& L, const SensorDev& S) {
   m.bt = L.c_bt >= 0 ? pc : -1; if (L.c_bt >= 0) pc += 3;
   m.r = pc;
   m.P1 = pc + 1;                 // prim columns incl. residual
-  m.PT = (m.P1 + 15) & ~15;      // padded to MFMA tiles (16 or 32)
+  m.PT = m.P1;                   // index of the latency row / column of M_ext (right behind the prim columns)
   m.PE = m.PT + 1;               // M_ext = [[M, Qᵀ], [Q, qq]]
   return m;
 }
@@ -1231,7 +1231,7 @@ void launch_mark_outliers(const double* res, const uint8_t* valid, uint8_t* acti
 // LDS doubles of a frame workgroup whose layout has Ps small prim columns, P1e prim columns (residual included both) and
 // n1 local columns; the worst case over all layouts the frame kernel takes (P1e <= 31, Ps <= 25)
 size_t frame_lds_doubles(int Ps, int P1e, int n1) {
-  const int PTs = (Ps + 15) & ~15, PE = ((P1e + 15) & ~15) + 1;
+  const int PTs = (Ps + 15) & ~15, PE = P1e + 1;
   const int after = PTs * PTs + ((Ps * P1e + 1) & ~1) + ((3 * P1e + 1) & ~1) + ((3 * P1e + 1) / 2 + 1);
   const int SA = (std::max(Ps * kFramePad, after) + 1) & ~1;
   return size_t(SA) + size_t((PE * PE + 1) & ~1) + size_t(n1) + 16;
