@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       if (e < BP * kBcrFS) Xp[(e >> 4) * XLD + CF + (e & 15)] = pr.f[u];
     }
   };
-  const bool dbg = a.debug && bid < 2 && lane == 0 && (wave == 0 || wave == 5);
+  const bool dbg = CAL_DEV_TIMING(a.debug && bid < 2 && lane == 0 && (wave == 0 || wave == 5));
   long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define LTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   double pmin = 1.0;
@@ -705,7 +705,7 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
   // update of the candidate point reads (gradient, damping, the control points' current values): a dependent global
   // load costs about a microsecond here, the arithmetic next to nothing. Chain indices are clamped, not predicated,
   // so that the loads stay unconditional.
-  const bool bdbg = a.debug && dbg_first && tid == 0;
+  const bool bdbg = CAL_DEV_TIMING(a.debug && dbg_first && tid == 0);
   long long bt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, btk = bdbg ? __builtin_readcyclecounter() : 0;
 #define BTICK(i) if (bdbg) { const long long t_ = __builtin_readcyclecounter(); bt[i] += t_ - btk; btk = t_; }
   double ysep, ycv;
@@ -753,7 +753,7 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
   for (int c = 0; c < 6; ++c) px[c] = x[my_off + c];
   if (terminated) return;
   BTICK(0)
-  if (a.debug > 1) {     // development aid: which input of the node is not finite?
+  if (CAL_DEV_TIMING(a.debug > 1)) {     // development aid: which input of the node is not finite?
     bool bz = false, bm = false, ba = false, bt = false;
 #pragma unroll
     for (int i = 0; i < QM; ++i) {
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveA
     }
   }
   if (terminated) return;
-  const bool dbg = a.debug && (tid == 0 || tid == 64 * 5);
+  const bool dbg = CAL_DEV_TIMING(a.debug && (tid == 0 || tid == 64 * 5));
   long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define DTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   __syncthreads();

@@ -292,7 +292,14 @@ SolveArgs make_solve_args(calico_problem* p) {
   a.R = p->d_R.p; a.r_stride = p->speculative ? p->r_size : 0; a.Lb = p->d_Lb.p; a.Linv = p->d_Linv.p; a.Y = p->d_Y.p; a.S = p->d_S.p; a.Spart = p->d_Spart.p;
   a.Swork = p->d_Swork.p; a.y = p->d_y.p; a.zbuf = p->d_zbuf.p; a.dadd = p->d_dadd.p;
   a.scale = p->d_scale.p; a.cp_active = p->d_cp_active.p; a.st = p->d_state.p; a.n_cp = p->n_cp; a.k = p->order; a.mc = p->m; a.sep_s = p->sep_s; a.sep_n = p->sep_n; a.m = p->m + p->border_extra();
-  static const int dbg = std::getenv("CALICO_KERNEL_TIMING") ? std::atoi(std::getenv("CALICO_KERNEL_TIMING")) : 0;
+  static const int dbg = [] {
+    const int v = std::getenv("CALICO_KERNEL_TIMING") ? std::atoi(std::getenv("CALICO_KERNEL_TIMING")) : 0;
+#ifndef CALICO_DEV_TIMING
+    if (v) std::fprintf(stderr, "[calico] CALICO_KERNEL_TIMING is set, but this library was built without the kernels' development "
+                                "instrumentation (rebuild with CALICO_DEV_TIMING=1 in the environment of __graft_entry__.build())\n");
+#endif
+    return v;
+  }();
   a.debug = dbg;
   a.progress = nullptr;
   return a;

@@ -561,7 +561,7 @@ DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds) {
   if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
   const int lane = threadIdx.x;
   const int row_pad = a.row_pad;
-  const bool dbg = JAC && a.debug && (item_id == 3 || item_id == a.n_items - 2) && lane == 0;
+  const bool dbg = CAL_DEV_TIMING(JAC && a.debug && (item_id == 3 || item_id == a.n_items - 2) && lane == 0);
   long long tph[4] = {0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define ITICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   const ItemDev* ip = a.items + item_id;
@@ -777,7 +777,7 @@ DEV int frame_area_a(int Ps, int PTs, int P1e) {
 DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
   const int lane = threadIdx.x;
-  const bool dbg = a.debug && fidx == 7 && lane == 0;
+  const bool dbg = CAL_DEV_TIMING(a.debug && fidx == 7 && lane == 0);
   long long tph[6] = {0, 0, 0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define FTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   const FrameItemDev* ip = a.fitems + fidx;
@@ -1011,10 +1011,10 @@ __global__ __launch_bounds__(64) void eval_frames_kernel(EvalArgs a) {
 // single-wave computation, so they go first) and the camera frames run side by side instead of back to back.
 __global__ __launch_bounds__(64) void eval_jacobian_kernel(EvalArgs a) {
   extern __shared__ double lds[];
-  const unsigned long long t0 = a.debug >= 3 ? __builtin_amdgcn_s_memrealtime() : 0;
+  const unsigned long long t0 = CAL_DEV_TIMING(a.debug >= 3) ? __builtin_amdgcn_s_memrealtime() : 0;
   if (int(blockIdx.x) < a.n_items) eval_items_body<true, 6>(a, blockIdx.x, lds);
   else eval_frames_body(a, blockIdx.x - a.n_items, lds);
-  if (a.debug >= 3 && a.wave_log && threadIdx.x == 0) {   // CALICO_KERNEL_TIMING=3: life span of every wave (100 MHz clock)
+  if (CAL_DEV_TIMING(a.debug >= 3) && a.wave_log && threadIdx.x == 0) {   // CALICO_KERNEL_TIMING=3: life span of every wave (100 MHz clock)
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
     if (t1 - t0 > 200) { a.wave_log[2 * blockIdx.x] = t0; a.wave_log[2 * blockIdx.x + 1] = t1; }   // not the early exits after termination
   }
@@ -1048,7 +1048,7 @@ DEV void row_cell_body(const EvalArgs& a, const CellDev& cell, double* lds) {
     }
   }
   const double* src = a.partials + cell.src_off;
-  const bool dbg = a.debug && int(blockIdx.x) == a.n_cells - 3 && lane == 0;
+  const bool dbg = CAL_DEV_TIMING(a.debug && int(blockIdx.x) == a.n_cells - 3 && lane == 0);
   long long tph[4] = {0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define RTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   for (int i0 = 0; i0 < cell.frame_count; i0 += a.row_cell_chunk) {
@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
     return;
   }
   const int tid = threadIdx.x;
-  const bool dbg = a.debug && blockIdx.x == 5 && tid == 0;
+  const bool dbg = CAL_DEV_TIMING(a.debug && blockIdx.x == 5 && tid == 0);
   long long tph[5] = {0, 0, 0, 0, 0}, tk = t_start;
 #define CTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   const int n1 = cell.n1, PE = cell.PE, nme = PE * PE, rec = nme + n1;

@@ -14,6 +14,16 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// Development instrumentation of the kernels (cycle counts printed by one wave per kernel, life span of every wave of the
+// Jacobian launch: CALICO_KERNEL_TIMING). Compiled in only with -DCALICO_DEV_TIMING (CALICO_DEV_TIMING=1 in the
+// environment of __graft_entry__.build()): switched off at run time it still cost ~4 us per LM iteration in registers
+// and branches on the latency chains.
+#ifdef CALICO_DEV_TIMING
+#define CAL_DEV_TIMING(expr) (expr)
+#else
+#define CAL_DEV_TIMING(expr) false
+#endif
+
 namespace cal {
 
 constexpr int kRowsPerItem = 128;   // LDS rows staged per work item (64 camera obs × 2)

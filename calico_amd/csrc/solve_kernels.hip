@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
     }
   }
   long long tk0 = 0, tc[5] = {0, 0, 0, 0, 0};
-  const bool dbg = a.debug && blockIdx.x == 0 && (lane == 0);
+  const bool dbg = CAL_DEV_TIMING(a.debug && blockIdx.x == 0 && (lane == 0));
 #define TICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tc[i] += t_ - tk0; tk0 = t_; }
   // wave 3 keeps the current pivot factor in registers
   double Lc[6][6], dinv_c[6], dmin = 1.0;
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256) void reduced_solve_reg_kernel(SolveArgs a) {
       A[aa][bb] = (i <= m && c <= i && c < m1) ? a.Spart[size_t(i) * m1 + c] : 0.0;
     }
   const double dflag = (ti >= tj) ? 1.0 : 0.0;   // diagonal tiles: only c <= i
-  const bool dbg = a.debug && tid == 0;
+  const bool dbg = CAL_DEV_TIMING(a.debug && tid == 0);
   const long long t_begin = dbg ? __builtin_readcyclecounter() : 0;
   long long tph[4] = {0, 0, 0, 0}, tk = t_begin;
 #define RTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(256) void reduced_solve_panel_kernel(SolveArgs a, i
     }
   }
   __syncthreads();
-  const bool dbg = a.debug && (tid == 0 || tid == 64);
+  const bool dbg = CAL_DEV_TIMING(a.debug && (tid == 0 || tid == 64));
   long long tph[4] = {0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define PTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   double pmin = 1.0;
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(256) void reduced_block_step_kernel(SolveArgs a, in
   double* A = a.Spart;
   const size_t msq = size_t(m1) * m1;
   double* L = a.Swork;
-  const bool dbg = a.debug && blockIdx.x == 0 && j <= 1;
+  const bool dbg = CAL_DEV_TIMING(a.debug && blockIdx.x == 0 && j <= 1);
   long long tph[6] = {}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define BTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   // ---- loads: this wave's 64 rows of panel j, and this lane's 4×4 piece of the tile ----
