@@ -240,6 +240,7 @@ struct calico_problem {
   DevBuf<int> d_counter;
   int gather_owner_block = 0;
   bool active_dirty = true;
+  bool any_tagged = false;       // some observation is tagged as an outlier: the kernels look at the tags only then
   bool xc_stale = true;       // the candidate buffer must be re-seeded with the constant blocks' values
   DevBuf<SensorDev> d_sensors;
   DevBuf<LayoutDev> d_layouts;
@@ -386,7 +387,7 @@ EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool
   a.partials = p->d_partials.p; a.item_cost = p->d_partials.p + p->partial_doubles;
   a.res_out = want_res ? p->d_res.p : nullptr; a.valid_out = want_res ? p->d_valid.p : nullptr;
   a.order = p->order; a.n_items = p->n_items; a.lds_cols = p->lds_cols; a.row_pad = p->row_pad; a.n_cells = int(p->h_cells.size()); a.cells = p->d_cells.p; a.prim_tab = p->d_prim_tab.p;
-  a.cell_chunk = p->cell_chunk; a.cell_rec_max = p->cell_rec_max; a.project = 0; a.row_cell_chunk = p->row_cell_chunk; a.frame_lds_doubles = p->frame_lds_doubles; a.pad5 = 0; a.wave_log = p->d_wave_log.p; a.active = p->d_active.p; a.apply_loss = apply_loss;
+  a.cell_chunk = p->cell_chunk; a.cell_rec_max = p->cell_rec_max; a.project = 0; a.row_cell_chunk = p->row_cell_chunk; a.frame_lds_doubles = p->frame_lds_doubles; a.pad5 = 0; a.wave_log = p->d_wave_log.p; a.active = p->any_tagged ? p->d_active.p : nullptr; a.apply_loss = apply_loss;
   a.st = nullptr; a.need_flag = 0; a.cost_index_base = 0;
   a.fitems = p->d_fitems.p; a.n_fitems = p->n_fitems;
   return a;
@@ -960,8 +961,10 @@ int finalize(calico_problem* p) {
 int upload_x(calico_problem* p, bool seed = true) {
   if (p->active_dirty) {   // outlier tags, in the sorted order of the device arrays
     std::vector<uint8_t> act(size_t(std::max<int64_t>(p->n_obs, 1)), 1);
+    bool tagged = false;
     for (const HSensor& s : p->sensors)
-      for (int64_t i = 0; i < s.n(); ++i) act[size_t(s.sorted_pos[size_t(i)])] = s.active[size_t(i)];
+      for (int64_t i = 0; i < s.n(); ++i) { act[size_t(s.sorted_pos[size_t(i)])] = s.active[size_t(i)]; tagged = tagged || !s.active[size_t(i)]; }
+    p->any_tagged = tagged;
     HIP_TRY(p, hipMemcpyAsync(p->d_active.p, act.data(), size_t(p->n_obs), hipMemcpyHostToDevice, p->stream));
     HIP_TRY(p, hipStreamSynchronize(p->stream));   // `act` is a local
     p->active_dirty = false;
@@ -1712,6 +1715,7 @@ int32_t calico_mark_outliers(calico_problem* p, int32_t sid, double threshold, i
   HIP_TRY(p, hipStreamSynchronize(p->stream));
   for (int64_t i = 0; i < s.n(); ++i) s.active[size_t(i)] = act[size_t(s.sorted_pos[size_t(i)] - s.sorted_begin)];
   s.n_active = -1;
+  if (marked > 0) p->any_tagged = true;
   if (n_marked) *n_marked = marked;
   return CALICO_OK;
 }

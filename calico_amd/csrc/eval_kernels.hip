@@ -828,6 +828,7 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   double px_nx = a.m0[o_nx], py_nx = a.m1[o_nx];
   const double* xm_p = a.x + a.point_off[o_nx];
   double xm_nx[3] = {xm_p[0], xm_p[1], xm_p[2]};
+  uint8_t act_nx = a.active ? a.active[o_nx] : uint8_t(1);     // outlier tag (nullptr: nothing is tagged), fetched ahead like the rest
   // expansion coefficients: item column lc = coef[lc] · prim column (spline columns carry their weight w_i)
   for (int lc = lane; lc < n1; lc += 64) {
     double cf = 1.0;
@@ -855,13 +856,14 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
     FTICK(1)
     const double px = px_nx, py = py_nx;
     const double xm[3] = {xm_nx[0], xm_nx[1], xm_nx[2]};
+    const bool on = lane < nb && act_nx != 0;   // not tagged as an outlier
     if (b0 + 64 < it.obs_count) {   // wave-uniform: next batch's observation
       o_nx = obs_index(b0 + 64);
       px_nx = a.m0[o_nx]; py_nx = a.m1[o_nx];
       xm_p = a.x + a.point_off[o_nx];
       xm_nx[0] = xm_p[0]; xm_nx[1] = xm_p[1]; xm_nx[2] = xm_p[2];
+      if (a.active) act_nx = a.active[o_nx];
     }
-    const bool on = lane < nb && (!a.active || a.active[it.obs_begin + b0 + lane] != 0);   // not tagged as an outlier
     if (lane < nb && !on) {
       for (int c = 0; c < Ps; ++c) { Jp[c * kFramePad + 2 * lane] = 0.0; Jp[c * kFramePad + 2 * lane + 1] = 0.0; }
     }
