@@ -375,7 +375,9 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         for (int r = 0; r < 4; ++r) Zb[(16 * it + lk + 4 * r) * XLD + 16 * jt + l16] = acc[r];
       };
       zjob(wave >> 1, wave & 1);
-      if (role > 0 && wave < 2) zjob(4, wave);
+      // the border roles' fifth column tile: its two jobs (4 and 8 MFMAs) go to the SIMDs that carry two 4-MFMA jobs
+      // (waves 0/4 and 2/6), not to those with two 8-MFMA jobs: 16 instead of 24 MFMAs on the busiest matrix pipe
+      if (role > 0 && (wave == 0 || wave == 2)) zjob(4, wave == 0 ? 1 : 0);
     }
     lds_barrier();
     LTICK(4)
