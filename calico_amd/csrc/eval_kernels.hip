@@ -1137,6 +1137,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
   constexpr int NQ = 12;             // pairs per thread: n1 <= 77
   int pi[NQ], pj[NQ], pm_off[NQ];
   double acc[NQ];
+  // the first chunk of records is requested together with the pair table (both only need the cell descriptor)
+  const double* cell_src0 = a.partials + cell.src_off;
+  const int nf0 = min(a.cell_chunk, cell.frame_count), nw0 = nf0 * rec;
+  double rv[12];
+#pragma unroll
+  for (int u = 0; u < 12; ++u) rv[u] = cell_src0[min(tid + 256 * u, nw0 - 1)];
   {
     int e[NQ];
 #pragma unroll
@@ -1150,7 +1156,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
     const int nf = min(a.cell_chunk, cell.frame_count - f0);
     __syncthreads();
     const double* src = cell_src + size_t(f0) * rec;
-    for (int i = tid; i < nf * rec; i += 256) lds[i] = src[i];
+    if (f0 == 0) {
+#pragma unroll
+      for (int u = 0; u < 12; ++u) if (tid + 256 * u < nw0) lds[tid + 256 * u] = rv[u];
+      for (int i = tid + 256 * 12; i < nf * rec; i += 256) lds[i] = src[i];
+    } else {
+      for (int i = tid; i < nf * rec; i += 256) lds[i] = src[i];
+    }
     __syncthreads();
     CTICK(1)
     for (int f = 0; f < nf; ++f) {

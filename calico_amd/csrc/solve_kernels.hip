@@ -47,6 +47,16 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
                                                      const int* __restrict__ idx_fat, int n_fat, int nb_fat,
                                                      const double* __restrict__ cost_src, int n_cost,
                                                      const LmState* st, int need_flag, size_t other_stride, ControlTail tail) {
+  // (the list pointers of this thread's output do not depend on the state: requested before the flags are looked at)
+  int64_t pre_q0 = 0, pre_q1 = 0;
+  {
+    const int bidp = int(blockIdx.x) - 1;
+    if (bidp >= nb_fat) {
+      const int o = ((bidp - nb_fat) * int(blockDim.x) + int(threadIdx.x)) >> 3;
+      const int oc = o < n_thin ? o : n_thin - 1;
+      if (n_thin > 0) { pre_q0 = ptr_thin[oc]; pre_q1 = ptr_thin[oc + 1]; }
+    }
+  }
   if (st && (st->terminated || (need_flag && !st->need_jacobian))) {
     if (tail.enabled && tail.progress && st->terminated && blockIdx.x == 0 && threadIdx.x == 0) publish_progress(tail.progress, st, tail.seq);
     return;
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
     const int o = gid >> 3, sub = gid & 7;
     const bool live = o < n_thin;
     const int oc = live ? o : n_thin - 1;
-    const int64_t q0 = ptr_thin[oc], q1 = ptr_thin[oc + 1];     // at most 48 sources: six per lane
+    const int64_t q0 = pre_q0, q1 = pre_q1;     // at most 48 sources: six per lane
     int id[6];
 #pragma unroll
     for (int u = 0; u < 6; ++u) { const int64_t q = q0 + sub + 8 * u; id[u] = idx_thin[q < q1 ? q : q1 - 1]; }
