@@ -231,7 +231,6 @@ DEVI void panel_factor(double* A, int LD, double* dinv, double* bcast, int j0, i
 #pragma unroll
     for (int r = 0; r < R; ++r) lprev[r] = l[r];
     if (DINV) rs_keep = lane == jj ? rs_own : rs_keep;
-    __builtin_amdgcn_sched_barrier(0);
   }
   if (DINV && lane < 16) dinv[j0 + lane] = rs_keep;
 #pragma unroll
