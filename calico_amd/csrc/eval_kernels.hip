@@ -774,6 +774,14 @@ DEV int frame_area_a(int Ps, int PTs, int P1e) {
   return (max(Ps * kFramePad, after) + 1) & ~1;
 }
 
+// LDS traffic inside ONE wave (the frame and work-item kernels run one wave per workgroup): the wave's own LDS stores
+// are complete before its lanes read what the others wrote. __syncthreads() would also wait for the global loads
+// requested ahead (the next batch's observations).
+DEV void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
   const int lane = threadIdx.x;
@@ -852,7 +860,7 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   FTICK(0)
   for (int b0 = 0; b0 < it.obs_count; b0 += 64) {
     const int nb = min(64, it.obs_count - b0);
-    __syncthreads();
+    wave_lds_sync();
     FTICK(1)
     const double px = px_nx, py = py_nx;
     const double xm[3] = {xm_nx[0], xm_nx[1], xm_nx[2]};
@@ -885,7 +893,7 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
         for (int c = 0; c < Ps; ++c) { Jp[c * kFramePad + 2 * lane] = 0.0; Jp[c * kFramePad + 2 * lane + 1] = 0.0; }
       }
     }
-    __syncthreads();
+    wave_lds_sync();
     FTICK(2)
     const int nrows = 2 * nb;
     // operands are fetched eight steps (32 rows) at a time so the LDS latency is paid once per group
@@ -923,7 +931,7 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   const double n_invalid = wave_sum(n_bad);
   if (lane == 0) { a.item_cost[2 * fidx] = item_cost; a.item_cost[2 * fidx + 1] = n_invalid; }
   // ---- M_s to LDS (full symmetric; C/D layout: col = lane & 15, row = (lane >> 4) + 4·reg) ----
-  __syncthreads();
+  wave_lds_sync();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = lk + 4 * r;
@@ -953,7 +961,7 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
     bsrc[3 * j] = s0; bsrc[3 * j + 1] = s1; bsrc[3 * j + 2] = s2;
     bco[3 * j] = c0; bco[3 * j + 1] = c1; bco[3 * j + 2] = c2;
   }
-  __syncthreads();
+  wave_lds_sync();
   for (int idx = lane; idx < Ps * P1e; idx += 64) {                  // N = M_s B
     const int ar = idx / P1e, j = idx - ar * P1e;
     double sN = 0.0;
@@ -961,7 +969,7 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
     for (int u = 0; u < 3; ++u) sN += bco[3 * j + u] * Ms[ar * PTs + bsrc[3 * j + u]];
     Nmat[idx] = sN;
   }
-  __syncthreads();
+  wave_lds_sync();
   for (int idx = lane; idx < P1e * P1e; idx += 64) {                 // M = Bᵀ N
     const int i = idx / P1e, j = idx - i * P1e;
     double sM = 0.0;
@@ -969,21 +977,21 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
     for (int u = 0; u < 3; ++u) sM += bco[3 * i + u] * Nmat[bsrc[3 * i + u] * P1e + j];
     Me[i * PE + j] = sM;
   }
-  __syncthreads();
+  wave_lds_sync();
   if (lane < P1e) {                                                  // latency: dp/dlat = -pdot
     double sQ = 0.0;
 #pragma unroll
     for (int c = 0; c < 6; ++c) sQ -= pd[c] * Me[c * PE + lane];
     Me[PT * PE + lane] = sQ; Me[lane * PE + PT] = sQ;
   }
-  __syncthreads();
+  wave_lds_sync();
   if (lane == 0) {
     double qq = 0.0;
 #pragma unroll
     for (int c = 0; c < 6; ++c) qq -= pd[c] * Me[PT * PE + c];
     Me[PT * PE + PT] = qq;
   }
-  __syncthreads();
+  wave_lds_sync();
   FTICK(4)
   // ---- compact record: M_ext (PE×PE) then coef (n1). The expansion TᵀMT -- out(i, j) = coef_i coef_j M_ext(prim_i, prim_j)
   //      -- is done once per CELL by expand_cells_kernel over all its frames. Only prim rows / columns < P1e and the
