@@ -551,6 +551,14 @@ __device__ __attribute__((noinline)) void stage_b_mfma(const double* lds, int pa
       }
 }
 
+// LDS traffic inside ONE wave (the frame and work-item kernels run one wave per workgroup): the wave's own LDS stores
+// are complete before its lanes read what the others wrote. __syncthreads() would also wait for the global loads
+// requested ahead (the next batch's observations).
+DEV void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // ---------------------------------------------------------------------------
 // The evaluation kernel. JAC: stage Jacobian rows and form the item's
 // [JᵀJ | Jᵀr] block; !JAC: residuals / cost only.
@@ -626,7 +634,7 @@ DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) if (r < dim) sink.put(ncols, r, res[r]);
     }
-    __syncthreads();
+    wave_lds_sync();
     // Stage B: P = [J r]ᵀ [J r] on the matrix cores, upper 16×16 tiles (same scheme as the frame kernel: operand
     // element (col = 16t + (lane & 15), row = r0 + (lane >> 4)) serves as A of tile row t and as B of tile column t).
     const int n1 = ncols + 1;
@@ -772,14 +780,6 @@ DEV bool frame_camera_block(const SensorDev& S, const double* intr, const M3& R_
 DEV int frame_area_a(int Ps, int PTs, int P1e) {
   const int after = PTs * PTs + ((Ps * P1e + 1) & ~1) + ((3 * P1e + 1) & ~1) + ((3 * P1e + 1) / 2 + 1);
   return (max(Ps * kFramePad, after) + 1) & ~1;
-}
-
-// LDS traffic inside ONE wave (the frame and work-item kernels run one wave per workgroup): the wave's own LDS stores
-// are complete before its lanes read what the others wrote. __syncthreads() would also wait for the global loads
-// requested ahead (the next batch's observations).
-DEV void wave_lds_sync() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
 }
 
 DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
