@@ -996,10 +996,13 @@ __global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveA
     const int t_first = 2 * (jb + 1), T = mp / 16 - t_first;
     const int ntile = T * (T + 1) / 2;
     // tile q of the row-major lower triangle: q = 0, 1, 2 are (0,0), (1,0), (1,1) -- the next diagonal block
-    const int per_wave = (ntile - 3 + 6) / 7, half = (per_wave + 1) / 2;
+    // (six waves: wave 4 shares the panel wave's SIMD and stays out of its way, as in the tree levels)
+    if (wave == 4) return;
+    const int widx = wave < 4 ? wave - 1 : wave - 2;
+    const int per_wave = (ntile - 3 + 5) / 6, half = (per_wave + 1) / 2;
     const int k0 = batch == 0 ? 0 : half, k1 = batch == 0 ? half : per_wave;
     for (int k = k0; k < k1; ++k) {
-      const int q = 3 + (wave - 1) + 7 * k;
+      const int q = 3 + widx + 6 * k;
       if (q >= ntile) break;
       int I = 0, rem = q;
       while (rem > I) { rem -= I + 1; ++I; }
