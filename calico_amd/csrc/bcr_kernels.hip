@@ -687,7 +687,8 @@ DEVI void back_calib(const SolveArgs& a, const BcrArgs& b, const double* __restr
 // reading b.zb. QM bounds the unrolled load batches (longest chain of the level).
 template <int QM>
 DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __restrict__ ndp, int top, int q_max, int terminated,
-                    bool dbg_first, const double* __restrict__ x, double* __restrict__ x_cand, double* lds, double* sh) {
+                    bool dbg_first, const double* __restrict__ x, double* __restrict__ x_cand, double* lds, double* sh,
+                    const BcrTopSeps& ts) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_s = a.n_s(), mc = a.mc, m1p = b.m1p;
   const size_t fblk = size_t(BP) * m1p;
@@ -702,6 +703,15 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
   double* wv = yn + BP;                                // [32]
   double* yc = wv + BP;                                // [m1p]
   double* ych = yc + m1p;                              // [q_max][32] the chain's solutions
+  double* wsep = ych + size_t(q_max) * BP;             // [2][32] top separators solved here: L⁻¹g - Z^F y_c - Z^A y_root - Z^B y_root
+  double* ysr = wsep + 2 * BP;                         // [32] solution of the top separator on the right (this node files it)
+  double* yroot = ysr + BP;                            // [32]
+  // Top separators next to this chain (their own launch is gone: see BcrTopSeps). Side 0 = left, 1 = right; the node
+  // that has one on its right files its solution and updates its control points (threads 480.. and 448..).
+  int sk[2] = {-1, -1};
+  for (int k = 0; k < ts.n; ++k) { if (nd_left == ts.blk[k]) sk[0] = k; if (nd_right == ts.blk[k]) sk[1] = k; }
+  const bool side = sk[0] >= 0 || sk[1] >= 0;
+  const int sep_r = sk[1] >= 0 ? nd_right : -1;
   // Everything the node needs is requested before anything is consumed -- the separators' solutions, Z^B and L⁻ᵀ of
   // every block (to LDS), this thread's entries of Z^A and of L⁻¹g - Z^F y_c (sixteen threads per row), and what the
   // update of the candidate point reads (gradient, damping, the control points' current values): a dependent global
@@ -712,8 +722,8 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
 #define BTICK(i) if (bdbg) { const long long t_ = __builtin_readcyclecounter(); bt[i] += t_ - btk; btk = t_; }
   double ysep, ycv;
   {
-    const double* pl = nd_left >= 0 ? sep_solution(a, b, nd_left) : a.y;
-    const double* pr = nd_right >= 0 ? sep_solution(a, b, nd_right) : a.y;
+    const double* pl = nd_left >= 0 && sk[0] < 0 ? sep_solution(a, b, nd_left) : a.y;
+    const double* pr = nd_right >= 0 && sk[1] < 0 ? sep_solution(a, b, nd_right) : a.y;
     const double vl = pl[tid & 31], vr = pr[tid & 31];
     // the root's solution comes from the reduced solve, which knows its 30 real rows only: the two padding rows are 0,
     // not whatever sits behind them in y (an uninitialised word there may be a NaN, and NaN times a zero column is NaN)
@@ -723,6 +733,23 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
     ycv = a.y[n_s + min(tid, mc - 1 > 0 ? mc - 1 : 0)];
   }
   const int r16 = tid >> 4, sub = tid & 15;
+  double s_yv[2][8], s_za[2][2], s_zb[2][2], s_mm[2][2], s_zt[2], yroot_v = 0.0;
+  if (side) {
+    // (the root's solution: its 30 real rows, see above)
+    yroot_v = (b.root >= 0 && (tid & 31) < RB) ? a.y[n_s + mc + (tid & 31)] : 0.0;
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd) {
+      const int eb = sk[sd] >= 0 ? ts.blk[sk[sd]] : blk0;       // (clamped, not predicated: harmless loads)
+      const double* yrow = b.Y + size_t(eb) * fblk + size_t(r16) * m1p;
+      s_zt[sd] = yrow[mc];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s_yv[sd][u] = yrow[min(sub + 16 * u, m1p - 1)];
+      const size_t g = size_t(eb) * BB + size_t(r16) * BP + sub;
+      s_za[sd][0] = b.ZA[g]; s_za[sd][1] = b.ZA[g + 16];
+      s_zb[sd][0] = b.ZB[g]; s_zb[sd][1] = b.ZB[g + 16];
+      s_mm[sd][0] = b.M[g]; s_mm[sd][1] = b.M[g + 16];
+    }
+  }
   double vz[QM][2], vm[QM][2], za[QM][2], zt[QM], yv[QM][8];
 #pragma unroll
   for (int i = 0; i < QM; ++i) {
@@ -742,11 +769,12 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
     }
   }
   // update stage: thread e < 32q owns row e of the chain (gradient, damping), thread e < 5q control point e
-  const int my_row_t = RB * (blk0 + (tid >> 5)) + (tid & 31);
-  const bool my_row_ok = tid < q * BP && (tid & 31) < RB && my_row_t < n_s;
+  const bool sep_row = sep_r >= 0 && tid >= 480, sep_cp = sep_r >= 0 && tid >= 448 && tid < 448 + kBcrCps;
+  const int my_row_t = sep_row ? RB * sep_r + (tid & 31) : RB * (blk0 + (tid >> 5)) + (tid & 31);
+  const bool my_row_ok = (tid < q * BP || sep_row) && (tid & 31) < RB && my_row_t < n_s;
   const double my_g = a.R[a.off_g() + (my_row_ok ? my_row_t : 0)], my_dadd = a.dadd[my_row_ok ? my_row_t : 0];
-  const int my_cp = kBcrCps * blk0 + tid;     // the chain's control points are consecutive
-  const bool my_cp_in = tid < q * kBcrCps && my_cp < a.n_cp;
+  const int my_cp = sep_cp ? kBcrCps * sep_r + (tid - 448) : kBcrCps * blk0 + tid;     // the chain's control points are consecutive
+  const bool my_cp_in = (tid < q * kBcrCps || sep_cp) && my_cp < a.n_cp;
   const int my_cp_c = my_cp_in ? my_cp : 0;
   const int my_off = b.ctrl_off[my_cp_c];
   const bool my_cp_ok = my_cp_in && (b.all_active || a.cp_active[my_cp_c] != 0);
@@ -767,6 +795,7 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
              nd_left, nd_right, tid, int(bz), int(bm), int(ba), int(bt), int(tid < 2 * BP && !isfinite(ysep)), int(top && tid < mc && !isfinite(ycv)));
   }
   if (tid < BP) ya[tid] = ysep; else if (tid < 2 * BP) yn[tid - BP] = ysep;
+  if (side && tid < BP) yroot[tid] = yroot_v;
   if (top) {
     if (tid < m1p) yc[tid] = tid < mc ? ycv : 0.0;
     for (int j = tid + kBackThreads; j < m1p; j += kBackThreads) yc[j] = j < mc ? a.y[n_s + j] : 0.0;
@@ -783,6 +812,34 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
     }
   }
   __syncthreads();
+  if (side) {
+    // y_e = L⁻ᵀ(L⁻¹g_e - Z^F y_c - Z^A y_root - Z^B y_root) of the top separators on either side (sixteen threads per row)
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd) {
+      if (sk[sd] >= 0) {
+        const int k = sk[sd];
+        const double* yrow = b.Y + size_t(ts.blk[k]) * fblk + size_t(r16) * m1p;
+        double part = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) part += sub + 16 * u < mc ? s_yv[sd][u] * yc[sub + 16 * u] : 0.0;
+        for (int j = sub + 128; j < mc; j += 16) part += yrow[j] * yc[j];
+        if (ts.left[k] >= 0) part += s_za[sd][0] * yroot[sub] + s_za[sd][1] * yroot[sub + 16];
+        if (ts.right[k] >= 0) part += s_zb[sd][0] * yroot[sub] + s_zb[sd][1] * yroot[sub + 16];
+        part += __shfl_xor(part, 8, 64); part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 1, 64);
+        if (sub == 0) wsep[sd * BP + r16] = s_zt[sd] - part;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd) {
+      if (sk[sd] >= 0) {
+        double yp = s_mm[sd][0] * wsep[sd * BP + sub] + s_mm[sd][1] * wsep[sd * BP + sub + 16];
+        yp += __shfl_xor(yp, 8, 64); yp += __shfl_xor(yp, 4, 64); yp += __shfl_xor(yp, 2, 64); yp += __shfl_xor(yp, 1, 64);
+        if (sub == 0) { if (sd == 0) ya[r16] = yp; else { yn[r16] = yp; ysr[r16] = yp; } }
+      }
+    }
+    __syncthreads();
+  }
   BTICK(1)
   // t_i = (L⁻¹g_i - Z^F y_c) - Z^A y_a : sixteen threads per row, fixed-shape reduction
 #pragma unroll
@@ -833,9 +890,9 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
   __syncthreads();
   BTICK(4)
   // file the solutions, update the candidate point of the chain's control points (delta = -y, plain vector blocks)
-  if (tid < q * BP) {
-    const double yj = ych[tid];
-    b.ysol[size_t(blk0) * BP + tid] = yj;
+  if (tid < q * BP || sep_row) {
+    const double yj = sep_row ? ysr[tid & 31] : ych[tid];
+    b.ysol[sep_row ? size_t(sep_r) * BP + (tid & 31) : size_t(blk0) * BP + tid] = yj;
     if (my_row_ok) {
       if (!isfinite(yj)) s.bad = 1;
       s.mcc += 0.5 * yj * (my_g + yj * my_dadd);
@@ -843,7 +900,7 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
     }
   }
   if (my_cp_ok) {
-    const double* yb = ych + (tid / kBcrCps) * BP + 6 * (tid % kBcrCps);
+    const double* yb = sep_cp ? ysr + 6 * (tid - 448) : ych + (tid / kBcrCps) * BP + 6 * (tid % kBcrCps);
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const double v = px[c] - yb[c];
@@ -866,7 +923,7 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
 template <int QM>     // longest chain of the level
 __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, BcrArgs b, int node0, int n_nodes, int top, int extras, int q_max,
                                                                 const double* __restrict__ x, double* __restrict__ x_cand,
-                                                                const BlockDev* __restrict__ blocks, int n_blocks) {
+                                                                const BlockDev* __restrict__ blocks, int n_blocks, BcrTopSeps ts) {
   LmState* st = a.st;
   const int terminated = st->terminated;     // tested after the loads are on their way
   use_current_R(a);
@@ -891,7 +948,7 @@ __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, Bcr
   }
   if (int(blockIdx.x) == n_nodes) { back_calib(a, b, x, x_cand, blocks, n_blocks, sh); return; }
   (void)extras;
-  back_node<QM>(a, b, b.nodes + node0 + blockIdx.x, top, q_max, terminated, blockIdx.x == 0, x, x_cand, lds, sh);
+  back_node<QM>(a, b, b.nodes + node0 + blockIdx.x, top, q_max, terminated, blockIdx.x == 0, x, x_cand, lds, sh, ts);
 }
 
 // ---------------------------------------------------------------------------
@@ -1152,7 +1209,7 @@ void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s) {
 // ---- launch helpers ---------------------------------------------------------
 size_t bcr_level_lds_bytes() { return size_t(2 * 64 * DLD + 3 * BP * XLD + 80 + 128 + kLevelThreads) * sizeof(double); }
 size_t bcr_back_lds_bytes(int q_max, int m1p) {
-  return (size_t(2) * q_max * BP * DLD + kBcrMaxChain * BP + 3 * BP + m1p + size_t(q_max) * BP) * sizeof(double);
+  return (size_t(2) * q_max * BP * DLD + kBcrMaxChain * BP + 3 * BP + m1p + size_t(q_max) * BP + 4 * BP) * sizeof(double);
 }
 hipError_t configure_bcr_kernels(int q_max, int m1p) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bcr_level_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1189,12 +1246,12 @@ void launch_bcr_schur(const SolveArgs& a, const BcrArgs& b, int ks, const LmOpti
   const int n_tile_wg = nt * (nt + 1) / 2 * ks;
   hipLaunchKernelGGL(bcr_schur_kernel, dim3(n_tile_wg + (b.root >= 0 ? 4 : 0)), dim3(256), 0, s, a, b, ks, n_tile_wg, o);
 }
-void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, bool top, bool extras, int q_max, const double* x,
-                     double* x_cand, const BlockDev* blocks, int n_blocks, hipStream_t s) {
-  const int n_mv = (b.N * BP + kBackThreads / 64 - 1) / (kBackThreads / 64);
+void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, bool top, bool extras, bool border_rows, int q_max,
+                     const double* x, double* x_cand, const BlockDev* blocks, int n_blocks, const BcrTopSeps& ts, hipStream_t s) {
+  const int n_mv = border_rows ? (b.N * BP + kBackThreads / 64 - 1) / (kBackThreads / 64) : 0;   // (nobody below reads b.zb: no sweep)
   const dim3 grid(n_nodes + (extras ? 1 + n_mv : 0)), block(kBackThreads);
   const size_t lds = bcr_back_lds_bytes(q_max, b.m1p);
-#define LAUNCH_BACK(QM) hipLaunchKernelGGL(bcr_back_kernel<QM>, grid, block, lds, s, a, b, node0, n_nodes, top ? 1 : 0, extras ? 1 : 0, q_max, x, x_cand, blocks, n_blocks)
+#define LAUNCH_BACK(QM) hipLaunchKernelGGL(bcr_back_kernel<QM>, grid, block, lds, s, a, b, node0, n_nodes, top ? 1 : 0, extras ? 1 : 0, q_max, x, x_cand, blocks, n_blocks, ts)
   if (q_max <= 1) LAUNCH_BACK(1); else if (q_max <= 2) LAUNCH_BACK(2); else if (q_max <= 4) LAUNCH_BACK(4); else LAUNCH_BACK(8);
 #undef LAUNCH_BACK
 }

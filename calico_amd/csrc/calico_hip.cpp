@@ -78,8 +78,8 @@ void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nod
                       const double* x, const BlockDev* blocks, int n_blocks, bool with_post_eval, IterLog* log, int log_cap, int jacobi,
                       hipStream_t s);
 void launch_bcr_schur(const SolveArgs& a, const BcrArgs& b, int ks, const LmOptionsDev& o, hipStream_t s);
-void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, bool top, bool extras, int q_max, const double* x,
-                     double* x_cand, const BlockDev* blocks, int n_blocks, hipStream_t s);
+void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, bool top, bool extras, bool border_rows, int q_max,
+                     const double* x, double* x_cand, const BlockDev* blocks, int n_blocks, const BcrTopSeps& ts, hipStream_t s);
 
 void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipStream_t s);
 int reduced_schur_slices(const SolveArgs& a);
@@ -1051,9 +1051,28 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
   const int ks = reduced_schur_slices(sa);
   launch_bcr_schur(sa, b, ks, o, s);
   launch_reduced_solve(sa, p->dense_in_lds, ks, s);
+  // The top level of the tree is one or two single superblocks next to the root: their back-substitution rides in the
+  // launch of the level below (every node there solves the top separators beside it itself -- a few more loads next to
+  // the ones it waits for anyway) instead of costing a launch of its own.
+  static const bool merge_env = [] { const char* e = std::getenv("CALICO_BCR_MERGE_TOP"); return !e || std::atoi(e) != 0; }();
+  BcrTopSeps ts = {};
+  if (merge_env && L >= 2) {
+    const calico_problem::BcrLevel& tl = p->bcr_levels[size_t(L - 1)];
+    bool ok = tl.n_nodes <= 2;
+    for (int i = 0; ok && i < tl.n_nodes; ++i) {
+      const BcrNodeDev& nd = p->h_bcr_nodes[size_t(tl.node0 + i)];
+      ok = nd.q == 1 && (nd.left < 0 || nd.left == p->bcr_root) && (nd.right < 0 || nd.right == p->bcr_root);
+      ts.blk[i] = nd.blk0; ts.left[i] = nd.left; ts.right[i] = nd.right;
+    }
+    ts.n = ok ? tl.n_nodes : 0;
+  }
   for (int l = L - 1; l >= 0; --l) {
     const calico_problem::BcrLevel& lv = p->bcr_levels[size_t(l)];
-    launch_bcr_back(sa, b, lv.node0, lv.n_nodes, l == L - 1, l == L - 1, lv.q_max, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, s);
+    if (ts.n > 0 && l == L - 1) continue;
+    const bool first = l == L - 1 || (ts.n > 0 && l == L - 2);     // the first launch behind the reduced solve
+    const BcrTopSeps none = {};
+    launch_bcr_back(sa, b, lv.node0, lv.n_nodes, first, first, /*border_rows=*/l > 0, lv.q_max, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks,
+                    first ? ts : none, s);
   }
   // development aid (CALICO_CHECK_FINITE=1): where does the first non-finite value of a solve sit?
   static const bool check = std::getenv("CALICO_CHECK_FINITE") != nullptr;

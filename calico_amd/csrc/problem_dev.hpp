@@ -260,6 +260,13 @@ struct BcrNodeDev {
   int pend;                  // bit 0 / 1: the (single) superblock carries a pending update from the chain on its left / right (previous level)
 };
 
+// The top level's nodes (single superblocks between the root and the ends) when their back-substitution rides in the
+// launch of the level below: every node there solves the top separators next to it itself (n = 0: separate launch).
+struct BcrTopSeps {
+  int n;
+  int blk[2], left[2], right[2];     // superblock, and its own separators (the root or -1)
+};
+
 struct BcrArgs {
   double* D;                 // [N][32][32]   diagonal superblocks (damped), symmetric, full storage
   double* G;                 // [2][N][32][32] coupling to the NEXT surviving superblock: G[b][r][c] = H(next row r, b column c); ping-pong by level

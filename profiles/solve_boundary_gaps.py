@@ -21,7 +21,26 @@ def main():
     starts = [i for i, r in enumerate(rows) if "begin_solve" in r[2]] or [i for i, r in enumerate(rows) if "init_state" in r[2]]
     if len(starts) < 4:
         raise SystemExit("not enough solves in the trace")
-    i0 = starts[len(starts) // 2]
+    # all boundaries: idle time from the last working kernel (> 6 us) of a solve to the next solve's begin kernel, and how
+    # many early-exit kernels of the old solve start before / after that begin kernel (two alternating streams: after)
+    gaps = []
+    for i in starts[1:]:
+        j = i - 1
+        while j > 0 and ((rows[j][1] - rows[j][0]) < 6000 or rows[j][0] > rows[i][0]):
+            j -= 1
+        before = sum(1 for r in rows[j + 1:i] if "memory copy" not in r[2])
+        k = i + 1
+        after = 0
+        while k < len(rows) and "bcr_level_kernelILb1" not in rows[k][2]:
+            after += (rows[k][1] - rows[k][0]) < 6000
+            k += 1
+        gaps.append(((rows[i][0] - rows[j][1]) / 1e3, before, after))
+    gs = sorted(g[0] for g in gaps)
+    print("solve boundaries: %d   idle before the begin kernel: min %.1f  median %.1f  p90 %.1f us" % (len(gs), gs[0], gs[len(gs) // 2], gs[int(len(gs) * 0.9)]))
+    print("early-exit kernels between the last working kernel and the begin kernel (median): %d; small kernels after it, before the first level kernel (median): %d" % (
+        sorted(g[1] for g in gaps)[len(gaps) // 2], sorted(g[2] for g in gaps)[len(gaps) // 2]))
+    med = gs[len(gs) // 2]
+    i0 = min(zip(starts[1:], gaps), key=lambda t: abs(t[1][0] - med))[0]     # a boundary of median length, in detail
     # walk back to the last kernel of the previous solve that did work (> 6 us)
     j = i0 - 1
     while j > 0 and (rows[j][1] - rows[j][0]) < 6000:
