@@ -685,14 +685,16 @@ DEVI void back_calib(const SolveArgs& a, const BcrArgs& b, const double* __restr
 // One node of the tree: back-substitution of its chain and update of the candidate point of its control points; one
 // workgroup of kBackThreads threads. `top`: the node forms L⁻¹g - Z^F y_c itself (sweeping its border rows) instead of
 // reading b.zb. QM bounds the unrolled load batches (longest chain of the level).
-template <int QM>
-DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __restrict__ ndp, int top, int q_max, int terminated,
+template <int QM, int MODE>      // MODE 0: reads b.zb; 1: `top`; 2: top + the top separators beside the chain (BcrTopSeps)
+DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __restrict__ ndp, int /*top*/, int q_max, int terminated,
                     bool dbg_first, const double* __restrict__ x, double* __restrict__ x_cand, double* lds, double* sh,
                     const BcrTopSeps& ts) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_s = a.n_s(), mc = a.mc, m1p = b.m1p;
   const size_t fblk = size_t(BP) * m1p;
   constexpr int RB = 6 * kBcrCps;
+  constexpr bool SIDE = MODE == 2;
+  constexpr int top = MODE >= 1 ? 1 : 0;       // compile-time: the border rows' registers exist only where they are used
   UpdSums s = {0.0, 0.0, 0.0, 0};
   const int q = ndp->q, nd_left = ndp->left, nd_right = ndp->right, nd_slot = ndp->slot, blk0 = ndp->blk0;
   double* ZBs = lds;                                   // [q][32][33]
@@ -709,8 +711,8 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
   // Top separators next to this chain (their own launch is gone: see BcrTopSeps). Side 0 = left, 1 = right; the node
   // that has one on its right files its solution and updates its control points (threads 480.. and 448..).
   int sk[2] = {-1, -1};
-  for (int k = 0; k < ts.n; ++k) { if (nd_left == ts.blk[k]) sk[0] = k; if (nd_right == ts.blk[k]) sk[1] = k; }
-  const bool side = sk[0] >= 0 || sk[1] >= 0;
+  if (SIDE) for (int k = 0; k < ts.n; ++k) { if (nd_left == ts.blk[k]) sk[0] = k; if (nd_right == ts.blk[k]) sk[1] = k; }
+  const bool side = SIDE && (sk[0] >= 0 || sk[1] >= 0);
   const int sep_r = sk[1] >= 0 ? nd_right : -1;
   // Everything the node needs is requested before anything is consumed -- the separators' solutions, Z^B and L⁻ᵀ of
   // every block (to LDS), this thread's entries of Z^A and of L⁻¹g - Z^F y_c (sixteen threads per row), and what the
@@ -720,6 +722,15 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
   const bool bdbg = CAL_DEV_TIMING(a.debug && dbg_first && tid == 0);
   long long bt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, btk = bdbg ? __builtin_readcyclecounter() : 0;
 #define BTICK(i) if (bdbg) { const long long t_ = __builtin_readcyclecounter(); bt[i] += t_ - btk; btk = t_; }
+  // update stage: thread e < 32q owns row e of the chain (gradient, damping), thread e < 5q control point e. The offset
+  // of the control point goes first: its values are a dependent load, and loads return in order.
+  const bool sep_row = sep_r >= 0 && tid >= 480, sep_cp = sep_r >= 0 && tid >= 448 && tid < 448 + kBcrCps;
+  const int my_row_t = sep_row ? RB * sep_r + (tid & 31) : RB * (blk0 + (tid >> 5)) + (tid & 31);
+  const bool my_row_ok = (tid < q * BP || sep_row) && (tid & 31) < RB && my_row_t < n_s;
+  const int my_cp = sep_cp ? kBcrCps * sep_r + (tid - 448) : kBcrCps * blk0 + tid;     // the chain's control points are consecutive
+  const bool my_cp_in = (tid < q * kBcrCps || sep_cp) && my_cp < a.n_cp;
+  const int my_cp_c = my_cp_in ? my_cp : 0;
+  const int my_off = b.ctrl_off[my_cp_c];
   double ysep, ycv;
   {
     const double* pl = nd_left >= 0 && sk[0] < 0 ? sep_solution(a, b, nd_left) : a.y;
@@ -733,7 +744,10 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
     ycv = a.y[n_s + min(tid, mc - 1 > 0 ? mc - 1 : 0)];
   }
   const int r16 = tid >> 4, sub = tid & 15;
-  double s_yv[2][8], s_za[2][2], s_zb[2][2], s_mm[2][2], s_zt[2], yroot_v = 0.0;
+  // (16-byte loads throughout: a workgroup issues a 64-lane load every ~12 clocks whatever its width, and the node waits
+  //  for a few hundred of them. Thread (r16, sub) owns columns 2·sub, 2·sub + 1 (+ 32u for the border) of row r16.)
+  double2 s_yv[2][4], s_za[2], s_zb[2], s_mm[2];
+  double s_zt[2], yroot_v = 0.0;
   if (side) {
     // (the root's solution: its 30 real rows, see above)
     yroot_v = (b.root >= 0 && (tid & 31) < RB) ? a.y[n_s + mc + (tid & 31)] : 0.0;
@@ -743,40 +757,31 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
       const double* yrow = b.Y + size_t(eb) * fblk + size_t(r16) * m1p;
       s_zt[sd] = yrow[mc];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s_yv[sd][u] = yrow[min(sub + 16 * u, m1p - 1)];
-      const size_t g = size_t(eb) * BB + size_t(r16) * BP + sub;
-      s_za[sd][0] = b.ZA[g]; s_za[sd][1] = b.ZA[g + 16];
-      s_zb[sd][0] = b.ZB[g]; s_zb[sd][1] = b.ZB[g + 16];
-      s_mm[sd][0] = b.M[g]; s_mm[sd][1] = b.M[g + 16];
+      for (int u = 0; u < 4; ++u) s_yv[sd][u] = reinterpret_cast<const double2*>(yrow)[min(sub + 16 * u, m1p / 2 - 1)];
+      const size_t g2 = size_t(eb) * (BB / 2) + tid;
+      s_za[sd] = reinterpret_cast<const double2*>(b.ZA)[g2];
+      s_zb[sd] = reinterpret_cast<const double2*>(b.ZB)[g2];
+      s_mm[sd] = reinterpret_cast<const double2*>(b.M)[g2];
     }
   }
-  double vz[QM][2], vm[QM][2], za[QM][2], zt[QM], yv[QM][8];
+  static_assert(kBackThreads * 2 == BB, "one 16-byte load per thread covers a 32x32 block");
+  double2 vz[QM], vm[QM], za[QM], yv[QM][4];
+  double zt[QM];
 #pragma unroll
   for (int i = 0; i < QM; ++i) {
     const int blk = blk0 + min(i, q - 1);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const size_t g = size_t(blk) * BB + tid + kBackThreads * u;
-      vz[i][u] = b.ZB[g]; vm[i][u] = b.M[g];
-    }
-    const double* arow = b.ZA + size_t(blk) * BB + size_t(r16) * BP;
-    za[i][0] = arow[sub]; za[i][1] = arow[sub + 16];
+    const size_t g2 = size_t(blk) * (BB / 2) + tid;
+    vz[i] = reinterpret_cast<const double2*>(b.ZB)[g2];
+    vm[i] = reinterpret_cast<const double2*>(b.M)[g2];
+    za[i] = reinterpret_cast<const double2*>(b.ZA)[g2];
     const double* yrow = b.Y + size_t(blk) * fblk + size_t(r16) * m1p;
     zt[i] = top ? yrow[mc] : b.zb[size_t(blk) * BP + r16];
     if (top) {       // this thread's share of the border row (the first 128 calibration columns)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) yv[i][u] = yrow[min(sub + 16 * u, m1p - 1)];
+      for (int u = 0; u < 4; ++u) yv[i][u] = reinterpret_cast<const double2*>(yrow)[min(sub + 16 * u, m1p / 2 - 1)];
     }
   }
-  // update stage: thread e < 32q owns row e of the chain (gradient, damping), thread e < 5q control point e
-  const bool sep_row = sep_r >= 0 && tid >= 480, sep_cp = sep_r >= 0 && tid >= 448 && tid < 448 + kBcrCps;
-  const int my_row_t = sep_row ? RB * sep_r + (tid & 31) : RB * (blk0 + (tid >> 5)) + (tid & 31);
-  const bool my_row_ok = (tid < q * BP || sep_row) && (tid & 31) < RB && my_row_t < n_s;
   const double my_g = a.R[a.off_g() + (my_row_ok ? my_row_t : 0)], my_dadd = a.dadd[my_row_ok ? my_row_t : 0];
-  const int my_cp = sep_cp ? kBcrCps * sep_r + (tid - 448) : kBcrCps * blk0 + tid;     // the chain's control points are consecutive
-  const bool my_cp_in = (tid < q * kBcrCps || sep_cp) && my_cp < a.n_cp;
-  const int my_cp_c = my_cp_in ? my_cp : 0;
-  const int my_off = b.ctrl_off[my_cp_c];
   const bool my_cp_ok = my_cp_in && (b.all_active || a.cp_active[my_cp_c] != 0);
   double px[6];
 #pragma unroll
@@ -787,8 +792,8 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
     bool bz = false, bm = false, ba = false, bt = false;
 #pragma unroll
     for (int i = 0; i < QM; ++i) {
-      if (i < q) { bz = bz || !isfinite(vz[i][0]) || !isfinite(vz[i][1]); bm = bm || !isfinite(vm[i][0]) || !isfinite(vm[i][1]);
-                   ba = ba || !isfinite(za[i][0]) || !isfinite(za[i][1]); bt = bt || !isfinite(zt[i]); }
+      if (i < q) { bz = bz || !isfinite(vz[i].x) || !isfinite(vz[i].y); bm = bm || !isfinite(vm[i].x) || !isfinite(vm[i].y);
+                   ba = ba || !isfinite(za[i].x) || !isfinite(za[i].y); bt = bt || !isfinite(zt[i]); }
     }
     if (bz || bm || ba || bt || (tid < 2 * BP && !isfinite(ysep)) || (top && tid < mc && !isfinite(ycv)))
       printf("bcr_back top %d node %d (blk0 %d q %d left %d right %d) tid %d: ZB %d M %d ZA %d zt %d ysep %d ycv %d\n", top, int(blockIdx.x), blk0, q,
@@ -803,12 +808,8 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
 #pragma unroll
   for (int i = 0; i < QM; ++i) {
     if (i < q) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int e = tid + kBackThreads * u;
-        const int o = (i * BP + (e >> 5)) * DLD + (e & 31);
-        ZBs[o] = vz[i][u]; Ms[o] = vm[i][u];
-      }
+      const int o = (i * BP + r16) * DLD + 2 * sub;
+      ZBs[o] = vz[i].x; ZBs[o + 1] = vz[i].y; Ms[o] = vm[i].x; Ms[o + 1] = vm[i].y;
     }
   }
   __syncthreads();
@@ -821,10 +822,14 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
         const double* yrow = b.Y + size_t(ts.blk[k]) * fblk + size_t(r16) * m1p;
         double part = 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) part += sub + 16 * u < mc ? s_yv[sd][u] * yc[sub + 16 * u] : 0.0;
+        for (int u = 0; u < 4; ++u) {      // (yc is zero from column mc on, and the padding of Y is finite)
+          const int c = 2 * sub + 32 * u;
+          part += c < mc ? s_yv[sd][u].x * yc[c] : 0.0;
+          part += c + 1 < mc ? s_yv[sd][u].y * yc[c + 1] : 0.0;
+        }
         for (int j = sub + 128; j < mc; j += 16) part += yrow[j] * yc[j];
-        if (ts.left[k] >= 0) part += s_za[sd][0] * yroot[sub] + s_za[sd][1] * yroot[sub + 16];
-        if (ts.right[k] >= 0) part += s_zb[sd][0] * yroot[sub] + s_zb[sd][1] * yroot[sub + 16];
+        if (ts.left[k] >= 0) part += s_za[sd].x * yroot[2 * sub] + s_za[sd].y * yroot[2 * sub + 1];
+        if (ts.right[k] >= 0) part += s_zb[sd].x * yroot[2 * sub] + s_zb[sd].y * yroot[2 * sub + 1];
         part += __shfl_xor(part, 8, 64); part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 1, 64);
         if (sub == 0) wsep[sd * BP + r16] = s_zt[sd] - part;
       }
@@ -833,7 +838,7 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
 #pragma unroll
     for (int sd = 0; sd < 2; ++sd) {
       if (sk[sd] >= 0) {
-        double yp = s_mm[sd][0] * wsep[sd * BP + sub] + s_mm[sd][1] * wsep[sd * BP + sub + 16];
+        double yp = s_mm[sd].x * wsep[sd * BP + 2 * sub] + s_mm[sd].y * wsep[sd * BP + 2 * sub + 1];
         yp += __shfl_xor(yp, 8, 64); yp += __shfl_xor(yp, 4, 64); yp += __shfl_xor(yp, 2, 64); yp += __shfl_xor(yp, 1, 64);
         if (sub == 0) { if (sd == 0) ya[r16] = yp; else { yn[r16] = yp; ysr[r16] = yp; } }
       }
@@ -845,11 +850,15 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
 #pragma unroll
   for (int i = 0; i < QM; ++i) {
     if (i < q) {
-      double part = nd_left >= 0 ? za[i][0] * ya[sub] + za[i][1] * ya[sub + 16] : 0.0;
+      double part = nd_left >= 0 ? za[i].x * ya[2 * sub] + za[i].y * ya[2 * sub + 1] : 0.0;
       if (top) {
         const double* yrow = b.Y + size_t(blk0 + i) * fblk + size_t(r16) * m1p;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) part += sub + 16 * u < mc ? yv[i][u] * yc[sub + 16 * u] : 0.0;
+        for (int u = 0; u < 4; ++u) {
+          const int c = 2 * sub + 32 * u;
+          part += c < mc ? yv[i][u].x * yc[c] : 0.0;
+          part += c + 1 < mc ? yv[i][u].y * yc[c + 1] : 0.0;
+        }
         for (int j = sub + 128; j < mc; j += 16) part += yrow[j] * yc[j];
       }
       part += __shfl_xor(part, 8, 64); part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 1, 64);
@@ -920,7 +929,7 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
 // grid = n_nodes; with `extras` (the first launch after the reduced solve when that kernel does not take the top
 // level along) + 1 workgroup for back_calib + N·32/8 workgroups that form L⁻¹g - Z^F y_c for the rows of every
 // superblock (b.zb), which nodes launched with top = 0 read instead of sweeping the border rows again.
-template <int QM>     // longest chain of the level
+template <int QM, int MODE>     // longest chain of the level; MODE: see back_node
 __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, BcrArgs b, int node0, int n_nodes, int top, int extras, int q_max,
                                                                 const double* __restrict__ x, double* __restrict__ x_cand,
                                                                 const BlockDev* __restrict__ blocks, int n_blocks, BcrTopSeps ts) {
@@ -948,7 +957,7 @@ __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, Bcr
   }
   if (int(blockIdx.x) == n_nodes) { back_calib(a, b, x, x_cand, blocks, n_blocks, sh); return; }
   (void)extras;
-  back_node<QM>(a, b, b.nodes + node0 + blockIdx.x, top, q_max, terminated, blockIdx.x == 0, x, x_cand, lds, sh, ts);
+  back_node<QM, MODE>(a, b, b.nodes + node0 + blockIdx.x, top, q_max, terminated, blockIdx.x == 0, x, x_cand, lds, sh, ts);
 }
 
 // ---------------------------------------------------------------------------
@@ -1218,8 +1227,12 @@ hipError_t configure_bcr_kernels(int q_max, int m1p) {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bcr_level_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           int(bcr_level_lds_bytes()));
   if (e != hipSuccess) return e;
-  for (const void* f : {reinterpret_cast<const void*>(&bcr_back_kernel<1>), reinterpret_cast<const void*>(&bcr_back_kernel<2>),
-                        reinterpret_cast<const void*>(&bcr_back_kernel<4>), reinterpret_cast<const void*>(&bcr_back_kernel<8>)}) {
+  for (const void* f : {reinterpret_cast<const void*>(&bcr_back_kernel<1, 0>), reinterpret_cast<const void*>(&bcr_back_kernel<2, 0>),
+                        reinterpret_cast<const void*>(&bcr_back_kernel<4, 0>), reinterpret_cast<const void*>(&bcr_back_kernel<8, 0>),
+                        reinterpret_cast<const void*>(&bcr_back_kernel<1, 1>), reinterpret_cast<const void*>(&bcr_back_kernel<2, 1>),
+                        reinterpret_cast<const void*>(&bcr_back_kernel<4, 1>), reinterpret_cast<const void*>(&bcr_back_kernel<8, 1>),
+                        reinterpret_cast<const void*>(&bcr_back_kernel<1, 2>), reinterpret_cast<const void*>(&bcr_back_kernel<2, 2>),
+                        reinterpret_cast<const void*>(&bcr_back_kernel<4, 2>)}) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(bcr_back_lds_bytes(q_max, m1p)));
     if (e != hipSuccess) return e;
   }
@@ -1251,8 +1264,17 @@ void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_node
   const int n_mv = border_rows ? (b.N * BP + kBackThreads / 64 - 1) / (kBackThreads / 64) : 0;   // (nobody below reads b.zb: no sweep)
   const dim3 grid(n_nodes + (extras ? 1 + n_mv : 0)), block(kBackThreads);
   const size_t lds = bcr_back_lds_bytes(q_max, b.m1p);
-#define LAUNCH_BACK(QM) hipLaunchKernelGGL(bcr_back_kernel<QM>, grid, block, lds, s, a, b, node0, n_nodes, top ? 1 : 0, extras ? 1 : 0, q_max, x, x_cand, blocks, n_blocks, ts)
-  if (q_max <= 1) LAUNCH_BACK(1); else if (q_max <= 2) LAUNCH_BACK(2); else if (q_max <= 4) LAUNCH_BACK(4); else LAUNCH_BACK(8);
+#define LAUNCH_BACK(QM) hipLaunchKernelGGL(HIP_KERNEL_NAME(bcr_back_kernel<QM, SD>), grid, block, lds, s, a, b, node0, n_nodes, top ? 1 : 0, extras ? 1 : 0, q_max, x, x_cand, blocks, n_blocks, ts)
+  if (ts.n > 0) {      // (the caller keeps chains longer than four out of this mode: the registers do not hold both)
+    constexpr int SD = 2;
+    if (q_max <= 1) LAUNCH_BACK(1); else if (q_max <= 2) LAUNCH_BACK(2); else LAUNCH_BACK(4);
+  } else if (top) {
+    constexpr int SD = 1;
+    if (q_max <= 1) LAUNCH_BACK(1); else if (q_max <= 2) LAUNCH_BACK(2); else if (q_max <= 4) LAUNCH_BACK(4); else LAUNCH_BACK(8);
+  } else {
+    constexpr int SD = 0;
+    if (q_max <= 1) LAUNCH_BACK(1); else if (q_max <= 2) LAUNCH_BACK(2); else if (q_max <= 4) LAUNCH_BACK(4); else LAUNCH_BACK(8);
+  }
 #undef LAUNCH_BACK
 }
 

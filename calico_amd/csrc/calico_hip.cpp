@@ -1058,7 +1058,7 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
   BcrTopSeps ts = {};
   if (merge_env && L >= 2) {
     const calico_problem::BcrLevel& tl = p->bcr_levels[size_t(L - 1)];
-    bool ok = tl.n_nodes <= 2;
+    bool ok = tl.n_nodes <= 2 && p->bcr_levels[size_t(L - 2)].q_max <= 4;
     for (int i = 0; ok && i < tl.n_nodes; ++i) {
       const BcrNodeDev& nd = p->h_bcr_nodes[size_t(tl.node0 + i)];
       ok = nd.q == 1 && (nd.left < 0 || nd.left == p->bcr_root) && (nd.right < 0 || nd.right == p->bcr_root);
