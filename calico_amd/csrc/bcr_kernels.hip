@@ -267,7 +267,8 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         const double g = RBnd[vB ? iB[u] : 0];
         pr.bt[u] = vB ? g : 0.0;
         const bool vA = okB[u] && has_a && r < nreal && act_r && act_cl;
-        const double ga = RBndA[vA ? iB[u] : 0];
+        double ga = 0.0;
+        if (has_a) ga = RBndA[vA ? iB[u] : 0];      // (only the first block of a chain touches the left separator)
         pr.at[u] = vA ? ga : 0.0;
       }
 #pragma unroll
@@ -293,8 +294,9 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       pr.d[u] = (v0 + ((mask & 1) ? v1 : 0.0)) + ((mask & 2) ? v2 : 0.0);
       const double g = Gr[size_t(blk) * BB + e];
       pr.bt[u] = has_next ? g : 0.0;
-      const double ga = Gr[lc * BB + e];
-      pr.at[u] = has_a ? ga : 0.0;
+      double ga = 0.0;
+      if (has_a) ga = Gr[lc * BB + e];
+      pr.at[u] = ga;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -822,14 +824,16 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
         const double* yrow = b.Y + size_t(ts.blk[k]) * fblk + size_t(r16) * m1p;
         double part = 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {      // (yc is zero from column mc on, and the padding of Y is finite)
+        for (int u = 0; u < 4; ++u) {      // (16-byte LDS reads: consecutive lanes, consecutive banks)
           const int c = 2 * sub + 32 * u;
-          part += c < mc ? s_yv[sd][u].x * yc[c] : 0.0;
-          part += c + 1 < mc ? s_yv[sd][u].y * yc[c + 1] : 0.0;
+          const double2 y2 = *reinterpret_cast<const double2*>(yc + min(c, m1p - 2));
+          part += c < mc ? s_yv[sd][u].x * y2.x : 0.0;
+          part += c + 1 < mc ? s_yv[sd][u].y * y2.y : 0.0;
         }
         for (int j = sub + 128; j < mc; j += 16) part += yrow[j] * yc[j];
-        if (ts.left[k] >= 0) part += s_za[sd].x * yroot[2 * sub] + s_za[sd].y * yroot[2 * sub + 1];
-        if (ts.right[k] >= 0) part += s_zb[sd].x * yroot[2 * sub] + s_zb[sd].y * yroot[2 * sub + 1];
+        const double2 yr2 = *reinterpret_cast<const double2*>(yroot + 2 * sub);
+        if (ts.left[k] >= 0) part += s_za[sd].x * yr2.x + s_za[sd].y * yr2.y;
+        if (ts.right[k] >= 0) part += s_zb[sd].x * yr2.x + s_zb[sd].y * yr2.y;
         part += __shfl_xor(part, 8, 64); part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 1, 64);
         if (sub == 0) wsep[sd * BP + r16] = s_zt[sd] - part;
       }
@@ -838,7 +842,8 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
 #pragma unroll
     for (int sd = 0; sd < 2; ++sd) {
       if (sk[sd] >= 0) {
-        double yp = s_mm[sd].x * wsep[sd * BP + 2 * sub] + s_mm[sd].y * wsep[sd * BP + 2 * sub + 1];
+        const double2 w2 = *reinterpret_cast<const double2*>(wsep + sd * BP + 2 * sub);
+        double yp = s_mm[sd].x * w2.x + s_mm[sd].y * w2.y;
         yp += __shfl_xor(yp, 8, 64); yp += __shfl_xor(yp, 4, 64); yp += __shfl_xor(yp, 2, 64); yp += __shfl_xor(yp, 1, 64);
         if (sub == 0) { if (sd == 0) ya[r16] = yp; else { yn[r16] = yp; ysr[r16] = yp; } }
       }
@@ -850,14 +855,16 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
 #pragma unroll
   for (int i = 0; i < QM; ++i) {
     if (i < q) {
-      double part = nd_left >= 0 ? za[i].x * ya[2 * sub] + za[i].y * ya[2 * sub + 1] : 0.0;
+      const double2 ya2 = *reinterpret_cast<const double2*>(ya + 2 * sub);
+      double part = nd_left >= 0 ? za[i].x * ya2.x + za[i].y * ya2.y : 0.0;
       if (top) {
         const double* yrow = b.Y + size_t(blk0 + i) * fblk + size_t(r16) * m1p;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int c = 2 * sub + 32 * u;
-          part += c < mc ? yv[i][u].x * yc[c] : 0.0;
-          part += c + 1 < mc ? yv[i][u].y * yc[c + 1] : 0.0;
+          const double2 y2 = *reinterpret_cast<const double2*>(yc + min(c, m1p - 2));
+          part += c < mc ? yv[i][u].x * y2.x : 0.0;
+          part += c + 1 < mc ? yv[i][u].y * y2.y : 0.0;
         }
         for (int j = sub + 128; j < mc; j += 16) part += yrow[j] * yc[j];
       }
