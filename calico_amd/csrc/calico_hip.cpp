@@ -212,6 +212,7 @@ struct calico_problem {
   std::vector<BcrLevel> bcr_levels;
   std::vector<BcrNodeDev> h_bcr_nodes;
   std::vector<int> h_bcr_keep, h_cp_block;
+  bool bcr_merge_top = true;      // the top level's back-substitution rides in the launch below it
   DevBuf<double> d_bD, d_bG, d_bF, d_bpD, d_bpF, d_bM, d_bZA, d_bZB, d_bY, d_bysol, d_bzb, d_bupd;
   DevBuf<BcrNodeDev> d_bnodes;
   DevBuf<int> d_bkeep, d_cp_block;
@@ -375,6 +376,7 @@ void build_bcr_plan(calico_problem* p) {
   p->bcr_br = alive.empty() ? 0 : 6 * kBcrCps;
   p->bcr_q_max = q_max_all;
   p->bcr_slots = int(p->h_bcr_nodes.size()) + 1;
+  { const char* e = std::getenv("CALICO_BCR_MERGE_TOP"); p->bcr_merge_top = !e || std::atoi(e) != 0; }   // (A/B switch, see enqueue_linear_solve)
 }
 
 EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool want_res) {
@@ -1054,9 +1056,8 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
   // The top level of the tree is one or two single superblocks next to the root: their back-substitution rides in the
   // launch of the level below (every node there solves the top separators beside it itself -- a few more loads next to
   // the ones it waits for anyway) instead of costing a launch of its own.
-  static const bool merge_env = [] { const char* e = std::getenv("CALICO_BCR_MERGE_TOP"); return !e || std::atoi(e) != 0; }();
   BcrTopSeps ts = {};
-  if (merge_env && L >= 2) {
+  if (p->bcr_merge_top && L >= 2) {
     const calico_problem::BcrLevel& tl = p->bcr_levels[size_t(L - 1)];
     bool ok = tl.n_nodes <= 2 && p->bcr_levels[size_t(L - 2)].q_max <= 4;
     for (int i = 0; ok && i < tl.n_nodes; ++i) {

@@ -1081,7 +1081,7 @@ DEV void row_cell_body(const EvalArgs& a, const CellDev& cell, double* lds) {
     for (int it = 0; it < ni; ++it) {
       const int nrows = min(cell.PE, cell.pad0 - (i0 + it) * cell.PE);
       const double* base = lds + it * words;
-      // column offsets and masks of this wave's tiles do not depend on the row: hoisted; four k-steps (sixteen rows) of
+      // column offsets and masks of this wave's tiles do not depend on the row: hoisted; KU k-steps (4·KU rows) of
       // operands are requested before the first of their MFMAs
       int oci[MAXT], ocj[MAXT];
       double mi[MAXT], mj[MAXT];
@@ -1091,10 +1091,11 @@ DEV void row_cell_body(const EvalArgs& a, const CellDev& cell, double* lds) {
         oci[q] = (ci < n1 ? ci : n1 - 1) * pad; ocj[q] = (cj < n1 ? cj : n1 - 1) * pad;
         mi[q] = ci < n1 ? 1.0 : 0.0; mj[q] = cj < n1 ? 1.0 : 0.0;
       }
-      for (int r0 = 0; r0 < nrows; r0 += 16) {
-        double oi[4][MAXT], oj[4][MAXT];
+      constexpr int KU = MAXT <= 3 ? 4 : 1;      // (seven tiles per wave: the registers hold one k-step of operands)
+      for (int r0 = 0; r0 < nrows; r0 += 4 * KU) {
+        double oi[KU][MAXT], oj[KU][MAXT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < KU; ++u) {
           const int r = r0 + 4 * u + lk;
           const int rc = r < nrows ? r : nrows - 1;
           const double rm = r < nrows ? 1.0 : 0.0;
@@ -1102,7 +1103,7 @@ DEV void row_cell_body(const EvalArgs& a, const CellDev& cell, double* lds) {
           for (int q = 0; q < MAXT; ++q) { oi[u][q] = base[oci[q] + rc] * (mi[q] * rm); oj[u][q] = base[ocj[q] + rc] * mj[q]; }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < KU; ++u)
 #pragma unroll
           for (int q = 0; q < MAXT; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(oi[u][q], oj[u][q], acc[q], 0, 0, 0);
       }

@@ -23,6 +23,8 @@ def main():
         raise SystemExit("not enough solves in the trace")
     # all boundaries: idle time from the last working kernel (> 6 us) of a solve to the next solve's begin kernel, and how
     # many early-exit kernels of the old solve start before / after that begin kernel (two alternating streams: after)
+    # (the second half of the trace only: the warm-up solves of bench.py bracket every kernel group with HIP events)
+    starts = starts[len(starts) // 2:]
     gaps = []
     for i in starts[1:]:
         j = i - 1
