@@ -623,10 +623,7 @@ DEVI void file_update_sums(const UpdSums& s, double* sh /* [4][waves] */, double
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   double v[4] = {s.mcc, s.sn, s.cn, s.bad ? 1.0 : 0.0};
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
-  }
+  for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
   if (lane == 0) { sh[wave] = v[0]; sh[16 + wave] = v[1]; sh[32 + wave] = v[2]; sh[48 + wave] = v[3]; }
   __syncthreads();
   if (tid < 4) {
@@ -815,62 +812,75 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
     }
   }
   __syncthreads();
-  if (side) {
-    // y_e = L⁻ᵀ(L⁻¹g_e - Z^F y_c - Z^A y_root - Z^B y_root) of the top separators on either side (sixteen threads per row)
+  // this thread's columns of y_c (2·sub + 32u, + 1), read once for all blocks: 16-byte LDS reads, zero from column mc on
+  double ycx[4], ycy[4];
+  if (top) {
 #pragma unroll
-    for (int sd = 0; sd < 2; ++sd) {
-      if (sk[sd] >= 0) {
-        const int k = sk[sd];
-        const double* yrow = b.Y + size_t(ts.blk[k]) * fblk + size_t(r16) * m1p;
-        double part = 0.0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {      // (16-byte LDS reads: consecutive lanes, consecutive banks)
-          const int c = 2 * sub + 32 * u;
-          const double2 y2 = *reinterpret_cast<const double2*>(yc + min(c, m1p - 2));
-          part += c < mc ? s_yv[sd][u].x * y2.x : 0.0;
-          part += c + 1 < mc ? s_yv[sd][u].y * y2.y : 0.0;
-        }
-        for (int j = sub + 128; j < mc; j += 16) part += yrow[j] * yc[j];
-        const double2 yr2 = *reinterpret_cast<const double2*>(yroot + 2 * sub);
-        if (ts.left[k] >= 0) part += s_za[sd].x * yr2.x + s_za[sd].y * yr2.y;
-        if (ts.right[k] >= 0) part += s_zb[sd].x * yr2.x + s_zb[sd].y * yr2.y;
-        part += __shfl_xor(part, 8, 64); part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 1, 64);
-        if (sub == 0) wsep[sd * BP + r16] = s_zt[sd] - part;
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int c = 2 * sub + 32 * u;
+      const double2 y2 = *reinterpret_cast<const double2*>(yc + min(c, m1p - 2));
+      ycx[u] = c < mc ? y2.x : 0.0; ycy[u] = c + 1 < mc ? y2.y : 0.0;
     }
-    __syncthreads();
+  }
+  if (side) {
+    // y_e = L⁻ᵀ(L⁻¹g_e - Z^F y_c - Z^A y_root - Z^B y_root) of the top separators on either side (sixteen threads per row),
+    // both sides at once (the loads of a side that does not exist were clamped to valid memory: its result is dropped)
+    const double2 yr2 = *reinterpret_cast<const double2*>(yroot + 2 * sub);
+    double part[2];
 #pragma unroll
     for (int sd = 0; sd < 2; ++sd) {
-      if (sk[sd] >= 0) {
-        const double2 w2 = *reinterpret_cast<const double2*>(wsep + sd * BP + 2 * sub);
-        double yp = s_mm[sd].x * w2.x + s_mm[sd].y * w2.y;
-        yp += __shfl_xor(yp, 8, 64); yp += __shfl_xor(yp, 4, 64); yp += __shfl_xor(yp, 2, 64); yp += __shfl_xor(yp, 1, 64);
-        if (sub == 0) { if (sd == 0) ya[r16] = yp; else { yn[r16] = yp; ysr[r16] = yp; } }
+      const int k = max(sk[sd], 0);
+      double pt = 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pt += s_yv[sd][u].x * ycx[u] + s_yv[sd][u].y * ycy[u];
+      if (mc > 128 && sk[sd] >= 0) {
+        const double* yrow = b.Y + size_t(ts.blk[k]) * fblk + size_t(r16) * m1p;
+        for (int j = sub + 128; j < mc; j += 16) pt += yrow[j] * yc[j];
       }
+      pt += ts.left[k] >= 0 ? s_za[sd].x * yr2.x + s_za[sd].y * yr2.y : 0.0;
+      pt += ts.right[k] >= 0 ? s_zb[sd].x * yr2.x + s_zb[sd].y * yr2.y : 0.0;
+      part[sd] = pt;
+    }
+    part[0] = row16_sum(part[0]); part[1] = row16_sum(part[1]);
+    if (sub == 0) { wsep[r16] = s_zt[0] - part[0]; wsep[BP + r16] = s_zt[1] - part[1]; }
+    __syncthreads();
+    double yp[2];
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd) {
+      const double2 w2 = *reinterpret_cast<const double2*>(wsep + sd * BP + 2 * sub);
+      yp[sd] = s_mm[sd].x * w2.x + s_mm[sd].y * w2.y;
+    }
+    yp[0] = row16_sum(yp[0]); yp[1] = row16_sum(yp[1]);
+    if (sub == 0) {
+      if (sk[0] >= 0) ya[r16] = yp[0];
+      if (sk[1] >= 0) { yn[r16] = yp[1]; ysr[r16] = yp[1]; }
     }
     __syncthreads();
   }
   BTICK(1)
-  // t_i = (L⁻¹g_i - Z^F y_c) - Z^A y_a : sixteen threads per row, fixed-shape reduction
+  // t_i = (L⁻¹g_i - Z^F y_c) - Z^A y_a : sixteen threads per row; all blocks' partial sums first, then their reductions
+  // side by side (independent chains), then the stores -- block by block behind branches each step waited for the last
+  {
+    double2 ya2 = {0.0, 0.0};
+    if (nd_left >= 0) ya2 = *reinterpret_cast<const double2*>(ya + 2 * sub);
+    double part[QM];
 #pragma unroll
-  for (int i = 0; i < QM; ++i) {
-    if (i < q) {
-      const double2 ya2 = *reinterpret_cast<const double2*>(ya + 2 * sub);
-      double part = nd_left >= 0 ? za[i].x * ya2.x + za[i].y * ya2.y : 0.0;
+    for (int i = 0; i < QM; ++i) {
+      double pt = za[i].x * ya2.x + za[i].y * ya2.y;
       if (top) {
-        const double* yrow = b.Y + size_t(blk0 + i) * fblk + size_t(r16) * m1p;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int c = 2 * sub + 32 * u;
-          const double2 y2 = *reinterpret_cast<const double2*>(yc + min(c, m1p - 2));
-          part += c < mc ? yv[i][u].x * y2.x : 0.0;
-          part += c + 1 < mc ? yv[i][u].y * y2.y : 0.0;
+        for (int u = 0; u < 4; ++u) pt += yv[i][u].x * ycx[u] + yv[i][u].y * ycy[u];
+        if (mc > 128 && i < q) {
+          const double* yrow = b.Y + size_t(blk0 + i) * fblk + size_t(r16) * m1p;
+          for (int j = sub + 128; j < mc; j += 16) pt += yrow[j] * yc[j];
         }
-        for (int j = sub + 128; j < mc; j += 16) part += yrow[j] * yc[j];
       }
-      part += __shfl_xor(part, 8, 64); part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 1, 64);
-      if (sub == 0) tv[i * BP + r16] = zt[i] - part;
+      part[i] = pt;
     }
+#pragma unroll
+    for (int i = 0; i < QM; ++i) part[i] = row16_sum(part[i]);
+#pragma unroll
+    for (int i = 0; i < QM; ++i) if (i < q && sub == 0) tv[i * BP + r16] = zt[i] - part[i];
   }
   __syncthreads();
   BTICK(2)
@@ -882,7 +892,7 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
       double wp = 0.0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) wp += zb[j] * yn[16 * h + j];
-      wp += __shfl_xor(wp, 32, 64);
+      wp += other_half(wp);
       const double w = tv[i * BP + r] - wp;
       if (h == 0) wv[r] = w;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -892,7 +902,7 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
       double yp = 0.0;
 #pragma unroll
       for (int c = 0; c < 16; ++c) yp += mr[c] * wv[16 * h + c];
-      yp += __shfl_xor(yp, 32, 64);
+      yp += other_half(yp);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
