@@ -967,8 +967,7 @@ __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, Bcr
     double part = 0.0;
 #pragma unroll 2
     for (int j = lane; j < mc; j += 64) part += yrow[j] * yc[j];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    part = wave_sum(part);
     if (lane == 0) b.zb[row] = yrow[mc] - part;
     return;
   }
@@ -1155,7 +1154,7 @@ __global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveA
 #pragma unroll
       for (int u = 0; u < 16; ++u) z4[u & 3] += (16 * h + u <= c ? g16[u] : 0.0) * mv[u];
       double zc = (z4[0] + z4[1]) + (z4[2] + z4[3]);
-      zc += __shfl_xor(zc, 32, 64);
+      zc += other_half(zc);
       if (h == 0) wv[c] = zc;
     }
     lds_barrier();
@@ -1202,7 +1201,7 @@ __global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveA
         const double mv = c == r ? dinvm[c0 + r] : mr[c];
         acc += (c >= r ? mv : 0.0) * wv[c];
       }
-      acc += __shfl_xor(acc, 4, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 1, 64);
+      acc = row8_sum(acc);
       if (part == 0) yv[c0 + r] = acc;
     }
     lds_barrier();
@@ -1211,7 +1210,7 @@ __global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveA
       double acc = 0.0;
 #pragma unroll
       for (int u = 0; u < 8; ++u) { const int r = 8 * part + u; acc += A[(c0 + r) * DNL + col] * yv[c0 + r]; }
-      acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 1, 64);
+      acc = row4_sum(acc);
       if (part == 0) pend[col] += acc;
     }
     lds_barrier();

@@ -500,11 +500,7 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
   return true;
 }
 
-DEV double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 // [J r]ᵀ[J r] of the staged rows (column-major, stride pad) -> upper triangle of the n1×n1 item block, NT = ceil(n1/16).

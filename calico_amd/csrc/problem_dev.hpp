@@ -290,4 +290,34 @@ struct BcrArgs {
   int n_slots;
 };
 
+// Sums across lanes without the LDS crossbar. `__shfl_xor` compiles to ds_bpermute_b32 (two per double, an LDS round
+// trip per step of a dependent chain); inside a row of 16 lanes the DPP modifiers exchange lanes in two v_mov_b32_dpp,
+// and v_permlane32_swap / v_permlane16_swap (gfx950) exchange the halves of a wave and the rows of a half
+// (`profiles/microbench/lane_sums.hip`: 132 against 336 clocks for a dependent 16-lane sum, 228 against 496 for a wave).
+// Every lane receives the sum, added in a fixed order.
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row4_sum(double v) { v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); return v; }       // quad_perm [1,0,3,2], [2,3,0,1]
+__device__ __forceinline__ double row8_sum(double v) { v = row4_sum(v); v += dpp_mov<0x141>(v); return v; }              // row_half_mirror
+__device__ __forceinline__ double row16_sum(double v) { v = row8_sum(v); v += dpp_mov<0x140>(v); return v; }             // row_mirror
+__device__ __forceinline__ double other_half(double v) {     // lane i receives lane i ^ 32
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const bool up = (threadIdx.x & 32) != 0;
+  return __hiloint2double(up ? b[0] : b[1], up ? a[0] : a[1]);
+}
+__device__ __forceinline__ double other_row(double v) {      // lane i receives lane i ^ 16
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const bool odd = (threadIdx.x & 16) != 0;
+  return __hiloint2double(odd ? b[0] : b[1], odd ? a[0] : a[1]);
+}
+__device__ __forceinline__ double wave_sum(double v) { v = row16_sum(v); v += other_half(v); v += other_row(v); return v; }
+
 }  // namespace cal

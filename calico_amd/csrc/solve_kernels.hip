@@ -80,8 +80,7 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
 #pragma unroll
       for (int u = 0; u < 4; ++u) if (i + 256 * u < n_cost) { c += cc[u]; v += vv[u]; }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off, 64); v += __shfl_xor(v, off, 64); }
+    c = wave_sum(c); v = wave_sum(v);
     __shared__ double s_w[2][4];
     if ((tid & 63) == 0) { s_w[0][tid >> 6] = c; s_w[1][tid >> 6] = v; }
     __syncthreads();
@@ -116,8 +115,7 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
 #pragma unroll
       for (int u = 0; u < 4; ++u) s += qb + lane + 64 * u < q1 ? v[u] : 0.0;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    s = wave_sum(s);
     if (live && lane == 0) R[out_fat[wave]] = s;
   } else {
     const int gid = (bid - nb_fat) * blockDim.x + threadIdx.x;
@@ -134,7 +132,7 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
     double s = 0.0;
 #pragma unroll
     for (int u = 0; u < 6; ++u) s += q0 + sub + 8 * u < q1 ? v[u] : 0.0;
-    s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+    s = row8_sum(s);
     if (live && sub == 0) R[out_thin[o]] = s;
   }
 }
@@ -1432,10 +1430,7 @@ DEVI void control_body(LmState* st_g, const LmOptionsDev& o, double* R2, double*
     // (a fixed-shape reduction: shuffle tree inside every wave, then the four waves in order)
     __shared__ double s_u[4][4];
     double u0 = pf.u0, u1 = pf.u1, u2 = pf.u2, u3 = pf.u3;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      u0 += __shfl_xor(u0, off, 64); u1 += __shfl_xor(u1, off, 64); u2 += __shfl_xor(u2, off, 64); u3 += __shfl_xor(u3, off, 64);
-    }
+    u0 = wave_sum(u0); u1 = wave_sum(u1); u2 = wave_sum(u2); u3 = wave_sum(u3);
     if ((tid & 63) == 0) { s_u[0][tid >> 6] = u0; s_u[1][tid >> 6] = u1; s_u[2][tid >> 6] = u2; s_u[3][tid >> 6] = u3; }
     __syncthreads();
     if (tid == 0) {
