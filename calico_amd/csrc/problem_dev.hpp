@@ -294,7 +294,8 @@ struct BcrArgs {
 // trip per step of a dependent chain); inside a row of 16 lanes the DPP modifiers exchange lanes in two v_mov_b32_dpp,
 // and v_permlane32_swap / v_permlane16_swap (gfx950) exchange the halves of a wave and the rows of a half
 // (`profiles/microbench/lane_sums.hip`: 132 against 336 clocks for a dependent 16-lane sum, 228 against 496 for a wave).
-// Every lane receives the sum, added in a fixed order.
+// Every lane receives the sum, added in a fixed order. ALL lanes of the wave must be active where these are called: a
+// DPP move from a disabled lane leaves the destination at zero instead of faulting.
 template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
