@@ -59,37 +59,105 @@ def algorithmic_bytes_per_iteration(scene):
     return total
 
 
-def cpu_baseline(scene, iters=25, min_seconds=12.0):
-    """The CPU oracle (restatement of the reference's Ceres path) on the host cores
-    of this box: a bounded sample of the same workload -- whole solves from the same
-    perturbed start, repeated until `min_seconds` of solver time. Reported, never shipped."""
+def cpu_baseline(scene, min_seconds=10.0):
+    """The CPU oracle (restatement of the reference's Ceres path: dual-number autodiff in 4-wide passes, dense normal
+    equations, dense Cholesky, std::thread pool honouring num_threads) on the host cores of this box, as SURVEY.md 8(d) /
+    BASELINE.md describe the baseline: num_threads in {1, 4 (the demos' setting), all cores}, seconds per iteration split
+    into evaluate / assemble / linear solve, iterations to convergence. A bounded sample of the same workload -- whole
+    solves from the same perturbed start; the headline `value` is the all-cores figure. Reported, never shipped."""
+    import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers
     from calico_amd import synthetic as syn
     api = helpers.oracle_api()
     cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 64))
-    o = api.default_options()
-    o.minimizer_progress_to_stdout = 0
-    o.max_num_iterations = iters
-    o.num_threads = threads
-    nit = solves = 0
-    dt = 0.0
-    while dt < min_seconds and solves < 20:
-        built = syn.build_problem(api, scene)      # fresh problem = same perturbed start
-        t = time.time()
-        s = built.problem.solve(o)
-        dt += time.time() - t
-        nit += max(1, s.num_iterations)
-        solves += 1
-    return {"value": nit / dt, "unit": "LM iterations/s", "cores": threads, "kind": "port",
-            "sample": "%d LM iterations in %d solves (+ initial evaluations) of the same %d-block problem, %.1f s of solver time"
-                      % (nit, solves, scene.num_blocks, dt)}
+    all_threads = max(1, min(cores, 64))
+
+    def run(threads, iters, budget_s, max_solves):
+        o = api.default_options()
+        o.minimizer_progress_to_stdout = 0
+        o.max_num_iterations = iters
+        o.num_threads = threads
+        nit = solves = 0
+        dt = 0.0
+        part = [0.0, 0.0, 0.0]
+        last = None
+        while dt < budget_s and solves < max_solves:
+            built = syn.build_problem(api, scene)      # fresh problem = same perturbed start
+            t = time.time()
+            last = built.problem.solve(o)
+            dt += time.time() - t
+            t3 = (C.c_double * 3)()
+            api.lib.oracle_get_solve_timing(built.problem.h, t3)
+            part = [part[i] + t3[i] for i in range(3)]
+            nit += max(1, last.num_iterations)
+            solves += 1
+        return {"num_threads": threads, "iterations_per_s": nit / dt, "s_per_iteration": dt / nit,
+                "s_per_iteration_evaluate": part[0] / nit, "s_per_iteration_assemble": part[1] / nit,
+                "s_per_iteration_linear_solve": part[2] / nit, "iterations": nit, "solves": solves, "seconds": dt}, last
+
+    sweep = []
+    for th, iters in ((1, 3), (4, 6)):
+        if th < all_threads:
+            sweep.append(run(th, iters, 0.0, 1)[0])
+    full, last = run(all_threads, 50, min_seconds, 20)
+    sweep.append(full)
+    return {"value": full["iterations_per_s"], "unit": "LM iterations/s", "cores": all_threads, "kind": "port",
+            "iterations_to_convergence": int(last.num_iterations), "termination": last.message.decode(),
+            "by_num_threads": sweep,
+            "sample": "%d LM iterations in %d solves to convergence (+ initial evaluations) of the same %d-block problem on %d threads, "
+                      "%.1f s of solver time; 1- and 4-thread legs: the first 3 / 6 iterations of the same solve"
+                      % (full["iterations"], full["solves"], scene.num_blocks, all_threads, full["seconds"])}
 
 
 class _DevArray:
     def __init__(self, ptr, n):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def visible_gpus():
+    try:
+        import torch
+        return torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except Exception:
+        return 0
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
+    torch.distributed.run would set them) and wait for all of them; rank 0 prints the JSON line. Fails loudly when the
+    node has fewer than N devices -- a run that silently used fewer GPUs than asked for would report the wrong n_gpus."""
+    import socket
+    import subprocess
+    have = visible_gpus()
+    if have < n:
+        sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible on this node -- refusing to run on fewer devices than asked for\n" % (n, have))
+        return 3
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        while procs and rc == 0:
+            for pr in list(procs):
+                code = pr.poll()
+                if code is None:
+                    continue
+                procs.remove(pr)
+                if code != 0:
+                    rc = code
+            time.sleep(0.05)
+    finally:
+        for pr in procs:       # a rank failed: stop the ones we started (exact PIDs)
+            pr.kill()
+    return rc
 
 
 def main():
@@ -104,12 +172,21 @@ def main():
                     help="exercise the sharding + all-reduce path even with one rank (validation)")
     ap.add_argument("--repeats", type=int, default=0,
                     help="timed samples of --steps iterations each (default: 25 when --steps <= 50, else 5); the median is reported")
+    ap.add_argument("--min-seconds", type=float, default=3.0,
+                    help="without --repeats: as many samples as it takes to keep the GPU busy this long")
     ap.add_argument("--poor-start", type=float, default=0.0,
                     help="move the start away from the truth: focal lengths x (1 + F/100), translations + F cm, control "
                          "points + F mrad / F mm of noise (context runs: many rejected steps); 0 = the reference test's perturbation")
     ap.add_argument("--tagging-passes", type=int, default=0,
                     help="outlier tagging loop (configs[4]): solve, tag |r| > 3 on the device, re-solve, N times; reported, untimed")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d does not match the launcher's WORLD_SIZE=%s" % (args.gpus, os.environ.get("WORLD_SIZE")))
 
     # stdout carries exactly ONE JSON line: libraries that print to the C-level stdout (RCCL's version banner at
     # communicator creation, kernel debug prints) are sent to stderr for the whole run
@@ -125,6 +202,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libcalico_hip.so is the only backend")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d of %d has no device (%d GPU(s) visible)" % (rank, world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     collective = world > 1 or args.force_collective
@@ -147,6 +226,18 @@ def main():
             idt = torch.tensor(list(_capi.comm_unique_id(api)), dtype=torch.uint8, device="cuda")
         dist.broadcast(idt, src=0)
         P.comm_init_rccl(bytes(idt.cpu().tolist()), rank, world)
+    # what the exchange really spans (ncclCommCount) and what this rank evaluates
+    comm_rank, comm_world, local_blocks, total_blocks = P.comm_info()
+    if comm_world != world or comm_rank != rank:
+        raise SystemExit("bench.py: the communicator spans %d ranks (this is rank %d), the launcher said %d (rank %d)" % (comm_world, comm_rank, world, rank))
+    blocks_per_rank = [local_blocks]
+    if dist is not None and world > 1:
+        t = torch.zeros(world, dtype=torch.int64, device="cuda")
+        t[rank] = local_blocks
+        dist.all_reduce(t)
+        blocks_per_rank = [int(v) for v in t.cpu().tolist()]
+        if sum(blocks_per_rank) != total_blocks:
+            raise SystemExit("bench.py: the shards hold %d residual blocks, the problem has %d" % (sum(blocks_per_rank), total_blocks))
 
     # initial values of every free block, to restart solves inside the timed region
     init = [(int(b), scene.ctrl[i].copy()) for i, b in enumerate(built.ctrl_blocks)]
@@ -251,7 +342,21 @@ def main():
     # timed region: only the dominant kernel (phase 0) carries events, and only every 16th of its launches -- an event
     # pair costs ~6 us of stream time on either side of the kernel. The K-step sample is a few milliseconds long, so it is
     # repeated and the MEDIAN sample is the one reported (box-to-box and run-to-run spread is several per cent).
-    repeats = args.repeats if args.repeats > 0 else (25 if args.steps <= 50 else 5)
+    # By default the samples add up to >= 3 s of GPU work (a 20-iteration sample is ~3 ms: the driver's utilisation
+    # sampler would otherwise never see the device busy); --repeats N fixes the count.
+    if args.repeats > 0:
+        repeats = args.repeats
+    else:
+        barrier()
+        t0 = time.perf_counter()
+        timed_solves(args.steps)
+        barrier()
+        est = time.perf_counter() - t0
+        repeats = int(min(5000, max(25 if args.steps <= 50 else 5, np.ceil(args.min_seconds / max(est, 1e-4)))))
+        if dist is not None:     # every rank must run the same number of samples
+            t = torch.tensor([repeats], device="cuda", dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            repeats = int(t.item())
     samples = []
     for _ in range(repeats):
         P.set_phase_timing(0x01 | (16 << 8))             # (restarts the accumulated phase times)
@@ -301,11 +406,12 @@ def main():
             except Exception:
                 traffic = None
         ms_per_step = 1e3 * elapsed / done
+        iter_bytes = algorithmic_bytes_per_iteration(scene)      # whole job: all ranks together
         out = {
             "metric": "LM iterations/sec on the 4-cam+IMU ~100k-observation problem",
             "value": done / elapsed,
             "unit": "LM iterations/s",
-            "n_gpus": world,
+            "n_gpus": comm_world,
             "steps": done,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
@@ -315,16 +421,23 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "repeats": repeats,
-            "ms_per_step_samples": [round(1e3 * z[0], 5) for z in samples],
+            "timed_seconds_total": sum(z[1] for z in samples),
+            # (sorted samples; the median is the one reported) quantiles of all of them + the 25 around the median
+            "ms_per_step_quantiles": {q: round(1e3 * samples[min(len(samples) - 1, int(q * len(samples) / 100))][0], 5) for q in (0, 10, 25, 50, 75, 90, 99)},
+            "ms_per_step_samples": [round(1e3 * z[0], 5) for z in samples[max(0, len(samples) // 2 - 12):len(samples) // 2 + 13]],
             "config": {
-                "workload": "BASELINE.json configs[%d]: %d cameras + %d gyro + %d accel, %d residual blocks (%d scalar residuals), "
+                "workload": "%s: %d cameras + %d gyro + %d accel, %d residual blocks (%d scalar residuals), "
                             "%d control points, robust kernels %s" % (
-                                args.config, sum(1 for s in scene.sensors if s.kind == 0),
+                                ("BASELINE.json configs[%d]" % args.config) if args.config <= 4 else
+                                {5: "context shape (not a BASELINE config): configs[3] with 50 Hz knots",
+                                 6: "context shape (not a BASELINE config): one camera + IMU, 1453 control points (the notebook run's shape)"}.get(args.config, "context shape %d" % args.config),
+                                sum(1 for s in scene.sensors if s.kind == 0),
                                 sum(1 for s in scene.sensors if s.kind == _capi.SENSOR_GYROSCOPE),
                                 sum(1 for s in scene.sensors if s.kind == _capi.SENSOR_ACCELEROMETER), n_blocks,
                                 sum(s.n * s.dim for s in scene.sensors), len(scene.ctrl),
                                 "on" if any(s.loss for s in scene.sensors) else "off"),
                 "residual_blocks": n_blocks,
+                "residual_blocks_per_rank": blocks_per_rank,
                 "effective_parameters": last.num_effective_parameters_reduced,
                 "solves_in_timed_region": solves,
                 "jacobian_evaluations": jac,
@@ -350,30 +463,34 @@ def main():
                     "control": wu_ms[4] / max(1, wu_n[4]),
                 },
             },
-            # `achieved`/`frac` follow SURVEY.md 8(d): ALGORITHMIC bytes of the unfused data flow (observation read, residual
-            # and Jacobian written and read back for assembly) over the launch time of the fused kernel. The kernel keeps the
-            # Jacobian on chip, so that ratio is a paper figure (it can exceed 1); what the hardware does is in
-            # `measured_frac` (HBM bytes from the PMC counters over the same time) and `bound` says what limits the kernel:
-            # one wave per SIMD issuing dependent FP64 work -- latency / issue, not HBM and not the FP64 pipes.
+            # `frac` is SURVEY.md 8(d)'s own definition: the ALGORITHMIC bytes of one LM iteration (per block: observation read
+            # twice, residual written, Jacobian written and read back for assembly, residual of the cost-only pass) over the
+            # measured time of an iteration, against the HBM peak. The fused kernels keep the Jacobian on chip, so the bytes
+            # the hardware really moves are far fewer (`traffic`, from the PMC counters, per launch of the dominant kernel);
+            # the per-launch paper ratio of that kernel alone (it can exceed 1) is kept as `fused_paper_ratio`.
             "roofline": {
-                "bound": "latency", "nominal_bound": "hbm",
+                "bound": "hbm", "limited_by": "latency (dependent FP64 chains of single waves; see DESIGN.md 4)",
+                "achieved": iter_bytes / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": iter_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_iteration": iter_bytes,
+                "traffic": traffic,
                 "kernel": "eval_jacobian_kernel (fused residual + analytic Jacobian + JtJ partials: IMU items + camera frames)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "frac_note": "algorithmic bytes of the UNFUSED data flow (SURVEY 8d) over the launch time: the fused kernel keeps "
-                             "the Jacobian on chip, so this ratio can exceed 1; the hardware's figure is measured_frac",
-                "measured_frac": (traffic / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "iteration_frac": algorithmic_bytes_per_iteration(scene) / world / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": jac_ms, "launches": jac,
-                "launches_bracketed": phase_n[6],
-                "avg_launch_ms_with_event_bracket": jac_ms_raw, "event_bracket_ms": bracket_ms,
-                "bracketed_launches_that_exited_early": n_skipped,
+                "kernel_avg_launch_ms": jac_ms, "kernel_launches": jac, "kernel_launches_bracketed": phase_n[6],
+                "kernel_avg_launch_ms_with_event_bracket": jac_ms_raw, "event_bracket_ms": bracket_ms,
+                "kernel_bracketed_launches_that_exited_early": n_skipped,
+                "kernel_algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_measured_frac": (traffic / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "fused_paper_ratio": achieved / HBM_PEAK_GBS,
+                "fused_paper_ratio_note": "algorithmic bytes of the UNFUSED data flow of one Jacobian launch over its time: a paper "
+                                          "figure, the kernel does not move those bytes",
             },
         }
         fp64 = os.path.join(ROOT, "profiles", "fp64_utilisation.json")
         if os.path.exists(fp64) and args.config == 3 and world == 1:
             try:
-                out["roofline"]["fp64_by_kernel"] = json.load(open(fp64))
+                fj = json.load(open(fp64))
+                out["roofline"]["fp64_by_kernel"] = fj
+                out["roofline"]["mfma_utilisation"] = fj.get("mfma_utilisation_dominant_kernel")
             except Exception:
                 pass
         if tagging is not None:

@@ -121,8 +121,10 @@ ABI_SYMBOLS = [
     "num_effective_parameters", "evaluate", "problem_set_allreduce", "problem_set_shard",
     "problem_set_stream", "get_phase_time", "set_phase_timing", "project",
     "problem_set_outlier_mask", "mark_outliers", "fit_spline", "residual_heatmap",
-    "debug_lm_control_replay", "comm_get_unique_id", "comm_init_rccl", "problem_finalize",
+    "comm_get_unique_id", "comm_init_rccl", "comm_info", "problem_finalize",
 ]
+# Test hooks (calico_amd/csrc/calico_hip_testing.h): exported, not part of the drop-in surface.
+TEST_SYMBOLS = ["debug_lm_control_replay"]
 
 
 class CApi:
@@ -172,6 +174,7 @@ class CApi:
             g("problem_finalize", C.c_int32, [P])
             g("comm_get_unique_id", C.c_int32, [C.POINTER(C.c_uint8)])
             g("comm_init_rccl", C.c_int32, [P, C.POINTER(C.c_uint8), C.c_int32, C.c_int32])
+            g("comm_info", C.c_int32, [P, I, I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
             g("debug_lm_control_replay", C.c_int32,
               [C.c_int32, C.c_int32, D, I, C.POINTER(SolverOptions), D, I, D])
 
@@ -349,6 +352,13 @@ class Problem:
         """Native exchange: the handle creates its own RCCL communicator from the 128-byte id (see comm_unique_id)."""
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         self._check(self.api.comm_init_rccl(self.h, buf, int(rank), int(world_size)))
+
+    def comm_info(self):
+        """(rank, world, local residual blocks, total residual blocks) as the handle's communicator / shard sees them."""
+        r, w = C.c_int32(0), C.c_int32(0)
+        nl, nt = C.c_int64(0), C.c_int64(0)
+        self._check(self.api.comm_info(self.h, C.byref(r), C.byref(w), C.byref(nl), C.byref(nt)))
+        return r.value, w.value, nl.value, nt.value
 
     def set_shard(self, rank, world_size):
         self._check(self.api.problem_set_shard(self.h, int(rank), int(world_size)))

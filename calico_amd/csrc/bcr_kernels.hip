@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     if (with_post && blockIdx.x == gridDim.x - 1) {
       if (terminated) return;
       if (threadIdx.x == 0 && a.st->commit_pending) a.st->commit_pending = 0;   // see commit_kernel (several ranks)
-      if (threadIdx.x < 256) post_eval_body(a, x, blocks, n_blocks, o, log, log_cap, 0, jacobi_scaling);
+      post_eval_body(a, x, blocks, n_blocks, o, log, log_cap, 0, jacobi_scaling);     // (all threads: it has barriers inside)
       return;
     }
     use_current_R(a);

@@ -12,7 +12,8 @@
 //   calico_get_residuals -> cost-only kernel without the loss function.
 // There is no CPU compute path in this library.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>     // types only: the library itself is loaded on first use (RcclApi below)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -26,6 +27,7 @@
 #include <vector>
 
 #include "../../include/calico_hip.h"
+#include "calico_hip_testing.h"
 #include "problem_dev.hpp"
 #include "shard.hpp"
 
@@ -93,6 +95,42 @@ namespace {
 constexpr size_t kMaxLds = 160 * 1024;
 constexpr int kLogCap = 4096;
 constexpr int kNumPhases = 6;   // 5 = calibration: the same event bracket around a trivial kernel
+
+// RCCL is loaded when the first communicator is asked for (calico_comm_get_unique_id / calico_comm_init_rccl), not at
+// link time: a single-GPU user needs no librccl on the machine. An already loaded librccl (e.g. the one torch ships) is
+// found by its soname; otherwise $ROCM_PATH/lib, then the loader's search path.
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+  bool ok() const { return lib != nullptr; }
+};
+RcclApi& rccl() {
+  static RcclApi api = [] {
+    RcclApi a;
+    std::vector<std::string> names = {"librccl.so.1", "librccl.so"};
+    for (const char* env : {"ROCM_PATH", "ROCM_HOME"})
+      if (const char* r = std::getenv(env)) { names.push_back(std::string(r) + "/lib/librccl.so.1"); names.push_back(std::string(r) + "/lib/librccl.so"); }
+    names.push_back("/opt/rocm/lib/librccl.so.1"); names.push_back("/opt/rocm/lib/librccl.so");
+    for (const std::string& n : names) { a.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL); if (a.lib) break; }
+    if (!a.lib) { a.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return a; }
+    auto sym = [&](const char* n) { void* f = dlsym(a.lib, n); if (!f && a.error.empty()) a.error = std::string("librccl lacks ") + n; return f; };
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(sym("ncclCommCount"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!a.error.empty()) { dlclose(a.lib); a.lib = nullptr; }
+    return a;
+  }();
+  return api;
+}
 
 struct HBlock {
   std::vector<double> v;
@@ -907,7 +945,10 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_state.alloc(1)); HIP_TRY(p, p->d_log.alloc(kLogCap));
   // fine-grained (coherent): the terminating stage of a solve writes its results here and the host reads them while
   // later kernels are still on the stream
-  if (!p->h_state) HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LmState), hipHostMallocMapped | hipHostMallocCoherent));
+  if (!p->h_state) {
+    HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LmState), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(p->h_state, 0, sizeof(LmState));
+  }
   if (!p->h_log) HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_log), size_t(kLogCap) * sizeof(IterLog), hipHostMallocMapped | hipHostMallocCoherent));
   if (p->h_xpin_n < size_t(p->n_amb)) {
     if (p->h_xpin) (void)hipHostFree(p->h_xpin);
@@ -918,6 +959,7 @@ int finalize(calico_problem* p) {
   if (!p->h_progress) {
     HIP_TRY(p, hipHostMalloc(reinterpret_cast<void**>(&p->h_progress), 64, hipHostMallocMapped | hipHostMallocCoherent));   // fine-grained: the host polls it while kernels run
     HIP_TRY(p, hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_progress), p->h_progress, 0));
+    std::memset(p->h_progress, 0, 64);     // epoch 0 is never used: words of "no solve yet"
   }
   section("uploads + allocations");
   // kernel attributes
@@ -989,8 +1031,8 @@ int upload_x(calico_problem* p, bool seed = true) {
 
 int do_allreduce(calico_problem* p, double* buf, int64_t n) {
   if (p->comm) {     // native: one in-place RCCL all-reduce on the handle's stream, no host code in between
-    const ncclResult_t r = ncclAllReduce(buf, buf, size_t(n), ncclDouble, ncclSum, p->comm, p->stream);
-    if (r != ncclSuccess) return p->set_error(CALICO_INTERNAL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    const ncclResult_t r = rccl().AllReduce(buf, buf, size_t(n), ncclDouble, ncclSum, p->comm, p->stream);
+    if (r != ncclSuccess) return p->set_error(CALICO_INTERNAL, std::string("ncclAllReduce: ") + rccl().GetErrorString(r));
     return CALICO_OK;
   }
   if (!p->allreduce) return CALICO_OK;
@@ -1162,10 +1204,12 @@ int32_t calico_problem_create(calico_problem** out, int32_t device) {
 }
 
 void calico_problem_destroy(calico_problem* p) {
-  if (p && p->comm) { (void)hipSetDevice(p->device); (void)ncclCommDestroy(p->comm); p->comm = nullptr; }
   if (!p) return;
   (void)hipSetDevice(p->device);
+  // first drain the stream -- the iterations enqueued ahead of a terminated multi-rank solve each still carry an
+  // all-reduce --, then give the communicator back
   if (p->stream) (void)hipStreamSynchronize(p->stream);
+  if (p->comm) { (void)rccl().CommDestroy(p->comm); p->comm = nullptr; }
   if (p->h_state) (void)hipHostFree(p->h_state);
   if (p->h_progress) (void)hipHostFree(p->h_progress);
   if (p->h_xpin) (void)hipHostFree(p->h_xpin);
@@ -1345,6 +1389,8 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   if (rc != CALICO_OK) return rc;
   fill_counts(p, sm);
   p->iterations.clear();
+  // event brackets nobody has asked about yet: resolved here once they pile up (a solve returns without draining them)
+  if (p->timer.pending.size() > 8192) { HIP_TRY(p, hipStreamSynchronize(p->stream)); p->timer.resolve(); }
   LmOptionsDev o;
   o.max_num_iterations = opt->max_num_iterations; o.max_num_consecutive_invalid_steps = opt->max_num_consecutive_invalid_steps;
   o.function_tolerance = opt->function_tolerance; o.gradient_tolerance = opt->gradient_tolerance;
@@ -1365,7 +1411,9 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   // terminates the solve writes the results (state, log, parameters) into pinned host memory itself, so the call
   // returns as soon as the flag is up: the early-exit kernels drain while the caller prepares its next call.
   const int stream_depth = [] { const char* e = std::getenv("CALICO_STREAM_DEPTH"); return e ? std::atoi(e) : 2; }();
-  const bool streaming = p->speculative && !p->has_exchange() && stream_depth > 0 && p->h_progress != nullptr;
+  // (the progress word carries the iteration count in 20 bits: budgets beyond that take the batched loop)
+  const bool streaming = p->speculative && !p->has_exchange() && stream_depth > 0 && p->h_progress != nullptr &&
+                         opt->max_num_iterations <= 0xfffff;
   const int log_rows = std::min(kLogCap, std::max(0, opt->max_num_iterations) + 2);
   ResultSink sink = {};
   if (streaming) {
@@ -1832,7 +1880,7 @@ int32_t calico_comm_get_unique_id(uint8_t* id_out) {
   if (!id_out) return CALICO_INVALID_ARGUMENT;
   static_assert(sizeof(ncclUniqueId) == CALICO_COMM_ID_BYTES, "RCCL unique id size");
   ncclUniqueId id;
-  if (ncclGetUniqueId(&id) != ncclSuccess) return CALICO_INTERNAL;
+  if (!rccl().ok() || rccl().GetUniqueId(&id) != ncclSuccess) return CALICO_INTERNAL;
   std::memcpy(id_out, &id, sizeof(id));
   return CALICO_OK;
 }
@@ -1840,13 +1888,32 @@ int32_t calico_comm_get_unique_id(uint8_t* id_out) {
 int32_t calico_comm_init_rccl(calico_problem* p, const uint8_t* id, int32_t rank, int32_t world_size) {
   if (!p || !id) return CALICO_INVALID_ARGUMENT;
   if (world_size < 1 || rank < 0 || rank >= world_size) return p->set_error(CALICO_INVALID_ARGUMENT, "bad rank / world size");
+  if (!rccl().ok()) return p->set_error(CALICO_INTERNAL, rccl().error);
   HIP_TRY(p, hipSetDevice(p->device));
-  if (p->comm) { (void)ncclCommDestroy(p->comm); p->comm = nullptr; }
+  if (p->comm) { if (p->stream) (void)hipStreamSynchronize(p->stream); (void)rccl().CommDestroy(p->comm); p->comm = nullptr; }
   ncclUniqueId uid;
   std::memcpy(&uid, id, sizeof(uid));
-  const ncclResult_t r = ncclCommInitRank(&p->comm, world_size, uid, rank);
-  if (r != ncclSuccess) { p->comm = nullptr; return p->set_error(CALICO_INTERNAL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+  const ncclResult_t r = rccl().CommInitRank(&p->comm, world_size, uid, rank);
+  if (r != ncclSuccess) { p->comm = nullptr; return p->set_error(CALICO_INTERNAL, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r)); }
   p->rank = rank; p->world = world_size; p->dirty = true;
+  return CALICO_OK;
+}
+
+int32_t calico_comm_info(calico_problem* p, int32_t* rank_out, int32_t* world_out, int64_t* local_blocks_out, int64_t* total_blocks_out) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  int world = p->world;
+  if (p->comm) {      // what the communicator itself says, not what the caller asked for
+    if (rccl().CommCount(p->comm, &world) != ncclSuccess) return p->set_error(CALICO_INTERNAL, "ncclCommCount failed");
+  }
+  const int rc = finalize(p);
+  if (rc != CALICO_OK) return rc;
+  int64_t local = 0, total = 0;
+  for (const ItemDev& it : p->h_items) local += it.obs_count;
+  for (const ItemDev& it : p->h_items_all) total += it.obs_count;
+  if (rank_out) *rank_out = p->rank;
+  if (world_out) *world_out = world;
+  if (local_blocks_out) *local_blocks_out = local;
+  if (total_blocks_out) *total_blocks_out = total;
   return CALICO_OK;
 }
 

@@ -75,6 +75,7 @@ DEVI void log_and_finalize(LmState* st, const LmOptionsDev& o, IterLog* log, int
 
 // After a Jacobian evaluation at x: x_cost, gradient norms |x - Plus(x,-g)|,
 // Jacobi scaling at iteration 0, the iteration's log row.
+// Call with ALL threads of the workgroup (256 or more): the first 256 do the work, every thread reaches every barrier.
 DEVI void post_eval_body(SolveArgs a, const double* __restrict__ x, const BlockDev* __restrict__ blocks, int n_blocks,
                          const LmOptionsDev& o, IterLog* log, int log_cap, int first, int jacobi_scaling) {
   LmState* st = a.st;
@@ -82,12 +83,13 @@ DEVI void post_eval_body(SolveArgs a, const double* __restrict__ x, const BlockD
   use_current_R(a);
   __shared__ double s_max[256], s_sum[256];
   const int tid = threadIdx.x;
+  const bool act = tid < 256;
   const int NT = a.NT();
-  if (first) {
+  if (first && act) {
     for (int j = tid; j < NT; j += 256) a.scale[j] = jacobi_scaling ? 1.0 / (1.0 + sqrt(diag_entry(a, j))) : 1.0;
   }
   double mx = 0.0, sm = 0.0;
-  for (int b = tid; b < n_blocks; b += 256) {
+  for (int b = act ? tid : n_blocks; b < n_blocks; b += 256) {
     const BlockDev B = blocks[b];
     const double* g = a.R + a.off_g() + B.tan_off;
     if (B.manifold == 1) {
@@ -109,7 +111,7 @@ DEVI void post_eval_body(SolveArgs a, const double* __restrict__ x, const BlockD
       for (int i = 0; i < B.size; ++i) { mx = fmax(mx, fabs(g[i])); sm += g[i] * g[i]; }
     }
   }
-  s_max[tid] = mx; s_sum[tid] = sm;
+  if (act) { s_max[tid] = mx; s_sum[tid] = sm; }
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if (tid < off) { s_max[tid] = fmax(s_max[tid], s_max[tid + off]); s_sum[tid] += s_sum[tid + off]; }
@@ -130,7 +132,7 @@ DEVI void post_eval_body(SolveArgs a, const double* __restrict__ x, const BlockD
   }
   __syncthreads();
   if (st->terminated) {   // (uniform) the host stops enqueueing iterations and reads the results
-    publish_results_block(st, tid, 256);
+    if (act) publish_results_block(st, tid, 256);
     __syncthreads();
     if (tid == 0) { st->published = 1; if (a.progress) publish(a.progress + 1, st->sink.epoch); }
   }

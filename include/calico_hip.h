@@ -220,17 +220,6 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* options,
 int32_t calico_get_iterations(calico_problem* p, calico_iteration* out,
                               int32_t max_rows, int32_t* n_out);
 
-/* Test hook, not part of the drop-in surface: the device's trust-region control stage (the accept / reject decision, the
- * radius schedule and the iteration log of ceres::TrustRegionMinimizer as restated in solve_kernels.hip) driven by a
- * given sequence of step qualities rho[i] (infinite[i] != 0: the candidate's cost could not be evaluated). Row i runs
- * the same control kernel a solve runs, seeded with x_cost = model_cost_change = 1 and candidate cost 1 - rho[i];
- * radius, decrease factor and counters carry over. Out: radius after the row, accepted flag, and the cost column the
- * row shows. tests/test_ceres_log.py replays the iteration table the reference ships
- * (demos/imu_camera_calibration.ipynb) through it. */
-int32_t calico_debug_lm_control_replay(int32_t device, int32_t n, const double* rho, const int32_t* infinite,
-                                       const calico_solver_options* options, double* radius_out, int32_t* accepted_out,
-                                       double* cost_column_out);
-
 /* Replaces Sensor::UpdateResiduals (camera.cpp:70-80, gyroscope.cpp:171-182,
  * accelerometer.cpp:58-69): sigma-weighted residuals WITHOUT the loss
  * function, in the order the residuals were added. out is n×dim (dim 2 for a
@@ -309,6 +298,11 @@ int32_t calico_evaluate(calico_problem* p, double* cost, double* gradient,
 #define CALICO_COMM_ID_BYTES 128
 int32_t calico_comm_get_unique_id(uint8_t* id_out /* CALICO_COMM_ID_BYTES */);
 int32_t calico_comm_init_rccl(calico_problem* p, const uint8_t* id, int32_t rank, int32_t world_size);
+/* What the handle's exchange really spans: rank and rank count as the RCCL communicator reports them (ncclCommCount; the
+ * shard set by calico_problem_set_shard when there is no communicator) and the number of residual blocks this rank
+ * evaluates out of the problem's total (finalises the problem). Any output pointer may be NULL. */
+int32_t calico_comm_info(calico_problem* p, int32_t* rank_out, int32_t* world_out, int64_t* local_blocks_out,
+                         int64_t* total_blocks_out);
 /* Host-side exchange (tests, exotic transports): a callback instead of the communicator. */
 typedef int32_t (*calico_allreduce_fn)(void* ctx, void* buf, int64_t n,
                                        void* stream);

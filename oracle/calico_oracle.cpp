@@ -105,6 +105,9 @@ struct Problem {
   int32_t (*allreduce)(void*, double*, int64_t) = nullptr;
   void* allreduce_ctx = nullptr;
   std::vector<char> own;  // per residual block
+  // wall time of the last Solve by part (bench.py's cpu_baseline): residual / Jacobian evaluation, normal-equation
+  // assembly (Ceres: both inside the evaluator / the Schur eliminator's block products), dense factorisation + solve
+  mutable double t_evaluate = 0, t_assemble = 0, t_linear_solve = 0;
   void reduce(double* buf, int64_t n) const { if (allreduce) allreduce(allreduce_ctx, buf, n); }
   int set_error(int code, const std::string& m) { error = m; return code; }
 };
@@ -443,7 +446,8 @@ static void AccumulateJtJ(const Problem& P, const Evaluation& E, const double* s
                           std::vector<double>* H) {
   const int n = P.n_eff;
   const int64_t nb = int64_t(P.rblocks.size());
-  const int T = std::max(1, std::min(num_threads, 16));
+  // one dense copy per thread: at most 16, and no more than ~2 GB of them
+  const int T = std::max(1, std::min(std::min(num_threads, 16), int(2.5e8 / (double(n) * n + 1.0))));
   std::vector<std::vector<double>> Ht(T);
   auto work = [&](int tid) {
     std::vector<double>& h = Ht[tid];
@@ -503,6 +507,69 @@ static bool CholeskySolve(std::vector<double>& A, int n, std::vector<double>& b)
   return true;
 }
 
+// The same factorisation for large systems (long trajectories: thousands of unknowns), blocked by 64 columns with the
+// panel solve and the trailing update spread over threads. Only the order of the additions differs from the loop above.
+static bool CholeskySolveBlocked(std::vector<double>& A, int n, std::vector<double>& b, int num_threads) {
+  const int NB = 64;
+  const int T = std::max(1, num_threads);
+  bool ok = true;
+  auto parallel_rows = [&](int lo, int hi, auto&& fn) {      // rows dealt cyclically: the work per row grows with the row
+    if (T == 1 || hi - lo < 4 * T) { for (int i = lo; i < hi; ++i) fn(i); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back([&, t] { for (int i = lo + t; i < hi; i += T) fn(i); });
+    for (auto& x : th) x.join();
+  };
+  for (int j0 = 0; j0 < n && ok; j0 += NB) {
+    const int jb = std::min(NB, n - j0), j1 = j0 + jb;
+    for (int j = j0; j < j1; ++j) {                             // diagonal block
+      double d = A[size_t(j) * n + j];
+      for (int k = j0; k < j; ++k) d -= A[size_t(j) * n + k] * A[size_t(j) * n + k];
+      if (!(d > 0.0) || !std::isfinite(d)) { ok = false; break; }
+      d = std::sqrt(d);
+      A[size_t(j) * n + j] = d;
+      for (int i = j + 1; i < j1; ++i) {
+        double v = A[size_t(i) * n + j];
+        for (int k = j0; k < j; ++k) v -= A[size_t(i) * n + k] * A[size_t(j) * n + k];
+        A[size_t(i) * n + j] = v / d;
+      }
+    }
+    if (!ok) break;
+    parallel_rows(j1, n, [&](int i) {                           // panel: L(i, j0:j1) = A(i, j0:j1) L_jj^-T
+      double* ri = &A[size_t(i) * n];
+      for (int j = j0; j < j1; ++j) {
+        const double* rj = &A[size_t(j) * n];
+        double v = ri[j];
+        for (int k = j0; k < j; ++k) v -= ri[k] * rj[k];
+        ri[j] = v / rj[j];
+      }
+    });
+    parallel_rows(j1, n, [&](int i) {                           // trailing update of the lower triangle
+      double* ri = &A[size_t(i) * n];
+      const double* li = ri + j0;
+      for (int c = j1; c <= i; ++c) {
+        const double* lc = &A[size_t(c) * n + j0];
+        double v = 0;
+        for (int k = 0; k < jb; ++k) v += li[k] * lc[k];
+        ri[c] -= v;
+      }
+    });
+  }
+  if (!ok) return false;
+  for (int i = 0; i < n; ++i) {
+    double v = b[i];
+    for (int k = 0; k < i; ++k) v -= A[size_t(i) * n + k] * b[k];
+    b[i] = v / A[size_t(i) * n + i];
+  }
+  // backward sweep in axpy form: the factor is stored by rows, a column walk would miss the cache on every element
+  for (int i = n - 1; i >= 0; --i) {
+    b[i] /= A[size_t(i) * n + i];
+    const double bi = b[i];
+    const double* ri = &A[size_t(i) * n];
+    for (int k = 0; k < i; ++k) b[k] -= ri[k] * bi;
+  }
+  return true;
+}
+
 // [Ceres] ProgramEvaluator::Plus over the reduced blocks.
 static void PlusAll(const Problem& P, const std::vector<std::vector<double>>& x, const double* delta,
                     std::vector<std::vector<double>>* out) {
@@ -556,6 +623,12 @@ static int Solve(Problem& P, const calico_solver_options& o, calico_summary* sm)
   std::vector<std::vector<double>> x(P.blocks.size()), cand;
   for (size_t i = 0; i < P.blocks.size(); ++i) x[i] = P.blocks[i].v;
   Evaluation E, Ec;
+  P.t_evaluate = P.t_assemble = P.t_linear_solve = 0;
+  auto timed = [](double& acc, auto&& fn) {
+    const auto t0 = std::chrono::steady_clock::now();
+    fn();
+    acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  };
   auto finish = [&](int term, const char* msg) {
     sm->termination_type = term;
     std::snprintf(sm->message, sizeof(sm->message), "%s", msg);
@@ -569,7 +642,7 @@ static int Solve(Problem& P, const calico_solver_options& o, calico_summary* sm)
   };
   // iteration 0
   double x_norm = ReducedNorm(P, x);
-  Evaluate(P, x, true, o.num_threads, &E);
+  timed(P.t_evaluate, [&] { Evaluate(P, x, true, o.num_threads, &E); });
   sm->num_jacobian_evaluations++;
   if (!E.ok) return finish(CALICO_FAILURE, "Initial residual and Jacobian evaluation failed.");
   double x_cost = E.cost;
@@ -578,10 +651,10 @@ static int Solve(Problem& P, const calico_solver_options& o, calico_summary* sm)
   std::vector<double> H;
   if (o.jacobi_scaling) {
     std::vector<double> Hd;
-    AccumulateJtJ(P, E, nullptr, o.num_threads, &Hd);
+    timed(P.t_assemble, [&] { AccumulateJtJ(P, E, nullptr, o.num_threads, &Hd); });
     for (int i = 0; i < n; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(Hd[size_t(i) * n + i]));
   }
-  AccumulateJtJ(P, E, scale.data(), o.num_threads, &H);
+  timed(P.t_assemble, [&] { AccumulateJtJ(P, E, scale.data(), o.num_threads, &H); });
   auto gradient_norms = [&](double* gmax, double* gnorm) {
     // |x - Plus(x, -g)|, [Ceres] trust_region_minimizer.cc EvaluateGradientAndJacobian
     std::vector<double> ng(n);
@@ -629,7 +702,8 @@ static int Solve(Problem& P, const calico_solver_options& o, calico_summary* sm)
     std::vector<double> gs(n);
     for (int i = 0; i < n; ++i) { A[size_t(i) * n + i] += diagonal[i] / radius; gs[i] = E.gradient[i] * scale[i]; }
     std::vector<double> y = gs;
-    bool solved = CholeskySolve(A, n, y);
+    bool solved = false;
+    timed(P.t_linear_solve, [&] { solved = n > 1500 ? CholeskySolveBlocked(A, n, y, o.num_threads) : CholeskySolve(A, n, y); });
     if (solved) for (int i = 0; i < n; ++i) if (!std::isfinite(y[i])) solved = false;
     reuse_diagonal = true;
     double model_cost_change = 0;
@@ -672,7 +746,7 @@ static int Solve(Problem& P, const calico_solver_options& o, calico_summary* sm)
     for (int i = 0; i < n; ++i) delta[i] = step[i] * scale[i];
     // ComputeCandidatePointAndEvaluateCost
     PlusAll(P, x, delta.data(), &cand);
-    Evaluate(P, cand, false, o.num_threads, &Ec);
+    timed(P.t_evaluate, [&] { Evaluate(P, cand, false, o.num_threads, &Ec); });
     sm->num_cost_evaluations++;
     double candidate_cost = Ec.ok ? Ec.cost : std::numeric_limits<double>::max();
     // ParameterToleranceReached
@@ -691,11 +765,11 @@ static int Solve(Problem& P, const calico_solver_options& o, calico_summary* sm)
     if (it.relative_decrease > o.min_relative_decrease) {
       // HandleSuccessfulStep
       x = cand; x_norm = ReducedNorm(P, x);
-      Evaluate(P, x, true, o.num_threads, &E);
+      timed(P.t_evaluate, [&] { Evaluate(P, x, true, o.num_threads, &E); });
       sm->num_jacobian_evaluations++;
       if (!E.ok) { finish(CALICO_FAILURE, "Residual and Jacobian evaluation failed."); break; }
       x_cost = E.cost;
-      AccumulateJtJ(P, E, scale.data(), o.num_threads, &H);
+      timed(P.t_assemble, [&] { AccumulateJtJ(P, E, scale.data(), o.num_threads, &H); });
       it.cost = x_cost; it.step_is_successful = 1;
       gradient_norms(&it.gradient_max_norm, &gnorm);
       tr.step_accepted(it.relative_decrease, o.max_trust_region_radius); reuse_diagonal = false;
@@ -835,6 +909,20 @@ int32_t oracle_problem_add_imu_residuals(Problem* p, int32_t sid, int64_t n, con
   return add_obs(p, sid, n, m, st, nullptr, nullptr);
 }
 int32_t oracle_solve(Problem* p, const calico_solver_options* o, calico_summary* sm) { return oracle::Solve(*p, *o, sm); }
+// Test hook: the blocked, threaded Cholesky (systems beyond 1500 unknowns) against the plain loop on the same SPD system
+// A (n x n, row-major) x = b; returns the largest |x_blocked - x_plain| / max|x_plain|, or -1 when either fails.
+double oracle_cholesky_blocked_vs_plain(int32_t n, const double* A, const double* b, int32_t num_threads) {
+  std::vector<double> A1(A, A + size_t(n) * n), A2 = A1, b1(b, b + n), b2 = b1;
+  if (!oracle::CholeskySolve(A1, n, b1) || !oracle::CholeskySolveBlocked(A2, n, b2, num_threads)) return -1.0;
+  double d = 0, m = 0;
+  for (int i = 0; i < n; ++i) { d = std::max(d, std::fabs(b1[i] - b2[i])); m = std::max(m, std::fabs(b1[i])); }
+  return m > 0 ? d / m : d;
+}
+// seconds of the last oracle_solve by part: [residual/Jacobian evaluation, normal-equation assembly, dense factorisation + solve]
+int32_t oracle_get_solve_timing(Problem* p, double* out3) {
+  out3[0] = p->t_evaluate; out3[1] = p->t_assemble; out3[2] = p->t_linear_solve;
+  return CALICO_OK;
+}
 int32_t oracle_problem_set_shard(Problem* p, int32_t rank, int32_t world) {
   if (world < 1 || rank < 0 || rank >= world) return p->set_error(CALICO_INVALID_ARGUMENT, "bad rank / world size");
   p->rank = rank; p->world = world; return CALICO_OK;

@@ -26,14 +26,16 @@ def main():
     for cell in nb["cells"]:
         if cell["cell_type"] != "code":
             continue
-        for out in cell.get("outputs", []):
-            text = "".join(out.get("text", [])) if "text" in out else ""
-            if "tr_ratio" not in text:
-                continue
-            for line in text.split("\n"):
-                f = line.split()
-                if len(f) >= 7 and f[0].isdigit():     # the last row of the notebook's output is cut short: left out
-                    rows.append([float(v) for v in f[:7]])
+        # the notebook stores the cell's stdout in several chunks (another stream's output sits between them) and the
+        # cut falls in the middle of row 19: the stdout chunks are stitched back together before the rows are parsed
+        text = "".join("".join(out.get("text", [])) for out in cell.get("outputs", [])
+                       if out.get("output_type") == "stream" and out.get("name") == "stdout")
+        if "tr_ratio" not in text:
+            continue
+        for line in text.split("\n"):
+            f = line.split()
+            if len(f) >= 7 and f[0].isdigit():
+                rows.append([float(v) for v in f[:7]])
     if not rows:
         sys.exit("no iteration table found in " + SRC)
     a = np.array(rows)

@@ -54,6 +54,45 @@ def test_normal_equations_and_first_iterations_match_oracle(config, hip, oracle)
     assert np.abs(ctg - ctr).max() <= 1e-6 * max(1.0, np.abs(ctr).max())
 
 
+@pytest.mark.parametrize("shape", [5, 6])
+def test_long_trajectories_match_oracle(shape, hip, oracle):
+    """Long trajectories against the oracle (they were only benchmarked before): configs[3] at 50 Hz knots -- 440 control
+    points, a 6-level elimination tree -- and the shape of the run the reference's notebook holds -- one camera + IMU,
+    1453 control points (8763 unknowns), an 8-level tree. One evaluation of [cost, Jtr, JtJ] to 1e-9 and the first three
+    LM iterations (accept / reject, cost per iteration, estimates). The oracle factors the dense normal equations (its
+    blocked, threaded Cholesky takes over beyond 1500 unknowns: tests/test_oracle_known_answers.py pins it to the plain one)."""
+    scene = syn.config_scene(shape)
+    assert len(scene.ctrl) == {5: 440, 6: 1453}[shape]
+    gpu, ref = syn.build_problem(hip, scene), syn.build_problem(oracle, scene)
+    cg, gg, Hg = gpu.problem.evaluate()
+    cr, gr, Hr = ref.problem.evaluate()
+    assert Hg.shape == Hr.shape and Hg.shape[0] == 6 * len(scene.ctrl) + (gg.size - 6 * len(scene.ctrl))
+    assert abs(cg - cr) <= 1e-10 * abs(cr)
+    assert np.abs(gg - gr).max() <= 1e-9 * np.abs(gr).max()
+    sd = np.sqrt(np.diag(Hr))
+    sd = np.where(sd > 0, sd, 1.0)
+    worst = 0.0
+    for r0 in range(0, Hr.shape[0], 512):          # by row panels: the dense matrices are 0.6 GB each at 1453 control points
+        blk = np.abs(Hg[r0:r0 + 512] - Hr[r0:r0 + 512]) / (sd[r0:r0 + 512, None] * sd[None, :])
+        worst = max(worst, float(blk.max()))
+    assert worst <= 1e-9
+    del Hg, Hr
+    n_it = 3
+    sg_, sr_ = gpu.problem.solve(_options(hip, n_it)), ref.problem.solve(_options(oracle, n_it))
+    assert sg_.num_effective_parameters_reduced == sr_.num_effective_parameters_reduced
+    ig, ir = gpu.problem.iterations(), ref.problem.iterations()
+    assert len(ig) == len(ir) == n_it + 1
+    for a, b in zip(ig, ir):
+        assert a.step_is_successful == b.step_is_successful
+        assert abs(a.cost - b.cost) <= 1e-7 * abs(b.cost)
+        assert abs(a.trust_region_radius - b.trust_region_radius) <= 1e-6 * b.trust_region_radius
+    eg, ctg = syn.read_back(gpu, scene)
+    er, ctr = syn.read_back(ref, scene)
+    for a, b in zip(eg, er):
+        assert np.abs(a["intrinsics"] - b["intrinsics"]).max() <= 1e-6 * np.abs(b["intrinsics"]).max()
+    assert np.abs(ctg - ctr).max() <= 1e-6 * max(1.0, np.abs(ctr).max())
+
+
 def test_full_solve_converges_and_repeats_bit_identically(config, hip):
     index, scene = config
     runs = []

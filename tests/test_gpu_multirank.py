@@ -165,3 +165,82 @@ def test_two_ranks_on_one_gpu_equal_single_rank(batched, hip):
             assert np.abs(a - b["intrinsics"]).max() <= 1e-9 * np.abs(b["intrinsics"]).max()
     # both ranks hold the same estimates bit for bit (deterministic all-reduce, replicated solve)
     assert np.array_equal(results[0][5], results[1][5])
+
+
+def _rccl_worker(rank, world, id_bytes, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import helpers
+    from calico_amd import synthetic as syn
+    torch.cuda.set_device(rank)
+    torch.zeros(1, device="cuda")
+    api = helpers.hip_api()
+    scene = _scene()
+    built = syn.build_problem(api, scene, device=rank)
+    P = built.problem
+    P.comm_init_rccl(id_bytes, rank, world)      # one process per GPU; the handle all-reduces natively
+    info = P.comm_info()
+    s, its = _solve(P, api, 4)
+    est, ctrl = syn.read_back(built, scene)
+    q.put((rank, s.final_cost, s.num_iterations, s.termination_type, [e["intrinsics"] for e in est], ctrl, its, info))
+    P.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_native_rccl_ranks_equal_single_rank(world, hip):
+    """The production exchange with more than one rank (one process per GPU, ncclAllReduce of the packed normal equations
+    over xGMI, commit by copy, zero-filled targets): every rank must walk the single-rank solve's iterations and reach its
+    estimates (1e-9: the sum over ranks is associated differently). Needs `world` GPUs in the box."""
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs, this box has %d" % (world, torch.cuda.device_count()))
+    import multiprocessing as mp
+    from calico_amd import _capi, synthetic as syn
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    uid = _capi.comm_unique_id(hip)
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, uid, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    scene = _scene()
+    single = syn.build_problem(hip, scene)
+    s, its = _solve(single.problem, hip, 4)
+    est, ctrl = syn.read_back(single, scene)
+    total = 0
+    for rank, final_cost, n_it, term, intr, c, rits, info in results:
+        assert info[0] == rank and info[1] == world and info[3] == scene.num_blocks
+        total += info[2]
+        assert term == s.termination_type and n_it == s.num_iterations
+        assert abs(final_cost - s.final_cost) <= 1e-9 * s.final_cost
+        assert [(a, b) for a, b, _ in rits] == [(a, b) for a, b, _ in its]
+        assert np.abs(c - ctrl).max() <= 1e-9 * np.abs(ctrl).max()
+        for a, b in zip(intr, est):
+            assert np.abs(a - b["intrinsics"]).max() <= 1e-9 * np.abs(b["intrinsics"]).max()
+        assert np.array_equal(c, results[0][5])      # replicated solve of a deterministic sum: bit-identical ranks
+    assert total == scene.num_blocks                 # every residual block has exactly one owner
+
+
+def test_comm_info_of_a_single_rank(hip):
+    from calico_amd import _capi, synthetic as syn
+    scene = _scene()
+    b = syn.build_problem(hip, scene)
+    assert b.problem.comm_info() == (0, 1, scene.num_blocks, scene.num_blocks)
+    b.problem.comm_init_rccl(_capi.comm_unique_id(hip), 0, 1)
+    assert b.problem.comm_info() == (0, 1, scene.num_blocks, scene.num_blocks)     # ncclCommCount of a world of one
+    b.problem.set_shard(1, 3)
+    r, w, nl, nt = b.problem.comm_info()
+    assert (r, nt) == (1, scene.num_blocks) and 0 < nl < nt
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """`python bench.py --gpus N` starts N ranks itself; with fewer than N devices it must fail, not report a smaller run."""
+    import subprocess
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "only %d GPU(s) visible" % (n - 1) in r.stderr and r.stdout.strip() == ""

@@ -159,7 +159,7 @@ def test_noisy_robust_solve_matches_oracle(hip, oracle):
             assert np.array_equal(mg, mr)
 
 
-@pytest.mark.parametrize("order", [4, 5, 7])
+@pytest.mark.parametrize("order", [4, 5, 7, 8])
 def test_other_spline_orders(order, hip, oracle):
     """Orders other than the reference's default 6 take the generic kernels (no camera-frame path, run-time spline
     order in the evaluation, K-templated band kernels): same parity bar -- evaluation to 1e-9, solve to 1e-6."""

@@ -327,3 +327,22 @@ def test_imu_model_round_trip(lib, model, intr):
         assert np.abs(syn.imu_project(model, k, w[None])[0] - f).max() < 1e-14
     assert lib.oracle_camera_num_params(1) == 8 and lib.oracle_camera_num_params(7) == 5
     assert lib.oracle_imu_num_params(3) == 12 and lib.oracle_imu_num_params(0) == -1
+
+
+def test_blocked_cholesky_equals_plain_cholesky():
+    """Beyond 1500 unknowns (long trajectories) the oracle factors its dense normal equations with a blocked, threaded
+    Cholesky; it must give what the plain loop gives (only the order of the additions differs)."""
+    import ctypes as C
+    lib = helpers.oracle_lib()
+    fn = lib.oracle_cholesky_blocked_vs_plain
+    fn.restype = C.c_double
+    fn.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32]
+    rng = np.random.default_rng(7)
+    for n, threads in ((1, 1), (63, 1), (64, 4), (65, 3), (200, 8), (517, 5)):
+        M = rng.standard_normal((n, n + 5))
+        A = np.ascontiguousarray(M @ M.T + 1e-3 * np.eye(n))      # SPD, condition number ~1e3-1e5
+        b = rng.standard_normal(n)
+        d = fn(n, A.ctypes.data_as(C.POINTER(C.c_double)), b.ctypes.data_as(C.POINTER(C.c_double)), threads)
+        assert 0.0 <= d <= 1e-10, (n, threads, d)
+    A = -np.eye(3)
+    assert fn(3, A.ctypes.data_as(C.POINTER(C.c_double)), np.ones(3).ctypes.data_as(C.POINTER(C.c_double)), 2) == -1.0
