@@ -82,7 +82,7 @@ def cpu_baseline(scene, min_seconds=10.0):
         dt = 0.0
         part = [0.0, 0.0, 0.0]
         last = None
-        while dt < budget_s and solves < max_solves:
+        while (solves == 0 or dt < budget_s) and solves < max_solves:
             built = syn.build_problem(api, scene)      # fresh problem = same perturbed start
             t = time.time()
             last = built.problem.solve(o)

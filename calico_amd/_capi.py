@@ -381,7 +381,8 @@ _hip_api = None
 
 
 def hip_library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _HIP_LIB_NAME)
+    # CALICO_HIP_LIB: another build of the same library (development A/B runs); the product path is the in-tree one
+    return os.environ.get("CALICO_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), _HIP_LIB_NAME)
 
 
 def load_hip():

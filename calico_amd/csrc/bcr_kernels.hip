@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 
 #include "problem_dev.hpp"
 #include "solve_dev.hpp"
@@ -587,6 +588,29 @@ DEVI const double* sep_solution(const SolveArgs& a, const BcrArgs& b, int blk) {
   return blk == b.root ? a.y + a.n_s() + a.mc : b.ysol + size_t(blk) * BP;
 }
 
+// ---- hand-off inside a launch (the dense reduced solve -> the back-substitution workgroups riding in its launch) ----
+// The producer's results leave with write-through (sc1) stores, are drained (s_waitcnt vmcnt(0)) and followed by an sc1
+// flag store; the consumers poll the flag from one lane with relaxed sc1 loads and read the results with sc1 loads (they
+// bypass the CU's vector L1, which another CU's stores never refresh). No agent-scope fence on either side: a release
+// would write back the XCD's L2, an acquire invalidate the L1 -- microseconds each (MI355X_MICROARCH.md, "inter-workgroup
+// visibility": the {sc1 stores, sc1 loads} form).
+struct Handoff { int* word; int seq; };       // word == nullptr: plain kernel boundary, no hand-off
+DEVI double load_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVI void store_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool HO> DEVI double load_y(const double* p) { return HO ? load_sc1(p) : *p; }
+// all threads of the workgroup; the stores of every thread are drained before the flag goes up
+DEVI void handoff_publish(const Handoff& h) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(h.word, h.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DEVI void handoff_wait(const Handoff& h) {
+  if (threadIdx.x == 0) {
+    while (__hip_atomic_load(h.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != h.seq) __builtin_amdgcn_s_sleep(4);
+  }
+  __syncthreads();
+}
+
 // delta = -y ; candidate = Plus(x, delta) for the parameter blocks selected by the caller; partial sums of the model
 // cost change and of the step norms go to the node's slot. (delta / Plus as in update_body, solve_kernels.hip.)
 struct UpdSums { double mcc, sn, cn; int bad; };
@@ -640,35 +664,49 @@ DEVI void file_update_sums(const UpdSums& s, double* sh /* [4][waves] */, double
 constexpr int kBackThreads = 512;
 // Update of the calibration blocks (their BlockDevs follow the control points') and of the root's control points,
 // whose solution comes from the reduced solve; one workgroup of kBackThreads threads.
+template <bool HO>
 DEVI void back_calib(const SolveArgs& a, const BcrArgs& b, const double* __restrict__ x, double* __restrict__ x_cand,
-                     const BlockDev* __restrict__ blocks, int n_blocks, double* sh) {
+                     const BlockDev* __restrict__ blocks, int n_blocks, double* sh, double* ylds, const Handoff& ho) {
   LmState* st = a.st;
   const int tid = threadIdx.x;
   const int n_s = a.n_s(), mc = a.mc;
   constexpr int RB = 6 * kBcrCps;
   UpdSums s = {0.0, 0.0, 0.0, 0};
   {
+    // what does not depend on the reduced solve is requested first
+    const int jg = min(tid, max(mc - 1, 0));
+    const double g_c = a.R[a.off_g() + n_s + jg], d_c = a.dadd[n_s + jg];
+    const int tr = RB * max(b.root, 0) + min(tid, RB - 1);
+    const bool root_row = b.root >= 0 && tid < RB && tr < n_s;
+    const double g_r = a.R[a.off_g() + (root_row ? tr : 0)], d_r = a.dadd[root_row ? tr : 0];
+    if (HO) handoff_wait(ho);
+    // the solution of the reduced system [calibration | root] into LDS
+    const int ny = mc + (b.root >= 0 ? RB : 0);
+    for (int j = tid; j < ny; j += kBackThreads) ylds[j] = load_y<HO>(a.y + n_s + j);
+    __syncthreads();
     // calibration blocks (their BlockDevs follow the control points') and the root's control points
-    for (int j = tid; j < mc; j += kBackThreads) {
-      const double yj = a.y[n_s + j];
+    if (tid < mc) {
+      const double yj = ylds[tid];
+      if (!isfinite(yj)) s.bad = 1;
+      s.mcc += 0.5 * yj * (g_c + yj * d_c);
+    }
+    for (int j = tid + kBackThreads; j < mc; j += kBackThreads) {
+      const double yj = ylds[j];
       if (!isfinite(yj)) s.bad = 1;
       s.mcc += 0.5 * yj * (a.R[a.off_g() + n_s + j] + yj * a.dadd[n_s + j]);
     }
     for (int bi = tid; bi < n_blocks; bi += kBackThreads) {
       const BlockDev B = blocks[bi];
       if (B.tan_off < n_s) continue;
-      update_block(B, a.y + B.tan_off, x, x_cand, s);
+      update_block(B, ylds + (B.tan_off - n_s), x, x_cand, s);
     }
     if (b.root >= 0) {
-      const double* yr = a.y + n_s + mc;
-      if (tid < RB) {
-        const int t = RB * b.root + tid;
-        if (t < n_s) {
-          const double yj = yr[tid];
-          if (!isfinite(yj)) s.bad = 1;
-          s.mcc += 0.5 * yj * (a.R[a.off_g() + t] + yj * a.dadd[t]);
-          a.y[t] = yj;
-        }
+      const double* yr = ylds + mc;
+      if (root_row) {
+        const double yj = yr[tid];
+        if (!isfinite(yj)) s.bad = 1;
+        s.mcc += 0.5 * yj * (g_r + yj * d_r);
+        a.y[tr] = yj;
       }
       if (tid < kBcrCps) {
         const int cp = kBcrCps * b.root + tid;
@@ -684,10 +722,10 @@ DEVI void back_calib(const SolveArgs& a, const BcrArgs& b, const double* __restr
 // One node of the tree: back-substitution of its chain and update of the candidate point of its control points; one
 // workgroup of kBackThreads threads. `top`: the node forms L⁻¹g - Z^F y_c itself (sweeping its border rows) instead of
 // reading b.zb. QM bounds the unrolled load batches (longest chain of the level).
-template <int QM, int MODE>      // MODE 0: reads b.zb; 1: `top`; 2: top + the top separators beside the chain (BcrTopSeps)
+template <int QM, int MODE, bool HO>      // MODE 0: reads b.zb; 1: `top`; 2: top + the top separators beside the chain (BcrTopSeps)
 DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __restrict__ ndp, int /*top*/, int q_max, int terminated,
                     bool dbg_first, const double* __restrict__ x, double* __restrict__ x_cand, double* lds, double* sh,
-                    const BcrTopSeps& ts) {
+                    const BcrTopSeps& ts, const Handoff& ho) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_s = a.n_s(), mc = a.mc, m1p = b.m1p;
   const size_t fblk = size_t(BP) * m1p;
@@ -730,18 +768,20 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
   const bool my_cp_in = (tid < q * kBcrCps || sep_cp) && my_cp < a.n_cp;
   const int my_cp_c = my_cp_in ? my_cp : 0;
   const int my_off = b.ctrl_off[my_cp_c];
-  double ysep, ycv;
-  {
+  // (HO: the reduced system's solution is requested behind the hand-off, further down; everything else goes first)
+  double ysep = 0.0, ycv = 0.0;
+  auto load_solution = [&]() {
     const double* pl = nd_left >= 0 && sk[0] < 0 ? sep_solution(a, b, nd_left) : a.y;
     const double* pr = nd_right >= 0 && sk[1] < 0 ? sep_solution(a, b, nd_right) : a.y;
-    const double vl = pl[tid & 31], vr = pr[tid & 31];
+    const double vl = load_y<HO>(pl + (tid & 31)), vr = load_y<HO>(pr + (tid & 31));
     // the root's solution comes from the reduced solve, which knows its 30 real rows only: the two padding rows are 0,
     // not whatever sits behind them in y (an uninitialised word there may be a NaN, and NaN times a zero column is NaN)
     const bool pad = (tid & 31) >= RB;
     ysep = tid < BP ? ((nd_left >= 0 && !(pad && nd_left == b.root)) ? vl : 0.0)
                     : ((nd_right >= 0 && !(pad && nd_right == b.root)) ? vr : 0.0);
-    ycv = a.y[n_s + min(tid, mc - 1 > 0 ? mc - 1 : 0)];
-  }
+    ycv = load_y<HO>(a.y + n_s + min(tid, mc - 1 > 0 ? mc - 1 : 0));
+  };
+  if (!HO) load_solution();
   const int r16 = tid >> 4, sub = tid & 15;
   // (16-byte loads throughout: a workgroup issues a 64-lane load every ~12 clocks whatever its width, and the node waits
   //  for a few hundred of them. Thread (r16, sub) owns columns 2·sub, 2·sub + 1 (+ 32u for the border) of row r16.)
@@ -749,7 +789,7 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
   double s_zt[2], yroot_v = 0.0;
   if (side) {
     // (the root's solution: its 30 real rows, see above)
-    yroot_v = (b.root >= 0 && (tid & 31) < RB) ? a.y[n_s + mc + (tid & 31)] : 0.0;
+    if (!HO) yroot_v = (b.root >= 0 && (tid & 31) < RB) ? a.y[n_s + mc + (tid & 31)] : 0.0;
 #pragma unroll
     for (int sd = 0; sd < 2; ++sd) {
       const int eb = sk[sd] >= 0 ? ts.blk[sk[sd]] : blk0;       // (clamped, not predicated: harmless loads)
@@ -786,6 +826,12 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
 #pragma unroll
   for (int c = 0; c < 6; ++c) px[c] = x[my_off + c];
   if (terminated) return;
+  if (HO) {
+    // everything above is on its way (or here) while the reduced solve is still running in workgroup 0 of this launch
+    handoff_wait(ho);
+    load_solution();
+    if (side) yroot_v = (b.root >= 0 && (tid & 31) < RB) ? load_sc1(a.y + n_s + mc + (tid & 31)) : 0.0;
+  }
   BTICK(0)
   if (CAL_DEV_TIMING(a.debug > 1)) {     // development aid: which input of the node is not finite?
     bool bz = false, bm = false, ba = false, bt = false;
@@ -802,7 +848,7 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
   if (side && tid < BP) yroot[tid] = yroot_v;
   if (top) {
     if (tid < m1p) yc[tid] = tid < mc ? ycv : 0.0;
-    for (int j = tid + kBackThreads; j < m1p; j += kBackThreads) yc[j] = j < mc ? a.y[n_s + j] : 0.0;
+    for (int j = tid + kBackThreads; j < m1p; j += kBackThreads) yc[j] = j < mc ? load_y<HO>(a.y + n_s + j) : 0.0;
   }
 #pragma unroll
   for (int i = 0; i < QM; ++i) {
@@ -946,21 +992,19 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
 // grid = n_nodes; with `extras` (the first launch after the reduced solve when that kernel does not take the top
 // level along) + 1 workgroup for back_calib + N·32/8 workgroups that form L⁻¹g - Z^F y_c for the rows of every
 // superblock (b.zb), which nodes launched with top = 0 read instead of sweeping the border rows again.
-template <int QM, int MODE>     // longest chain of the level; MODE: see back_node
-__global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, BcrArgs b, int node0, int n_nodes, int top, int extras, int q_max,
-                                                                const double* __restrict__ x, double* __restrict__ x_cand,
-                                                                const BlockDev* __restrict__ blocks, int n_blocks, BcrTopSeps ts) {
+template <int QM, int MODE, bool HO>     // longest chain of the level; MODE: see back_node; HO: rides in the dense solve's launch
+DEVI void bcr_back_body(SolveArgs a, const BcrArgs& b, int wg, int node0, int n_nodes, int top, int q_max,
+                        const double* __restrict__ x, double* __restrict__ x_cand,
+                        const BlockDev* __restrict__ blocks, int n_blocks, const BcrTopSeps& ts, double* lds, double* sh, const Handoff& ho) {
   LmState* st = a.st;
   const int terminated = st->terminated;     // tested after the loads are on their way
   use_current_R(a);
-  extern __shared__ double lds[];
-  __shared__ double sh[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_s = a.n_s(), mc = a.mc, m1p = b.m1p;
-  if (int(blockIdx.x) >= n_nodes && terminated) return;
-  if (int(blockIdx.x) > n_nodes) {
-    // z - Z^F y_c, one wave per row of Y
-    const int row = (int(blockIdx.x) - n_nodes - 1) * (kBackThreads / 64) + wave;
+  if (wg >= n_nodes && terminated) return;
+  if (wg > n_nodes) {
+    // z - Z^F y_c, one wave per row of Y   (never part of a launch with a hand-off: see launch_dense_back)
+    const int row = (wg - n_nodes - 1) * (kBackThreads / 64) + wave;
     if (row >= b.N * BP) return;
     const double* yrow = b.Y + size_t(row) * m1p;
     const double* yc = a.y + n_s;
@@ -971,9 +1015,17 @@ __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, Bcr
     if (lane == 0) b.zb[row] = yrow[mc] - part;
     return;
   }
-  if (int(blockIdx.x) == n_nodes) { back_calib(a, b, x, x_cand, blocks, n_blocks, sh); return; }
+  if (wg == n_nodes) { back_calib<HO>(a, b, x, x_cand, blocks, n_blocks, sh, lds, ho); return; }
+  back_node<QM, MODE, HO>(a, b, b.nodes + node0 + wg, top, q_max, terminated, wg == 0, x, x_cand, lds, sh, ts, ho);
+}
+template <int QM, int MODE>
+__global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, BcrArgs b, int node0, int n_nodes, int top, int extras, int q_max,
+                                                                const double* __restrict__ x, double* __restrict__ x_cand,
+                                                                const BlockDev* __restrict__ blocks, int n_blocks, BcrTopSeps ts) {
+  extern __shared__ double lds[];
+  __shared__ double sh[64];
   (void)extras;
-  back_node<QM, MODE>(a, b, b.nodes + node0 + blockIdx.x, top, q_max, terminated, blockIdx.x == 0, x, x_cand, lds, sh, ts);
+  bcr_back_body<QM, MODE, false>(a, b, int(blockIdx.x), node0, n_nodes, top, q_max, x, x_cand, blocks, n_blocks, ts, lds, sh, Handoff{nullptr, 0});
 }
 
 // ---------------------------------------------------------------------------
@@ -992,10 +1044,9 @@ constexpr int DNL = 129;     // row stride of the dense matrix in LDS
 // (Taking the top level of the tree along in this workgroup -- back_calib + back_node for its one to three nodes -- was
 //  tried and lost: two nodes one after the other cost 12 us of dependent loads here against the 7 us of a launch that
 //  runs them side by side, and the levels below then sweep their own border rows.)
-__global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveArgs a, int nsl) {
+DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const Handoff& ho) {
   LmState* st = a.st;
   const int terminated = st->terminated;
-  extern __shared__ double lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, lk = lane >> 4;
   const int m = a.m, M1 = a.m + 1, n = a.n_s();
@@ -1219,8 +1270,31 @@ __global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveA
   if (dbg) printf("dense_block_solve wave %d cycles: load %lld | stage %lld  panel0 (rest tiles beside it) %lld  tile %lld  panel1 (rest tiles) %lld  Z %lld  file+rhs+next diagonal %lld | backward %lld\n",
                   wave, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7]);
 #undef DTICK
-  if (tid < m) a.y[n + tid] = yv[tid];
+  if (ho.word) {      // the back-substitution workgroups of this launch are waiting for the solution
+    if (tid < m) store_sc1(a.y + n + tid, yv[tid]);
+    handoff_publish(ho);
+  } else if (tid < m) a.y[n + tid] = yv[tid];
   if (wave == 0 && lane == 0 && !(pmin > 0.0)) st->chol_failed = 1;
+}
+__global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveArgs a, int nsl) {
+  extern __shared__ double lds[];
+  dense_block_solve_body(a, nsl, lds, Handoff{nullptr, 0});
+}
+// The dense reduced solve (workgroup 0) and the first back-substitution launch behind it (the other workgroups) in ONE
+// launch: the nodes request everything they need that the reduced solve does not produce -- L⁻ᵀ, Z^A, Z^B, border rows,
+// gradient, damping, current values: a few hundred loads per workgroup, ~3 us behind a kernel boundary -- while the solve
+// is still running, wait for its hand-off, and go on with the solution. Saves a kernel boundary and the load phase.
+static_assert(kDenseThreads == kBackThreads, "one launch, one workgroup size");
+template <int QM, int MODE>
+__global__ __launch_bounds__(kDenseThreads) void dense_back_kernel(SolveArgs a, BcrArgs b, int nsl, int node0, int n_nodes, int q_max,
+                                                                   const double* __restrict__ x, double* __restrict__ x_cand,
+                                                                   const BlockDev* __restrict__ blocks, int n_blocks, BcrTopSeps ts,
+                                                                   int* word, int seq) {
+  extern __shared__ double lds[];
+  __shared__ double sh[64];
+  const Handoff ho = {word, seq};
+  if (blockIdx.x == 0) { dense_block_solve_body(a, nsl, lds, ho); return; }
+  bcr_back_body<QM, MODE, true>(a, b, int(blockIdx.x) - 1, node0, n_nodes, 1, q_max, x, x_cand, blocks, n_blocks, ts, lds, sh, ho);
 }
 size_t dense_block_solve_lds_bytes() { return size_t(128 * DNL + 128 + 64 * DLD + 128 * 3 + 32 + 128 + kDenseThreads) * sizeof(double); }
 hipError_t configure_dense_block_solve() {
@@ -1229,6 +1303,33 @@ hipError_t configure_dense_block_solve() {
 }
 void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s) {
   hipLaunchKernelGGL(dense_block_solve_kernel, dim3(1), dim3(kDenseThreads), dense_block_solve_lds_bytes(), s, a, ks);
+}
+size_t bcr_back_lds_bytes(int q_max, int m1p);
+// Can the first back-substitution launch ride in the dense solve's launch? Only the shapes the in-LDS solve takes, no
+// border-row sweep workgroups (those would sit on every CU with the dense solve's LDS footprint), chains of at most four.
+bool dense_back_fusable(const SolveArgs& a, int ks, int q_max, bool border_rows) {
+  static const bool on = [] { const char* e = std::getenv("CALICO_FUSE_BACK"); return !e || std::atoi(e) != 0; }();
+  static const bool use_block = [] { const char* e = std::getenv("CALICO_DENSE"); return !(e && std::string(e) == "panel"); }();
+  return on && use_block && a.m + 1 <= 128 && a.m >= 1 && ks <= 2 && q_max <= 4 && !border_rows;
+}
+hipError_t configure_dense_back(int q_max, int m1p) {
+  const size_t lds = std::max(dense_block_solve_lds_bytes(), bcr_back_lds_bytes(q_max, m1p));
+  for (const void* f : {reinterpret_cast<const void*>(&dense_back_kernel<1, 1>), reinterpret_cast<const void*>(&dense_back_kernel<2, 1>),
+                        reinterpret_cast<const void*>(&dense_back_kernel<4, 1>), reinterpret_cast<const void*>(&dense_back_kernel<1, 2>),
+                        reinterpret_cast<const void*>(&dense_back_kernel<2, 2>), reinterpret_cast<const void*>(&dense_back_kernel<4, 2>)}) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+void launch_dense_back(const SolveArgs& a, const BcrArgs& b, int ks, int node0, int n_nodes, int q_max, const double* x, double* x_cand,
+                       const BlockDev* blocks, int n_blocks, const BcrTopSeps& ts, int* word, int seq, hipStream_t s) {
+  const size_t lds = std::max(dense_block_solve_lds_bytes(), bcr_back_lds_bytes(q_max, b.m1p));
+  const dim3 grid(1 + n_nodes + 1), block(kDenseThreads);       // dense solve, the nodes, the calibration / root update
+#define LAUNCH_DB(QM, SD) hipLaunchKernelGGL(HIP_KERNEL_NAME(dense_back_kernel<QM, SD>), grid, block, lds, s, a, b, ks, node0, n_nodes, q_max, x, x_cand, blocks, n_blocks, ts, word, seq)
+  if (ts.n > 0) { if (q_max <= 1) LAUNCH_DB(1, 2); else if (q_max <= 2) LAUNCH_DB(2, 2); else LAUNCH_DB(4, 2); }
+  else { if (q_max <= 1) LAUNCH_DB(1, 1); else if (q_max <= 2) LAUNCH_DB(2, 1); else LAUNCH_DB(4, 1); }
+#undef LAUNCH_DB
 }
 
 // ---- launch helpers ---------------------------------------------------------

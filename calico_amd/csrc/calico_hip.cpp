@@ -84,6 +84,10 @@ void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_node
                      const double* x, double* x_cand, const BlockDev* blocks, int n_blocks, const BcrTopSeps& ts, hipStream_t s);
 
 void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipStream_t s);
+bool dense_back_fusable(const SolveArgs& a, int ks, int q_max, bool border_rows);
+hipError_t configure_dense_back(int q_max, int m1p);
+void launch_dense_back(const SolveArgs& a, const BcrArgs& b, int ks, int node0, int n_nodes, int q_max, const double* x, double* x_cand,
+                       const BlockDev* blocks, int n_blocks, const BcrTopSeps& ts, int* word, int seq, hipStream_t s);
 int reduced_schur_slices(const SolveArgs& a);
 
 }  // namespace cal
@@ -277,6 +281,8 @@ struct calico_problem {
   DevBuf<int64_t> d_ptr_thin, d_ptr_fat;
   DevBuf<uint8_t> d_cp_active, d_valid, d_active;
   DevBuf<int> d_counter;
+  DevBuf<int> d_handoff;         // hand-off word of the fused dense-solve + back-substitution launch
+  int handoff_seq = 0;           // number of the last such launch (the word carries it when the solve part is through)
   int gather_owner_block = 0;
   bool active_dirty = true;
   bool any_tagged = false;       // some observation is tagged as an outlier: the kernels look at the tags only then
@@ -995,6 +1001,10 @@ int finalize(calico_problem* p) {
     if (bcr_level_lds_bytes() > kMaxLds || bcr_back_lds_bytes(p->bcr_q_max, p->bcr_m1p) > kMaxLds)
       return p->set_error(CALICO_UNIMPLEMENTED, "tree solver workspace exceeds the LDS");
     HIP_TRY(p, configure_bcr_kernels(p->bcr_q_max, p->bcr_m1p));
+    if (std::max(dense_block_solve_lds_bytes(), bcr_back_lds_bytes(std::min(p->bcr_q_max, 4), p->bcr_m1p)) + 1024 <= kMaxLds)
+      HIP_TRY(p, configure_dense_back(std::min(p->bcr_q_max, 4), p->bcr_m1p));
+    HIP_TRY(p, p->d_handoff.alloc(16)); HIP_TRY(p, hipMemsetAsync(p->d_handoff.p, 0, 16 * sizeof(int), s));
+    p->handoff_seq = 0;
   }
   HIP_TRY(p, hipStreamSynchronize(s));
   section("kernel attributes + tree plan");
@@ -1094,7 +1104,6 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
   }
   const int ks = reduced_schur_slices(sa);
   launch_bcr_schur(sa, b, ks, o, s);
-  launch_reduced_solve(sa, p->dense_in_lds, ks, s);
   // The top level of the tree is one or two single superblocks next to the root: their back-substitution rides in the
   // launch of the level below (every node there solves the top separators beside it itself -- a few more loads next to
   // the ones it waits for anyway) instead of costing a launch of its own.
@@ -1109,10 +1118,23 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
     }
     ts.n = ok ? tl.n_nodes : 0;
   }
+  // The first back-substitution launch rides in the launch of the dense reduced solve where the shapes allow it (the
+  // nodes fetch what they need while the solve runs and take its solution over a hand-off word: dense_back_kernel).
+  const int l_first = ts.n > 0 ? L - 2 : L - 1;
+  const calico_problem::BcrLevel& lf = p->bcr_levels[size_t(l_first)];
+  const bool fused = l_first == 0 && dense_back_fusable(sa, ks, lf.q_max, /*border_rows=*/l_first > 0) &&
+                     std::max(dense_block_solve_lds_bytes(), bcr_back_lds_bytes(lf.q_max, p->bcr_m1p)) + 1024 <= kMaxLds;
+  if (fused) {
+    p->handoff_seq = p->handoff_seq % 0x3fffffff + 1;
+    launch_dense_back(sa, b, ks, lf.node0, lf.n_nodes, lf.q_max, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, ts, p->d_handoff.p, p->handoff_seq, s);
+  } else {
+    launch_reduced_solve(sa, p->dense_in_lds, ks, s);
+  }
   for (int l = L - 1; l >= 0; --l) {
     const calico_problem::BcrLevel& lv = p->bcr_levels[size_t(l)];
     if (ts.n > 0 && l == L - 1) continue;
     const bool first = l == L - 1 || (ts.n > 0 && l == L - 2);     // the first launch behind the reduced solve
+    if (first && fused) continue;
     const BcrTopSeps none = {};
     launch_bcr_back(sa, b, lv.node0, lv.n_nodes, first, first, /*border_rows=*/l > 0, lv.q_max, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks,
                     first ? ts : none, s);
