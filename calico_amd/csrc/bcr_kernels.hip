@@ -827,7 +827,15 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
   for (int c = 0; c < 6; ++c) px[c] = x[my_off + c];
   if (terminated) return;
   if (HO) {
-    // everything above is on its way (or here) while the reduced solve is still running in workgroup 0 of this launch
+    // everything above is on its way (or here) while the reduced solve is still running in workgroup 0 of this launch;
+    // what does not depend on its solution goes to LDS before the wait, too
+#pragma unroll
+    for (int i = 0; i < QM; ++i) {
+      if (i < q) {
+        const int o = (i * BP + r16) * DLD + 2 * sub;
+        ZBs[o] = vz[i].x; ZBs[o + 1] = vz[i].y; Ms[o] = vm[i].x; Ms[o + 1] = vm[i].y;
+      }
+    }
     handoff_wait(ho);
     load_solution();
     if (side) yroot_v = (b.root >= 0 && (tid & 31) < RB) ? load_sc1(a.y + n_s + mc + (tid & 31)) : 0.0;
@@ -850,11 +858,13 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
     if (tid < m1p) yc[tid] = tid < mc ? ycv : 0.0;
     for (int j = tid + kBackThreads; j < m1p; j += kBackThreads) yc[j] = j < mc ? load_y<HO>(a.y + n_s + j) : 0.0;
   }
+  if (!HO) {
 #pragma unroll
-  for (int i = 0; i < QM; ++i) {
-    if (i < q) {
-      const int o = (i * BP + r16) * DLD + 2 * sub;
-      ZBs[o] = vz[i].x; ZBs[o + 1] = vz[i].y; Ms[o] = vm[i].x; Ms[o + 1] = vm[i].y;
+    for (int i = 0; i < QM; ++i) {
+      if (i < q) {
+        const int o = (i * BP + r16) * DLD + 2 * sub;
+        ZBs[o] = vz[i].x; ZBs[o + 1] = vz[i].y; Ms[o] = vm[i].x; Ms[o + 1] = vm[i].y;
+      }
     }
   }
   __syncthreads();
