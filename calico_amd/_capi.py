@@ -114,14 +114,14 @@ def _i32(a):
 # Every symbol include/calico_hip.h declares (without prefix).
 ABI_SYMBOLS = [
     "problem_create", "problem_destroy", "last_error", "default_solver_options",
-    "problem_add_param_block", "get_param_block", "set_param_block", "set_param_blocks",
+    "problem_add_param_block", "problem_add_param_blocks", "get_param_block", "set_param_block", "set_param_blocks",
     "problem_set_spline", "problem_add_rigid_body", "problem_add_sensor",
     "problem_add_camera_residuals", "problem_add_imu_residuals", "solve",
     "get_iterations", "get_residuals", "get_inlier_mask",
     "num_effective_parameters", "evaluate", "problem_set_allreduce", "problem_set_shard",
     "problem_set_stream", "get_phase_time", "set_phase_timing", "project",
     "problem_set_outlier_mask", "mark_outliers", "fit_spline", "residual_heatmap",
-    "comm_get_unique_id", "comm_init_rccl", "comm_info", "problem_finalize",
+    "comm_get_unique_id", "comm_init_rccl", "comm_info", "problem_finalize", "plan_cache_stats", "plan_cache_clear",
 ]
 # Test hooks (calico_amd/csrc/calico_hip_testing.h): exported, not part of the drop-in surface.
 TEST_SYMBOLS = ["debug_lm_control_replay"]
@@ -144,6 +144,8 @@ class CApi:
         g("last_error", C.c_char_p, [P])
         g("default_solver_options", None, [C.POINTER(SolverOptions)])
         g("problem_add_param_block", C.c_int32, [P, D, C.c_int32, C.c_int32, C.c_int32, I])
+        if has_device:
+            g("problem_add_param_blocks", C.c_int32, [P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8), D, I])
         g("get_param_block", C.c_int32, [P, C.c_int32, D])
         g("set_param_block", C.c_int32, [P, C.c_int32, D])
         g("set_param_blocks", C.c_int32, [P, C.c_int32, I, D])
@@ -175,6 +177,8 @@ class CApi:
             g("comm_get_unique_id", C.c_int32, [C.POINTER(C.c_uint8)])
             g("comm_init_rccl", C.c_int32, [P, C.POINTER(C.c_uint8), C.c_int32, C.c_int32])
             g("comm_info", C.c_int32, [P, I, I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
+            g("plan_cache_stats", C.c_int32, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
+            g("plan_cache_clear", C.c_int32, [])
             g("debug_lm_control_replay", C.c_int32,
               [C.c_int32, C.c_int32, D, I, C.POINTER(SolverOptions), D, I, D])
 
@@ -188,6 +192,13 @@ class CApi:
         o = SolverOptions()
         self.default_solver_options(C.byref(o))
         return o
+
+
+def plan_cache_stats(api):
+    """(hits, misses, plans held) of the library's plan cache."""
+    h, m, e = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    api.plan_cache_stats(C.byref(h), C.byref(m), C.byref(e))
+    return h.value, m.value, e.value
 
 
 def comm_unique_id(api):
@@ -234,6 +245,18 @@ class Problem:
         self._check(self.api.problem_add_param_block(self.h, _dp(v), v.size, manifold, int(bool(constant)),
                                                      C.byref(out)))
         return out.value
+
+    def add_param_blocks(self, values, manifold=MANIFOLD_EUCLIDEAN, constant=False):
+        """n blocks of one size (rows of `values`); one ABI call where the library has the bulk form. Returns the ids."""
+        v = _f64(values)
+        v = v.reshape(len(v), -1)
+        n, size = v.shape
+        const = np.ascontiguousarray(np.broadcast_to(np.asarray(constant, bool), (n,)), dtype=np.uint8)
+        if not hasattr(self.api, "problem_add_param_blocks"):
+            return np.array([self.add_param_block(v[i], manifold, bool(const[i])) for i in range(n)], np.int32)
+        ids = np.zeros(n, np.int32)
+        self._check(self.api.problem_add_param_blocks(self.h, n, size, manifold, const.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(v), _ip(ids)))
+        return ids
 
     def get_param_block(self, block_id, size):
         out = np.zeros(size)

@@ -23,6 +23,8 @@
 #include <cstring>
 #include <array>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -163,12 +165,19 @@ struct HSensor {
 
 template <class T> struct DevBuf {
   T* p = nullptr; size_t n = 0;
+  bool owner = true;        // false: a view of a buffer the plan cache owns (structure shared between handles)
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
-  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  void release() { if (p && owner) (void)hipFree(p); p = nullptr; n = 0; owner = true; }
+  void alias(const DevBuf& o) { release(); p = o.p; n = o.n; owner = false; }
+  void take(DevBuf& o) { release(); p = o.p; n = o.n; owner = o.owner; o.p = nullptr; o.n = 0; o.owner = true; }
+  void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(owner, o.owner); }
   hipError_t alloc(size_t count) {
-    if (count == n && p) return hipSuccess;
-    release();
     if (count == 0) count = 1;
+    if (count == n && p && owner) return hipSuccess;
+    release();        // (a view is dropped, never written through)
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
     if (e == hipSuccess) n = count;
     return e;
@@ -225,7 +234,109 @@ struct PhaseTimer {
 
 }  // namespace
 
-struct calico_problem {
+// ---- what calico_problem_finalize derives from the STRUCTURE of a problem (not from any value): shared between handles
+//      of identical structure through the plan cache -------------------------------------------------------------------
+struct BcrLevel { int node0, n_nodes, keep0, n_keep, q_max; };
+struct PlanHost {
+  bool speculative = true;    // evaluate cost AND Jacobian at the candidate point in one pass (two reduce buffers)
+  size_t r_size = 0;
+  int sep_s = 0, sep_n = 0;   // separator control points of the nested-dissection split (sep_n = 0: none)
+  // tree solver (bcr_kernels.hip): elimination plan, level after level
+  bool use_bcr = false, bcr_all_active = false;
+  int bcr_N = 0, bcr_m1p = 16, bcr_root = -1, bcr_root_pend = 0, bcr_root_par = 0, bcr_br = 0, bcr_q_max = 1, bcr_slots = 1;
+  std::vector<BcrLevel> bcr_levels;
+  std::vector<BcrNodeDev> h_bcr_nodes;
+  std::vector<int> h_bcr_keep, h_cp_block;
+  bool bcr_merge_top = true;      // the top level's back-substitution rides in the launch below it
+  int border_extra() const { return use_bcr ? bcr_br : 6 * sep_n; }   // rows the band hands to the dense reduced solve
+  int n_cp = 0, m = 0, n_amb = 0, n_eff = 0, n_items = 0, n_items_all = 0, lds_cols = 0, row_pad = kRowPad;
+  int64_t n_obs = 0;
+  size_t partial_doubles = 0, partials_alloc = 0;
+  std::vector<int> eff_to_tan;
+  std::vector<BlockDev> h_blocks;
+  std::vector<ItemDev> h_items, h_items_all, h_jac_items;
+  std::vector<FrameItemDev> h_fitems;
+  std::vector<CellDev> h_cells;
+  int cell_chunk = 1, cell_rec_max = 1, row_cell_chunk = 1;
+  int frame_lds_doubles = 0;
+  int n_fitems = 0, n_jac_items = 0;
+  int n_thin = 0, n_fat = 0;
+  bool dense_in_lds = true;
+  int gather_owner_block = 0;
+};
+struct PlanDev {      // structure on the device: immutable once uploaded
+  DevBuf<double> d_knots, d_basis, d_stamp;
+  DevBuf<int> d_ctrl_off, d_point_off, d_out_thin, d_idx_thin, d_out_fat, d_idx_fat, d_prim_tab, d_bkeep, d_cp_block;
+  DevBuf<int64_t> d_ptr_thin, d_ptr_fat;
+  DevBuf<uint8_t> d_cp_active;
+  DevBuf<SensorDev> d_sensors;
+  DevBuf<LayoutDev> d_layouts;
+  DevBuf<ItemDev> d_items, d_items_all, d_jac_items;
+  DevBuf<FrameItemDev> d_fitems;
+  DevBuf<CellDev> d_cells;
+  DevBuf<BlockDev> d_blocks;
+  DevBuf<BcrNodeDev> d_bnodes;
+#define PLAN_DEV_BUFS(X) X(d_knots) X(d_basis) X(d_stamp) X(d_ctrl_off) X(d_point_off) X(d_out_thin) X(d_idx_thin) X(d_out_fat) X(d_idx_fat) \
+  X(d_prim_tab) X(d_bkeep) X(d_cp_block) X(d_ptr_thin) X(d_ptr_fat) X(d_cp_active) X(d_sensors) X(d_layouts) X(d_items) X(d_items_all)     \
+  X(d_jac_items) X(d_fitems) X(d_cells) X(d_blocks) X(d_bnodes)
+  void take_from(PlanDev& o) {
+#define X(n) n.take(o.n);
+    PLAN_DEV_BUFS(X)
+#undef X
+  }
+  void alias_from(const PlanDev& o) {
+#define X(n) n.alias(o.n);
+    PLAN_DEV_BUFS(X)
+#undef X
+  }
+};
+// ---- what a handle works in: values, normal equations, solver workspaces, result staging. Recycled between handles of
+//      identical structure (a destroyed handle leaves its workspace with the cached plan) ----------------------------------
+struct Workspace {
+  DevBuf<unsigned long long> d_wave_log;   // CALICO_KERNEL_TIMING=3
+  DevBuf<double> d_x, d_xc, d_m0, d_m1, d_m2, d_partials, d_R, d_R2, d_Lb, d_Linv, d_Y, d_S, d_Spart, d_Swork, d_zbuf, d_y, d_dadd, d_scale, d_res;
+  DevBuf<double> d_bD, d_bG, d_bF, d_bpD, d_bpF, d_bM, d_bZA, d_bZB, d_bY, d_bysol, d_bzb, d_bupd;
+  DevBuf<uint8_t> d_valid, d_active;
+  DevBuf<int> d_counter;
+  DevBuf<int> d_handoff;         // hand-off word of the fused dense-solve + back-substitution launch
+  DevBuf<LmState> d_state;
+  DevBuf<IterLog> d_log;
+  int handoff_seq = 0;           // number of the last such launch (the word carries it when the solve part is through)
+  LmState* h_state = nullptr;  // pinned
+  int* h_progress = nullptr;   // pinned, device-visible: [epoch << 20 | iterations the control kernel is through with, epoch of the terminated solve]
+  int solve_epoch = 0;         // number of the streaming solve under way (1 .. 2047, wraps)
+  int* d_progress = nullptr;
+  double* h_xpin = nullptr;    // pinned staging for the parameter vector (upload at the start of a call, download at its end)
+  size_t h_xpin_n = 0;
+  IterLog* h_log = nullptr;    // pinned
+  bool ws_ready = false;       // allocated and initialised for the plan at hand
+#define WS_BUFS(X) X(d_wave_log) X(d_x) X(d_xc) X(d_m0) X(d_m1) X(d_m2) X(d_partials) X(d_R) X(d_R2) X(d_Lb) X(d_Linv) X(d_Y) X(d_S) X(d_Spart)      \
+  X(d_Swork) X(d_zbuf) X(d_y) X(d_dadd) X(d_scale) X(d_res) X(d_bD) X(d_bG) X(d_bF) X(d_bpD) X(d_bpF) X(d_bM) X(d_bZA) X(d_bZB) X(d_bY) X(d_bysol) \
+  X(d_bzb) X(d_bupd) X(d_valid) X(d_active) X(d_counter) X(d_handoff) X(d_state) X(d_log)
+  void swap_ws(Workspace& o) {
+#define X(n) n.swap(o.n);
+    WS_BUFS(X)
+#undef X
+    std::swap(handoff_seq, o.handoff_seq); std::swap(h_state, o.h_state); std::swap(h_progress, o.h_progress);
+    std::swap(solve_epoch, o.solve_epoch); std::swap(d_progress, o.d_progress); std::swap(h_xpin, o.h_xpin);
+    std::swap(h_xpin_n, o.h_xpin_n); std::swap(h_log, o.h_log); std::swap(ws_ready, o.ws_ready);
+  }
+  void free_pinned() {
+    if (h_state) (void)hipHostFree(h_state);
+    if (h_progress) (void)hipHostFree(h_progress);
+    if (h_xpin) (void)hipHostFree(h_xpin);
+    if (h_log) (void)hipHostFree(h_log);
+    h_state = nullptr; h_progress = nullptr; d_progress = nullptr; h_xpin = nullptr; h_xpin_n = 0; h_log = nullptr;
+  }
+  Workspace() = default;
+  Workspace(const Workspace&) = delete;
+  Workspace& operator=(const Workspace&) = delete;
+  ~Workspace() { free_pinned(); }
+};
+
+struct PlanEntry;      // plan cache entry (below)
+
+struct calico_problem : PlanHost, PlanDev, Workspace {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -242,67 +353,12 @@ struct calico_problem {
   ncclComm_t comm = nullptr;      // native exchange: RCCL communicator owned by the handle (calico_comm_init_rccl)
   bool has_exchange() const { return allreduce != nullptr || comm != nullptr; }
   int rank = 0, world = 1;
+  std::shared_ptr<PlanEntry> plan;    // the cached plan this handle's structure buffers are views of (null: it owns them)
 
-  // flattened problem
-  bool speculative = true;    // evaluate cost AND Jacobian at the candidate point in one pass (two reduce buffers)
-  size_t r_size = 0;
-  int sep_s = 0, sep_n = 0;   // separator control points of the nested-dissection split (sep_n = 0: none)
-  // tree solver (bcr_kernels.hip): elimination plan, level after level
-  struct BcrLevel { int node0, n_nodes, keep0, n_keep, q_max; };
-  bool use_bcr = false, bcr_all_active = false;
-  int bcr_N = 0, bcr_m1p = 16, bcr_root = -1, bcr_root_pend = 0, bcr_root_par = 0, bcr_br = 0, bcr_q_max = 1, bcr_slots = 1;
-  std::vector<BcrLevel> bcr_levels;
-  std::vector<BcrNodeDev> h_bcr_nodes;
-  std::vector<int> h_bcr_keep, h_cp_block;
-  bool bcr_merge_top = true;      // the top level's back-substitution rides in the launch below it
-  DevBuf<double> d_bD, d_bG, d_bF, d_bpD, d_bpF, d_bM, d_bZA, d_bZB, d_bY, d_bysol, d_bzb, d_bupd;
-  DevBuf<BcrNodeDev> d_bnodes;
-  DevBuf<int> d_bkeep, d_cp_block;
-  int border_extra() const { return use_bcr ? bcr_br : 6 * sep_n; }   // rows the band hands to the dense reduced solve
-  int n_cp = 0, m = 0, n_amb = 0, n_eff = 0, n_items = 0, n_items_all = 0, lds_cols = 0, row_pad = kRowPad;
-  int64_t n_obs = 0;
-  size_t partial_doubles = 0;
-  std::vector<int> eff_to_tan;
-  std::vector<BlockDev> h_blocks;
-  std::vector<ItemDev> h_items, h_items_all, h_jac_items;
-  std::vector<FrameItemDev> h_fitems;
-  std::vector<CellDev> h_cells;
-  int cell_chunk = 1, cell_rec_max = 1, row_cell_chunk = 1;
-  int frame_lds_doubles = 0;
-  int n_fitems = 0, n_jac_items = 0;
-  std::vector<double> h_x;
-  int n_thin = 0, n_fat = 0;
-  bool dense_in_lds = true;
-
-  DevBuf<unsigned long long> d_wave_log;   // CALICO_KERNEL_TIMING=3
-  DevBuf<double> d_x, d_xc, d_knots, d_basis, d_m0, d_m1, d_m2, d_stamp, d_partials, d_R, d_R2, d_Lb, d_Linv, d_Y, d_S, d_Spart, d_Swork, d_zbuf, d_y,
-      d_dadd, d_scale, d_res;
-  DevBuf<int> d_ctrl_off, d_point_off, d_out_thin, d_idx_thin, d_out_fat, d_idx_fat;
-  DevBuf<int64_t> d_ptr_thin, d_ptr_fat;
-  DevBuf<uint8_t> d_cp_active, d_valid, d_active;
-  DevBuf<int> d_counter;
-  DevBuf<int> d_handoff;         // hand-off word of the fused dense-solve + back-substitution launch
-  int handoff_seq = 0;           // number of the last such launch (the word carries it when the solve part is through)
-  int gather_owner_block = 0;
+  std::vector<double> h_x, h_m0, h_m1, h_m2;     // staging of the values (alive until the uploads are through)
   bool active_dirty = true;
   bool any_tagged = false;       // some observation is tagged as an outlier: the kernels look at the tags only then
   bool xc_stale = true;       // the candidate buffer must be re-seeded with the constant blocks' values
-  DevBuf<SensorDev> d_sensors;
-  DevBuf<LayoutDev> d_layouts;
-  DevBuf<ItemDev> d_items, d_items_all, d_jac_items;
-  DevBuf<FrameItemDev> d_fitems;
-  DevBuf<CellDev> d_cells;
-  DevBuf<int> d_prim_tab;
-  DevBuf<BlockDev> d_blocks;
-  DevBuf<LmState> d_state;
-  DevBuf<IterLog> d_log;
-  LmState* h_state = nullptr;  // pinned
-  int* h_progress = nullptr;   // pinned, device-visible: [epoch << 20 | iterations the control kernel is through with, epoch of the terminated solve]
-  int solve_epoch = 0;         // number of the streaming solve under way (1 .. 2047, wraps)
-  int* d_progress = nullptr;
-  double* h_xpin = nullptr;    // pinned staging for the parameter vector (upload at the start of a call, download at its end)
-  size_t h_xpin_n = 0;
-  IterLog* h_log = nullptr;    // pinned
   std::vector<calico_iteration> iterations;
   PhaseTimer timer;
 
@@ -324,8 +380,17 @@ namespace {
 int spline_index(const calico_problem* p, double t) {
   const std::vector<double>& vk = p->valid_knots;
   if (t == vk.back()) return int(vk.size()) - 2;
-  if (t < vk.back()) return int(std::upper_bound(vk.begin(), vk.end(), t) - vk.begin()) - 1;
-  return -1;
+  if (!(t < vk.back())) return -1;
+  // upper_bound(vk, t) - 1, found from a guess on the (uniform) knot spacing and corrected by comparisons with the knots
+  // themselves, so the result is the binary search's for any knot vector
+  const int n = int(vk.size());
+  if (t < vk.front()) return -1;
+  const double dt = (vk.back() - vk.front()) / double(n - 1);
+  int i = dt > 0.0 ? int((t - vk.front()) / dt) : 0;
+  i = std::max(0, std::min(n - 2, i));
+  while (i > 0 && t < vk[size_t(i)]) --i;
+  while (i + 1 < n && !(t < vk[size_t(i) + 1])) ++i;
+  return i;
 }
 int camera_num_params(int model) {
   switch (model) { case 1: return 8; case 2: return 11; case 3: return 7; case 4: return 5; case 5: return 4; case 6: return 4;
@@ -384,7 +449,7 @@ void build_bcr_plan(calico_problem* p) {
   int level = 0, q_max_all = 1;
   while (!alive.empty() && (level == 0 || alive.size() > 1)) {
     const int chain = level == 0 ? q : 1;
-    calico_problem::BcrLevel L;
+    BcrLevel L;
     L.node0 = int(p->h_bcr_nodes.size()); L.keep0 = int(p->h_bcr_keep.size() / 2); L.q_max = 1;
     std::vector<int> kept, new_mask(size_t(N), 0);
     const size_t n = alive.size();
@@ -439,13 +504,10 @@ EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool
   return a;
 }
 
-// Flatten the host tables into cells / work items / gather lists and upload.
-int finalize(calico_problem* p) {
-  if (!p->dirty) return CALICO_OK;
-  if (p->order <= 0) return p->set_error(CALICO_FAILED_PRECONDITION, "spline not set");
+// Flatten the host tables into cells / work items / gather lists, plan the elimination, upload the STRUCTURE (everything
+// here depends on what the problem looks like, nothing on a value: the result is what the plan cache shares).
+int build_plan(calico_problem* p) {
   const int k = p->order;
-  if (k > 8) return p->set_error(CALICO_UNIMPLEMENTED, "spline order > 8 is not supported by the HIP kernels");
-  HIP_TRY(p, hipSetDevice(p->device));
   const int n_cp = int(p->ctrl.size());
   p->n_cp = n_cp;
   // CALICO_SETUP_TIMING=1: wall time of the sections of this function (development aid)
@@ -598,7 +660,7 @@ int finalize(calico_problem* p) {
     if (a.seg != b.seg) return a.seg < b.seg;
     return a.stamp < b.stamp; });
   p->n_obs = n_obs;
-  std::vector<double> m0(n_obs), m1(n_obs), m2(n_obs), st(n_obs);
+  std::vector<double> st(n_obs);
   std::vector<int> point_off(n_obs, 0);
   p->h_items.clear(); p->h_items_all.clear();
   const int imu_chunk_items = [] { const char* e = std::getenv("CALICO_IMU_CHUNK"); return e ? std::max(1, std::min(21, std::atoi(e))) : 21; }();   // (the Jacobian kernel gives an IMU block three lanes)
@@ -778,8 +840,6 @@ int finalize(calico_problem* p) {
     const int64_t i = keys[q].idx;
     s.sorted_pos[size_t(i)] = q;
     s.sorted_begin = std::min(s.sorted_begin, q); s.sorted_end = std::max(s.sorted_end, q + 1);   // layouts are per sensor: contiguous
-    const int dim = s.dim();
-    m0[q] = s.meas[i * dim]; m1[q] = s.meas[i * dim + 1]; m2[q] = dim == 3 ? s.meas[i * dim + 2] : 0.0;
     st[q] = s.stamps[i];
     if (s.kind == CALICO_SENSOR_CAMERA) point_off[q] = p->blocks[s.point[i]].amb_off;
   }
@@ -897,10 +957,8 @@ int finalize(calico_problem* p) {
   p->n_thin = int(out_thin.size()); p->n_fat = int(out_fat.size());
   p->gather_owner_block = 0;
   section("gather lists");
-  // ---- upload ----
+  // ---- upload of the structure ----
   hipStream_t s = p->stream;
-  p->h_x.assign(size_t(p->n_amb), 0.0);
-  for (const HBlock& b : p->blocks) std::copy(b.v.begin(), b.v.end(), p->h_x.begin() + b.amb_off);
   std::vector<int> ctrl_off(n_cp);
   for (int i = 0; i < n_cp; ++i) ctrl_off[i] = p->blocks[p->ctrl[i]].amb_off;
   {
@@ -915,10 +973,8 @@ int finalize(calico_problem* p) {
     for (ItemDev& it : p->h_jac_items) fill(it);
     for (FrameItemDev& it : p->h_fitems) fill(it);
   }
-  HIP_TRY(p, p->d_x.upload(p->h_x, s)); HIP_TRY(p, p->d_xc.upload(p->h_x, s));
   HIP_TRY(p, p->d_knots.upload(p->knots, s)); HIP_TRY(p, p->d_basis.upload(p->basis, s));
   HIP_TRY(p, p->d_ctrl_off.upload(ctrl_off, s));
-  HIP_TRY(p, p->d_m0.upload(m0, s)); HIP_TRY(p, p->d_m1.upload(m1, s)); HIP_TRY(p, p->d_m2.upload(m2, s));
   HIP_TRY(p, p->d_stamp.upload(st, s)); HIP_TRY(p, p->d_point_off.upload(point_off, s));
   HIP_TRY(p, p->d_sensors.upload(sd, s)); HIP_TRY(p, p->d_layouts.upload(layouts, s));
   HIP_TRY(p, p->d_items.upload(p->h_items, s)); HIP_TRY(p, p->d_items_all.upload(p->h_items_all, s));
@@ -929,14 +985,151 @@ int finalize(calico_problem* p) {
   HIP_TRY(p, p->d_ptr_thin.upload(ptr_thin, s));
   HIP_TRY(p, p->d_out_fat.upload(out_fat, s)); HIP_TRY(p, p->d_idx_fat.upload(idx_fat, s));
   HIP_TRY(p, p->d_ptr_fat.upload(ptr_fat, s));
-  HIP_TRY(p, p->d_partials.alloc(comp_base + comp_off + row_store));
-  if (std::getenv("CALICO_KERNEL_TIMING") && std::atoi(std::getenv("CALICO_KERNEL_TIMING")) >= 3) HIP_TRY(p, p->d_wave_log.alloc(2 * size_t(p->n_jac_items + p->n_fitems)));
   HIP_TRY(p, p->d_cells.upload(p->h_cells, s)); HIP_TRY(p, p->d_prim_tab.upload(prim_tab, s));
+  p->partials_alloc = comp_base + comp_off + row_store;
   p->r_size = r_size;
   {
     const char* env = std::getenv("CALICO_SPECULATIVE");
     p->speculative = !env || std::atoi(env) != 0;
   }
+  {
+    sa = make_solve_args(p);
+    if (band_cholesky_lds_bytes(sa) > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "spline order too high for the banded factorisation window");
+    p->dense_in_lds = reduced_solve_lds_bytes(sa) <= kMaxLds - 1024;
+    if (band_backsolve_lds_bytes(sa) > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "trajectory too long for the back-substitution window");
+  }
+  if (p->use_bcr) {
+    HIP_TRY(p, p->d_bnodes.upload(p->h_bcr_nodes, s)); HIP_TRY(p, p->d_bkeep.upload(p->h_bcr_keep, s));
+    // (a member, not a local: the asynchronous upload reads it until the synchronisation below)
+    p->h_cp_block.assign(size_t(n_cp), -1);
+    for (size_t bi = 0; bi < p->h_blocks.size(); ++bi)
+      if (p->h_blocks[bi].tan_off < NS) p->h_cp_block[size_t(p->h_blocks[bi].tan_off / 6)] = int(bi);
+    HIP_TRY(p, p->d_cp_block.upload(p->h_cp_block, s));
+    if (bcr_level_lds_bytes() > kMaxLds || bcr_back_lds_bytes(p->bcr_q_max, p->bcr_m1p) > kMaxLds)
+      return p->set_error(CALICO_UNIMPLEMENTED, "tree solver workspace exceeds the LDS");
+  }
+  HIP_TRY(p, hipStreamSynchronize(s));      // the uploads read locals of this function
+  section("structure uploads");
+  return CALICO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Plan cache. The reference rebuilds its ceres::Problem on every Optimize() (batch_optimizer.cpp:57-70); rebuilt here,
+// the flattening would cost more than the solve it feeds. What finalize derives depends on the STRUCTURE of the problem
+// only -- block sizes / manifolds / constancy, the spline's knots and basis, the sensors' models, blocks, noise and loss
+// settings, and per observation its stamp, rigid body and model point -- so it is keyed on a 128-bit hash of exactly
+// that and shared: a handle whose structure has been seen before adopts the cached plan (views of its device buffers)
+// and a pooled workspace, and only uploads its values. A changed structure hashes differently and is planned afresh.
+// CALICO_PLAN_CACHE=0 switches the cache off; calico_plan_cache_clear() empties it.
+// ---------------------------------------------------------------------------------------------------------------------
+struct PlanKey {
+  uint64_t h1 = 0, h2 = 0; size_t n_blocks = 0, n_obs = 0; int device = 0;
+  bool operator==(const PlanKey& o) const { return h1 == o.h1 && h2 == o.h2 && n_blocks == o.n_blocks && n_obs == o.n_obs && device == o.device; }
+};
+}  // namespace
+struct PlanEntry {
+  PlanKey key;
+  PlanHost host;
+  PlanDev dev;
+  // per parameter block / per sensor: what finalize writes into the handle's own tables
+  struct BlockMeta { int amb_off, tan, eff; bool used; };
+  std::vector<BlockMeta> block_meta;
+  struct SensorMeta { std::vector<int64_t> sorted_pos; int64_t sorted_begin, sorted_end; };
+  std::vector<SensorMeta> sensor_meta;
+  std::vector<std::unique_ptr<Workspace>> pool;     // workspaces of destroyed handles, ready for the next one
+  uint64_t last_use = 0;
+};
+namespace {
+struct PlanCache {
+  std::mutex mu;
+  std::vector<std::shared_ptr<PlanEntry>> entries;
+  uint64_t tick = 0;
+  int64_t hits = 0, misses = 0;
+  static constexpr size_t kMaxEntries = 8, kMaxPool = 2;
+};
+PlanCache& plan_cache() { static PlanCache c; return c; }
+bool plan_cache_enabled() {
+  static const bool on = [] { const char* e = std::getenv("CALICO_PLAN_CACHE"); return !e || std::atoi(e) != 0; }();
+  return on;
+}
+struct Hasher {
+  uint64_t a = 0x9E3779B97F4A7C15ull, b = 0xC2B2AE3D27D4EB4Full;
+  void word(uint64_t w) {
+    a = (a ^ w) * 0xff51afd7ed558ccdull; a ^= a >> 32;
+    b = (b + w) * 0xc4ceb9fe1a85ec53ull; b ^= b >> 29;
+  }
+  void bytes(const void* p, size_t n) {
+    const unsigned char* c = static_cast<const unsigned char*>(p);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, c + i, 8); word(w); }
+    if (i < n) { uint64_t w = 0; std::memcpy(&w, c + i, n - i); word(w ^ (uint64_t(n - i) << 56)); }
+  }
+  template <class T> void vec(const std::vector<T>& v) { word(v.size()); bytes(v.data(), v.size() * sizeof(T)); }
+  void dbl(double d) { uint64_t w; std::memcpy(&w, &d, 8); word(w); }
+};
+PlanKey structure_key(const calico_problem* p) {
+  Hasher h;
+  h.word(uint64_t(p->order)); h.vec(p->knots); h.vec(p->basis); h.vec(p->ctrl);
+  h.word(uint64_t(p->rank)); h.word(uint64_t(p->world));
+  h.word(p->blocks.size());
+  for (const HBlock& b : p->blocks) h.word(uint64_t(b.size) | (uint64_t(b.manifold) << 32) | (uint64_t(b.constant) << 40));
+  h.word(p->bodies.size());
+  for (const HBody& b : p->bodies) h.word(uint64_t(uint32_t(b.q)) | (uint64_t(uint32_t(b.t)) << 32));
+  h.word(p->sensors.size());
+  size_t n_obs = 0;
+  for (const HSensor& s : p->sensors) {
+    h.word(uint64_t(s.kind) | (uint64_t(s.model) << 8) | (uint64_t(s.K) << 16) | (uint64_t(s.loss) << 32));
+    h.word(uint64_t(uint32_t(s.intr)) | (uint64_t(uint32_t(s.q)) << 32)); h.word(uint64_t(uint32_t(s.t)) | (uint64_t(uint32_t(s.lat)) << 32));
+    h.word(uint64_t(uint32_t(s.grav)));
+    h.dbl(s.sigma); h.dbl(s.info); h.dbl(s.loss_scale);
+    h.vec(s.stamps); h.vec(s.body); h.vec(s.point);
+    n_obs += s.stamps.size();
+  }
+  // the switches finalize reads from the environment
+  for (const char* name : {"CALICO_SOLVER", "CALICO_SPECULATIVE", "CALICO_BAND_SPLIT", "CALICO_BCR_LEAF", "CALICO_BCR_MERGE_TOP", "CALICO_IMU_CHUNK",
+                           "CALICO_ROW_CELLS"}) {
+    const char* e = std::getenv(name);
+    h.word(e ? 1 : 0);
+    if (e) h.bytes(e, std::strlen(e));
+  }
+  PlanKey k; k.h1 = h.a; k.h2 = h.b; k.n_blocks = p->blocks.size(); k.n_obs = n_obs; k.device = p->device;
+  return k;
+}
+
+// A handle adopts a cached plan: copies of the host-side plan, views of the device-side structure.
+void adopt_plan(calico_problem* p, const std::shared_ptr<PlanEntry>& e) {
+  static_cast<PlanHost&>(*p) = e->host;
+  static_cast<PlanDev&>(*p).alias_from(e->dev);
+  for (size_t i = 0; i < p->blocks.size(); ++i) {
+    const PlanEntry::BlockMeta& bm = e->block_meta[i];
+    p->blocks[i].amb_off = bm.amb_off; p->blocks[i].tan = bm.tan; p->blocks[i].eff = bm.eff; p->blocks[i].used = bm.used;
+  }
+  for (size_t i = 0; i < p->sensors.size(); ++i) {
+    p->sensors[i].sorted_pos = e->sensor_meta[i].sorted_pos;
+    p->sensors[i].sorted_begin = e->sensor_meta[i].sorted_begin; p->sensors[i].sorted_end = e->sensor_meta[i].sorted_end;
+  }
+  p->plan = e;
+}
+
+// Everything a handle works in, sized by the plan: a pooled workspace of the same plan if there is one, else allocated
+// (and the parts the kernels expect zero-filled cleared) here.
+int prepare_workspace(calico_problem* p) {
+  hipStream_t s = p->stream;
+  if (p->plan) {
+    std::unique_ptr<Workspace> w;
+    {
+      std::lock_guard<std::mutex> lock(plan_cache().mu);
+      if (!p->plan->pool.empty()) { w = std::move(p->plan->pool.back()); p->plan->pool.pop_back(); }
+    }
+    if (w) { static_cast<Workspace&>(*p).swap_ws(*w); p->active_dirty = true; p->xc_stale = true; return CALICO_OK; }   // (w takes the handle's old one along)
+  }
+  const int n_cp = p->n_cp, m = p->m, k = p->order, NS = 6 * n_cp;
+  const int64_t n_obs = p->n_obs;
+  const size_t r_size = p->r_size;
+  HIP_TRY(p, p->d_x.alloc(size_t(p->n_amb))); HIP_TRY(p, p->d_xc.alloc(size_t(p->n_amb)));
+  HIP_TRY(p, p->d_m0.alloc(size_t(n_obs))); HIP_TRY(p, p->d_m1.alloc(size_t(n_obs))); HIP_TRY(p, p->d_m2.alloc(size_t(n_obs)));
+  HIP_TRY(p, p->d_partials.alloc(p->partials_alloc));
+  if (std::getenv("CALICO_KERNEL_TIMING") && std::atoi(std::getenv("CALICO_KERNEL_TIMING")) >= 3) HIP_TRY(p, p->d_wave_log.alloc(2 * size_t(p->n_jac_items + p->n_fitems)));
   HIP_TRY(p, p->d_R.alloc(2 * r_size)); HIP_TRY(p, hipMemsetAsync(p->d_R.p, 0, 2 * r_size * sizeof(double), s));
   HIP_TRY(p, p->d_R2.alloc(2));
   const int NT = 6 * n_cp + m;
@@ -967,21 +1160,10 @@ int finalize(calico_problem* p) {
     HIP_TRY(p, hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_progress), p->h_progress, 0));
     std::memset(p->h_progress, 0, 64);     // epoch 0 is never used: words of "no solve yet"
   }
-  section("uploads + allocations");
-  // kernel attributes
-  HIP_TRY(p, configure_eval_kernels(size_t(p->lds_cols) * p->row_pad * sizeof(double)));
-  sa = make_solve_args(p);
-  const size_t band_lds = band_cholesky_lds_bytes(sa);
-  if (band_lds > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "spline order too high for the banded factorisation window");
+  const SolveArgs sa = make_solve_args(p);
   const size_t reduced_lds = reduced_solve_lds_bytes(sa);
-  p->dense_in_lds = reduced_lds <= kMaxLds - 1024;
   HIP_TRY(p, p->d_Spart.alloc(4 * size_t(mw + 1) * (mw + 1) + 64));   // four K-slices of the Schur complement (+ slack: the blocked factorisation reads whole 32-column panels)
-  const size_t back_lds = band_backsolve_lds_bytes(sa);
-  if (back_lds > kMaxLds) return p->set_error(CALICO_UNIMPLEMENTED, "trajectory too long for the back-substitution window");
   HIP_TRY(p, p->d_Swork.alloc(std::max<size_t>(reduced_lds / sizeof(double) + 8, size_t(mw + 1) * 16 * 13 + 8)));
-  sa = make_solve_args(p);
-  HIP_TRY(p, configure_solve_kernels(band_lds, p->dense_in_lds ? reduced_lds : 0, back_lds));
-  HIP_TRY(p, configure_dense_block_solve());
   if (p->use_bcr) {
     const size_t N = size_t(p->bcr_N), bb = size_t(kBcrBP) * kBcrBP, fb = size_t(kBcrBP) * p->bcr_m1p;
     HIP_TRY(p, p->d_bD.alloc(N * bb)); HIP_TRY(p, p->d_bG.alloc(2 * N * bb)); HIP_TRY(p, p->d_bF.alloc(N * fb));
@@ -992,22 +1174,130 @@ int finalize(calico_problem* p) {
     HIP_TRY(p, hipMemsetAsync(p->d_bG.p, 0, 2 * N * bb * sizeof(double), s));
     HIP_TRY(p, hipMemsetAsync(p->d_bpD.p, 0, 4 * N * bb * sizeof(double), s)); HIP_TRY(p, hipMemsetAsync(p->d_bpF.p, 0, 4 * N * fb * sizeof(double), s));
     HIP_TRY(p, hipMemsetAsync(p->d_bupd.p, 0, size_t(p->bcr_slots) * 4 * sizeof(double), s));
-    HIP_TRY(p, p->d_bnodes.upload(p->h_bcr_nodes, s)); HIP_TRY(p, p->d_bkeep.upload(p->h_bcr_keep, s));
-    // (a member, not a local: the asynchronous upload reads it until the synchronisation at the end of finalize)
-    p->h_cp_block.assign(size_t(n_cp), -1);
-    for (size_t bi = 0; bi < p->h_blocks.size(); ++bi)
-      if (p->h_blocks[bi].tan_off < NS) p->h_cp_block[size_t(p->h_blocks[bi].tan_off / 6)] = int(bi);
-    HIP_TRY(p, p->d_cp_block.upload(p->h_cp_block, s));
-    if (bcr_level_lds_bytes() > kMaxLds || bcr_back_lds_bytes(p->bcr_q_max, p->bcr_m1p) > kMaxLds)
-      return p->set_error(CALICO_UNIMPLEMENTED, "tree solver workspace exceeds the LDS");
-    HIP_TRY(p, configure_bcr_kernels(p->bcr_q_max, p->bcr_m1p));
-    if (std::max(dense_block_solve_lds_bytes(), bcr_back_lds_bytes(std::min(p->bcr_q_max, 4), p->bcr_m1p)) + 1024 <= kMaxLds)
-      HIP_TRY(p, configure_dense_back(std::min(p->bcr_q_max, 4), p->bcr_m1p));
     HIP_TRY(p, p->d_handoff.alloc(16)); HIP_TRY(p, hipMemsetAsync(p->d_handoff.p, 0, 16 * sizeof(int), s));
     p->handoff_seq = 0;
   }
-  HIP_TRY(p, hipStreamSynchronize(s));
-  section("kernel attributes + tree plan");
+  p->ws_ready = true;
+  return CALICO_OK;
+}
+
+// The values: measurements in the device's (sorted) order, parameter vector.
+int upload_values(calico_problem* p) {
+  hipStream_t s = p->stream;
+  const size_t n = size_t(std::max<int64_t>(p->n_obs, 1));
+  p->h_m0.assign(n, 0.0); p->h_m1.assign(n, 0.0); p->h_m2.assign(n, 0.0);
+  for (const HSensor& sn : p->sensors) {
+    const int dim = sn.dim();
+    const int64_t ns = sn.n();
+    const double* me = sn.meas.data();
+    const int64_t* sp = sn.sorted_pos.data();
+    if (dim == 2) for (int64_t i = 0; i < ns; ++i) { const size_t q = size_t(sp[i]); p->h_m0[q] = me[2 * i]; p->h_m1[q] = me[2 * i + 1]; }
+    else for (int64_t i = 0; i < ns; ++i) { const size_t q = size_t(sp[i]); p->h_m0[q] = me[3 * i]; p->h_m1[q] = me[3 * i + 1]; p->h_m2[q] = me[3 * i + 2]; }
+  }
+  if (p->n_obs > 0) {
+    HIP_TRY(p, hipMemcpyAsync(p->d_m0.p, p->h_m0.data(), size_t(p->n_obs) * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(p, hipMemcpyAsync(p->d_m1.p, p->h_m1.data(), size_t(p->n_obs) * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(p, hipMemcpyAsync(p->d_m2.p, p->h_m2.data(), size_t(p->n_obs) * sizeof(double), hipMemcpyHostToDevice, s));
+  }
+  p->h_x.assign(size_t(p->n_amb), 0.0);
+  for (const HBlock& b : p->blocks) std::copy(b.v.begin(), b.v.end(), p->h_x.begin() + b.amb_off);
+  if (p->n_amb > 0) {
+    HIP_TRY(p, hipMemcpyAsync(p->d_x.p, p->h_x.data(), p->h_x.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(p, hipMemcpyAsync(p->d_xc.p, p->h_x.data(), p->h_x.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  }
+  return CALICO_OK;
+}
+
+int configure_kernels(calico_problem* p) {
+  HIP_TRY(p, configure_eval_kernels(size_t(p->lds_cols) * p->row_pad * sizeof(double)));
+  const SolveArgs sa = make_solve_args(p);
+  const size_t reduced_lds = reduced_solve_lds_bytes(sa);
+  HIP_TRY(p, configure_solve_kernels(band_cholesky_lds_bytes(sa), p->dense_in_lds ? reduced_lds : 0, band_backsolve_lds_bytes(sa)));
+  HIP_TRY(p, configure_dense_block_solve());
+  if (p->use_bcr) {
+    HIP_TRY(p, configure_bcr_kernels(p->bcr_q_max, p->bcr_m1p));
+    if (std::max(dense_block_solve_lds_bytes(), bcr_back_lds_bytes(std::min(p->bcr_q_max, 4), p->bcr_m1p)) + 1024 <= kMaxLds)
+      HIP_TRY(p, configure_dense_back(std::min(p->bcr_q_max, 4), p->bcr_m1p));
+  }
+  return CALICO_OK;
+}
+
+// Plan (cached or built), workspace (pooled or allocated), values.
+int finalize(calico_problem* p) {
+  if (!p->dirty) return CALICO_OK;
+  if (p->order <= 0) return p->set_error(CALICO_FAILED_PRECONDITION, "spline not set");
+  if (p->order > 8) return p->set_error(CALICO_UNIMPLEMENTED, "spline order > 8 is not supported by the HIP kernels");
+  HIP_TRY(p, hipSetDevice(p->device));
+  static const bool setup_timing = std::getenv("CALICO_SETUP_TIMING") != nullptr;
+  auto t_sec = std::chrono::steady_clock::now();
+  auto section = [&](const char* name) {
+    if (!setup_timing) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[calico] finalize %-28s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(t - t_sec).count());
+    t_sec = t;
+  };
+  // a workspace that belongs to the plan the handle is leaving goes back to that plan's pool
+  const bool use_cache = plan_cache_enabled();
+  PlanKey key;
+  std::shared_ptr<PlanEntry> hit;
+  if (use_cache) {
+    key = structure_key(p);
+    PlanCache& c = plan_cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    for (const std::shared_ptr<PlanEntry>& e : c.entries) if (e->key == key) { hit = e; break; }
+    if (hit) { hit->last_use = ++c.tick; ++c.hits; } else ++c.misses;
+  }
+  section("structure key + look-up");
+  if (hit && p->plan == hit && p->ws_ready) {
+    // same structure as before on the same handle (values re-registered): nothing to rebuild
+  } else {
+    if (p->plan && p->ws_ready) {        // leaving another plan: its workspace stays with it
+      HIP_TRY(p, hipStreamSynchronize(p->stream));
+      auto w = std::make_unique<Workspace>();
+      w->swap_ws(static_cast<Workspace&>(*p));
+      std::lock_guard<std::mutex> lock(plan_cache().mu);
+      if (p->plan->pool.size() < PlanCache::kMaxPool) p->plan->pool.push_back(std::move(w));
+    }
+    p->plan.reset();
+    p->ws_ready = false;
+    if (hit) adopt_plan(p, hit);
+    else {
+      const int rc = build_plan(p);
+      if (rc != CALICO_OK) return rc;
+      if (use_cache) {
+        auto e = std::make_shared<PlanEntry>();
+        e->key = key;
+        e->host = static_cast<const PlanHost&>(*p);
+        e->block_meta.resize(p->blocks.size());
+        for (size_t i = 0; i < p->blocks.size(); ++i) e->block_meta[i] = {p->blocks[i].amb_off, p->blocks[i].tan, p->blocks[i].eff, p->blocks[i].used};
+        e->sensor_meta.resize(p->sensors.size());
+        for (size_t i = 0; i < p->sensors.size(); ++i)
+          e->sensor_meta[i] = {p->sensors[i].sorted_pos, p->sensors[i].sorted_begin, p->sensors[i].sorted_end};
+        e->dev.take_from(static_cast<PlanDev&>(*p));
+        static_cast<PlanDev&>(*p).alias_from(e->dev);
+        p->plan = e;
+        PlanCache& c = plan_cache();
+        std::lock_guard<std::mutex> lock(c.mu);
+        e->last_use = ++c.tick;
+        if (c.entries.size() >= PlanCache::kMaxEntries) {
+          size_t old = 0;
+          for (size_t i = 1; i < c.entries.size(); ++i) if (c.entries[i]->last_use < c.entries[old]->last_use) old = i;
+          c.entries.erase(c.entries.begin() + long(old));      // (handles that still use it keep it alive)
+        }
+        c.entries.push_back(e);
+      }
+    }
+    section(hit ? "plan adopted" : "plan built");
+    const int rc = prepare_workspace(p);
+    if (rc != CALICO_OK) return rc;
+    section("workspace");
+  }
+  int rc = upload_values(p);
+  if (rc != CALICO_OK) return rc;
+  rc = configure_kernels(p);
+  if (rc != CALICO_OK) return rc;
+  HIP_TRY(p, hipStreamSynchronize(p->stream));
+  section("values + kernel attributes");
   p->dirty = false;
   return CALICO_OK;
 }
@@ -1098,7 +1388,7 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
   const BcrArgs b = make_bcr_args(p);
   const int L = int(p->bcr_levels.size());
   for (int l = 0; l < L; ++l) {
-    const calico_problem::BcrLevel& lv = p->bcr_levels[size_t(l)];
+    const BcrLevel& lv = p->bcr_levels[size_t(l)];
     launch_bcr_level(sa, b, lv.node0, lv.n_nodes, l, lv.keep0, lv.n_keep, o, p->d_x.p, p->d_blocks.p, n_blocks, l == 0 && with_post_eval,
                      p->d_log.p, kLogCap, jacobi, s);
   }
@@ -1109,7 +1399,7 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
   // the ones it waits for anyway) instead of costing a launch of its own.
   BcrTopSeps ts = {};
   if (p->bcr_merge_top && L >= 2) {
-    const calico_problem::BcrLevel& tl = p->bcr_levels[size_t(L - 1)];
+    const BcrLevel& tl = p->bcr_levels[size_t(L - 1)];
     bool ok = tl.n_nodes <= 2 && p->bcr_levels[size_t(L - 2)].q_max <= 4;
     for (int i = 0; ok && i < tl.n_nodes; ++i) {
       const BcrNodeDev& nd = p->h_bcr_nodes[size_t(tl.node0 + i)];
@@ -1121,7 +1411,7 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
   // The first back-substitution launch rides in the launch of the dense reduced solve where the shapes allow it (the
   // nodes fetch what they need while the solve runs and take its solution over a hand-off word: dense_back_kernel).
   const int l_first = ts.n > 0 ? L - 2 : L - 1;
-  const calico_problem::BcrLevel& lf = p->bcr_levels[size_t(l_first)];
+  const BcrLevel& lf = p->bcr_levels[size_t(l_first)];
   const bool fused = l_first == 0 && dense_back_fusable(sa, ks, lf.q_max, /*border_rows=*/l_first > 0) &&
                      std::max(dense_block_solve_lds_bytes(), bcr_back_lds_bytes(lf.q_max, p->bcr_m1p)) + 1024 <= kMaxLds;
   if (fused) {
@@ -1131,7 +1421,7 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
     launch_reduced_solve(sa, p->dense_in_lds, ks, s);
   }
   for (int l = L - 1; l >= 0; --l) {
-    const calico_problem::BcrLevel& lv = p->bcr_levels[size_t(l)];
+    const BcrLevel& lv = p->bcr_levels[size_t(l)];
     if (ts.n > 0 && l == L - 1) continue;
     const bool first = l == L - 1 || (ts.n > 0 && l == L - 2);     // the first launch behind the reduced solve
     if (first && fused) continue;
@@ -1232,12 +1522,35 @@ void calico_problem_destroy(calico_problem* p) {
   // all-reduce --, then give the communicator back
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   if (p->comm) { (void)rccl().CommDestroy(p->comm); p->comm = nullptr; }
-  if (p->h_state) (void)hipHostFree(p->h_state);
-  if (p->h_progress) (void)hipHostFree(p->h_progress);
-  if (p->h_xpin) (void)hipHostFree(p->h_xpin);
-  if (p->h_log) (void)hipHostFree(p->h_log);
+  // the workspace stays with the cached plan: the next handle of this structure takes it over instead of allocating
+  if (p->plan && p->ws_ready) {
+    auto w = std::make_unique<Workspace>();
+    w->swap_ws(static_cast<Workspace&>(*p));
+    std::lock_guard<std::mutex> lock(plan_cache().mu);
+    if (p->plan->pool.size() < PlanCache::kMaxPool) p->plan->pool.push_back(std::move(w));
+  }
   if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
+}
+
+int32_t calico_plan_cache_stats(int64_t* hits, int64_t* misses, int64_t* entries) {
+  PlanCache& c = plan_cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  if (hits) *hits = c.hits;
+  if (misses) *misses = c.misses;
+  if (entries) *entries = int64_t(c.entries.size());
+  return CALICO_OK;
+}
+
+int32_t calico_plan_cache_clear(void) {
+  PlanCache& c = plan_cache();
+  std::vector<std::shared_ptr<PlanEntry>> drop;
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    drop.swap(c.entries);      // (entries that live handles still refer to are freed with the last of them)
+    for (const std::shared_ptr<PlanEntry>& e : drop) e->pool.clear();
+  }
+  return CALICO_OK;
 }
 
 const char* calico_last_error(const calico_problem* p) { return p ? p->error.c_str() : "null problem"; }
@@ -1263,6 +1576,25 @@ int32_t calico_problem_add_param_block(calico_problem* p, const double* values, 
   p->blocks.push_back(b);
   p->dirty = true;
   if (block_id_out) *block_id_out = int32_t(p->blocks.size()) - 1;
+  return CALICO_OK;
+}
+
+int32_t calico_problem_add_param_blocks(calico_problem* p, int32_t n, int32_t size, int32_t manifold, const uint8_t* is_constant,
+                                        const double* values, int32_t* block_ids_out) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  if (n < 0 || size <= 0 || (n > 0 && !values)) return p->set_error(CALICO_INVALID_ARGUMENT, "bad parameter blocks");
+  if (manifold == CALICO_MANIFOLD_EIGEN_QUATERNION && size != 4)
+    return p->set_error(CALICO_INVALID_ARGUMENT, "quaternion manifold needs size 4");
+  if (manifold != CALICO_MANIFOLD_EUCLIDEAN && manifold != CALICO_MANIFOLD_EIGEN_QUATERNION)
+    return p->set_error(CALICO_INVALID_ARGUMENT, "unknown manifold");
+  p->blocks.reserve(p->blocks.size() + size_t(n));
+  for (int i = 0; i < n; ++i) {
+    HBlock b; b.v.assign(values + size_t(i) * size, values + size_t(i + 1) * size); b.size = size; b.manifold = manifold;
+    b.constant = is_constant && is_constant[i] != 0;
+    p->blocks.push_back(std::move(b));
+    if (block_ids_out) block_ids_out[i] = int32_t(p->blocks.size()) - 1;
+  }
+  p->dirty = true;
   return CALICO_OK;
 }
 
@@ -1354,9 +1686,12 @@ static int32_t add_obs(calico_problem* p, int32_t sid, int64_t n, const double* 
   HSensor& s = p->sensors[sid];
   const int dim = s.dim();
   // validate first so a failing call adds nothing
+  std::vector<int> segs(static_cast<size_t>(n));
   for (int64_t i = 0; i < n; ++i) {
-    if (spline_index(p, stamps[i]) < 0)
+    const int sg = spline_index(p, stamps[i]);
+    if (sg < 0)
       return p->set_error(CALICO_INVALID_ARGUMENT, "measurement stamp is outside the spline's valid knots");
+    segs[size_t(i)] = sg;
     if (body) {
       // camera.cpp:126-131
       if (body[i] < 0 || body[i] >= int(p->bodies.size()))
@@ -1366,13 +1701,12 @@ static int32_t add_obs(calico_problem* p, int32_t sid, int64_t n, const double* 
         return p->set_error(CALICO_INVALID_ARGUMENT, "model point block must be a 3-vector");
     }
   }
-  for (int64_t i = 0; i < n; ++i) {
-    s.seg.push_back(spline_index(p, stamps[i]));
-    s.stamps.push_back(stamps[i]);
-    if (body) { s.body.push_back(body[i]); s.point.push_back(point[i]); }
-    for (int c = 0; c < dim; ++c) s.meas.push_back(meas[i * dim + c]);
-    s.active.push_back(1); s.n_active = -1;
-  }
+  s.seg.insert(s.seg.end(), segs.begin(), segs.end());
+  s.stamps.insert(s.stamps.end(), stamps, stamps + n);
+  if (body) { s.body.insert(s.body.end(), body, body + n); s.point.insert(s.point.end(), point, point + n); }
+  s.meas.insert(s.meas.end(), meas, meas + n * dim);
+  s.active.insert(s.active.end(), size_t(n), uint8_t(1));
+  s.n_active = -1;
   p->dirty = true;
   return CALICO_OK;
 }

@@ -485,13 +485,13 @@ def build_problem(api, scene, device=0, obs_slices=None):
     P = _capi.Problem(api, device)
     # WorldModel::AddParametersToProblem (world_model.cpp:40-77)
     pc = np.broadcast_to(np.asarray(scene.points_constant, bool), (len(scene.points),))
-    point_blocks = np.array([P.add_param_block(p, constant=bool(c)) for p, c in zip(scene.points, pc)], np.int32)
+    point_blocks = P.add_param_blocks(np.asarray(scene.points, float), constant=pc)
     bt = P.add_param_block(scene.body_t, constant=scene.body_pose_constant)
     bq = P.add_param_block(scene.body_q, _capi.MANIFOLD_EIGEN_QUATERNION, scene.body_pose_constant)
     grav = P.add_param_block(scene.gravity, constant=True)  # Q6: gravity can never be enabled
     body = P.add_rigid_body(bq, bt)
     # Trajectory::AddParametersToProblem (bspline.hpp:10-17)
-    ctrl_blocks = np.array([P.add_param_block(c) for c in scene.ctrl], np.int32)
+    ctrl_blocks = P.add_param_blocks(np.asarray(scene.ctrl, float))
     P.set_spline(scene.order, scene.knots, scene.basis, ctrl_blocks)
     sids, sblocks = [], []
     for i, s in enumerate(scene.sensors):

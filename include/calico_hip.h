@@ -149,6 +149,10 @@ int32_t calico_problem_add_param_block(calico_problem* p, const double* values,
                                        int32_t size, int32_t manifold,
                                        int32_t is_constant,
                                        int32_t* block_id_out);
+/* Bulk form for n blocks of one size and manifold (the model points of a chart, the control points of the spline):
+ * values n x size row-major, is_constant one byte per block (NULL: none is constant), ids returned in block_ids_out. */
+int32_t calico_problem_add_param_blocks(calico_problem* p, int32_t n, int32_t size, int32_t manifold,
+                                        const uint8_t* is_constant, const double* values, int32_t* block_ids_out);
 /* Read / overwrite the current value of a block (the reference hands Ceres
  * pointers into the user's objects and reads them back in place). */
 int32_t calico_get_param_block(calico_problem* p, int32_t block_id,
@@ -206,6 +210,18 @@ int32_t calico_problem_add_imu_residuals(calico_problem* p, int32_t sensor_id,
  * ceres::Solve on every call (batch_optimizer.cpp:57-70: it rebuilds the ceres::Problem each time), made separately
  * callable so that its cost can be measured (bench.py: config.setup_ms). */
 int32_t calico_problem_finalize(calico_problem* p);
+
+/* The plan -- everything calico_problem_finalize derives -- depends on the STRUCTURE of the problem only (block sizes,
+ * manifolds and constancy; the spline's knots, basis and control-point blocks; every sensor's model, blocks, sigma and
+ * loss; per observation its stamp, rigid body and model point), not on parameter values or measurements. The library
+ * keeps the plans of the last few structures it has seen (keyed on a 128-bit hash of exactly those inputs, per device)
+ * together with the device workspaces of destroyed handles: BatchOptimizer::Optimize rebuilds its problem on every call
+ * (batch_optimizer.cpp:57-70), and a rebuilt problem of known structure then only uploads its values. A structure that
+ * differs in any of those inputs is planned afresh. CALICO_PLAN_CACHE=0 in the environment switches the cache off.
+ * calico_plan_cache_stats: look-ups served from the cache / planned afresh since the process started, plans held.
+ * calico_plan_cache_clear: drops the cached plans and workspaces (device memory of plans no live handle uses is freed). */
+int32_t calico_plan_cache_stats(int64_t* hits_out, int64_t* misses_out, int64_t* entries_out);
+int32_t calico_plan_cache_clear(void);
 
 /* ---- solve ------------------------------------------------------------ */
 /* Replaces ceres::Solve (batch_optimizer.cpp:72-73): Levenberg–Marquardt
