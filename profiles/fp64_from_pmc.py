@@ -8,9 +8,19 @@
 
 FP64 flops per launch = 64 · (2·FMA_F64 + ADD_F64 + MUL_F64) + 512 · MFMA_MOPS_F64 (wave-level instruction counts times 64
 lanes; one MFMA "MOPS" unit = 512 operations -- the gfx94x convention, ROCm 7.2 ships no gfx950 derived-counter
-section). Peak: 78.6 TFLOP/s FP64 on MI355X, vector and matrix pipes alike. `mfma_busy_frac` = SQ_VALU_MFMA_BUSY_CYCLES /
-SQ_BUSY_CYCLES as counted (both summed over the shader engines). Launches that exit at once are dropped (below 1 % of
-the kernel's largest count)."""
+section). Peak: 78.6 TFLOP/s FP64 on MI355X, vector and matrix pipes alike.
+
+MFMA utilisation (what fraction of the chip's matrix-pipe cycles a kernel keeps busy), two ways that must agree:
+  `mfma_util` = SQ_VALU_MFMA_BUSY_CYCLES / (kernel duration x 2.4 GHz x 1024 SIMDs). The counter is the sum over all SIMDs
+  of the cycles their matrix pipe is held: measured here it is EXACTLY 64 x the number of v_mfma_f64_16x16x4_f64 issued
+  (MOPS / 4) for every kernel of the run. The duration is the un-profiled one of the kernel-trace pass.
+  `mfma_util_from_flops` = MFMA flops / duration / 78.6 TFLOP/s (2048 flops per instruction, 64 cycles of one SIMD's pipe:
+  32 flops per cycle and SIMD = 78.6 TFLOP/s over 1024 SIMDs at 2.4 GHz).
+Both are <= 1 by construction. GRBM_GUI_ACTIVE (optional 5th argument: a pass of its own) is NOT used as the denominator: as
+rocprofv3 reports it per dispatch it is summed over the eight XCDs and spans the profiler's counter window (a one-thread
+kernel reads 177k = 9 us x 8 x 2.4 GHz); it is kept in the CSV (`grbm_gui_active_raw`) for reference. (`mfma_busy_cycles_over_sq_busy_cycles`, the figure round 2 printed, divides a per-SIMD sum
+by a per-shader-engine sum and is not a utilisation; kept in the CSV for continuity only.)
+Launches that exit at once are dropped (below 1 % of the kernel's largest count)."""
 import collections
 import csv
 import json
@@ -39,8 +49,17 @@ def mangled_fragment(demangled):
     return frag
 
 
+N_SIMD = 1024
+CLOCK_HZ = 2.4e9
+
+
 def main():
     pmc_csv, stats_csv, out_csv, out_json = sys.argv[1:5]
+    gui = collections.defaultdict(list)
+    if len(sys.argv) > 5:
+        for r in csv.DictReader(open(sys.argv[5])):
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                gui[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(pmc_csv)):
         if r["Counter_Name"] in NAMES:
@@ -63,26 +82,46 @@ def main():
         frag = mangled_fragment(k)
         ns = next((v for n, v in dur.items() if frag in n), None)
         frac = ((flops_valu + flops_mfma) / (ns * 1e-9) / PEAK_FP64) if ns else None
+        g = gui.get(k, [])
+        g = [v for v in g if v > 0.1 * max(g)] if g else []
+        gui_raw = (sum(g) / len(g)) if g else None
+        active = (ns * 1e-9 * CLOCK_HZ) if ns else None
+        util = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (active * N_SIMD) if active else None
+        util_flops = (flops_mfma / (ns * 1e-9) / PEAK_FP64) if ns else None
         rows.append((k, ns, flops_valu, flops_mfma, frac,
-                     a["SQ_VALU_MFMA_BUSY_CYCLES"] / a["SQ_BUSY_CYCLES"] if a["SQ_BUSY_CYCLES"] else None, len(keep)))
+                     a["SQ_VALU_MFMA_BUSY_CYCLES"] / a["SQ_BUSY_CYCLES"] if a["SQ_BUSY_CYCLES"] else None, len(keep), util, util_flops,
+                     active, gui_raw))
     rows.sort(key=lambda r: -(r[1] or 0))
     with open(out_csv, "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(["Kernel", "avg_working_ns", "fp64_flops_valu_per_launch", "fp64_flops_mfma_per_launch", "fp64_frac_of_78.6TF",
-                    "mfma_busy_cycles_over_sq_busy_cycles", "launches_counted"])
+                    "mfma_busy_cycles_over_sq_busy_cycles", "launches_counted", "mfma_util", "mfma_util_from_flops",
+                    "duration_x_2.4GHz_cycles", "grbm_gui_active_raw"])
         for r in rows:
             w.writerow([r[0], "%.0f" % (r[1] or 0), "%.0f" % r[2], "%.0f" % r[3], "" if r[4] is None else "%.5f" % r[4],
-                        "" if r[5] is None else "%.5f" % r[5], r[6]])
+                        "" if r[5] is None else "%.5f" % r[5], r[6], "" if r[7] is None else "%.5f" % r[7],
+                        "" if r[8] is None else "%.5f" % r[8], "" if r[9] is None else "%.0f" % r[9], "" if r[10] is None else "%.0f" % r[10]])
     js = {"source": "rocprofv3 --pmc (SQ counters, own pass) + kernel-trace durations; see profiles/fp64_from_pmc.py",
           "peak_fp64_tflops": 78.6,
           "kernels": {r[0].split("(")[0][:60]: {"us": None if r[1] is None else round(r[1] / 1e3, 2),
                                                 "fp64_frac": None if r[4] is None else round(r[4], 5),
                                                 "mfma_share_of_flops": round(r[3] / (r[2] + r[3]), 3) if r[2] + r[3] > 0 else None,
-                                                "mfma_busy_frac": None if r[5] is None else round(r[5], 5)} for r in rows[:12]}}
+                                                "mfma_util": None if r[7] is None else round(r[7], 5),
+                                                "mfma_util_from_flops": None if r[8] is None else round(r[8], 5)} for r in rows[:12]}}
+    dom = [r for r in rows if "eval_jacobian_kernel" in r[0]]
+    if dom:
+        js["mfma_utilisation_dominant_kernel"] = {
+            "kernel": "eval_jacobian_kernel", "mfma_util": None if dom[0][7] is None else round(dom[0][7], 5),
+            "mfma_util_from_flops": None if dom[0][8] is None else round(dom[0][8], 5),
+            "definition": "SQ_VALU_MFMA_BUSY_CYCLES (sum over SIMDs) / (kernel duration x 2.4 GHz x 1024 SIMDs); cross-check: MFMA flops / duration / 78.6 TFLOP/s"}
+    bad = [r[0] for r in rows if (r[7] is not None and r[7] > 1.0) or (r[8] is not None and r[8] > 1.0)]
+    if bad:
+        raise SystemExit("utilisation above 1 for %s: the counters are being read wrongly" % bad)
     json.dump(js, open(out_json, "w"), indent=1)
     for r in rows[:12]:
-        print("%-60s %8.2f us  valu %.3e  mfma %.3e flops  fp64 frac %s  mfma busy %s" % (
-            r[0][:60], (r[1] or 0) / 1e3, r[2], r[3], "-" if r[4] is None else "%.4f" % r[4], "-" if r[5] is None else "%.4f" % r[5]))
+        print("%-60s %8.2f us  valu %.3e  mfma %.3e flops  fp64 frac %s  mfma util %s (from flops %s)" % (
+            r[0][:60], (r[1] or 0) / 1e3, r[2], r[3], "-" if r[4] is None else "%.4f" % r[4], "-" if r[7] is None else "%.4f" % r[7],
+            "-" if r[8] is None else "%.4f" % r[8]))
 
 
 if __name__ == "__main__":
