@@ -172,7 +172,7 @@ def main():
                     help="exercise the sharding + all-reduce path even with one rank (validation)")
     ap.add_argument("--repeats", type=int, default=0,
                     help="timed samples of --steps iterations each (default: 25 when --steps <= 50, else 5); the median is reported")
-    ap.add_argument("--min-seconds", type=float, default=3.0,
+    ap.add_argument("--min-seconds", type=float, default=4.0,
                     help="without --repeats: as many samples as it takes to keep the GPU busy this long")
     ap.add_argument("--poor-start", type=float, default=0.0,
                     help="move the start away from the truth: focal lengths x (1 + F/100), translations + F cm, control "
@@ -354,7 +354,7 @@ def main():
     # timed region: only the dominant kernel (phase 0) carries events, and only every 16th of its launches -- an event
     # pair costs ~6 us of stream time on either side of the kernel. The K-step sample is a few milliseconds long, so it is
     # repeated and the MEDIAN sample is the one reported (box-to-box and run-to-run spread is several per cent).
-    # By default the samples add up to >= 3 s of GPU work (a 20-iteration sample is ~3 ms: the driver's utilisation
+    # By default the samples add up to >= 3 s of GPU work (4 s are aimed at: the first, estimating sample runs slower) (a 20-iteration sample is ~3 ms: the driver's utilisation
     # sampler would otherwise never see the device busy); --repeats N fixes the count.
     if args.repeats > 0:
         repeats = args.repeats
