@@ -1318,7 +1318,8 @@ size_t bcr_back_lds_bytes(int q_max, int m1p);
 // Can the first back-substitution launch ride in the dense solve's launch? Only the shapes the in-LDS solve takes, no
 // border-row sweep workgroups (those would sit on every CU with the dense solve's LDS footprint), chains of at most four.
 bool dense_back_fusable(const SolveArgs& a, int ks, int q_max, bool border_rows) {
-  static const bool on = [] { const char* e = std::getenv("CALICO_FUSE_BACK"); return !e || std::atoi(e) != 0; }();
+  const char* fe = std::getenv("CALICO_FUSE_BACK");       // (read per solve: an A/B switch, and what the tests toggle)
+  const bool on = !fe || std::atoi(fe) != 0;
   static const bool use_block = [] { const char* e = std::getenv("CALICO_DENSE"); return !(e && std::string(e) == "panel"); }();
   return on && use_block && a.m + 1 <= 128 && a.m >= 1 && ks <= 2 && q_max <= 4 && !border_rows;
 }

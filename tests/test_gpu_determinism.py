@@ -89,6 +89,37 @@ def test_solver_variants_agree(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_fused_dense_solve_and_back_substitution_launch_agrees(monkeypatch):
+    """Round 3: on trees of up to two levels the first back-substitution launch rides in the launch of the dense reduced
+    solve and takes its solution over an in-launch hand-off (sc1 stores + flag; dense_back_kernel). Same arithmetic in
+    the same order: with the fusion switched off (two launches, CALICO_FUSE_BACK=0) the solve must walk the same
+    iterations BIT FOR BIT -- a stale read behind the hand-off would show here. Chains of 4 (two levels, top merged),
+    2 and 1 superblocks that still end at level 0 behind the reduced solve are covered through CALICO_BCR_LEAF."""
+    api = helpers.hip_api()
+    # 4 cameras + IMU, robust kernels, ~90 control points like configs[3] (19 superblocks: two tree levels)
+    scene = syn.make_scene(4, 1, True, 3, cam_rate=10.0, imu_rate=100.0, duration=8.7, chart="april", seed=21,
+                           pixel_noise=0.1, gyro_noise=1e-3, accel_noise=1e-2, robust=True, segment_duration=8.7 / 23.9,
+                           max_cam_obs=6000)
+    for leaf in ("", "4", "9"):
+        if leaf:
+            monkeypatch.setenv("CALICO_BCR_LEAF", leaf)
+        else:
+            monkeypatch.delenv("CALICO_BCR_LEAF", raising=False)
+        runs = {}
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("CALICO_FUSE_BACK", fuse)
+            runs[fuse] = _solve_repeatedly(api, scene, repeats=3, max_iter=30)
+        monkeypatch.delenv("CALICO_FUSE_BACK")
+        ref = runs["0"][0]
+        assert ref[0] > 3
+        for fuse in ("1", "0"):
+            for r in runs[fuse]:
+                assert r[0] == ref[0] and r[1] == ref[1], (leaf, fuse)
+                assert r[2] == ref[2], (leaf, fuse)
+                assert np.array_equal(r[3], ref[3]), (leaf, fuse)
+
+
+@pytest.mark.gpu
 def test_back_to_back_solves_behind_leftover_kernels():
     """calico_solve returns as soon as the device reports the end of the solve; the early-exit kernels of the iterations
     enqueued ahead are still on the stream when the next call starts. Solves of different lengths, restarts, residual
