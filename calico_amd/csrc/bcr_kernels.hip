@@ -113,6 +113,153 @@ struct FromR {
   }
 };
 
+// ---- hand-off inside a launch (the dense reduced solve -> the back-substitution workgroups riding in its launch) ----
+// The producer's results leave with write-through (sc1) stores, are drained (s_waitcnt vmcnt(0)) and followed by an sc1
+// flag store; the consumers poll the flag from one lane with relaxed sc1 loads and read the results with sc1 loads (they
+// bypass the CU's vector L1, which another CU's stores never refresh). No agent-scope fence on either side: a release
+// would write back the XCD's L2, an acquire invalidate the L1 -- microseconds each (MI355X_MICROARCH.md, "inter-workgroup
+// visibility": the {sc1 stores, sc1 loads} form).
+struct Handoff { int* word; int seq; };       // word == nullptr: plain kernel boundary, no hand-off
+DEVI double load_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVI void store_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool HO> DEVI double load_y(const double* p) { return HO ? load_sc1(p) : *p; }
+// all threads of the workgroup; the stores of every thread are drained before the flag goes up
+DEVI void handoff_publish(const Handoff& h) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(h.word, h.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// fan-in: every producing workgroup of a launch arrives once (its stores drained first), consumers wait for all of them
+DEVI void fanin_arrive(int* word) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DEVI void fanin_wait(const int* word, int n) {
+  if (threadIdx.x == 0) {
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(4);
+  }
+  __syncthreads();
+}
+DEVI void handoff_wait(const Handoff& h) {
+  if (threadIdx.x == 0) {
+    while (__hip_atomic_load(h.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != h.seq) __builtin_amdgcn_s_sleep(4);
+  }
+  __syncthreads();
+}
+
+// One 16x16 tile (tr, tc) of the reduced system's calibration part, K-slice `slice` of `ks`: C(r, c) (+ damping on the
+// diagonal, slice 0 only) - Σ_rows Y(row, r) Y(row, c) over the slice's rows of Y, on the matrix cores straight from
+// global memory; NW waves split the rows and add up in a fixed order. With `late` (the tile rides in the last level's
+// launch): the rows of the superblocks that level eliminates (late0, late1) are left out of the first pass -- they are
+// being written by that very launch --, the workgroup then waits for the level's workgroups (fan-in word) and adds
+// them, read with L1-bypassing loads.
+template <int NW, bool LATE>
+DEVI void schur_tile(const SolveArgs& a, const BcrArgs& b, const FromR& fr, int tile, int slice, int ks, double* sacc /* [NW][256] */,
+                     const int* fan_word, int n_prod, int late0, int late1) {
+  const int mc = a.mc, m = a.m, m1 = a.m + 1, m1p = b.m1p, m1y = a.mc + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t msq = size_t(m1) * m1;
+  const int n = b.N * BP;                       // rows of Y (padding and root rows are zero)
+  int tr = 0, rem = tile;
+  while (rem > tr) { rem -= tr + 1; ++tr; }
+  const int tc = rem;
+  const int lc16 = lane & 15, lk = lane >> 4;
+  const int rows_per = ((n + ks - 1) / ks + 15) & ~15;
+  const int r_begin = slice * rows_per, r_end = min(n, r_begin + rows_per);
+  const int per_wave = (((r_end - r_begin + NW - 1) / NW + 3) / 4) * 4;
+  const int w_begin = r_begin + wave * per_wave, w_end = min(r_end, w_begin + per_wave);
+  const int ca = 16 * tr + lc16, cb = 16 * tc + lc16;      // columns of Y: always < m1p
+  const double* pa = b.Y + ca;
+  const double* pb = b.Y + cb;
+  const int f0 = LATE ? late0 : -1, f1 = LATE ? late1 : -1;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = w_begin; k0 < w_end; k0 += 32) {
+    double va[8], vb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int row = k0 + 4 * u + lk;
+      const size_t ro = size_t(min(row, n - 1)) * m1p;
+      va[u] = pa[ro]; vb[u] = pb[ro];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int row = k0 + 4 * u + lk, sb = row >> 5;
+      const bool use = row < w_end && sb != f0 && sb != f1;      // (a select, not a product: a skipped row may hold anything)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(use ? va[u] : 0.0, vb[u], acc, 0, 0, 0);
+    }
+  }
+  if (LATE) {
+    fanin_wait(fan_word, n_prod);
+    // rows 32·blk + 4·wave + lk of the late superblocks (NW = 8 waves x 4 rows = 32), where they fall into this slice
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int sb = f == 0 ? f0 : f1;
+      const int row = BP * max(sb, 0) + 4 * wave + lk;
+      const bool use = sb >= 0 && wave < 8 && row >= r_begin && row < r_end;
+      const size_t ro = size_t(min(row, n - 1)) * m1p;
+      const double va = load_sc1(pa + ro), vb = load_sc1(pb + ro);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(use ? va : 0.0, vb, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sacc[wave * 256 + (lk + 4 * r) * 16 + lc16] = acc[r];
+  __syncthreads();
+  if (tid < 256) {
+    const int ti = tid >> 4, tj = tid & 15;
+    const int r = tr * 16 + ti, c = tc * 16 + tj;      // columns of Y
+    double sum = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sum += sacc[w * 256 + tid];
+    if (r < m1y && c <= r) {
+      const int fi = r < mc ? r : m, fc = c < mc ? c : m;   // final index: the right-hand side sits behind the root rows
+      // corner of the damped system: C(r, c) (+ damping on the diagonal), right-hand side g_c in row m; (m, m) is unused
+      double s0 = 0.0;
+      if (slice == 0) {
+        if (r < mc) {
+          s0 = a.R[a.off_C() + size_t(r) * mc + c];
+          if (r == c) { const double d = fr.damping(s0, a.n_s() + r); a.dadd[a.n_s() + r] = d; s0 += d; }
+        } else if (c < mc) s0 = a.R[a.off_g() + a.n_s() + c];
+      }
+      a.Spart[size_t(slice) * msq + size_t(fi) * m1 + fc] = s0 - sum;
+    }
+  }
+}
+// Root rows of the reduced system: Spart(mc + r, j) = F_root(r, j), Spart(mc + r, mc + r2) = D_root(r, r2), Spart(m, mc + r) =
+// F_root(r, mc), each plus the root's pending slots; workgroup w0 of nw, NT threads. SC1: read behind an in-launch fan-in.
+template <bool SC1>
+DEVI void schur_root_rows(const SolveArgs& a, const BcrArgs& b, int ks, int w0, int nw, int NT) {
+  if (b.root < 0) return;
+  const int mc = a.mc, m = a.m, m1 = a.m + 1, m1p = b.m1p, m1y = a.mc + 1;
+  const size_t msq = size_t(m1) * m1;
+  const int tid = threadIdx.x;
+  const int br = m - mc;
+  const size_t fblk = size_t(BP) * m1p;
+  const double* pD = b.pendD + size_t(b.root_par) * size_t(b.N) * 2 * BB;
+  const double* pF = b.pendF + size_t(b.root_par) * size_t(b.N) * 2 * fblk;
+  const int mask = b.root_pend;
+  const int total = br * (m1y + br);
+  auto ld = [](const double* p) { return SC1 ? load_sc1(p) : *p; };
+  for (int e = w0 * NT + tid; e < total; e += nw * NT) {
+    const int r = e / (m1y + br), j = e % (m1y + br);
+    const bool in_f = j < m1y;
+    const int r2 = j - m1y;
+    if (!in_f && r2 > r) continue;
+    // the three sources of an entry are requested together (clamped, unconditional): one round trip per entry, not three
+    const size_t o = in_f ? size_t(r) * m1p + j : size_t(r) * BP + r2;
+    const double* base = in_f ? b.F + size_t(b.root) * fblk : b.D + size_t(b.root) * BB;
+    const double* p0 = in_f ? pF + (size_t(b.root) * 2 + 0) * fblk : pD + (size_t(b.root) * 2 + 0) * BB;
+    const double* p1 = in_f ? pF + (size_t(b.root) * 2 + 1) * fblk : pD + (size_t(b.root) * 2 + 1) * BB;
+    const double v0 = ld(base + o), v1 = ld(p0 + o), v2 = ld(p1 + o);
+    const double v = (v0 + ((mask & 1) ? v1 : 0.0)) + ((mask & 2) ? v2 : 0.0);
+    int fi, fc;
+    if (in_f) { if (j < mc) { fi = mc + r; fc = j; } else { fi = m; fc = mc + r; } }
+    else { fi = mc + r; fc = mc + r2; }
+    a.Spart[size_t(fi) * m1 + fc] = v;
+    for (int k = 1; k < ks; ++k) a.Spart[size_t(k) * msq + size_t(fi) * m1 + fc] = 0.0;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // One level of the elimination tree. Workgroup (node, role): role 0 owns the spine (it files L⁻ᵀ, Z^A, Z^B, the
 // separators' diagonal updates and the fill between them), role s >= 1 the border columns [16(s-1), 16s) (Z^F and the
@@ -127,10 +274,34 @@ template <bool FROM_R>
 __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, BcrArgs b, int node0, int n_nodes, int nfs, int level,
                                                                    int keep0, int n_keep, LmOptionsDev o, int with_post,
                                                                    const double* __restrict__ x, const BlockDev* __restrict__ blocks,
-                                                                   int n_blocks, IterLog* log, int log_cap, int jacobi_scaling) {
+                                                                   int n_blocks, IterLog* log, int log_cap, int jacobi_scaling,
+                                                                   int n_schur_wg, int n_root_wg, int schur_ks, int* fan_word, int n_prod) {
   LmState* st = a.st;
   const int terminated = st->terminated;     // tested after the first loads are on their way (they are harmless)
   const double radius = st->radius;
+  // `pub` (the last level's launch when the Schur complement rides in it): this level's workgroups are the PRODUCERS of
+  // an in-launch fan-in -- what the riders read (Y rows, the root's pending slots, separators updated in place) leaves
+  // with write-through stores, and every producing workgroup arrives at `fan_word` once, terminated or not; the riders
+  // behind them in the grid are the Schur complement's tiles and the root's rows of the reduced system.
+  const bool pub = !FROM_R && fan_word != nullptr;
+  if (FROM_R && fan_word != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *fan_word = 0;     // (the next fan-in counts from zero)
+  if (pub && int(blockIdx.x) >= int(gridDim.x) - n_schur_wg - n_root_wg) {
+    if (terminated) return;
+    use_current_R(a);
+    const FromR frs = {a, o, radius};
+    extern __shared__ double lds_s[];
+    const int w = int(blockIdx.x) - (int(gridDim.x) - n_schur_wg - n_root_wg);
+    if (w < n_schur_wg) {
+      // (the last level has one or two nodes of one superblock each)
+      const int lb0 = b.nodes[node0].blk0, lb1 = n_nodes > 1 ? b.nodes[node0 + 1].blk0 : -1;
+      schur_tile<kLevelThreads / 64, true>(a, b, frs, w / schur_ks, w % schur_ks, schur_ks, lds_s, fan_word, n_prod, lb0, lb1);
+    } else {
+      fanin_wait(fan_word, n_prod);
+      schur_root_rows<true>(a, b, schur_ks, w - n_schur_wg, n_root_wg, kLevelThreads);
+    }
+    return;
+  }
+  auto put = [&](double* dst, double v) { if (pub) store_sc1(dst, v); else *dst = v; };
   if (FROM_R) {
     if (with_post && blockIdx.x == gridDim.x - 1) {
       if (terminated) return;
@@ -153,7 +324,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   const bool extra_wg = int(blockIdx.x) >= main_span;
   if (!extra_wg && node_l >= n_nodes) return;
   const int bid = extra_wg ? n_nodes * per + (int(blockIdx.x) - main_span) : node_l * per + pslot % per;
-  const int grid_l = n_nodes * per + (int(gridDim.x) - main_span);      // logical grid: nodes × roles, then the extras
+  const int grid_l = n_nodes * per + (int(gridDim.x) - n_schur_wg - n_root_wg - main_span);      // logical grid: nodes × roles, then the extras
   const int m1p = b.m1p, par = level & 1;
   const size_t NB = size_t(b.N);
   const size_t fblk = size_t(BP) * m1p;
@@ -164,7 +335,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   const double* const Gr = b.G + size_t(par) * NB * BB;
   double* const Gw = b.G + size_t(par ^ 1) * NB * BB;
   if (bid >= n_nodes * per) {
-    if (terminated) return;
+    if (terminated) { if (pub) fanin_arrive(fan_word); return; }
     // surviving separators that are not eliminated at this level: D += pending, F += pending (in place; nobody else
     // reads them in this launch). At level 0 they are initialised from R(x) instead.
     const size_t aw = size_t(bid - n_nodes * per), naw = size_t(grid_l - n_nodes * per - (FROM_R && with_post ? 1 : 0));
@@ -182,15 +353,16 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         double v = b.D[size_t(blk) * BB + rem];
         if (mask & 1) v += pendD_r[(size_t(blk) * 2 + 0) * BB + rem];
         if (mask & 2) v += pendD_r[(size_t(blk) * 2 + 1) * BB + rem];
-        b.D[size_t(blk) * BB + rem] = v;
+        put(b.D + size_t(blk) * BB + rem, v);
       } else {
         const size_t q = rem - BB;
         double v = b.F[size_t(blk) * fblk + q];
         if (mask & 1) v += pendF_r[(size_t(blk) * 2 + 0) * fblk + q];
         if (mask & 2) v += pendF_r[(size_t(blk) * 2 + 1) * fblk + q];
-        b.F[size_t(blk) * fblk + q] = v;
+        put(b.F + size_t(blk) * fblk + q, v);
       }
     }
+    if (pub) fanin_arrive(fan_word);
     return;
   }
   const BcrNodeDev* __restrict__ ndp = b.nodes + node0 + bid / per;
@@ -340,7 +512,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   {
     Pre pr;
     if (loader) fetch(0, pr);
-    if (terminated) return;
+    if (terminated) { if (pub) fanin_arrive(fan_word); return; }
     if (loader) commit(0, pr);
   }
   __syncthreads();
@@ -396,7 +568,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       }
     } else {
       const int r = tid >> 4, j = tid & 15;
-      b.Y[size_t(blk) * fblk + size_t(r) * m1p + f0 + j] = Zb[r * XLD + CF + j];
+      put(b.Y + size_t(blk) * fblk + size_t(r) * m1p + f0 + j, Zb[r * XLD + CF + j]);
     }
     // ---- Schur updates of the next block of the chain (in LDS) or of the right separator (pending slots) ----
     const int it = (wave & 3) >> 1, jt = wave & 1;
@@ -433,7 +605,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           acc = atb_tile<true>(Zb, XLD, CB + 16 * it, Zb, XLD, CB + 16 * jt, 0, BP, acc, lane);
           double* dst = pendD_w + (size_t(right) * 2 + 0) * BB;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dst[(row0 + 4 * r) * BP + col0] = acc[r];
+          for (int r = 0; r < 4; ++r) put(dst + (row0 + 4 * r) * BP + col0, acc[r]);
         } else if (left >= 0) {   // fill T(right, left): the left separator's coupling to its next survivor
           f64x4 acc = {0.0, 0.0, 0.0, 0.0};
           acc = atb_tile<true>(Zb, XLD, CB + 16 * it, Zb, XLD, CA + 16 * jt, 0, BP, acc, lane);
@@ -447,7 +619,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         acc = atb_tile<true>(Zb, XLD, CB + 16 * wave, Zb, XLD, CF, 0, BP, acc, lane);
         double* dst = pendF_w + (size_t(right) * 2 + 0) * fblk + f0 + l16;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[size_t(rw + 4 * r) * m1p] = acc[r];
+        for (int r = 0; r < 4; ++r) put(dst + size_t(rw + 4 * r) * m1p, acc[r]);
       }
     }
     // ---- what the left separator collects over the chain ----
@@ -471,15 +643,16 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         const int it = wave >> 1, jt = wave & 1;
         double* dst = pendD_w + (size_t(left) * 2 + 1) * BB;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(16 * it + lk + 4 * r) * BP + 16 * jt + l16] = acc_a[r];
+        for (int r = 0; r < 4; ++r) put(dst + (16 * it + lk + 4 * r) * BP + 16 * jt + l16, acc_a[r]);
       }
     } else if (wave == 2 || wave == 3) {
       double* dst = pendF_w + (size_t(left) * 2 + 1) * fblk + f0 + l16;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dst[size_t(16 * (wave - 2) + lk + 4 * r) * m1p] = acc_a[r];
+      for (int r = 0; r < 4; ++r) put(dst + size_t(16 * (wave - 2) + lk + 4 * r) * m1p, acc_a[r]);
     }
   }
   if (role == 0 && wave == 0 && lane == 0 && !(pmin > 0.0)) st->chol_failed = 1;
+  if (pub) fanin_arrive(fan_word);
 }
 
 // ---------------------------------------------------------------------------
@@ -492,91 +665,12 @@ __global__ __launch_bounds__(256) void bcr_schur_kernel(SolveArgs a, BcrArgs b, 
   if (st->terminated) return;
   use_current_R(a);
   const FromR fr = {a, o, st->radius};
-  const int mc = a.mc, m = a.m, m1 = a.m + 1, m1p = b.m1p, m1y = a.mc + 1;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const size_t msq = size_t(m1) * m1;
   if (int(blockIdx.x) >= n_tile_wg) {
-    // root rows: Spart(mc + r, j) = F_root(r, j), Spart(mc + r, mc + r2) = D_root(r, r2), Spart(m, mc + r) = F_root(r, mc)
-    if (b.root < 0) return;
-    const int br = m - mc;
-    const size_t fblk = size_t(BP) * m1p;
-    const double* pD = b.pendD + size_t(b.root_par) * size_t(b.N) * 2 * BB;
-    const double* pF = b.pendF + size_t(b.root_par) * size_t(b.N) * 2 * fblk;
-    const int mask = b.root_pend;
-    const int nw = gridDim.x - n_tile_wg, w0 = blockIdx.x - n_tile_wg;
-    const int total = br * (m1y + br);
-    for (int e = w0 * 256 + tid; e < total; e += nw * 256) {
-      const int r = e / (m1y + br), j = e % (m1y + br);
-      double v; int fi, fc;
-      if (j < m1y) {
-        const size_t o = size_t(b.root) * fblk + size_t(r) * m1p + j;
-        v = b.F[o];
-        if (mask & 1) v += pF[(size_t(b.root) * 2 + 0) * fblk + size_t(r) * m1p + j];
-        if (mask & 2) v += pF[(size_t(b.root) * 2 + 1) * fblk + size_t(r) * m1p + j];
-        if (j < mc) { fi = mc + r; fc = j; } else { fi = m; fc = mc + r; }
-      } else {
-        const int r2 = j - m1y;
-        if (r2 > r) continue;
-        const size_t o = size_t(r) * BP + r2;
-        v = b.D[size_t(b.root) * BB + o];
-        if (mask & 1) v += pD[(size_t(b.root) * 2 + 0) * BB + o];
-        if (mask & 2) v += pD[(size_t(b.root) * 2 + 1) * BB + o];
-        fi = mc + r; fc = mc + r2;
-      }
-      a.Spart[size_t(fi) * m1 + fc] = v;
-      for (int k = 1; k < ks; ++k) a.Spart[size_t(k) * msq + size_t(fi) * m1 + fc] = 0.0;
-    }
+    schur_root_rows<false>(a, b, ks, int(blockIdx.x) - n_tile_wg, int(gridDim.x) - n_tile_wg, 256);
     return;
   }
-  __shared__ double sacc[4][256];
-  const int n = b.N * BP;                       // rows of Y (padding and root rows are zero)
-  const int tile = blockIdx.x / ks, slice = blockIdx.x % ks;
-  int tr = 0, rem = tile;
-  while (rem > tr) { rem -= tr + 1; ++tr; }
-  const int tc = rem;
-  const int lc16 = lane & 15, lk = lane >> 4;
-  const int rows_per = ((n + ks - 1) / ks + 15) & ~15;
-  const int r_begin = slice * rows_per, r_end = min(n, r_begin + rows_per);
-  const int per_wave = (((r_end - r_begin + 3) / 4 + 3) / 4) * 4;
-  const int w_begin = r_begin + wave * per_wave, w_end = min(r_end, w_begin + per_wave);
-  const int ca = 16 * tr + lc16, cb = 16 * tc + lc16;      // columns of Y: always < m1p
-  const double* pa = b.Y + ca;
-  const double* pb = b.Y + cb;
-  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-  for (int k0 = w_begin; k0 < w_end; k0 += 32) {
-    double va[8], vb[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int row = k0 + 4 * u + lk;
-      const size_t ro = size_t(min(row, n - 1)) * m1p;
-      va[u] = pa[ro]; vb[u] = pb[ro];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const double rm = k0 + 4 * u + lk < w_end ? 1.0 : 0.0;
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u] * rm, vb[u], acc, 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) sacc[wave][(lk + 4 * r) * 16 + lc16] = acc[r];
-  __syncthreads();
-  {
-    const int ti = tid >> 4, tj = tid & 15;
-    const int r = tr * 16 + ti, c = tc * 16 + tj;      // columns of Y
-    const double sum = ((sacc[0][tid] + sacc[1][tid]) + sacc[2][tid]) + sacc[3][tid];
-    if (r < m1y && c <= r) {
-      const int fi = r < mc ? r : m, fc = c < mc ? c : m;   // final index: the right-hand side sits behind the root rows
-      // corner of the damped system: C(r, c) (+ damping on the diagonal), right-hand side g_c in row m; (m, m) is unused
-      double s0 = 0.0;
-      if (slice == 0) {
-        if (r < mc) {
-          s0 = a.R[a.off_C() + size_t(r) * mc + c];
-          if (r == c) { const double d = fr.damping(s0, a.n_s() + r); a.dadd[a.n_s() + r] = d; s0 += d; }
-        } else if (c < mc) s0 = a.R[a.off_g() + a.n_s() + c];
-      }
-      a.Spart[size_t(slice) * msq + size_t(fi) * m1 + fc] = s0 - sum;
-    }
-  }
+  __shared__ double sacc[4 * 256];
+  schur_tile<4, false>(a, b, fr, int(blockIdx.x) / ks, int(blockIdx.x) % ks, ks, sacc, nullptr, 0, -1, -1);
 }
 
 // ---------------------------------------------------------------------------
@@ -586,29 +680,6 @@ __global__ __launch_bounds__(256) void bcr_schur_kernel(SolveArgs a, BcrArgs b, 
 // from the level above.
 DEVI const double* sep_solution(const SolveArgs& a, const BcrArgs& b, int blk) {
   return blk == b.root ? a.y + a.n_s() + a.mc : b.ysol + size_t(blk) * BP;
-}
-
-// ---- hand-off inside a launch (the dense reduced solve -> the back-substitution workgroups riding in its launch) ----
-// The producer's results leave with write-through (sc1) stores, are drained (s_waitcnt vmcnt(0)) and followed by an sc1
-// flag store; the consumers poll the flag from one lane with relaxed sc1 loads and read the results with sc1 loads (they
-// bypass the CU's vector L1, which another CU's stores never refresh). No agent-scope fence on either side: a release
-// would write back the XCD's L2, an acquire invalidate the L1 -- microseconds each (MI355X_MICROARCH.md, "inter-workgroup
-// visibility": the {sc1 stores, sc1 loads} form).
-struct Handoff { int* word; int seq; };       // word == nullptr: plain kernel boundary, no hand-off
-DEVI double load_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEVI void store_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <bool HO> DEVI double load_y(const double* p) { return HO ? load_sc1(p) : *p; }
-// all threads of the workgroup; the stores of every thread are drained before the flag goes up
-DEVI void handoff_publish(const Handoff& h) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(h.word, h.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-DEVI void handoff_wait(const Handoff& h) {
-  if (threadIdx.x == 0) {
-    while (__hip_atomic_load(h.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != h.seq) __builtin_amdgcn_s_sleep(4);
-  }
-  __syncthreads();
 }
 
 // delta = -y ; candidate = Plus(x, delta) for the parameter blocks selected by the caller; partial sums of the model
@@ -1315,6 +1386,12 @@ void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s) {
   hipLaunchKernelGGL(dense_block_solve_kernel, dim3(1), dim3(kDenseThreads), dense_block_solve_lds_bytes(), s, a, ks);
 }
 size_t bcr_back_lds_bytes(int q_max, int m1p);
+// Does the Schur complement ride in the last level's launch? Trees of at least two levels whose last level has one or two
+// single-superblock nodes (it always has, by construction of the plan); CALICO_FUSE_SCHUR=0: a launch of its own (A/B).
+bool schur_rides_in_last_level(int n_levels, int n_last_nodes, int root) {
+  const char* e = std::getenv("CALICO_FUSE_SCHUR");
+  return (!e || std::atoi(e) != 0) && n_levels >= 2 && n_last_nodes >= 1 && n_last_nodes <= 2 && root >= 0;
+}
 // Can the first back-substitution launch ride in the dense solve's launch? Only the shapes the in-LDS solve takes, no
 // border-row sweep workgroups (those would sit on every CU with the dense solve's LDS footprint), chains of at most four.
 bool dense_back_fusable(const SolveArgs& a, int ks, int q_max, bool border_rows) {
@@ -1367,19 +1444,28 @@ hipError_t configure_bcr_kernels(int q_max, int m1p) {
   return hipSuccess;
 }
 
+// `schur_ks` > 0 (the LAST level of a tree of at least two): the Schur complement's tiles and the root's rows ride behind
+// this level's workgroups and take its results over the fan-in word; level 0 (`fan_word` given) resets the word.
 void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, int level, int keep0, int n_keep, const LmOptionsDev& o,
                       const double* x, const BlockDev* blocks, int n_blocks, bool with_post_eval, IterLog* log, int log_cap, int jacobi,
-                      hipStream_t s) {
+                      hipStream_t s, int schur_ks, int* fan_word) {
   const int nfs = (a.mc + 1 + kBcrFS - 1) / kBcrFS;
   const int n_apply = n_keep > 0 ? std::min(64, std::max(1, n_keep * 4)) : 0;
   const int main_span = 8 * ((n_nodes + 7) / 8) * (1 + nfs);      // (node, role) workgroups laid out by XCD: see the kernel
   if (level == 0) {
     hipLaunchKernelGGL(bcr_level_kernel<true>, dim3(main_span + n_apply + (with_post_eval ? 1 : 0)), dim3(kLevelThreads),
                        bcr_level_lds_bytes(), s, a, b, node0, n_nodes, nfs, level, keep0, n_keep, o, with_post_eval ? 1 : 0, x, blocks, n_blocks,
-                       log, log_cap, jacobi);
+                       log, log_cap, jacobi, 0, 0, 1, fan_word, 0);
   } else {
-    hipLaunchKernelGGL(bcr_level_kernel<false>, dim3(main_span + n_apply), dim3(kLevelThreads), bcr_level_lds_bytes(), s, a, b,
-                       node0, n_nodes, nfs, level, keep0, n_keep, o, 0, x, blocks, n_blocks, log, log_cap, jacobi);
+    const int nt = (a.mc + 1 + 15) / 16;
+    const int br = a.m - a.mc;
+    // (the root's rows: one entry per thread, so that the riders' tail behind the fan-in is a single round trip)
+    const int n_schur_wg = schur_ks > 0 ? nt * (nt + 1) / 2 * schur_ks : 0;
+    const int n_root_wg = schur_ks > 0 ? std::max(1, (br * (a.mc + 1 + br) + kLevelThreads - 1) / kLevelThreads) : 0;
+    const int n_prod = n_nodes * (1 + nfs) + n_apply;        // the workgroups of this level that really exist
+    hipLaunchKernelGGL(bcr_level_kernel<false>, dim3(main_span + n_apply + n_schur_wg + n_root_wg), dim3(kLevelThreads), bcr_level_lds_bytes(), s, a, b,
+                       node0, n_nodes, nfs, level, keep0, n_keep, o, 0, x, blocks, n_blocks, log, log_cap, jacobi, n_schur_wg, n_root_wg,
+                       std::max(1, schur_ks), schur_ks > 0 ? fan_word : nullptr, n_prod);
   }
 }
 void launch_bcr_schur(const SolveArgs& a, const BcrArgs& b, int ks, const LmOptionsDev& o, hipStream_t s) {

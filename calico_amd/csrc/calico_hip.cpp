@@ -80,7 +80,8 @@ hipError_t configure_dense_block_solve();
 size_t dense_block_solve_lds_bytes();
 void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, int level, int keep0, int n_keep, const LmOptionsDev& o,
                       const double* x, const BlockDev* blocks, int n_blocks, bool with_post_eval, IterLog* log, int log_cap, int jacobi,
-                      hipStream_t s);
+                      hipStream_t s, int schur_ks = 0, int* fan_word = nullptr);
+bool schur_rides_in_last_level(int n_levels, int n_last_nodes, int root);
 void launch_bcr_schur(const SolveArgs& a, const BcrArgs& b, int ks, const LmOptionsDev& o, hipStream_t s);
 void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, bool top, bool extras, bool border_rows, int q_max,
                      const double* x, double* x_cand, const BlockDev* blocks, int n_blocks, const BcrTopSeps& ts, hipStream_t s);
@@ -1387,13 +1388,19 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
   }
   const BcrArgs b = make_bcr_args(p);
   const int L = int(p->bcr_levels.size());
+  const int ks = reduced_schur_slices(sa);
+  // The Schur complement rides in the last level's launch (its tiles over the rows eliminated below that level run beside
+  // the level's chains; the level's own rows and the root's rows follow an in-launch fan-in): one launch less.
+  bool schur_rides = schur_rides_in_last_level(L, p->bcr_levels[size_t(L - 1)].n_nodes, p->bcr_root);
+  for (int i = 0; schur_rides && i < p->bcr_levels[size_t(L - 1)].n_nodes; ++i)
+    schur_rides = p->h_bcr_nodes[size_t(p->bcr_levels[size_t(L - 1)].node0 + i)].q == 1;
+  int* const fan_word = p->d_handoff.p + 4;
   for (int l = 0; l < L; ++l) {
     const BcrLevel& lv = p->bcr_levels[size_t(l)];
     launch_bcr_level(sa, b, lv.node0, lv.n_nodes, l, lv.keep0, lv.n_keep, o, p->d_x.p, p->d_blocks.p, n_blocks, l == 0 && with_post_eval,
-                     p->d_log.p, kLogCap, jacobi, s);
+                     p->d_log.p, kLogCap, jacobi, s, schur_rides && l == L - 1 ? ks : 0, schur_rides ? fan_word : nullptr);
   }
-  const int ks = reduced_schur_slices(sa);
-  launch_bcr_schur(sa, b, ks, o, s);
+  if (!schur_rides) launch_bcr_schur(sa, b, ks, o, s);
   // The top level of the tree is one or two single superblocks next to the root: their back-substitution rides in the
   // launch of the level below (every node there solves the top separators beside it itself -- a few more loads next to
   // the ones it waits for anyway) instead of costing a launch of its own.
