@@ -1070,10 +1070,229 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
 #undef BTICK
 }
 
+// ---------------------------------------------------------------------------
+// A node riding in the dense solve's launch, with its work moved IN FRONT of the hand-off. Everything a node computes is
+// affine in what the reduced solve hands over, u = [y_c | y_root | 1]:
+//     top separator s beside the chain:  y_s = M_s (z_s - Y_s y_c - Z^A_s y_root - Z^B_s y_root)
+//     chain block i (last first):        y_i = M_i (z_i - Y_i y_c - Z^A_i y_a - Z^B_i y_next)
+// so while the solve is running the node forms X with y = X u block by block -- X_i = M_i ([-Y_i | 0 | z_i] - Z^A_i X_a -
+// Z^B_i X_next), products of 32x32 blocks with 32 x 128 tiles on the matrix cores -- and behind the hand-off all that is
+// left is one product with u: the t-phase, the top separators' solves and the chain of dependent 32x32 matrix-vector
+// products (~14k clocks behind the hand-off in back_node) become ~4k.
+// Wave w owns columns [16w, 16w + 16) of every X through the whole recursion: the MFMA result layout (row = lk + 4r,
+// column = l16) of one step IS the B-operand layout (k = lk + 4u, column = l16) of the next, so the tiles never leave
+// the wave's registers and the recursion needs no barrier. NCOL = mc + 33 <= 128 (the host checks).
+// ---------------------------------------------------------------------------
+DEVI void mat_times_tile(const double* Z /* LDS [32][DLD] */, const f64x4& b0, const f64x4& b1, f64x4& d0, f64x4& d1, int l16, int lk, bool neg) {
+  double a0[8], a1[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { a0[u] = Z[l16 * DLD + lk + 4 * u]; a1[u] = Z[(16 + l16) * DLD + lk + 4 * u]; }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const double bv = u < 4 ? b0[u & 3] : b1[u & 3];
+    d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(neg ? -a0[u] : a0[u], bv, d0, 0, 0, 0);
+    d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(neg ? -a1[u] : a1[u], bv, d1, 0, 0, 0);
+  }
+}
+size_t bcr_back_pre_lds_doubles(int q_max) { return size_t(3 * q_max + 2) * BP * DLD + 128 + size_t(8) * (q_max + 1) * BP + size_t(q_max + 1) * BP; }
+template <int QM, bool SIDE>
+DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __restrict__ ndp, int terminated,
+                        const double* __restrict__ x, double* __restrict__ x_cand, double* lds, double* sh,
+                        const BcrTopSeps& ts, const Handoff& ho) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lk = lane >> 4;
+  const int n_s = a.n_s(), mc = a.mc, m1p = b.m1p;
+  const size_t fblk = size_t(BP) * m1p;
+  constexpr int RB = 6 * kBcrCps;
+  UpdSums s = {0.0, 0.0, 0.0, 0};
+  const int q = ndp->q, nd_left = ndp->left, nd_right = ndp->right, nd_slot = ndp->slot, blk0 = ndp->blk0;
+  double* ZAs = lds;                                   // [QM][32][33]
+  double* ZBs = ZAs + size_t(QM) * BP * DLD;           // [QM][32][33]
+  double* Ms = ZBs + size_t(QM) * BP * DLD;            // [QM][32][33]
+  double* Msep = Ms + size_t(QM) * BP * DLD;           // [2][32][33]  L⁻ᵀ of the top separators beside the chain
+  double* uv = Msep + 2 * BP * DLD;                    // [128] u = [y_c | y_root | 1 | 0...]
+  double* part = uv + 128;                             // [8][QM + 1][32] per-wave partial products
+  double* ych = part + 8 * (QM + 1) * BP;              // [QM][32] the chain's solutions, then [32] the right top separator's
+  double* ysr = ych + QM * BP;
+  int sk[2] = {-1, -1};
+  if (SIDE) for (int k = 0; k < ts.n; ++k) { if (nd_left == ts.blk[k]) sk[0] = k; if (nd_right == ts.blk[k]) sk[1] = k; }
+  const int sep_r = sk[1] >= 0 ? nd_right : -1;
+  // update stage (as in back_node): thread e < 32q owns row e of the chain, thread e < 5q control point e; the node that has
+  // a top separator on its right files that one's solution, too (threads 480.. and 448..)
+  const bool sep_row = sep_r >= 0 && tid >= 480, sep_cp = sep_r >= 0 && tid >= 448 && tid < 448 + kBcrCps;
+  const int my_row_t = sep_row ? RB * sep_r + (tid & 31) : RB * (blk0 + (tid >> 5)) + (tid & 31);
+  const bool my_row_ok = (tid < q * BP || sep_row) && (tid & 31) < RB && my_row_t < n_s;
+  const int my_cp = sep_cp ? kBcrCps * sep_r + (tid - 448) : kBcrCps * blk0 + tid;
+  const bool my_cp_in = (tid < q * kBcrCps || sep_cp) && my_cp < a.n_cp;
+  const int my_cp_c = my_cp_in ? my_cp : 0;
+  const int my_off = b.ctrl_off[my_cp_c];
+  // ---- requests: operands for LDS (thread (r16, sub): two entries of a row) ----
+  const int r16 = tid >> 4, sub = tid & 15;
+  double2 vza[QM], vzb[QM], vm[QM], vms[2];
+#pragma unroll
+  for (int i = 0; i < QM; ++i) {
+    const size_t g2 = size_t(blk0 + min(i, q - 1)) * (BB / 2) + tid;
+    vza[i] = reinterpret_cast<const double2*>(b.ZA)[g2];
+    vzb[i] = reinterpret_cast<const double2*>(b.ZB)[g2];
+    vm[i] = reinterpret_cast<const double2*>(b.M)[g2];
+  }
+#pragma unroll
+  for (int sd = 0; sd < 2; ++sd) {
+    const int eb = SIDE && sk[sd] >= 0 ? ts.blk[sk[sd]] : blk0;
+    vms[sd] = reinterpret_cast<const double2*>(b.M)[size_t(eb) * (BB / 2) + tid];
+  }
+  // ---- requests: right-hand-side tiles in the MFMA result layout: rows lk + 4r (+ 16), column 16·wave + l16 of
+  //      [-Y | 0 | z] (chain) and [-Y | -Z^A - Z^B | z] (top separators) ----
+  const int col = 16 * wave + l16;
+  const int cy = min(col, mc);                          // column of Y to read (mc: the right-hand side z = L⁻¹g)
+  const bool is_y = col < mc, is_z = col == mc + BP, is_r = col >= mc && col < mc + BP;
+  const int cr = min(max(col - mc, 0), BP - 1);
+  double rh[QM][8], ws[2][8];
+#pragma unroll
+  for (int i = 0; i < QM; ++i) {
+    const double* yb = b.Y + size_t(blk0 + min(i, q - 1)) * fblk;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rh[i][e] = yb[size_t(lk + 4 * (e & 3) + 16 * (e >> 2)) * m1p + (is_z ? mc : cy)];
+  }
+  if (SIDE) {
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd) {
+      const int k = max(sk[sd], 0);
+      const int eb = sk[sd] >= 0 ? ts.blk[k] : blk0;
+      const double* yb = b.Y + size_t(eb) * fblk;
+      const double* za = b.ZA + size_t(eb) * BB;
+      const double* zb = b.ZB + size_t(eb) * BB;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int row = lk + 4 * (e & 3) + 16 * (e >> 2);
+        const double vy = yb[size_t(row) * m1p + (is_z ? mc : cy)];
+        const double va = za[row * BP + cr], vb = zb[row * BP + cr];
+        const double vr = (ts.left[k] >= 0 ? va : 0.0) + (ts.right[k] >= 0 ? vb : 0.0);
+        ws[sd][e] = is_y ? -vy : (is_r ? -vr : (is_z ? vy : 0.0));
+      }
+    }
+  }
+  const double my_g = a.R[a.off_g() + (my_row_ok ? my_row_t : 0)], my_dadd = a.dadd[my_row_ok ? my_row_t : 0];
+  const bool my_cp_ok = my_cp_in && (b.all_active || a.cp_active[my_cp_c] != 0);
+  double px[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) px[c] = x[my_off + c];
+  if (terminated) return;
+  // ---- operands into LDS ----
+#pragma unroll
+  for (int i = 0; i < QM; ++i) {
+    if (i < q) {
+      const int o = (i * BP + r16) * DLD + 2 * sub;
+      ZAs[o] = vza[i].x; ZAs[o + 1] = vza[i].y; ZBs[o] = vzb[i].x; ZBs[o + 1] = vzb[i].y; Ms[o] = vm[i].x; Ms[o + 1] = vm[i].y;
+    }
+  }
+#pragma unroll
+  for (int sd = 0; sd < 2; ++sd) { const int o = (sd * BP + r16) * DLD + 2 * sub; Msep[o] = vms[sd].x; Msep[o + 1] = vms[sd].y; }
+  __syncthreads();
+  // ---- the recursion, per wave on its column tile ----
+  const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+  f64x4 xr0, xr1;          // y_root = u[mc .. mc + 30): rows lk + 4r (+16), column `col`
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row0 = lk + 4 * r, row1 = 16 + lk + 4 * r;
+    xr0[r] = (col == mc + row0 && row0 < RB) ? 1.0 : 0.0;
+    xr1[r] = (col == mc + row1 && row1 < RB) ? 1.0 : 0.0;
+  }
+  f64x4 xs0[2] = {zero4, zero4}, xs1[2] = {zero4, zero4};
+  if (SIDE) {
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd) {
+      if (sk[sd] >= 0) {
+        const f64x4 w0 = {ws[sd][0], ws[sd][1], ws[sd][2], ws[sd][3]}, w1 = {ws[sd][4], ws[sd][5], ws[sd][6], ws[sd][7]};
+        mat_times_tile(Msep + sd * BP * DLD, w0, w1, xs0[sd], xs1[sd], l16, lk, false);
+      }
+    }
+  }
+  const bool has_a = nd_left >= 0, has_n = nd_right >= 0;
+  const f64x4 xa0 = sk[0] >= 0 ? xs0[0] : (has_a ? xr0 : zero4), xa1 = sk[0] >= 0 ? xs1[0] : (has_a ? xr1 : zero4);
+  f64x4 xn0 = sk[1] >= 0 ? xs0[1] : (has_n ? xr0 : zero4), xn1 = sk[1] >= 0 ? xs1[1] : (has_n ? xr1 : zero4);
+  f64x4 X0[QM], X1[QM];
+#pragma unroll
+  for (int ii = 0; ii < QM; ++ii) {
+    const int i = QM - 1 - ii;
+    X0[i] = zero4; X1[i] = zero4;
+    if (i < q) {
+      f64x4 t0, t1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        t0[r] = is_y ? -rh[i][r] : (is_z ? rh[i][r] : 0.0);
+        t1[r] = is_y ? -rh[i][4 + r] : (is_z ? rh[i][4 + r] : 0.0);
+      }
+      if (has_a) mat_times_tile(ZAs + i * BP * DLD, xa0, xa1, t0, t1, l16, lk, true);
+      if (i + 1 < q || has_n) mat_times_tile(ZBs + i * BP * DLD, xn0, xn1, t0, t1, l16, lk, true);
+      mat_times_tile(Ms + i * BP * DLD, t0, t1, X0[i], X1[i], l16, lk, false);
+      xn0 = X0[i]; xn1 = X1[i];
+    }
+  }
+  // ---- hand-off: u, then one product with it ----
+  handoff_wait(ho);
+  if (tid < 128) {
+    const int j = tid;
+    const double* src = a.y + n_s + min(j, mc + RB - 1);
+    const double v = load_sc1(src);
+    uv[j] = j < mc ? v : ((j < mc + RB && b.root >= 0) ? v : (j == mc + BP ? 1.0 : 0.0));
+  }
+  __syncthreads();
+  {
+    const double uj = uv[col];
+    double pv[QM + 1][8];
+#pragma unroll
+    for (int i = 0; i < QM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pv[i][r] = X0[i][r] * uj; pv[i][4 + r] = X1[i][r] * uj; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pv[QM][r] = xs0[1][r] * uj; pv[QM][4 + r] = xs1[1][r] * uj; }
+#pragma unroll
+    for (int i = 0; i <= QM; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pv[i][e] = row16_sum(pv[i][e]);
+    if (l16 == 0) {
+#pragma unroll
+      for (int i = 0; i <= QM; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[(wave * (QM + 1) + i) * BP + lk + 4 * (e & 3) + 16 * (e >> 2)] = pv[i][e];
+    }
+  }
+  __syncthreads();
+  if (tid < (QM + 1) * BP) {
+    const int i = tid >> 5, r = tid & 31;
+    double y = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) y += part[(w * (QM + 1) + i) * BP + r];
+    ych[i * BP + r] = y;      // (block QM: the right top separator = ysr)
+  }
+  __syncthreads();
+  // ---- file the solutions, update the candidate point (as back_node) ----
+  if (tid < q * BP || sep_row) {
+    const double yj = sep_row ? ysr[tid & 31] : ych[tid];
+    b.ysol[sep_row ? size_t(sep_r) * BP + (tid & 31) : size_t(blk0) * BP + tid] = yj;
+    if (my_row_ok) {
+      if (!isfinite(yj)) s.bad = 1;
+      s.mcc += 0.5 * yj * (my_g + yj * my_dadd);
+      a.y[my_row_t] = yj;
+    }
+  }
+  if (my_cp_ok) {
+    const double* yb = sep_cp ? ysr + 6 * (tid - 448) : ych + (tid / kBcrCps) * BP + 6 * (tid % kBcrCps);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double v = px[c] - yb[c];
+      x_cand[my_off + c] = v;
+      const double e = px[c] - v;
+      s.sn += e * e; s.cn += v * v;
+    }
+  }
+  file_update_sums(s, sh, b.upd, nd_slot);
+}
+
 // grid = n_nodes; with `extras` (the first launch after the reduced solve when that kernel does not take the top
 // level along) + 1 workgroup for back_calib + N·32/8 workgroups that form L⁻¹g - Z^F y_c for the rows of every
 // superblock (b.zb), which nodes launched with top = 0 read instead of sweeping the border rows again.
-template <int QM, int MODE, bool HO>     // longest chain of the level; MODE: see back_node; HO: rides in the dense solve's launch
+template <int QM, int MODE, bool HO, bool PRE = false>     // longest chain of the level; MODE: see back_node; HO: rides in the dense solve's launch; PRE: back_node_pre
 DEVI void bcr_back_body(SolveArgs a, const BcrArgs& b, int wg, int node0, int n_nodes, int top, int q_max,
                         const double* __restrict__ x, double* __restrict__ x_cand,
                         const BlockDev* __restrict__ blocks, int n_blocks, const BcrTopSeps& ts, double* lds, double* sh, const Handoff& ho) {
@@ -1097,7 +1316,8 @@ DEVI void bcr_back_body(SolveArgs a, const BcrArgs& b, int wg, int node0, int n_
     return;
   }
   if (wg == n_nodes) { back_calib<HO>(a, b, x, x_cand, blocks, n_blocks, sh, lds, ho); return; }
-  back_node<QM, MODE, HO>(a, b, b.nodes + node0 + wg, top, q_max, terminated, wg == 0, x, x_cand, lds, sh, ts, ho);
+  if (PRE) back_node_pre<QM, MODE == 2>(a, b, b.nodes + node0 + wg, terminated, x, x_cand, lds, sh, ts, ho);
+  else back_node<QM, MODE, HO>(a, b, b.nodes + node0 + wg, top, q_max, terminated, wg == 0, x, x_cand, lds, sh, ts, ho);
 }
 template <int QM, int MODE>
 __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, BcrArgs b, int node0, int n_nodes, int top, int extras, int q_max,
@@ -1366,7 +1586,7 @@ __global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveA
 // gradient, damping, current values: a few hundred loads per workgroup, ~3 us behind a kernel boundary -- while the solve
 // is still running, wait for its hand-off, and go on with the solution. Saves a kernel boundary and the load phase.
 static_assert(kDenseThreads == kBackThreads, "one launch, one workgroup size");
-template <int QM, int MODE>
+template <int QM, int MODE, bool PRE>
 __global__ __launch_bounds__(kDenseThreads) void dense_back_kernel(SolveArgs a, BcrArgs b, int nsl, int node0, int n_nodes, int q_max,
                                                                    const double* __restrict__ x, double* __restrict__ x_cand,
                                                                    const BlockDev* __restrict__ blocks, int n_blocks, BcrTopSeps ts,
@@ -1375,7 +1595,7 @@ __global__ __launch_bounds__(kDenseThreads) void dense_back_kernel(SolveArgs a, 
   __shared__ double sh[64];
   const Handoff ho = {word, seq};
   if (blockIdx.x == 0) { dense_block_solve_body(a, nsl, lds, ho); return; }
-  bcr_back_body<QM, MODE, true>(a, b, int(blockIdx.x) - 1, node0, n_nodes, 1, q_max, x, x_cand, blocks, n_blocks, ts, lds, sh, ho);
+  bcr_back_body<QM, MODE, true, PRE>(a, b, int(blockIdx.x) - 1, node0, n_nodes, 1, q_max, x, x_cand, blocks, n_blocks, ts, lds, sh, ho);
 }
 size_t dense_block_solve_lds_bytes() { return size_t(128 * DNL + 128 + 64 * DLD + 128 * 3 + 32 + 128 + kDenseThreads) * sizeof(double); }
 hipError_t configure_dense_block_solve() {
@@ -1400,11 +1620,24 @@ bool dense_back_fusable(const SolveArgs& a, int ks, int q_max, bool border_rows)
   static const bool use_block = [] { const char* e = std::getenv("CALICO_DENSE"); return !(e && std::string(e) == "panel"); }();
   return on && use_block && a.m + 1 <= 128 && a.m >= 1 && ks <= 2 && q_max <= 4 && !border_rows;
 }
+// PRE: the nodes form their solution as an affine map of the reduced solve's output while they wait (back_node_pre);
+// needs mc + 33 <= 128 columns (one 16-column tile per wave). CALICO_BACK_PRE=0: the plain nodes (A/B switch).
+static bool dense_back_pre(const SolveArgs& a) {
+  const char* e = std::getenv("CALICO_BACK_PRE");
+  return (!e || std::atoi(e) != 0) && a.mc + BP + 1 <= 128;
+}
+static size_t dense_back_lds(int q_max, int m1p) {
+  const int qm = q_max <= 1 ? 1 : (q_max <= 2 ? 2 : 4);
+  return std::max(std::max(dense_block_solve_lds_bytes(), bcr_back_lds_bytes(q_max, m1p)), bcr_back_pre_lds_doubles(qm) * sizeof(double));
+}
 hipError_t configure_dense_back(int q_max, int m1p) {
-  const size_t lds = std::max(dense_block_solve_lds_bytes(), bcr_back_lds_bytes(q_max, m1p));
-  for (const void* f : {reinterpret_cast<const void*>(&dense_back_kernel<1, 1>), reinterpret_cast<const void*>(&dense_back_kernel<2, 1>),
-                        reinterpret_cast<const void*>(&dense_back_kernel<4, 1>), reinterpret_cast<const void*>(&dense_back_kernel<1, 2>),
-                        reinterpret_cast<const void*>(&dense_back_kernel<2, 2>), reinterpret_cast<const void*>(&dense_back_kernel<4, 2>)}) {
+  const size_t lds = dense_back_lds(q_max, m1p);
+  for (const void* f : {reinterpret_cast<const void*>(&dense_back_kernel<1, 1, false>), reinterpret_cast<const void*>(&dense_back_kernel<2, 1, false>),
+                        reinterpret_cast<const void*>(&dense_back_kernel<4, 1, false>), reinterpret_cast<const void*>(&dense_back_kernel<1, 2, false>),
+                        reinterpret_cast<const void*>(&dense_back_kernel<2, 2, false>), reinterpret_cast<const void*>(&dense_back_kernel<4, 2, false>),
+                        reinterpret_cast<const void*>(&dense_back_kernel<1, 1, true>), reinterpret_cast<const void*>(&dense_back_kernel<2, 1, true>),
+                        reinterpret_cast<const void*>(&dense_back_kernel<4, 1, true>), reinterpret_cast<const void*>(&dense_back_kernel<1, 2, true>),
+                        reinterpret_cast<const void*>(&dense_back_kernel<2, 2, true>), reinterpret_cast<const void*>(&dense_back_kernel<4, 2, true>)}) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return e;
   }
@@ -1412,11 +1645,16 @@ hipError_t configure_dense_back(int q_max, int m1p) {
 }
 void launch_dense_back(const SolveArgs& a, const BcrArgs& b, int ks, int node0, int n_nodes, int q_max, const double* x, double* x_cand,
                        const BlockDev* blocks, int n_blocks, const BcrTopSeps& ts, int* word, int seq, hipStream_t s) {
-  const size_t lds = std::max(dense_block_solve_lds_bytes(), bcr_back_lds_bytes(q_max, b.m1p));
+  const size_t lds = dense_back_lds(q_max, b.m1p);
   const dim3 grid(1 + n_nodes + 1), block(kDenseThreads);       // dense solve, the nodes, the calibration / root update
-#define LAUNCH_DB(QM, SD) hipLaunchKernelGGL(HIP_KERNEL_NAME(dense_back_kernel<QM, SD>), grid, block, lds, s, a, b, ks, node0, n_nodes, q_max, x, x_cand, blocks, n_blocks, ts, word, seq)
-  if (ts.n > 0) { if (q_max <= 1) LAUNCH_DB(1, 2); else if (q_max <= 2) LAUNCH_DB(2, 2); else LAUNCH_DB(4, 2); }
-  else { if (q_max <= 1) LAUNCH_DB(1, 1); else if (q_max <= 2) LAUNCH_DB(2, 1); else LAUNCH_DB(4, 1); }
+#define LAUNCH_DB(QM, SD, PR) hipLaunchKernelGGL(HIP_KERNEL_NAME(dense_back_kernel<QM, SD, PR>), grid, block, lds, s, a, b, ks, node0, n_nodes, q_max, x, x_cand, blocks, n_blocks, ts, word, seq)
+  if (dense_back_pre(a)) {
+    if (ts.n > 0) { if (q_max <= 1) LAUNCH_DB(1, 2, true); else if (q_max <= 2) LAUNCH_DB(2, 2, true); else LAUNCH_DB(4, 2, true); }
+    else { if (q_max <= 1) LAUNCH_DB(1, 1, true); else if (q_max <= 2) LAUNCH_DB(2, 1, true); else LAUNCH_DB(4, 1, true); }
+  } else {
+    if (ts.n > 0) { if (q_max <= 1) LAUNCH_DB(1, 2, false); else if (q_max <= 2) LAUNCH_DB(2, 2, false); else LAUNCH_DB(4, 2, false); }
+    else { if (q_max <= 1) LAUNCH_DB(1, 1, false); else if (q_max <= 2) LAUNCH_DB(2, 1, false); else LAUNCH_DB(4, 1, false); }
+  }
 #undef LAUNCH_DB
 }
 

@@ -94,8 +94,8 @@ def test_fused_dense_solve_and_back_substitution_launch_agrees(monkeypatch):
     """Round 3: on trees of up to two levels the first back-substitution launch rides in the launch of the dense reduced
     solve and takes its solution over an in-launch hand-off (sc1 stores + flag; dense_back_kernel). Same arithmetic in
     the same order: with the fusion switched off (two launches, CALICO_FUSE_BACK=0) the solve must walk the same
-    iterations BIT FOR BIT -- a stale read behind the hand-off would show here. Chains of 4 (two levels, top merged),
-    2 and 1 superblocks that still end at level 0 behind the reduced solve are covered through CALICO_BCR_LEAF."""
+    iterations BIT FOR BIT -- a stale read behind the hand-off would show here (CALICO_BACK_PRE=0: the nodes as in the
+    separate launch). Several chain lengths through CALICO_BCR_LEAF."""
     api = helpers.hip_api()
     # 4 cameras + IMU, robust kernels, ~90 control points like configs[3] (19 superblocks: two tree levels)
     scene = syn.make_scene(4, 1, True, 3, cam_rate=10.0, imu_rate=100.0, duration=8.7, chart="april", seed=21,
@@ -107,17 +107,27 @@ def test_fused_dense_solve_and_back_substitution_launch_agrees(monkeypatch):
         else:
             monkeypatch.delenv("CALICO_BCR_LEAF", raising=False)
         runs = {}
-        for fuse in ("1", "0"):
+        for fuse, pre in (("1", "0"), ("0", "0"), ("1", "1")):
             monkeypatch.setenv("CALICO_FUSE_BACK", fuse)
-            runs[fuse] = _solve_repeatedly(api, scene, repeats=3, max_iter=30)
+            monkeypatch.setenv("CALICO_BACK_PRE", pre)
+            runs[(fuse, pre)] = _solve_repeatedly(api, scene, repeats=3, max_iter=30)
         monkeypatch.delenv("CALICO_FUSE_BACK")
-        ref = runs["0"][0]
+        monkeypatch.delenv("CALICO_BACK_PRE")
+        ref = runs[("0", "0")][0]
         assert ref[0] > 3
-        for fuse in ("1", "0"):
-            for r in runs[fuse]:
-                assert r[0] == ref[0] and r[1] == ref[1], (leaf, fuse)
-                assert r[2] == ref[2], (leaf, fuse)
-                assert np.array_equal(r[3], ref[3]), (leaf, fuse)
+        for key in (("1", "0"), ("0", "0")):
+            for r in runs[key]:
+                assert r[0] == ref[0] and r[1] == ref[1], (leaf, key)
+                assert r[2] == ref[2], (leaf, key)
+                assert np.array_equal(r[3], ref[3]), (leaf, key)
+        # the nodes that form their solution as an affine map of the reduced solve's output BEFORE the hand-off
+        # (back_node_pre, the default) associate the same products differently: equal to rounding, and reproducible
+        pre = runs[("1", "1")]
+        for r in pre:
+            assert r[0] == ref[0] and r[1] == ref[1], leaf
+            np.testing.assert_allclose(r[2], ref[2], rtol=1e-9)
+            np.testing.assert_allclose(r[3], ref[3], rtol=1e-7, atol=1e-10)
+            assert r[2] == pre[0][2] and np.array_equal(r[3], pre[0][3]), leaf
 
 
 @pytest.mark.gpu
