@@ -1125,6 +1125,9 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* 
   const bool my_cp_in = (tid < q * kBcrCps || sep_cp) && my_cp < a.n_cp;
   const int my_cp_c = my_cp_in ? my_cp : 0;
   const int my_off = b.ctrl_off[my_cp_c];
+  const bool pdbg = CAL_DEV_TIMING(a.debug && nd_slot == ndp->slot && blk0 == 0 && tid == 0);
+  long long pt[6] = {0, 0, 0, 0, 0, 0}, ptk = pdbg ? __builtin_readcyclecounter() : 0;
+#define PTICK(i) if (pdbg) { const long long t_ = __builtin_readcyclecounter(); pt[i] += t_ - ptk; ptk = t_; }
   // ---- requests: operands for LDS (thread (r16, sub): two entries of a row) ----
   const int r16 = tid >> 4, sub = tid & 15;
   double2 vza[QM], vzb[QM], vm[QM], vms[2];
@@ -1177,6 +1180,7 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* 
 #pragma unroll
   for (int c = 0; c < 6; ++c) px[c] = x[my_off + c];
   if (terminated) return;
+  PTICK(0)
   // ---- operands into LDS ----
 #pragma unroll
   for (int i = 0; i < QM; ++i) {
@@ -1188,6 +1192,7 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* 
 #pragma unroll
   for (int sd = 0; sd < 2; ++sd) { const int o = (sd * BP + r16) * DLD + 2 * sub; Msep[o] = vms[sd].x; Msep[o + 1] = vms[sd].y; }
   __syncthreads();
+  PTICK(1)
   // ---- the recursion, per wave on its column tile ----
   const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
   f64x4 xr0, xr1;          // y_root = u[mc .. mc + 30): rows lk + 4r (+16), column `col`
@@ -1228,8 +1233,10 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* 
       xn0 = X0[i]; xn1 = X1[i];
     }
   }
+  PTICK(2)
   // ---- hand-off: u, then one product with it ----
   handoff_wait(ho);
+  PTICK(3)
   if (tid < 128) {
     const int j = tid;
     const double* src = a.y + n_s + min(j, mc + RB - 1);
@@ -1287,6 +1294,10 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* 
     }
   }
   file_update_sums(s, sh, b.upd, nd_slot);
+  PTICK(4)
+  if (pdbg) printf("back_node_pre (q %d) cycles: requests issued + arrived %lld  to LDS %lld  recursion %lld  wait for the solve %lld  product + outputs %lld\n",
+                   q, pt[0], pt[1], pt[2], pt[3], pt[4]);
+#undef PTICK
 }
 
 // grid = n_nodes; with `extras` (the first launch after the reduced solve when that kernel does not take the top
@@ -1621,10 +1632,15 @@ bool dense_back_fusable(const SolveArgs& a, int ks, int q_max, bool border_rows)
   return on && use_block && a.m + 1 <= 128 && a.m >= 1 && ks <= 2 && q_max <= 4 && !border_rows;
 }
 // PRE: the nodes form their solution as an affine map of the reduced solve's output while they wait (back_node_pre);
-// needs mc + 33 <= 128 columns (one 16-column tile per wave). CALICO_BACK_PRE=0: the plain nodes (A/B switch).
+// needs mc + 33 <= 128 columns (one 16-column tile per wave) and a reduced solve long enough to hide the recursion behind:
+// it takes ~50k clocks (requests 15k, staging 15k, recursion 20k; dev-timing dump), a reduced solve 11k + 16k per
+// 32-column block -- four blocks (m + 1 > 96: configs[3]) cover it, two (configs[1]: 9450 with, 10200 it/s without) do
+// not. CALICO_BACK_PRE=0 / 1: never / whenever the columns fit (A/B switch).
 static bool dense_back_pre(const SolveArgs& a) {
   const char* e = std::getenv("CALICO_BACK_PRE");
-  return (!e || std::atoi(e) != 0) && a.mc + BP + 1 <= 128;
+  if (a.mc + BP + 1 > 128) return false;
+  if (e) return std::atoi(e) != 0;
+  return a.m + 1 > 96;
 }
 static size_t dense_back_lds(int q_max, int m1p) {
   const int qm = q_max <= 1 ? 1 : (q_max <= 2 ? 2 : 4);
