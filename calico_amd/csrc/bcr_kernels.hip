@@ -1094,6 +1094,22 @@ DEVI void mat_times_tile(const double* Z /* LDS [32][DLD] */, const f64x4& b0, c
     d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(neg ? -a1[u] : a1[u], bv, d1, 0, 0, 0);
   }
 }
+// D = Z·B as above AND Dᵗ-tiles of the same product for the final product with u: (Z B)ᵀ = Bᵀ Zᵀ, whose A operand is B in
+// the MFMA RESULT layout (in-lane again) and whose B operand is the very values read for Z above. dt0 / dt1: rows 0..15 /
+// 16..31 of D along the lanes (l16), this wave's columns lk + 4r along the registers.
+DEVI void mat_times_tile_both(const double* Z, const f64x4& b0, const f64x4& b1, f64x4& d0, f64x4& d1, f64x4& dt0, f64x4& dt1, int l16, int lk) {
+  double a0[8], a1[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { a0[u] = Z[l16 * DLD + lk + 4 * u]; a1[u] = Z[(16 + l16) * DLD + lk + 4 * u]; }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const double bv = u < 4 ? b0[u & 3] : b1[u & 3];
+    d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], bv, d0, 0, 0, 0);
+    d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], bv, d1, 0, 0, 0);
+    dt0 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, a0[u], dt0, 0, 0, 0);
+    dt1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, a1[u], dt1, 0, 0, 0);
+  }
+}
 size_t bcr_back_pre_lds_doubles(int q_max) { return size_t(3 * q_max + 2) * BP * DLD + 128 + size_t(8) * (q_max + 1) * BP + size_t(q_max + 1) * BP; }
 template <int QM, bool SIDE>
 DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __restrict__ ndp, int terminated,
@@ -1202,25 +1218,29 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* 
     xr0[r] = (col == mc + row0 && row0 < RB) ? 1.0 : 0.0;
     xr1[r] = (col == mc + row1 && row1 < RB) ? 1.0 : 0.0;
   }
+  // (a wave whose 16 columns lie beyond u -- a small calibration part -- has nothing to do: all of its tiles are zero)
+  const bool act = 16 * wave < mc + BP + 1;
   f64x4 xs0[2] = {zero4, zero4}, xs1[2] = {zero4, zero4};
-  if (SIDE) {
+  f64x4 XT0[QM + 1], XT1[QM + 1];          // transposed tiles of every block's map (QM: the right top separator's)
+#pragma unroll
+  for (int i = 0; i <= QM; ++i) { XT0[i] = zero4; XT1[i] = zero4; }
+  if (SIDE && act) {
 #pragma unroll
     for (int sd = 0; sd < 2; ++sd) {
       if (sk[sd] >= 0) {
         const f64x4 w0 = {ws[sd][0], ws[sd][1], ws[sd][2], ws[sd][3]}, w1 = {ws[sd][4], ws[sd][5], ws[sd][6], ws[sd][7]};
-        mat_times_tile(Msep + sd * BP * DLD, w0, w1, xs0[sd], xs1[sd], l16, lk, false);
+        if (sd == 1) mat_times_tile_both(Msep + sd * BP * DLD, w0, w1, xs0[sd], xs1[sd], XT0[QM], XT1[QM], l16, lk);
+        else mat_times_tile(Msep + sd * BP * DLD, w0, w1, xs0[sd], xs1[sd], l16, lk, false);
       }
     }
   }
   const bool has_a = nd_left >= 0, has_n = nd_right >= 0;
   const f64x4 xa0 = sk[0] >= 0 ? xs0[0] : (has_a ? xr0 : zero4), xa1 = sk[0] >= 0 ? xs1[0] : (has_a ? xr1 : zero4);
   f64x4 xn0 = sk[1] >= 0 ? xs0[1] : (has_n ? xr0 : zero4), xn1 = sk[1] >= 0 ? xs1[1] : (has_n ? xr1 : zero4);
-  f64x4 X0[QM], X1[QM];
 #pragma unroll
   for (int ii = 0; ii < QM; ++ii) {
     const int i = QM - 1 - ii;
-    X0[i] = zero4; X1[i] = zero4;
-    if (i < q) {
+    if (i < q && act) {
       f64x4 t0, t1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -1229,39 +1249,38 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* 
       }
       if (has_a) mat_times_tile(ZAs + i * BP * DLD, xa0, xa1, t0, t1, l16, lk, true);
       if (i + 1 < q || has_n) mat_times_tile(ZBs + i * BP * DLD, xn0, xn1, t0, t1, l16, lk, true);
-      mat_times_tile(Ms + i * BP * DLD, t0, t1, X0[i], X1[i], l16, lk, false);
-      xn0 = X0[i]; xn1 = X1[i];
+      f64x4 x0 = zero4, x1 = zero4;
+      mat_times_tile_both(Ms + i * BP * DLD, t0, t1, x0, x1, XT0[i], XT1[i], l16, lk);
+      xn0 = x0; xn1 = x1;
     }
   }
   PTICK(2)
   // ---- hand-off: u, then one product with it ----
   handoff_wait(ho);
   PTICK(3)
-  if (tid < 128) {
-    const int j = tid;
-    const double* src = a.y + n_s + min(j, mc + RB - 1);
-    const double v = load_sc1(src);
-    uv[j] = j < mc ? v : ((j < mc + RB && b.root >= 0) ? v : (j == mc + BP ? 1.0 : 0.0));
-  }
-  __syncthreads();
   {
-    const double uj = uv[col];
-    double pv[QM + 1][8];
+    // this lane's four entries of u: columns 16·wave + lk + 4r (y_c and the root's 30 real rows sit back to back in y)
+    double uj[4];
 #pragma unroll
-    for (int i = 0; i < QM; ++i)
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * wave + lk + 4 * r;
+      const double v = load_sc1(a.y + n_s + min(j, mc + RB - 1));
+      uj[r] = j < mc ? v : ((j < mc + RB && b.root >= 0) ? v : (j == mc + BP ? 1.0 : 0.0));
+    }
+    // rows 16·ct + l16 of every block: four products in the lane, then the four lane groups (lk) added up
+    double pv[QM + 1][2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { pv[i][r] = X0[i][r] * uj; pv[i][4 + r] = X1[i][r] * uj; }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { pv[QM][r] = xs0[1][r] * uj; pv[QM][4 + r] = xs1[1][r] * uj; }
+    for (int i = 0; i <= QM; ++i) {
+      pv[i][0] = (XT0[i][0] * uj[0] + XT0[i][1] * uj[1]) + (XT0[i][2] * uj[2] + XT0[i][3] * uj[3]);
+      pv[i][1] = (XT1[i][0] * uj[0] + XT1[i][1] * uj[1]) + (XT1[i][2] * uj[2] + XT1[i][3] * uj[3]);
+    }
 #pragma unroll
     for (int i = 0; i <= QM; ++i)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) pv[i][e] = row16_sum(pv[i][e]);
-    if (l16 == 0) {
+      for (int c = 0; c < 2; ++c) { pv[i][c] += other_half(pv[i][c]); pv[i][c] += other_row(pv[i][c]); }
+    if (lk == 0) {
 #pragma unroll
-      for (int i = 0; i <= QM; ++i)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) part[(wave * (QM + 1) + i) * BP + lk + 4 * (e & 3) + 16 * (e >> 2)] = pv[i][e];
+      for (int i = 0; i <= QM; ++i) { part[(wave * (QM + 1) + i) * BP + l16] = pv[i][0]; part[(wave * (QM + 1) + i) * BP + 16 + l16] = pv[i][1]; }
     }
   }
   __syncthreads();
