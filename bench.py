@@ -325,9 +325,11 @@ def main():
             fresh.problem.finalize()                                      # plan (built or from the cache), workspace, value uploads
             torch.cuda.synchronize()
             return fresh, 1e3 * (time.perf_counter() - t), 1e3 * (t_add - t)
-        # (a) a structure the library has not seen (plan cache emptied): cells, work items, gather lists, elimination plan, H2D
+        # (a) a structure the library has not seen (plan cache emptied): cells, work items, gather lists, elimination plan, H2D.
+        # First in a cold process (first allocations of the host tables, first hipMalloc of the sizes), then, after (b), on a
+        # structural variant in the warm process.
         api.plan_cache_clear()
-        fresh, setup_ms, setup_add_ms = one_setup()
+        fresh, setup_cold_ms, setup_cold_add_ms = one_setup()
         o1 = api.default_options()
         o1.minimizer_progress_to_stdout = 0
         o1.max_num_iterations = 3
@@ -346,6 +348,29 @@ def main():
             fresh.problem.close()
         known.sort()
         setup_known = known[len(known) // 2]
+        # (a') unseen structures in the warm process: the same scene with one camera observation left out (another one
+        # each time: every variant is planned afresh), median of 5
+        import copy
+        unseen = []
+        for drop in range(5):
+            var = copy.copy(scene)
+            var.sensors = list(scene.sensors)
+            cam = copy.copy(scene.sensors[0])
+            keep = np.ones(cam.n, bool)
+            keep[17 + drop] = False
+            cam.meas, cam.stamps, cam.point_idx = cam.meas[keep], cam.stamps[keep], cam.point_idx[keep]
+            var.sensors[0] = cam
+            h0, m0, _ = _capi.plan_cache_stats(api)
+            t = time.perf_counter()
+            fresh = syn.build_problem(api, var, device=local_rank)
+            t_add = time.perf_counter()
+            fresh.problem.finalize()
+            torch.cuda.synchronize()
+            unseen.append((1e3 * (time.perf_counter() - t), 1e3 * (t_add - t)))
+            assert _capi.plan_cache_stats(api)[1] == m0 + 1          # really planned afresh
+            fresh.problem.close()
+        unseen.sort()
+        setup_ms, setup_add_ms = unseen[len(unseen) // 2]
 
     # warmup: all phases bracketed by HIP events -> per-phase breakdown (reported, untimed)
     P.set_phase_timing(0x3f)   # all phases + the bracket calibration (phase 5)
@@ -462,8 +487,9 @@ def main():
                 "poor_start": args.poor_start,
                 "successful_steps_last_solve": last.num_successful_steps, "unsuccessful_steps_last_solve": last.num_unsuccessful_steps,
                 "linear_solver": os.environ.get("CALICO_SOLVER", "tree (block cyclic reduction over 5-control-point superblocks)"),
-                # fresh handle, structure not seen before (plan cache emptied first): add_* calls + plan + workspace + uploads
+                # fresh handle, structure not seen before (planned afresh), warm process: add_* calls + plan + workspace + uploads
                 "setup_ms": setup_ms,
+                "setup_ms_cold_process": setup_cold_ms, "setup_ms_cold_process_add_calls": setup_cold_add_ms,
                 "setup_ms_add_calls": setup_add_ms,        # of which: the add_* calls through the C ABI (python + ctypes here)
                 "setup_ms_finalize": (setup_ms - setup_add_ms) if setup_ms else None,
                 # fresh handle, structure seen before (the reference rebuilds the same problem per Optimize()): median of 5
