@@ -5,6 +5,6 @@ cd /root/repo
 for i in $(seq $R); do
   for lib in base $V; do
     if [ "$lib" = base ]; then unset CALICO_HIP_LIB; else export CALICO_HIP_LIB=/root/repo/gpurun_ab/$lib; fi
-    python bench.py --no-cpu-baseline --repeats 60 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$lib', round(d['value'],1), d['ms_per_step'])"
+    timeout 120 python bench.py --no-cpu-baseline --repeats 60 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$lib', round(d['value'],1), d['ms_per_step'])"
   done
 done
