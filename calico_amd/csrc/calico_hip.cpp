@@ -656,10 +656,30 @@ int build_plan(calico_problem* p) {
       keys.push_back({layout_of[layout_key(si, s, i)], s.seg[i], int(si), i, s.stamps[size_t(i)]});
     }
   }
-  std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
-    if (a.layout != b.layout) return a.layout < b.layout;
-    if (a.seg != b.seg) return a.seg < b.seg;
-    return a.stamp < b.stamp; });
+  {
+    // order: (layout, segment, stamp), ties in insertion order. A stable counting sort over the cells (layout, segment)
+    // does almost all of it -- measurements arrive in time order, sensor by sensor --; a cell whose stamps are not in
+    // order gets a stable comparison sort of its own. (One comparison sort over all keys was 1.5 ms of the set-up.)
+    const int nseg_all = std::max(1, int(p->valid_knots.size()) - 1);
+    const size_t n_cell_ids = layouts.size() * size_t(nseg_all);
+    std::vector<int64_t> cstart(n_cell_ids + 1, 0);
+    auto cell_of = [&](const Key& kq) { return size_t(kq.layout) * size_t(nseg_all) + size_t(std::max(0, std::min(nseg_all - 1, kq.seg))); };
+    for (const Key& kq : keys) ++cstart[cell_of(kq) + 1];
+    for (size_t c = 0; c < n_cell_ids; ++c) cstart[c + 1] += cstart[c];
+    std::vector<Key> sorted(keys.size());
+    {
+      std::vector<int64_t> fill(cstart.begin(), cstart.end() - 1);
+      for (const Key& kq : keys) sorted[size_t(fill[cell_of(kq)]++)] = kq;
+    }
+    for (size_t c = 0; c < n_cell_ids; ++c) {
+      const int64_t q0 = cstart[c], q1 = cstart[c + 1];
+      bool ordered = true;
+      for (int64_t q = q0 + 1; q < q1 && ordered; ++q) ordered = !(sorted[size_t(q)].stamp < sorted[size_t(q - 1)].stamp);
+      if (!ordered)
+        std::stable_sort(sorted.begin() + q0, sorted.begin() + q1, [](const Key& a, const Key& b) { return a.stamp < b.stamp; });
+    }
+    keys.swap(sorted);
+  }
   p->n_obs = n_obs;
   std::vector<double> st(n_obs);
   std::vector<int> point_off(n_obs, 0);
