@@ -52,6 +52,7 @@ hipError_t configure_eval_kernels(size_t max_lds_bytes);
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
                    int n_thin, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
                    const double* cost_src, int n_cost, const LmState* st, int need_flag, size_t other_stride, hipStream_t s, const ControlTail* tail = nullptr);
+void launch_gather_lists(const GatherStruct& gs, int n_out, int* cnt, int* out_idx, int64_t* ptr, int* idx, int zero_slot, hipStream_t s);
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s);
 size_t band_cholesky_lds_bytes(const SolveArgs& a);
@@ -264,10 +265,11 @@ struct PlanHost {
   int n_thin = 0, n_fat = 0;
   bool dense_in_lds = true;
   int gather_owner_block = 0;
+  bool gs_lists_on_device = false;   // the band / border / spline right-hand side lists were built by the device (launch_gather_lists)
 };
 struct PlanDev {      // structure on the device: immutable once uploaded
   DevBuf<double> d_knots, d_basis, d_stamp;
-  DevBuf<int> d_ctrl_off, d_point_off, d_out_thin, d_idx_thin, d_out_fat, d_idx_fat, d_prim_tab, d_bkeep, d_cp_block;
+  DevBuf<int> d_ctrl_off, d_point_off, d_out_thin, d_idx_thin, d_out_fat, d_idx_fat, d_prim_tab, d_bkeep, d_cp_block, d_gs_tab;
   DevBuf<int64_t> d_ptr_thin, d_ptr_fat;
   DevBuf<uint8_t> d_cp_active;
   DevBuf<SensorDev> d_sensors;
@@ -278,7 +280,7 @@ struct PlanDev {      // structure on the device: immutable once uploaded
   DevBuf<BlockDev> d_blocks;
   DevBuf<BcrNodeDev> d_bnodes;
 #define PLAN_DEV_BUFS(X) X(d_knots) X(d_basis) X(d_stamp) X(d_ctrl_off) X(d_point_off) X(d_out_thin) X(d_idx_thin) X(d_out_fat) X(d_idx_fat) \
-  X(d_prim_tab) X(d_bkeep) X(d_cp_block) X(d_ptr_thin) X(d_ptr_fat) X(d_cp_active) X(d_sensors) X(d_layouts) X(d_items) X(d_items_all)     \
+  X(d_prim_tab) X(d_bkeep) X(d_cp_block) X(d_gs_tab) X(d_ptr_thin) X(d_ptr_fat) X(d_cp_active) X(d_sensors) X(d_layouts) X(d_items) X(d_items_all)     \
   X(d_jac_items) X(d_fitems) X(d_cells) X(d_blocks) X(d_bnodes)
   void take_from(PlanDev& o) {
 #define X(n) n.take(o.n);
@@ -908,9 +910,36 @@ int build_plan(calico_problem* p) {
   if (r_size >= size_t(0x7fffffff)) return p->set_error(CALICO_UNIMPLEMENTED, "normal-equation buffer too large");
   struct Pair { int dst, src; };
   std::vector<Pair> pairs;
-  pairs.reserve(poff / 2 + 4 * size_t(p->n_items));
   const int n_cells = int(p->h_cells.size());
   const int n_part = n_cells + p->n_jac_items;     // producers of expanded partial blocks
+  // Lists built on the device: when every producer is a cell (camera frames' cells, IMU row cells) and the layouts are
+  // few, the sources of the band, the border and the spline part of the right-hand side follow from the outputs' indices
+  // (the band is uniform in time): the host uploads three small tables and the device builds those lists itself
+  // (launch_gather_lists: count, scan, fill -- the same CSR form the per-iteration gather reads). Only the corner and the
+  // calibration part of the right-hand side (2 % of the outputs, sources in every segment) are listed here.
+  // CALICO_GATHER_STRUCT=0: everything listed by the host (A/B switch, and the path of problems with free model points or
+  // other spline orders' generic items).
+  bool gs_ok = [] { const char* e = std::getenv("CALICO_GATHER_STRUCT"); return !e || std::atoi(e) != 0; }();
+  gs_ok = gs_ok && int(layouts.size()) * k <= 48 && int(layouts.size()) >= 1 && m >= 1 && n_cells > 0;
+  for (int itn = n_cells; gs_ok && itn < n_part; ++itn) gs_ok = p->h_jac_items[size_t(itn - n_cells)].rows_off >= 0;   // no block of its own
+  const int64_t gs_n_out = int64_t(NS) * m + int64_t(n_cp) * k * 36 + NS;
+  gs_ok = gs_ok && gs_n_out * 48 < int64_t(0x7fffffff);
+  p->gs_lists_on_device = gs_ok;
+  std::vector<int> gs_tab;
+  GatherStruct gsd = {};
+  if (gs_ok) {
+    const int n_lay = int(layouts.size()), nsg = int(p->valid_knots.size()) - 1;
+    gs_tab.assign(size_t(n_lay) * nsg + size_t(n_lay) * m + size_t(n_lay), -1);
+    for (const CellDev& c : p->h_cells) gs_tab[size_t(c.layout) * nsg + size_t(c.seg)] = int(c.partial_off);
+    for (int l = 0; l < n_lay; ++l) {
+      const std::vector<int>& gmap = layout_gmap[size_t(l)];
+      for (size_t q = 0; q < gmap.size(); ++q) gs_tab[size_t(n_lay) * nsg + size_t(l) * m + size_t(gmap[q] - NS)] = 6 * k + int(q);
+      gs_tab[size_t(n_lay) * nsg + size_t(n_lay) * m + size_t(l)] = layouts[size_t(l)].ncols + 1;
+    }
+    gsd.n_lay = n_lay; gsd.nseg = nsg; gsd.n_cp = n_cp; gsd.k = k; gsd.m = m;
+    gsd.off_g = sa.off_g(); gsd.off_B = sa.off_B(); gsd.off_E = sa.off_E();
+  }
+  pairs.reserve(gs_ok ? size_t(n_part) * 256 : poff / 2 + 4 * size_t(p->n_items));
   for (int itn = 0; itn < n_part; ++itn) {
     const bool is_cell = itn < n_cells;
     if (!is_cell && p->h_jac_items[size_t(itn - n_cells)].rows_off >= 0) continue;   // its block is the row cell's
@@ -921,7 +950,7 @@ int build_plan(calico_problem* p) {
     const std::vector<int>& gmap = layout_gmap[size_t(it_layout)];
     const int nc = L.ncols, n1 = nc + 1;
     auto tan_of = [&](int c) { return c < 6 * k ? 6 * (it_seg + c / 6) + c % 6 : gmap[size_t(c - 6 * k)]; };
-    for (int i = 0; i < nc; ++i) {
+    for (int i = gs_ok ? 6 * k : 0; i < nc; ++i) {      // (structured gather: the spline rows have no lists)
       const int ti = tan_of(i);
       pairs.push_back({int(sa.off_g()) + ti, int(it_poff) + i * n1 + nc});
       for (int j = i; j < nc; ++j) {
@@ -960,13 +989,13 @@ int build_plan(calico_problem* p) {
     size_t n_thin_src = 0, n_fat_src = 0;
     for (size_t d = 0; d < r_size; ++d) {
       const int64_t c = start[d + 1] - start[d];
-      if (c > 48) n_fat_src += size_t(c); else n_thin_src += size_t(c);
+      if (gs_ok || c > 48) n_fat_src += size_t(c); else n_thin_src += size_t(c);
     }
     idx_thin.reserve(n_thin_src); idx_fat.reserve(n_fat_src);
     for (size_t d = 0; d < r_size; ++d) {
       const int64_t q0 = start[d], q1 = start[d + 1];
       if (q1 == q0) continue;
-      const bool fat = (q1 - q0) > 48;
+      const bool fat = gs_ok || (q1 - q0) > 48;        // (the device's lists are the thin ones: what the host lists goes to the waves)
       std::vector<int>& out = fat ? out_fat : out_thin;
       std::vector<int>& idx = fat ? idx_fat : idx_thin;
       std::vector<int64_t>& ptr = fat ? ptr_fat : ptr_thin;
@@ -1002,12 +1031,25 @@ int build_plan(calico_problem* p) {
   HIP_TRY(p, p->d_jac_items.upload(p->h_jac_items, s)); HIP_TRY(p, p->d_fitems.upload(p->h_fitems, s));
   HIP_TRY(p, p->d_blocks.upload(p->h_blocks, s));
   HIP_TRY(p, p->d_cp_active.upload(cp_active, s));
-  HIP_TRY(p, p->d_out_thin.upload(out_thin, s)); HIP_TRY(p, p->d_idx_thin.upload(idx_thin, s));
-  HIP_TRY(p, p->d_ptr_thin.upload(ptr_thin, s));
+  DevBuf<int> d_cnt;                    // (scratch of the device's list build; freed behind the synchronisation below)
+  const int zero_slot = int(comp_base + comp_off + row_store);      // a word of the partials nobody writes: allocated and cleared with them
+  if (gs_ok) {
+    if (size_t(zero_slot) + 2 >= size_t(0x7fffffff)) return p->set_error(CALICO_UNIMPLEMENTED, "problem too large for 32-bit gather indices");
+    HIP_TRY(p, p->d_gs_tab.upload(gs_tab, s));
+    gsd.tab = p->d_gs_tab.p;
+    const int per_out = std::min(48, int(layouts.size()) * k);
+    HIP_TRY(p, p->d_out_thin.alloc(size_t(gs_n_out))); HIP_TRY(p, p->d_ptr_thin.alloc(size_t(gs_n_out) + 1));
+    HIP_TRY(p, p->d_idx_thin.alloc(size_t(gs_n_out) * per_out)); HIP_TRY(p, d_cnt.alloc(size_t(gs_n_out)));
+    launch_gather_lists(gsd, int(gs_n_out), d_cnt.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, zero_slot, s);
+    p->n_thin = int(gs_n_out);
+  } else {
+    HIP_TRY(p, p->d_out_thin.upload(out_thin, s)); HIP_TRY(p, p->d_idx_thin.upload(idx_thin, s));
+    HIP_TRY(p, p->d_ptr_thin.upload(ptr_thin, s));
+  }
   HIP_TRY(p, p->d_out_fat.upload(out_fat, s)); HIP_TRY(p, p->d_idx_fat.upload(idx_fat, s));
   HIP_TRY(p, p->d_ptr_fat.upload(ptr_fat, s));
   HIP_TRY(p, p->d_cells.upload(p->h_cells, s)); HIP_TRY(p, p->d_prim_tab.upload(prim_tab, s));
-  p->partials_alloc = comp_base + comp_off + row_store;
+  p->partials_alloc = comp_base + comp_off + row_store + 2;      // (+ the word that is always zero, see zero_slot)
   p->r_size = r_size;
   {
     const char* env = std::getenv("CALICO_SPECULATIVE");
@@ -1108,7 +1150,7 @@ PlanKey structure_key(const calico_problem* p) {
   }
   // the switches finalize reads from the environment
   for (const char* name : {"CALICO_SOLVER", "CALICO_SPECULATIVE", "CALICO_BAND_SPLIT", "CALICO_BCR_LEAF", "CALICO_BCR_MERGE_TOP", "CALICO_IMU_CHUNK",
-                           "CALICO_ROW_CELLS"}) {
+                           "CALICO_ROW_CELLS", "CALICO_GATHER_STRUCT"}) {
     const char* e = std::getenv(name);
     h.word(e ? 1 : 0);
     if (e) h.bytes(e, std::strlen(e));
@@ -1150,6 +1192,7 @@ int prepare_workspace(calico_problem* p) {
   HIP_TRY(p, p->d_x.alloc(size_t(p->n_amb))); HIP_TRY(p, p->d_xc.alloc(size_t(p->n_amb)));
   HIP_TRY(p, p->d_m0.alloc(size_t(n_obs))); HIP_TRY(p, p->d_m1.alloc(size_t(n_obs))); HIP_TRY(p, p->d_m2.alloc(size_t(n_obs)));
   HIP_TRY(p, p->d_partials.alloc(p->partials_alloc));
+  HIP_TRY(p, hipMemsetAsync(p->d_partials.p + (p->partials_alloc - 2), 0, 2 * sizeof(double), s));      // the word the lists point to for "nothing"
   if (std::getenv("CALICO_KERNEL_TIMING") && std::atoi(std::getenv("CALICO_KERNEL_TIMING")) >= 3) HIP_TRY(p, p->d_wave_log.alloc(2 * size_t(p->n_jac_items + p->n_fitems)));
   HIP_TRY(p, p->d_R.alloc(2 * r_size)); HIP_TRY(p, hipMemsetAsync(p->d_R.p, 0, 2 * r_size * sizeof(double), s));
   HIP_TRY(p, p->d_R2.alloc(2));

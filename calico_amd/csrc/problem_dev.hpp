@@ -175,6 +175,17 @@ struct BlockDev {  // one reduced (free, used) parameter block
 // LM control stage riding in the gather kernel (single rank, speculative evaluation): the workgroup that sums the
 // candidate's [cost, invalid] (outputs 0 and 1 of the gather, always in one workgroup) takes the accept / reject
 // decision at once, while the other workgroups are still assembling the normal equations.
+// What the device needs to build the source lists of the band, the border and the spline right-hand side itself
+// (solve_kernels.hip, launch_gather_lists). `tab` (ints): the expanded block of every cell [n_lay][nseg] (offset into the
+// partials, -1: no such cell), the local column of every calibration tangent column in every layout [n_lay][m] (-1: not a
+// column of that layout), the block side n1 of every layout [n_lay].
+struct GatherStruct {
+  const int* tab;
+  int n_lay, nseg, n_cp, k, m;      // m: calibration tangent columns (SolveArgs.mc)
+  int pad0;
+  unsigned long long off_g, off_B, off_E;
+};
+
 struct ControlTail {
   int enabled, n_amb, log_cap, seq;
   LmOptionsDev o;

@@ -39,6 +39,115 @@ DEVI void control_body(LmState* st, const LmOptionsDev& o, double* R2, double* x
                        int log_cap, const double* __restrict__ item_cost, int n_items, const double* Rbase, size_t r_stride,
                        int no_swap, int* progress, int seq, LmState* s_st, const ControlStage* staged = nullptr);
 DEVI void publish(int* word, int value);
+// ---------------------------------------------------------------------------
+// Source lists built ON THE DEVICE (once per plan). For the band, the border and the spline part of the right-hand side
+// -- 98 % of the outputs, 90 % of the list entries -- the sources of an output follow from its indices, because the band
+// is uniform in time: output (control points a <= b, components r, c | calibration column tc) sums entry (i, j) of the
+// expanded block of every cell (layout l, segment sg) whose segment covers a and b, i = 6(a - sg) + r, j = 6(b - sg) + c
+// (or the local column of tc in layout l, or the block's last column for the right-hand side), in the order (layout,
+// segment). The host therefore uploads three small tables instead of building the lists (4.4 of the 8.9 ms a fresh
+// finalize took at configs[3]): the cells' blocks [n_lay][nseg], the local column of every calibration column in every
+// layout [n_lay][m], the block side of every layout [n_lay] -- and three launches turn them into the same CSR lists the
+// per-iteration gather reads (count, scan, fill). Outputs are numbered in the order of R: the spline right-hand side, the band blocks, the
+// border (row-major over the spline rows and the calibration columns). An output nothing
+// contributes to (a control point beyond the trajectory's end in the band's layout) gets one source, a word that is
+// always zero (`zero_slot`), so that every output has a list.
+// ---------------------------------------------------------------------------
+struct StructOut { int a, b, r, c, tc, rhs; size_t dst; };
+DEVI StructOut struct_output(const GatherStruct& gs, int o) {
+  const int NS = 6 * gs.n_cp, n_e = NS * gs.m, n_b = gs.n_cp * gs.k * 36;
+  StructOut q;
+  q.tc = -1; q.rhs = 0; q.c = 0;
+  // (the spline right-hand side and the band first: they have the longest lists -- up to n_lay x k sources against k for most
+  //  border entries --, and the workgroups that start last should be the light ones; it is also the order of R itself)
+  if (o < NS) {
+    const int ti = o;
+    q.a = q.b = ti / 6; q.r = ti % 6; q.rhs = 1;
+    q.dst = size_t(gs.off_g) + size_t(ti);
+  } else if (o < NS + n_b) {
+    const int e = o - NS, blk = e / 36, w = e - 36 * blk;
+    q.a = blk / gs.k; q.b = q.a + blk % gs.k;
+    q.r = w / 6; q.c = w % 6;
+    q.dst = size_t(gs.off_B) + size_t(e);
+  } else {
+    const int e = o - NS - n_b, ti = e / gs.m;
+    q.tc = e - ti * gs.m;
+    q.a = q.b = ti / 6; q.r = ti % 6;
+    q.dst = size_t(gs.off_E) + size_t(e);
+  }
+  return q;
+}
+// calls f(src_index) for every source of output q, in list order; returns their number
+template <class F>
+DEVI int struct_sources(const GatherStruct& gs, const StructOut& q, F f) {
+  const int n_lay = gs.n_lay, nseg = gs.nseg, m = gs.m, k = gs.k;
+  const int* poff = gs.tab;
+  const int* inv = gs.tab + n_lay * nseg;
+  const int* n1s = inv + n_lay * m;
+  if (q.b >= gs.n_cp) return 0;
+  const int lo = max(0, q.b - (k - 1)), hi = min(q.a, nseg - 1);
+  int n = 0;
+  for (int l = 0; l < n_lay; ++l) {
+    const int n1 = n1s[l];
+    const int jc = q.tc >= 0 ? inv[l * m + q.tc] : 0;
+    if (jc < 0) continue;
+    for (int sg = lo; sg <= hi; ++sg) {
+      const int po = poff[l * nseg + sg];
+      if (po < 0) continue;
+      int i = 6 * (q.a - sg) + q.r, j;
+      if (q.tc >= 0) j = jc;
+      else if (q.rhs) j = n1 - 1;
+      else { j = 6 * (q.b - sg) + q.c; if (q.a == q.b && i > j) { const int t = i; i = j; j = t; } }
+      f(po + i * n1 + j);
+      ++n;
+    }
+  }
+  return n;
+}
+__global__ __launch_bounds__(256) void gather_lists_count_kernel(GatherStruct gs, int n_out, int* __restrict__ cnt, int* __restrict__ out_idx) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= n_out) return;
+  const StructOut q = struct_output(gs, o);
+  const int n = struct_sources(gs, q, [](int) {});
+  cnt[o] = n > 0 ? n : 1;
+  out_idx[o] = int(q.dst);
+}
+// exclusive prefix sum of cnt[0..n) into ptr[0..n] (one workgroup; n is a few 10^4 .. 10^6)
+__global__ __launch_bounds__(1024) void gather_lists_scan_kernel(const int* __restrict__ cnt, int n, int64_t* __restrict__ ptr) {
+  __shared__ long long part[1024];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024, i0 = tid * per, i1 = min(n, i0 + per);
+  long long sum = 0;
+  for (int i = i0; i < i1; ++i) sum += cnt[i];
+  part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const long long v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  long long run = part[tid] - sum;       // exclusive
+  for (int i = i0; i < i1; ++i) { ptr[i] = run; run += cnt[i]; }
+  if (tid == 1023) ptr[n] = part[1023];
+}
+__global__ __launch_bounds__(256) void gather_lists_fill_kernel(GatherStruct gs, int n_out, const int64_t* __restrict__ ptr, int* __restrict__ idx,
+                                                                int zero_slot) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= n_out) return;
+  const StructOut q = struct_output(gs, o);
+  int64_t w = ptr[o];
+  const int n = struct_sources(gs, q, [&](int srci) { idx[w++] = srci; });
+  if (n == 0) idx[w] = zero_slot;
+}
+// n_out outputs; idx must hold 48 entries per output at most (the host sizes it by that bound); returns the total through
+// ptr[n_out] (device)
+void launch_gather_lists(const GatherStruct& gs, int n_out, int* cnt, int* out_idx, int64_t* ptr, int* idx, int zero_slot, hipStream_t s) {
+  hipLaunchKernelGGL(gather_lists_count_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, gs, n_out, cnt, out_idx);
+  hipLaunchKernelGGL(gather_lists_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, n_out, ptr);
+  hipLaunchKernelGGL(gather_lists_fill_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, gs, n_out, ptr, idx, zero_slot);
+}
+
 // `tail`: the LM control stage rides in the workgroup that finishes last (see ControlTail).
 __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, const double* __restrict__ src,
                                                      const int* __restrict__ out_thin, const int64_t* __restrict__ ptr_thin,

@@ -69,14 +69,15 @@ def test_solver_variants_agree(monkeypatch):
         results[(solver, leaf, split, spec)] = _solve_repeatedly(api, scene, repeats=1, max_iter=50)[0]
     # the other development toggles (read per solve / per finalisation): blocking batches instead of the polled loop,
     # stand-alone control kernel, IMU items forming their own blocks, smaller IMU work items, the tree's top level
-    # back-substituted in a launch of its own, the Schur complement / the first back-substitution in launches of their own
+    # back-substituted in a launch of its own, the Schur complement / the first back-substitution in launches of their own,
+    # the gather's source lists built on the host instead of by the device from the cell structure
     monkeypatch.delenv("CALICO_SOLVER")
     monkeypatch.delenv("CALICO_BCR_LEAF", raising=False)
     monkeypatch.setenv("CALICO_BAND_SPLIT", "1")
     monkeypatch.setenv("CALICO_SPECULATIVE", "1")
     for name, value in [("CALICO_STREAM_DEPTH", "0"), ("CALICO_FUSED_CONTROL", "0"), ("CALICO_ROW_CELLS", "0"),
                         ("CALICO_IMU_CHUNK", "7"), ("CALICO_STREAM_DEPTH", "1"), ("CALICO_BCR_MERGE_TOP", "0"),
-                        ("CALICO_FUSE_SCHUR", "0"), ("CALICO_FUSE_BACK", "0")]:
+                        ("CALICO_FUSE_SCHUR", "0"), ("CALICO_FUSE_BACK", "0"), ("CALICO_GATHER_STRUCT", "0")]:
         monkeypatch.setenv(name, value)
         results[(name, value)] = _solve_repeatedly(api, scene, repeats=1, max_iter=50)[0]
         monkeypatch.delenv(name)
