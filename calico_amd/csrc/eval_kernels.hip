@@ -778,11 +778,18 @@ DEV int frame_area_a(int Ps, int PTs, int P1e) {
   return (max(Ps * kFramePad, after) + 1) & ~1;
 }
 
+// value of `v` in lane `l` (l a compile-time constant after unrolling), wave-uniform
+DEV double lane_value(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
 DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
   const int lane = threadIdx.x;
   const bool dbg = CAL_DEV_TIMING(a.debug && fidx == 7 && lane == 0);
-  long long tph[6] = {0, 0, 0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
+  long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define FTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   const FrameItemDev* ip = a.fitems + fidx;
   const FrameItemDev it = *ip;
@@ -926,6 +933,7 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   const double item_cost = wave_sum(cost);
   const double n_invalid = wave_sum(n_bad);
   if (lane == 0) { a.item_cost[2 * fidx] = item_cost; a.item_cost[2 * fidx + 1] = n_invalid; }
+  FTICK(6)
   // ---- M_s to LDS (full symmetric; C/D layout: col = lane & 15, row = (lane >> 4) + 4·reg) ----
   wave_lds_sync();
 #pragma unroll
@@ -939,53 +947,73 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
     }
   }
   // ---- M = Bᵀ M_s B over the prim columns [pose 6 | intrinsics | q | t | body q | body t | r] ----
-  if (lane < P1e) {   // column `lane` of B: M-column = Σ_u co[u] · (small prim column src[u])
-    const int j = lane;
-    int s0 = 0, s1 = 0, s2 = 0;
-    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-    if (j < 3) { s0 = 0; s1 = 1; s2 = 2; c0 = Jl.m[0][j]; c1 = Jl.m[1][j]; c2 = Jl.m[2][j]; }          // rotation: Y·J_l
-    else if (j < 6) { s0 = 3; s1 = 4; s2 = 5; c0 = -R_rw.m[0][j - 3]; c1 = -R_rw.m[1][j - 3]; c2 = -R_rw.m[2][j - 3]; }   // position: -T·R_rw
-    else if (pm.intr >= 0 && j >= pm.intr && j < pm.intr + Kin) { s0 = sm.k + (j - pm.intr); c0 = 1.0; }
-    else if (pm.q >= 0 && j >= pm.q && j < pm.q + 3) {                    // camera q: 2Y - 2T[t_rc]×
-      const int c = j - pm.q, ka = (c + 1) % 3, kb = (c + 2) % 3;
-      s0 = c; c0 = 2.0; s1 = 3 + ka; c1 = -2.0 * comp(t_rc, kb); s2 = 3 + kb; c2 = 2.0 * comp(t_rc, ka);
+  // Lane (h, j) = (lane >> 5, lane & 31) owns column j of B -- M-column = Σ_u co[u] · (small prim column src[u]), at most
+  // three terms, kept in registers -- and works on every other row: N = M_s B column by column, then M = Bᵀ N through
+  // M(j, i) = Σ_u co_j[u] · N(src_j[u], i), which needs nothing but the lane's own column again (M is symmetric). No
+  // index division, no coefficient table in LDS, four rows in flight per lane.
+  const int j = lane & 31, hh = lane >> 5;
+  const bool jok = j < P1e;          // (P1e <= 31)
+  int s0 = 0, s1 = 0, s2 = 0;
+  double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+  if (j < 3) { s0 = 0; s1 = 1; s2 = 2; c0 = Jl.m[0][j]; c1 = Jl.m[1][j]; c2 = Jl.m[2][j]; }          // rotation: Y·J_l
+  else if (j < 6) { s0 = 3; s1 = 4; s2 = 5; c0 = -R_rw.m[0][j - 3]; c1 = -R_rw.m[1][j - 3]; c2 = -R_rw.m[2][j - 3]; }   // position: -T·R_rw
+  else if (pm.intr >= 0 && j >= pm.intr && j < pm.intr + Kin) { s0 = sm.k + (j - pm.intr); c0 = 1.0; }
+  else if (pm.q >= 0 && j >= pm.q && j < pm.q + 3) {                    // camera q: 2Y - 2T[t_rc]×
+    const int c = j - pm.q, ka = (c + 1) % 3, kb = (c + 2) % 3;
+    s0 = c; c0 = 2.0; s1 = 3 + ka; c1 = -2.0 * comp(t_rc, kb); s2 = 3 + kb; c2 = 2.0 * comp(t_rc, ka);
+  }
+  else if (pm.t >= 0 && j >= pm.t && j < pm.t + 3) { s0 = 3 + (j - pm.t); c0 = -1.0; }                 // camera t: -T
+  else if (pm.bq >= 0 && j >= pm.bq && j < pm.bq + 3) { s0 = sm.z + (j - pm.bq); c0 = -2.0; }         // body q: -2Z
+  else if (pm.bt >= 0 && j >= pm.bt && j < pm.bt + 3) { const int c = j - pm.bt; s0 = 3; s1 = 4; s2 = 5; c0 = R_rw.m[0][c]; c1 = R_rw.m[1][c]; c2 = R_rw.m[2][c]; }
+  else { s0 = sm.r; c0 = 1.0; }
+  FTICK(7)
+  wave_lds_sync();
+  if (jok) {                                                           // N = M_s B
+    for (int ar = hh; ar < Ps; ar += 8) {
+      double m0[4], m1[4], m2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int a2 = min(ar + 2 * u, Ps - 1);
+        m0[u] = Ms[a2 * PTs + s0]; m1[u] = Ms[a2 * PTs + s1]; m2[u] = Ms[a2 * PTs + s2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        double sN = 0.0;
+        sN += c0 * m0[u]; sN += c1 * m1[u]; sN += c2 * m2[u];
+        if (ar + 2 * u < Ps) Nmat[(ar + 2 * u) * P1e + j] = sN;
+      }
     }
-    else if (pm.t >= 0 && j >= pm.t && j < pm.t + 3) { s0 = 3 + (j - pm.t); c0 = -1.0; }                 // camera t: -T
-    else if (pm.bq >= 0 && j >= pm.bq && j < pm.bq + 3) { s0 = sm.z + (j - pm.bq); c0 = -2.0; }         // body q: -2Z
-    else if (pm.bt >= 0 && j >= pm.bt && j < pm.bt + 3) { const int c = j - pm.bt; s0 = 3; s1 = 4; s2 = 5; c0 = R_rw.m[0][c]; c1 = R_rw.m[1][c]; c2 = R_rw.m[2][c]; }
-    else { s0 = sm.r; c0 = 1.0; }
-    bsrc[3 * j] = s0; bsrc[3 * j + 1] = s1; bsrc[3 * j + 2] = s2;
-    bco[3 * j] = c0; bco[3 * j + 1] = c1; bco[3 * j + 2] = c2;
   }
+  FTICK(8)
   wave_lds_sync();
-  for (int idx = lane; idx < Ps * P1e; idx += 64) {                  // N = M_s B
-    const int ar = idx / P1e, j = idx - ar * P1e;
-    double sN = 0.0;
+  if (jok) {                                                           // M = Bᵀ N
+    for (int i = hh; i < P1e; i += 8) {
+      double n0[4], n1v[4], n2[4];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) sN += bco[3 * j + u] * Ms[ar * PTs + bsrc[3 * j + u]];
-    Nmat[idx] = sN;
-  }
-  wave_lds_sync();
-  for (int idx = lane; idx < P1e * P1e; idx += 64) {                 // M = Bᵀ N
-    const int i = idx / P1e, j = idx - i * P1e;
-    double sM = 0.0;
+      for (int u = 0; u < 4; ++u) {
+        const int i2 = min(i + 2 * u, P1e - 1);
+        n0[u] = Nmat[s0 * P1e + i2]; n1v[u] = Nmat[s1 * P1e + i2]; n2[u] = Nmat[s2 * P1e + i2];
+      }
 #pragma unroll
-    for (int u = 0; u < 3; ++u) sM += bco[3 * i + u] * Nmat[bsrc[3 * i + u] * P1e + j];
-    Me[i * PE + j] = sM;
+      for (int u = 0; u < 4; ++u) {
+        double sM = 0.0;
+        sM += c0 * n0[u]; sM += c1 * n1v[u]; sM += c2 * n2[u];
+        if (i + 2 * u < P1e) Me[j * PE + i + 2 * u] = sM;
+      }
+    }
   }
+  FTICK(9)
   wave_lds_sync();
-  if (lane < P1e) {                                                  // latency: dp/dlat = -pdot
+  {                                                                    // latency: dp/dlat = -pdot
     double sQ = 0.0;
+    const int lq = min(lane, P1e - 1);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) sQ -= pd[c] * Me[c * PE + lane];
-    Me[PT * PE + lane] = sQ; Me[lane * PE + PT] = sQ;
-  }
-  wave_lds_sync();
-  if (lane == 0) {
-    double qq = 0.0;
+    for (int c = 0; c < 6; ++c) sQ -= pd[c] * Me[c * PE + lq];
+    if (lane < P1e) { Me[PT * PE + lane] = sQ; Me[lane * PE + PT] = sQ; }
+    double qq = 0.0;                                                   // (lanes 0..5 hold the entries the corner needs)
 #pragma unroll
-    for (int c = 0; c < 6; ++c) qq -= pd[c] * Me[PT * PE + c];
-    Me[PT * PE + PT] = qq;
+    for (int c = 0; c < 6; ++c) qq -= pd[c] * lane_value(sQ, c);
+    if (lane == 0) Me[PT * PE + PT] = qq;
   }
   wave_lds_sync();
   FTICK(4)
@@ -997,8 +1025,8 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   for (int i = lane; i < nme; i += 64) out[i] = Me[i];
   for (int i = lane; i < n1; i += 64) out[nme + i] = coef[i];
   FTICK(5)
-  if (dbg) printf("eval_frames cycles (frame of %d blocks, %d small / %d prim cols): frame-constants %lld  barrier %lld  blocks %lld  M-mfma %lld  M-to-lds %lld  record %lld\n",
-                  it.obs_count, Ps, P1e, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
+  if (dbg) printf("eval_frames cycles (frame of %d blocks, %d small / %d prim cols): frame-constants %lld  barrier %lld  blocks %lld  M-mfma %lld  M-to-lds [sums %lld  Ms+B %lld  N %lld  M %lld  latency %lld]  record %lld\n",
+                  it.obs_count, Ps, P1e, tph[0], tph[1], tph[2], tph[3], tph[6], tph[7], tph[8], tph[9], tph[4], tph[5]);
 #undef FTICK
 }
 
