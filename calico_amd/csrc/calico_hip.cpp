@@ -50,7 +50,7 @@ void launch_mark_outliers(const double* res, const uint8_t* valid, uint8_t* acti
 hipError_t configure_eval_kernels(size_t max_lds_bytes);
 
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
-                   int n_thin, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
+                   int n_thin, int thin_per_lane, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
                    const double* cost_src, int n_cost, const LmState* st, int need_flag, size_t other_stride, hipStream_t s, const ControlTail* tail = nullptr);
 void launch_gather_lists(const GatherStruct& gs, int n_out, int* cnt, int* out_idx, int64_t* ptr, int* idx, int zero_slot, hipStream_t s);
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
@@ -263,6 +263,7 @@ struct PlanHost {
   int frame_lds_doubles = 0;
   int n_fitems = 0, n_jac_items = 0;
   int n_thin = 0, n_fat = 0;
+  int thin_per_lane = 6;       // sources per lane of a thin output's eight lanes (6: up to 48 sources, 12: up to 96)
   bool dense_in_lds = true;
   int gather_owner_block = 0;
   bool gs_lists_on_device = false;   // the band / border / spline right-hand side lists were built by the device (launch_gather_lists)
@@ -920,10 +921,10 @@ int build_plan(calico_problem* p) {
   // CALICO_GATHER_STRUCT=0: everything listed by the host (A/B switch, and the path of problems with free model points or
   // other spline orders' generic items).
   bool gs_ok = [] { const char* e = std::getenv("CALICO_GATHER_STRUCT"); return !e || std::atoi(e) != 0; }();
-  gs_ok = gs_ok && int(layouts.size()) * k <= 48 && int(layouts.size()) >= 1 && m >= 1 && n_cells > 0;
+  gs_ok = gs_ok && int(layouts.size()) * k <= 96 && int(layouts.size()) >= 1 && m >= 1 && n_cells > 0;
   for (int itn = n_cells; gs_ok && itn < n_part; ++itn) gs_ok = p->h_jac_items[size_t(itn - n_cells)].rows_off >= 0;   // no block of its own
   const int64_t gs_n_out = int64_t(NS) * m + int64_t(n_cp) * k * 36 + NS;
-  gs_ok = gs_ok && gs_n_out * 48 < int64_t(0x7fffffff);
+  gs_ok = gs_ok && gs_n_out * 96 < int64_t(0x7fffffff);
   p->gs_lists_on_device = gs_ok;
   std::vector<int> gs_tab;
   GatherStruct gsd = {};
@@ -986,16 +987,26 @@ int build_plan(calico_problem* p) {
       std::vector<int64_t> fill(start.begin(), start.end() - 1);
       for (const Pair& pr : pairs) sorted_src[size_t(fill[size_t(pr.dst)]++)] = pr.src;
     }
+    // thin outputs: eight lanes, 6 sources per lane -- or 12 when the problem has outputs of 49..96 sources (many
+    // layouts: their band and right-hand-side entries would each take a whole wave otherwise)
+    int thin_cap = 48;
+    if (gs_ok) thin_cap = int(layouts.size()) * k <= 48 ? 48 : 96;
+    else {
+      size_t n_mid = 0;
+      for (size_t d = 0; d < r_size; ++d) { const int64_t c = start[d + 1] - start[d]; if (c > 48 && c <= 96) ++n_mid; }
+      if (n_mid > 0) thin_cap = 96;
+    }
+    p->thin_per_lane = thin_cap / 8;
     size_t n_thin_src = 0, n_fat_src = 0;
     for (size_t d = 0; d < r_size; ++d) {
       const int64_t c = start[d + 1] - start[d];
-      if (gs_ok || c > 48) n_fat_src += size_t(c); else n_thin_src += size_t(c);
+      if (gs_ok || c > thin_cap) n_fat_src += size_t(c); else n_thin_src += size_t(c);
     }
     idx_thin.reserve(n_thin_src); idx_fat.reserve(n_fat_src);
     for (size_t d = 0; d < r_size; ++d) {
       const int64_t q0 = start[d], q1 = start[d + 1];
       if (q1 == q0) continue;
-      const bool fat = gs_ok || (q1 - q0) > 48;        // (the device's lists are the thin ones: what the host lists goes to the waves)
+      const bool fat = gs_ok || (q1 - q0) > thin_cap;        // (the device's lists are the thin ones: what the host lists goes to the waves)
       std::vector<int>& out = fat ? out_fat : out_thin;
       std::vector<int>& idx = fat ? idx_fat : idx_thin;
       std::vector<int64_t>& ptr = fat ? ptr_fat : ptr_thin;
@@ -1037,7 +1048,7 @@ int build_plan(calico_problem* p) {
     if (size_t(zero_slot) + 2 >= size_t(0x7fffffff)) return p->set_error(CALICO_UNIMPLEMENTED, "problem too large for 32-bit gather indices");
     HIP_TRY(p, p->d_gs_tab.upload(gs_tab, s));
     gsd.tab = p->d_gs_tab.p;
-    const int per_out = std::min(48, int(layouts.size()) * k);
+    const int per_out = int(layouts.size()) * k;      // (<= 96)
     HIP_TRY(p, p->d_out_thin.alloc(size_t(gs_n_out))); HIP_TRY(p, p->d_ptr_thin.alloc(size_t(gs_n_out) + 1));
     HIP_TRY(p, p->d_idx_thin.alloc(size_t(gs_n_out) * per_out)); HIP_TRY(p, d_cnt.alloc(size_t(gs_n_out)));
     launch_gather_lists(gsd, int(gs_n_out), d_cnt.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, zero_slot, s);
@@ -1433,7 +1444,7 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, c
     HIP_TRY(p, hipMemsetAsync(target, 0, p->r_size * sizeof(double), p->stream));
   }
   launch_expand_cells(ea, p->stream);                     // compact frame records -> one expanded block per cell
-  launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->d_out_fat.p,
+  launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->thin_per_lane, p->d_out_fat.p,
                 p->d_ptr_fat.p, p->d_idx_fat.p, p->n_fat, p->d_partials.p + p->partial_doubles, p->n_fitems + p->n_jac_items, st, need_flag,
                 spec ? p->r_size : 0, p->stream, tail);
   p->timer.end(p->stream);

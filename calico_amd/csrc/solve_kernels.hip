@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void gather_lists_fill_kernel(GatherStruct gs,
   const int n = struct_sources(gs, q, [&](int srci) { idx[w++] = srci; });
   if (n == 0) idx[w] = zero_slot;
 }
-// n_out outputs; idx must hold 48 entries per output at most (the host sizes it by that bound); returns the total through
+// n_out outputs; idx must hold n_lay x k entries per output at most (the host sizes it by that bound); returns the total through
 // ptr[n_out] (device)
 void launch_gather_lists(const GatherStruct& gs, int n_out, int* cnt, int* out_idx, int64_t* ptr, int* idx, int zero_slot, hipStream_t s) {
   hipLaunchKernelGGL(gather_lists_count_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, gs, n_out, cnt, out_idx);
@@ -149,6 +149,8 @@ void launch_gather_lists(const GatherStruct& gs, int n_out, int* cnt, int* out_i
 }
 
 // `tail`: the LM control stage rides in the workgroup that finishes last (see ControlTail).
+// U: sources per lane of a thin output (eight lanes): 6, or 12 for problems with outputs of 49..96 sources.
+template <int U>
 __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, const double* __restrict__ src,
                                                      const int* __restrict__ out_thin, const int64_t* __restrict__ ptr_thin,
                                                      const int* __restrict__ idx_thin, int n_thin,
@@ -231,16 +233,32 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
     const int o = gid >> 3, sub = gid & 7;
     const bool live = o < n_thin;
     const int oc = live ? o : n_thin - 1;
-    const int64_t q0 = pre_q0, q1 = pre_q1;     // at most 48 sources: six per lane
+    const int64_t q0 = pre_q0, q1 = pre_q1;     // at most 8·U sources: U per lane
+    // the first six per lane unconditionally; the others (U = 12) only where the list is that long -- most outputs
+    // (the border's) have a handful of sources, and a wave whose groups are all short skips the second batch
     int id[6];
 #pragma unroll
     for (int u = 0; u < 6; ++u) { const int64_t q = q0 + sub + 8 * u; id[u] = idx_thin[q < q1 ? q : q1 - 1]; }
     double v[6];
 #pragma unroll
     for (int u = 0; u < 6; ++u) v[u] = src[id[u]];
+    double s2 = 0.0;
+    if constexpr (U > 6) {
+      if (q1 - q0 > 48) {
+        int id2[U - 6];
+#pragma unroll
+        for (int u = 6; u < U; ++u) { const int64_t q = q0 + sub + 8 * u; id2[u - 6] = idx_thin[q < q1 ? q : q1 - 1]; }
+        double v2[U - 6];
+#pragma unroll
+        for (int u = 6; u < U; ++u) v2[u - 6] = src[id2[u - 6]];
+#pragma unroll
+        for (int u = 6; u < U; ++u) s2 += q0 + sub + 8 * u < q1 ? v2[u - 6] : 0.0;
+      }
+    }
     double s = 0.0;
 #pragma unroll
     for (int u = 0; u < 6; ++u) s += q0 + sub + 8 * u < q1 ? v[u] : 0.0;
+    s += s2;
     s = row8_sum(s);
     if (live && sub == 0) R[out_thin[o]] = s;
   }
@@ -1728,15 +1746,19 @@ __global__ void init_state_kernel(LmState* st, double radius, double x_norm, con
 
 // ---- launch helpers ---------------------------------------------------------
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
-                   int n_thin, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
+                   int n_thin, int thin_per_lane, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
                    const double* cost_src, int n_cost,
                    const LmState* st, int need_flag, size_t other_stride, hipStream_t s, const ControlTail* tail) {
   const int nb_thin = (n_thin + 31) / 32, nb_fat = (n_fat + 3) / 4;
   ControlTail t;
   if (tail) t = *tail; else { t = ControlTail(); t.enabled = 0; }
   // workgroup 0: cost / invalid count (+ control stage), then the fat outputs, then the thin ones
-  hipLaunchKernelGGL(gather_kernel, dim3(1 + nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin,
-                     out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, cost_src, n_cost, st, need_flag, other_stride, t);
+  if (thin_per_lane <= 6)
+    hipLaunchKernelGGL(gather_kernel<6>, dim3(1 + nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin,
+                       out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, cost_src, n_cost, st, need_flag, other_stride, t);
+  else
+    hipLaunchKernelGGL(gather_kernel<12>, dim3(1 + nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin,
+                       out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, cost_src, n_cost, st, need_flag, other_stride, t);
 }
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s) {
