@@ -150,22 +150,29 @@ void launch_gather_lists(const GatherStruct& gs, int n_out, int* cnt, int* out_i
 
 // `tail`: the LM control stage rides in the workgroup that finishes last (see ControlTail).
 // U: sources per lane of a thin output (eight lanes): 6, or 12 for problems with outputs of 49..96 sources.
+// Thin outputs [n_thin8, n_thin) have at most EIGHT sources each (the border: one layout's cells over the k segments of
+// a control point) and take one lane instead of eight: an eighth of the threads for two thirds of the outputs.
 template <int U>
 __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, const double* __restrict__ src,
                                                      const int* __restrict__ out_thin, const int64_t* __restrict__ ptr_thin,
-                                                     const int* __restrict__ idx_thin, int n_thin,
+                                                     const int* __restrict__ idx_thin, int n_thin, int n_thin8,
                                                      const int* __restrict__ out_fat, const int64_t* __restrict__ ptr_fat,
                                                      const int* __restrict__ idx_fat, int n_fat, int nb_fat,
                                                      const double* __restrict__ cost_src, int n_cost,
                                                      const LmState* st, int need_flag, size_t other_stride, ControlTail tail) {
   // (the list pointers of this thread's output do not depend on the state: requested before the flags are looked at)
   int64_t pre_q0 = 0, pre_q1 = 0;
+  const int nb_thin8 = (n_thin8 + 31) / 32;
+  int o_thin = 0;
+  bool tiny = false;
   {
     const int bidp = int(blockIdx.x) - 1;
-    if (bidp >= nb_fat) {
-      const int o = ((bidp - nb_fat) * int(blockDim.x) + int(threadIdx.x)) >> 3;
-      const int oc = o < n_thin ? o : n_thin - 1;
-      if (n_thin > 0) { pre_q0 = ptr_thin[oc]; pre_q1 = ptr_thin[oc + 1]; }
+    if (bidp >= nb_fat && n_thin > 0) {
+      const int tb = bidp - nb_fat;
+      int oc;
+      if (tb < nb_thin8) { o_thin = (tb * int(blockDim.x) + int(threadIdx.x)) >> 3; oc = o_thin < n_thin8 ? o_thin : n_thin8 - 1; }
+      else { tiny = true; o_thin = n_thin8 + (tb - nb_thin8) * int(blockDim.x) + int(threadIdx.x); oc = o_thin < n_thin ? o_thin : n_thin - 1; }
+      pre_q0 = ptr_thin[oc]; pre_q1 = ptr_thin[oc + 1];
     }
   }
   if (st && (st->terminated || (need_flag && !st->need_jacobian))) {
@@ -229,10 +236,24 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
     s = wave_sum(s);
     if (live && lane == 0) R[out_fat[wave]] = s;
   } else {
-    const int gid = (bid - nb_fat) * blockDim.x + threadIdx.x;
-    const int o = gid >> 3, sub = gid & 7;
-    const bool live = o < n_thin;
-    const int oc = live ? o : n_thin - 1;
+    if (tiny) {      // one lane per output, at most eight sources, summed in list order
+      const int o = o_thin;
+      const int64_t q0 = pre_q0, q1 = pre_q1;
+      int id[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int64_t q = q0 + u; id[u] = idx_thin[q < q1 ? q : q1 - 1]; }
+      const int dst = out_thin[o < n_thin ? o : n_thin - 1];
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[id[u]];
+      double s = 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += q0 + u < q1 ? v[u] : 0.0;
+      if (o < n_thin) R[dst] = s;
+      return;
+    }
+    const int o = o_thin, sub = int(threadIdx.x) & 7;
+    const bool live = o < n_thin8;
     const int64_t q0 = pre_q0, q1 = pre_q1;     // at most 8·U sources: U per lane
     // the first six per lane unconditionally; the others (U = 12) only where the list is that long -- most outputs
     // (the border's) have a handful of sources, and a wave whose groups are all short skips the second batch
@@ -1746,18 +1767,18 @@ __global__ void init_state_kernel(LmState* st, double radius, double x_norm, con
 
 // ---- launch helpers ---------------------------------------------------------
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
-                   int n_thin, int thin_per_lane, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
+                   int n_thin, int n_thin8, int thin_per_lane, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
                    const double* cost_src, int n_cost,
                    const LmState* st, int need_flag, size_t other_stride, hipStream_t s, const ControlTail* tail) {
-  const int nb_thin = (n_thin + 31) / 32, nb_fat = (n_fat + 3) / 4;
+  const int nb_thin = (n_thin8 + 31) / 32 + (n_thin - n_thin8 + 255) / 256, nb_fat = (n_fat + 3) / 4;
   ControlTail t;
   if (tail) t = *tail; else { t = ControlTail(); t.enabled = 0; }
   // workgroup 0: cost / invalid count (+ control stage), then the fat outputs, then the thin ones
   if (thin_per_lane <= 6)
-    hipLaunchKernelGGL(gather_kernel<6>, dim3(1 + nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin,
+    hipLaunchKernelGGL(gather_kernel<6>, dim3(1 + nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin, n_thin8,
                        out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, cost_src, n_cost, st, need_flag, other_stride, t);
   else
-    hipLaunchKernelGGL(gather_kernel<12>, dim3(1 + nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin,
+    hipLaunchKernelGGL(gather_kernel<12>, dim3(1 + nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin, n_thin8,
                        out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, cost_src, n_cost, st, need_flag, other_stride, t);
 }
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
