@@ -1375,12 +1375,15 @@ constexpr int DNL = 129;     // row stride of the dense matrix in LDS
 // (Taking the top level of the tree along in this workgroup -- back_calib + back_node for its one to three nodes -- was
 //  tried and lost: two nodes one after the other cost 12 us of dependent loads here against the 7 us of a launch that
 //  runs them side by side, and the levels below then sweep their own border rows.)
-DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const Handoff& ho) {
+// t0 > 0: the system is what the blocked multi-launch factorisation (reduced_block_step_kernel) left of a larger one --
+// unknowns t0 .. a.m - 1, in place in slice 0 of a.Spart with the full system's row stride, right-hand side in its row a.m.
+DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const Handoff& ho, int t0 = 0) {
   LmState* st = a.st;
   const int terminated = st->terminated;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, lk = lane >> 4;
-  const int m = a.m, M1 = a.m + 1, n = a.n_s();
+  const int m = a.m - t0, M1 = a.m + 1, n = a.n_s() + t0;
+  const double* Sp = a.Spart + size_t(t0) * M1 + t0;      // entry (0, 0) of the system
   const int nb = (m + BP - 1) / BP;              // 32-column blocks
   const int mp = BP * nb;                        // padded size (identity beyond m)
   double* A = lds;                               // [128][DNL]
@@ -1406,7 +1409,7 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
           const int c = min(lane + 64 * h, r);
           double acc = 0.0;
 #pragma unroll
-          for (int k = 0; k < 2; ++k) acc += a.Spart[size_t(min(k, nsl - 1)) * mm + size_t(r) * M1 + c] * (k < nsl ? 1.0 : 0.0);
+          for (int k = 0; k < 2; ++k) acc += Sp[size_t(min(k, nsl - 1)) * mm + size_t(r) * M1 + c] * (k < nsl ? 1.0 : 0.0);
           v[u][h] = acc;
         }
       }
@@ -1425,7 +1428,7 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
       const int c = min(tid, m - 1);
       double acc = 0.0;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) acc += a.Spart[size_t(min(k, nsl - 1)) * mm + size_t(m) * M1 + c] * (k < nsl ? 1.0 : 0.0);
+      for (int k = 0; k < 2; ++k) acc += Sp[size_t(min(k, nsl - 1)) * mm + size_t(m) * M1 + c] * (k < nsl ? 1.0 : 0.0);
       gv[tid] = tid < m ? acc : 0.0;
       pend[tid] = 0.0;
     }
@@ -1607,9 +1610,9 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
   } else if (tid < m) a.y[n + tid] = yv[tid];
   if (wave == 0 && lane == 0 && !(pmin > 0.0)) st->chol_failed = 1;
 }
-__global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveArgs a, int nsl) {
+__global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveArgs a, int nsl, int t0) {
   extern __shared__ double lds[];
-  dense_block_solve_body(a, nsl, lds, Handoff{nullptr, 0});
+  dense_block_solve_body(a, nsl, lds, Handoff{nullptr, 0}, t0);
 }
 // The dense reduced solve (workgroup 0) and the first back-substitution launch behind it (the other workgroups) in ONE
 // launch: the nodes request everything they need that the reduced solve does not produce -- L⁻ᵀ, Z^A, Z^B, border rows,
@@ -1632,8 +1635,8 @@ hipError_t configure_dense_block_solve() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_block_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                              int(dense_block_solve_lds_bytes()));
 }
-void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s) {
-  hipLaunchKernelGGL(dense_block_solve_kernel, dim3(1), dim3(kDenseThreads), dense_block_solve_lds_bytes(), s, a, ks);
+void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s, int t0) {
+  hipLaunchKernelGGL(dense_block_solve_kernel, dim3(1), dim3(kDenseThreads), dense_block_solve_lds_bytes(), s, a, ks, t0);
 }
 size_t bcr_back_lds_bytes(int q_max, int m1p);
 // Does the Schur complement ride in the last level's launch? Trees of at least two levels whose last level has one or two

@@ -1829,7 +1829,7 @@ static bool reduced_is_blocked(const SolveArgs& a) {
 // K-slices of the Schur complement the reduced solve adds up on load
 int reduced_schur_slices(const SolveArgs& a) { return (a.m + 1 <= 128 || reduced_is_blocked(a)) ? kSchurSlices : 1; }
 // Dense solve of the (m+1)x(m+1) augmented reduced system in a.Spart (ks K-slices) -> a.y[n_s ...]
-void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s);     // bcr_kernels.hip
+void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s, int t0 = 0);     // bcr_kernels.hip
 void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipStream_t s) {
   const int m1 = a.m + 1;
   const bool blocked = reduced_is_blocked(a);
@@ -1848,9 +1848,12 @@ void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipSt
       const int rows = m1 - kRB * (j + 1), T = rows > 0 ? (rows + 63) / 64 : 0;
       hipLaunchKernelGGL(reduced_block_step_kernel, dim3(T > 0 ? T * (T + 1) / 2 : 1), dim3(256), 0, s, a, j, j == 0 ? ks : 1);
     }
-    const size_t lds = (size_t(mt1) * ((16 * ((mt1 + 15) / 16)) | 1) + mt1 + 32 + 128 + 256) * sizeof(double);
-    if (mt1 <= 64) hipLaunchKernelGGL(reduced_solve_panel_kernel<1>, dim3(1), dim3(256), lds, s, a, t0, 1);
-    else hipLaunchKernelGGL(reduced_solve_panel_kernel<2>, dim3(1), dim3(256), lds, s, a, t0, 1);
+    if (use_block && mt1 >= 2) launch_dense_block_solve(a, 1, s, t0);     // (the 32-column-block solver of the small systems)
+    else {
+      const size_t lds = (size_t(mt1) * ((16 * ((mt1 + 15) / 16)) | 1) + mt1 + 32 + 128 + 256) * sizeof(double);
+      if (mt1 <= 64) hipLaunchKernelGGL(reduced_solve_panel_kernel<1>, dim3(1), dim3(256), lds, s, a, t0, 1);
+      else hipLaunchKernelGGL(reduced_solve_panel_kernel<2>, dim3(1), dim3(256), lds, s, a, t0, 1);
+    }
     hipLaunchKernelGGL(reduced_block_back_kernel, dim3(1), dim3(256), 0, s, a, steps);
   } else if (m1 <= 16 * 13) {
     const int NT = m1 <= 64 ? 4 : (m1 <= 112 ? 7 : (m1 <= 160 ? 10 : 13));
