@@ -1638,6 +1638,153 @@ hipError_t configure_dense_block_solve() {
 void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s, int t0) {
   hipLaunchKernelGGL(dense_block_solve_kernel, dim3(1), dim3(kDenseThreads), dense_block_solve_lds_bytes(), s, a, ks, t0);
 }
+// ---------------------------------------------------------------------------
+// Large reduced systems (m + 1 > 128): one step of the blocked right-looking factorisation, 32 columns, over several
+// workgroups -- the same building blocks as a tree node. Workgroup (I, K), I >= K, owns the 64x64 tile of the trailing
+// matrix at rows t0 + 64·I, columns t0 + 64·K (t0 = first row under the panel). Each workgroup factors the pivot
+// block A_jj itself (two in-wave panels + one MFMA tile update, L⁻ᵀ riding along as 32 identity rows: identical in
+// every workgroup, no communication), forms Zᵀ = L⁻¹ Pᵀ for its two row blocks P_I, P_K of the panel on the matrix
+// cores and subtracts Z_I Z_Kᵀ from its tile in 16x16 MFMA tiles. The panel rows are read along the rows (a wave reads
+// two 256-byte row segments per instruction) and transposed through LDS; the tile itself travels through the MFMA
+// accumulators. Replaces reduced_block_step_kernel's 64-row in-wave column Cholesky (14k clocks per step) and its
+// one-row-per-lane loads (64 cache lines per instruction: 21k clocks for the first step, which also sums the K-slices
+// of the Schur complement). The first tile column files the panel into the factor L (Swork): L_jj by workgroup 0, the
+// rows below by the workgroups with K = 0; the right-hand side rides as row m.
+// ---------------------------------------------------------------------------
+constexpr int kStepThreads = 512;
+constexpr int PTL = 65;       // row stride of the transposed panel blocks [32][64]
+__global__ __launch_bounds__(kStepThreads) void reduced_block_step_mfma_kernel(SolveArgs a, int j, int nsl) {
+  LmState* st = a.st;
+  if (st->terminated) return;
+  extern __shared__ double lds[];
+  double* const Daug = lds;                        // [64][DLD]: rows 0..31 A_jj -> L_jj, rows 32..63 identity -> L⁻ᵀ
+  double* const PT = Daug + 64 * DLD;              // [2][32][PTL]: panel rows of block rows I and K, transposed
+  double* const ZT = PT + 2 * BP * PTL;            // [2][32][PTL]: Zᵀ = L⁻¹ Pᵀ
+  double* const dinv = ZT + 2 * BP * PTL;          // [80]
+  double* const bcast = dinv + 80;                 // [128]
+  double* const dump = bcast + 128 + threadIdx.x;  // [512]
+  const int m1 = a.m + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, lk = lane >> 4;
+  const int c0 = BP * j, t0 = c0 + BP;
+  int I = 0, rem = blockIdx.x;
+  while (rem > I) { rem -= I + 1; ++I; }
+  const int K = rem;
+  const int rI = t0 + 64 * I, rK = t0 + 64 * K;
+  double* A = a.Spart;
+  const size_t msq = size_t(m1) * m1;
+  double* L = a.Swork;
+  // ---- requests: pivot block, the two row blocks of the panel (along the rows), this wave's two tiles of the trailing
+  //      matrix (straight into the accumulator layout) ----
+  double dv[2], pv[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {      // pivot block: the lower triangle is stored, the upper one mirrored
+    const int e = tid + kStepThreads * u, r = e >> 5, c = e & 31;
+    const size_t o = size_t(c0 + max(r, c)) * m1 + c0 + min(r, c);
+    double v = A[o];
+    for (int k = 1; k < nsl; ++k) v += A[size_t(k) * msq + o];
+    dv[u] = v;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int rb = h == 0 ? rI : rK;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + kStepThreads * u, r = e >> 5, c = e & 31;
+      const int row = rb + r;
+      const size_t o = size_t(min(row, m1 - 1)) * m1 + c0 + c;
+      double v = A[o];
+      for (int k = 1; k < nsl; ++k) v += A[size_t(k) * msq + o];
+      pv[h][u] = row < m1 ? v : 0.0;
+    }
+  }
+  // tiles (ti, tj) of the 64x64 tile: wave w takes (w >> 1, 2 (w & 1)) and (w >> 1, 2 (w & 1) + 1)
+  f64x4 tacc[2];
+  const int ti = wave >> 1;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int tj = 2 * (wave & 1) + q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ur = rI + 16 * ti + lk + 4 * r, uc = rK + 16 * tj + l16;
+      const size_t o = size_t(min(ur, m1 - 1)) * m1 + min(uc, m1 - 1);
+      double v = A[o];
+      for (int k = 1; k < nsl; ++k) v += A[size_t(k) * msq + o];
+      tacc[q][r] = v;
+    }
+  }
+  // ---- to LDS ----
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + kStepThreads * u, r = e >> 5, c = e & 31;
+    Daug[r * DLD + c] = dv[u];
+    Daug[(BP + r) * DLD + c] = r == c ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + kStepThreads * u, r = e >> 5, c = e & 31;
+      PT[(h * BP + c) * PTL + r] = pv[h][u];
+    }
+  __syncthreads();
+  // ---- A_jj = L Lᵀ and L⁻ᵀ ----
+  double pmin = 1.0;
+  if (wave == 0) panel_factor<1, false, false>(Daug, DLD, dinv, bcast, 0, 63, 16, lane, &pmin);
+  lds_barrier();
+  if (wave < 3) update_tile(Daug, DLD, 63, 1 + wave, 1, 0, 1, lane, dump);
+  lds_barrier();
+  if (wave == 0) panel_factor<1, false, false>(Daug, DLD, dinv, bcast, 16, 63, 16, lane, &pmin);
+  lds_barrier();
+  // ---- Zᵀ = L⁻¹ Pᵀ = Mᵀ Pᵀ, M = L⁻ᵀ in rows 32..63 (upper triangular: row tile it needs k < 16(it+1)) ----
+  {
+    const double* M = Daug + BP * DLD;
+    // 16 jobs (h, it, jt): block row h, row tile it of Zᵀ (the panel's columns), column tile jt (the block's rows)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int job = wave + 8 * q, h = job >> 3, it = (job >> 2) & 1, jt = job & 3;
+      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      acc = atb_tile<false>(M, DLD, 16 * it, PT + h * BP * PTL, PTL, 16 * jt, 0, 16 * (it + 1), acc, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ZT[(h * BP + 16 * it + lk + 4 * r) * PTL + 16 * jt + l16] = acc[r];
+    }
+  }
+  lds_barrier();
+  // ---- file the panel: L_jj (workgroup 0), the rows below (first tile column) ----
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + kStepThreads * u, r = e >> 5, c = e & 31;
+      if (c <= r) L[size_t(c0 + r) * m1 + c0 + c] = Daug[r * DLD + c];
+    }
+  }
+  if (K == 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + kStepThreads * u, r = e >> 5, c = e & 31;
+      if (rI + r < m1) L[size_t(rI + r) * m1 + c0 + c] = ZT[c * PTL + r];
+    }
+  }
+  // ---- tile update: A_IK -= Z_I Z_Kᵀ ----
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int tj = 2 * (wave & 1) + q;
+    tacc[q] = atb_tile<true>(ZT, PTL, 16 * ti, ZT + BP * PTL, PTL, 16 * tj, 0, BP, tacc[q], lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ur = rI + 16 * ti + lk + 4 * r, uc = rK + 16 * tj + l16;
+      if (ur < m1 && uc <= ur) A[size_t(ur) * m1 + uc] = tacc[q][r];
+    }
+  }
+}
+size_t reduced_block_step_lds_bytes() { return size_t(64 * DLD + 4 * BP * PTL + 80 + 128 + kStepThreads) * sizeof(double); }
+hipError_t configure_reduced_block_step() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&reduced_block_step_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             int(reduced_block_step_lds_bytes()));
+}
+void launch_reduced_block_step(const SolveArgs& a, int j, int nsl, int n_wg, hipStream_t s) {
+  hipLaunchKernelGGL(reduced_block_step_mfma_kernel, dim3(n_wg), dim3(kStepThreads), reduced_block_step_lds_bytes(), s, a, j, nsl);
+}
 size_t bcr_back_lds_bytes(int q_max, int m1p);
 // Does the Schur complement ride in the last level's launch? Trees of at least two levels whose last level has one or two
 // single-superblock nodes (it always has, by construction of the plan); CALICO_FUSE_SCHUR=0: a launch of its own (A/B).

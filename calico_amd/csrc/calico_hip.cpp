@@ -78,6 +78,7 @@ size_t bcr_level_lds_bytes();
 size_t bcr_back_lds_bytes(int q_max, int m1p);
 hipError_t configure_bcr_kernels(int q_max, int m1p);
 hipError_t configure_dense_block_solve();
+hipError_t configure_reduced_block_step();
 size_t dense_block_solve_lds_bytes();
 void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, int level, int keep0, int n_keep, const LmOptionsDev& o,
                       const double* x, const BlockDev* blocks, int n_blocks, bool with_post_eval, IterLog* log, int log_cap, int jacobi,
@@ -1301,6 +1302,7 @@ int configure_kernels(calico_problem* p) {
   const size_t reduced_lds = reduced_solve_lds_bytes(sa);
   HIP_TRY(p, configure_solve_kernels(band_cholesky_lds_bytes(sa), p->dense_in_lds ? reduced_lds : 0, band_backsolve_lds_bytes(sa)));
   HIP_TRY(p, configure_dense_block_solve());
+  HIP_TRY(p, configure_reduced_block_step());
   if (p->use_bcr) {
     HIP_TRY(p, configure_bcr_kernels(p->bcr_q_max, p->bcr_m1p));
     if (std::max(dense_block_solve_lds_bytes(), bcr_back_lds_bytes(std::min(p->bcr_q_max, 4), p->bcr_m1p)) + 1024 <= kMaxLds)
