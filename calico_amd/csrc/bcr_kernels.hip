@@ -1377,7 +1377,7 @@ constexpr int DNL = 129;     // row stride of the dense matrix in LDS
 //  runs them side by side, and the levels below then sweep their own border rows.)
 // t0 > 0: the system is what the blocked multi-launch factorisation (reduced_block_step_kernel) left of a larger one --
 // unknowns t0 .. a.m - 1, in place in slice 0 of a.Spart with the full system's row stride, right-hand side in its row a.m.
-DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const Handoff& ho, int t0 = 0) {
+DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const Handoff& ho, int t0 = 0, int outer_back = 0) {
   LmState* st = a.st;
   const int terminated = st->terminated;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1604,15 +1604,64 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
   if (dbg) printf("dense_block_solve wave %d cycles: load %lld | stage %lld  panel0 (rest tiles beside it) %lld  tile %lld  panel1 (rest tiles) %lld  Z %lld  file+rhs+next diagonal %lld | backward %lld\n",
                   wave, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7]);
 #undef DTICK
+  if (t0 > 0 && outer_back) {
+    // ---- the panels the step kernels eliminated, from the last to the first: y_j = L_jj⁻ᵀ (z_j - Σ_{i below} L_ijᵀ y_i).
+    // L (rows below the panel: read along the rows, sixteen row groups), L_jj⁻ᵀ (filed by reduced_block_step_mfma_kernel
+    // in the strict upper triangle of its diagonal block) and the forward-substituted right-hand side (row a.m of L) come
+    // from global memory; the matrix area of this kernel is free by now. ----
+    double* ybig = A;                    // [a.m <= 1024] solution by unknown
+    double* ps = ybig + 1024;            // [16][33] partial sums of the row groups
+    double* w32 = ps + 16 * 33;          // [32]
+    double* Mt = w32 + 32;               // [32][33] L_jj⁻ᵀ
+    const double* Lg = a.Swork;
+    const int mt = a.m, ns0 = a.n_s();
+    if (tid < m) ybig[t0 + tid] = yv[tid];
+    for (int jb = t0 / BP - 1; jb >= 0; --jb) {
+      const int c0 = BP * jb, c = tid & 31, g = tid >> 5;
+      lds_barrier();
+      double part = 0.0;
+      for (int i0 = c0 + BP + g; i0 < mt; i0 += 64) {
+        double lv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) lv[u] = Lg[size_t(min(i0 + 16 * u, mt - 1)) * M1 + c0 + c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) part += i0 + 16 * u < mt ? lv[u] * ybig[i0 + 16 * u] : 0.0;
+      }
+      ps[g * 33 + c] = part;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + kDenseThreads * u, r = e >> 5, c2 = e & 31;
+        const double v = Lg[size_t(c0 + r) * M1 + c0 + c2];
+        Mt[r * 33 + c2] = c2 > r ? v : (c2 == r ? 1.0 / v : 0.0);
+      }
+      const double zq = tid < BP ? Lg[size_t(mt) * M1 + c0 + tid] : 0.0;
+      lds_barrier();
+      if (tid < BP) {
+        double pd = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pd += ps[q * 33 + tid];
+        w32[tid] = zq - pd;
+      }
+      lds_barrier();
+      if (tid < 8 * BP) {
+        const int r = tid >> 3, part8 = tid & 7;
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += Mt[r * 33 + 4 * part8 + u] * w32[4 * part8 + u];
+        acc = row8_sum(acc);
+        if (part8 == 0) { ybig[c0 + r] = acc; a.y[ns0 + c0 + r] = acc; }
+      }
+    }
+  }
   if (ho.word) {      // the back-substitution workgroups of this launch are waiting for the solution
     if (tid < m) store_sc1(a.y + n + tid, yv[tid]);
     handoff_publish(ho);
   } else if (tid < m) a.y[n + tid] = yv[tid];
   if (wave == 0 && lane == 0 && !(pmin > 0.0)) st->chol_failed = 1;
 }
-__global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveArgs a, int nsl, int t0) {
+__global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveArgs a, int nsl, int t0, int outer_back) {
   extern __shared__ double lds[];
-  dense_block_solve_body(a, nsl, lds, Handoff{nullptr, 0}, t0);
+  dense_block_solve_body(a, nsl, lds, Handoff{nullptr, 0}, t0, outer_back);
 }
 // The dense reduced solve (workgroup 0) and the first back-substitution launch behind it (the other workgroups) in ONE
 // launch: the nodes request everything they need that the reduced solve does not produce -- L⁻ᵀ, Z^A, Z^B, border rows,
@@ -1635,8 +1684,8 @@ hipError_t configure_dense_block_solve() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_block_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                              int(dense_block_solve_lds_bytes()));
 }
-void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s, int t0) {
-  hipLaunchKernelGGL(dense_block_solve_kernel, dim3(1), dim3(kDenseThreads), dense_block_solve_lds_bytes(), s, a, ks, t0);
+void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s, int t0, int outer_back) {
+  hipLaunchKernelGGL(dense_block_solve_kernel, dim3(1), dim3(kDenseThreads), dense_block_solve_lds_bytes(), s, a, ks, t0, outer_back);
 }
 // ---------------------------------------------------------------------------
 // Large reduced systems (m + 1 > 128): one step of the blocked right-looking factorisation, 32 columns, over several
@@ -1751,11 +1800,11 @@ __global__ __launch_bounds__(kStepThreads) void reduced_block_step_mfma_kernel(S
   }
   lds_barrier();
   // ---- file the panel: L_jj (workgroup 0), the rows below (first tile column) ----
-  if (blockIdx.x == 0) {
+  if (blockIdx.x == 0) {      // (L⁻ᵀ in the strict upper triangle beside L: the backward sweep multiplies by it, its diagonal is 1 / L_rr)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int e = tid + kStepThreads * u, r = e >> 5, c = e & 31;
-      if (c <= r) L[size_t(c0 + r) * m1 + c0 + c] = Daug[r * DLD + c];
+      L[size_t(c0 + r) * m1 + c0 + c] = c <= r ? Daug[r * DLD + c] : Daug[(BP + r) * DLD + c];
     }
   }
   if (K == 0) {

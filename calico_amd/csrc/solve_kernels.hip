@@ -1829,7 +1829,7 @@ static bool reduced_is_blocked(const SolveArgs& a) {
 // K-slices of the Schur complement the reduced solve adds up on load
 int reduced_schur_slices(const SolveArgs& a) { return (a.m + 1 <= 128 || reduced_is_blocked(a)) ? kSchurSlices : 1; }
 // Dense solve of the (m+1)x(m+1) augmented reduced system in a.Spart (ks K-slices) -> a.y[n_s ...]
-void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s, int t0 = 0);     // bcr_kernels.hip
+void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s, int t0 = 0, int outer_back = 0);     // bcr_kernels.hip
 void launch_reduced_block_step(const SolveArgs& a, int j, int nsl, int n_wg, hipStream_t s);     // bcr_kernels.hip
 void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipStream_t s) {
   const int m1 = a.m + 1;
@@ -1845,20 +1845,22 @@ void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipSt
     // panels are eliminated over all CUs until what is left fits the in-LDS solver, which finishes the factorisation
     // and solves for its unknowns; the blocked backward sweep takes it from there
     const int steps = (m1 - 128 + kRB - 1) / kRB, t0 = kRB * steps, mt1 = m1 - t0;
+    // CALICO_BLOCK_STEP=valu: round 2's step kernel (in-wave column Cholesky on 64 rows, VALU tile update) and backward
+    // sweep in a launch of its own -- A/B switch
+    static const bool step_mfma = [] { const char* e = std::getenv("CALICO_BLOCK_STEP"); return !(e && std::string(e) == "valu"); }();
     for (int j = 0; j < steps; ++j) {
       const int rows = m1 - kRB * (j + 1), T = rows > 0 ? (rows + 63) / 64 : 0;
-      // CALICO_BLOCK_STEP=valu: round 2's step kernel (in-wave column Cholesky on 64 rows, VALU tile update) -- A/B switch
-      static const bool step_mfma = [] { const char* e = std::getenv("CALICO_BLOCK_STEP"); return !(e && std::string(e) == "valu"); }();
       if (step_mfma) launch_reduced_block_step(a, j, j == 0 ? ks : 1, T > 0 ? T * (T + 1) / 2 : 1, s);
       else hipLaunchKernelGGL(reduced_block_step_kernel, dim3(T > 0 ? T * (T + 1) / 2 : 1), dim3(256), 0, s, a, j, j == 0 ? ks : 1);
     }
-    if (use_block && mt1 >= 2) launch_dense_block_solve(a, 1, s, t0);     // (the 32-column-block solver of the small systems)
+    const bool fused_back = step_mfma && use_block && mt1 >= 2 && a.m <= 1024;     // (the dense solver goes on with the panels' backward sweep)
+    if (use_block && mt1 >= 2) launch_dense_block_solve(a, 1, s, t0, fused_back ? 1 : 0);     // (the 32-column-block solver of the small systems)
     else {
       const size_t lds = (size_t(mt1) * ((16 * ((mt1 + 15) / 16)) | 1) + mt1 + 32 + 128 + 256) * sizeof(double);
       if (mt1 <= 64) hipLaunchKernelGGL(reduced_solve_panel_kernel<1>, dim3(1), dim3(256), lds, s, a, t0, 1);
       else hipLaunchKernelGGL(reduced_solve_panel_kernel<2>, dim3(1), dim3(256), lds, s, a, t0, 1);
     }
-    hipLaunchKernelGGL(reduced_block_back_kernel, dim3(1), dim3(256), 0, s, a, steps);
+    if (!fused_back) hipLaunchKernelGGL(reduced_block_back_kernel, dim3(1), dim3(256), 0, s, a, steps);
   } else if (m1 <= 16 * 13) {
     const int NT = m1 <= 64 ? 4 : (m1 <= 112 ? 7 : (m1 <= 160 ? 10 : 13));
     const int NP = 16 * NT;
