@@ -50,7 +50,7 @@ void launch_mark_outliers(const double* res, const uint8_t* valid, uint8_t* acti
 hipError_t configure_eval_kernels(size_t max_lds_bytes);
 
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
-                   int n_thin, int n_thin8, int thin_per_lane, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
+                   int n_thin, int n_thin8, int n_thin4, int thin_per_lane, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
                    const double* cost_src, int n_cost, const LmState* st, int need_flag, size_t other_stride, hipStream_t s, const ControlTail* tail = nullptr);
 void launch_gather_lists(const GatherStruct& gs, int n_out, int* cnt, int* out_idx, int64_t* ptr, int* idx, int zero_slot, hipStream_t s);
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
@@ -264,7 +264,7 @@ struct PlanHost {
   int frame_lds_doubles = 0;
   int n_fitems = 0, n_jac_items = 0;
   int n_thin = 0, n_fat = 0;
-  int n_thin8 = 0;             // thin outputs [0, n_thin8) take eight lanes, [n_thin8, n_thin) one (at most eight sources each)
+  int n_thin8 = 0, n_thin4 = 0;  // thin outputs [0, n_thin8) take eight lanes, [n_thin8, n_thin4) four (<= 24 sources), [n_thin4, n_thin) one (<= 8)
   int thin_per_lane = 6;       // sources per lane of a thin output's eight lanes (6: up to 48 sources, 12: up to 96)
   bool dense_in_lds = true;
   int gather_owner_block = 0;
@@ -1018,7 +1018,7 @@ int build_plan(calico_problem* p) {
     }
   }
   p->n_thin = int(out_thin.size()); p->n_fat = int(out_fat.size());
-  p->n_thin8 = p->n_thin;
+  p->n_thin8 = p->n_thin; p->n_thin4 = p->n_thin;
   p->gather_owner_block = 0;
   section("gather lists");
   // ---- upload of the structure ----
@@ -1065,7 +1065,12 @@ int build_plan(calico_problem* p) {
       one_layout = holders <= 1;
     }
     static const bool tiny_env = [] { const char* e = std::getenv("CALICO_GATHER_TINY"); return !e || std::atoi(e) != 0; }();
-    p->n_thin8 = (one_layout && tiny_env) ? NS + n_cp * k * 36 : p->n_thin;
+    const int n_border0 = NS + n_cp * k * 36;          // first border output
+    p->n_thin4 = (one_layout && tiny_env) ? n_border0 : p->n_thin;
+    // band blocks at distance d from the diagonal have (k - d) segments per layout: four lanes where that is <= 24 sources
+    int d4 = k;
+    while (d4 > 0 && (k - (d4 - 1)) * gsd.n_lay <= 24) --d4;
+    p->n_thin8 = (one_layout && tiny_env) ? std::min(n_border0, NS + d4 * n_cp * 36) : p->n_thin;     // (the classes are ranges: [8 | 4 | 1])
   } else {
     HIP_TRY(p, p->d_out_thin.upload(out_thin, s)); HIP_TRY(p, p->d_idx_thin.upload(idx_thin, s));
     HIP_TRY(p, p->d_ptr_thin.upload(ptr_thin, s));
@@ -1458,7 +1463,7 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, c
     HIP_TRY(p, hipMemsetAsync(target, 0, p->r_size * sizeof(double), p->stream));
   }
   launch_expand_cells(ea, p->stream);                     // compact frame records -> one expanded block per cell
-  launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->n_thin8, p->thin_per_lane, p->d_out_fat.p,
+  launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->n_thin8, p->n_thin4, p->thin_per_lane, p->d_out_fat.p,
                 p->d_ptr_fat.p, p->d_idx_fat.p, p->n_fat, p->d_partials.p + p->partial_doubles, p->n_fitems + p->n_jac_items, st, need_flag,
                 spec ? p->r_size : 0, p->stream, tail);
   p->timer.end(p->stream);

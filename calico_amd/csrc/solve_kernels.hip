@@ -48,8 +48,8 @@ DEVI void publish(int* word, int value);
 // segment). The host therefore uploads three small tables instead of building the lists (4.4 of the 8.9 ms a fresh
 // finalize took at configs[3]): the cells' blocks [n_lay][nseg], the local column of every calibration column in every
 // layout [n_lay][m], the block side of every layout [n_lay] -- and three launches turn them into the same CSR lists the
-// per-iteration gather reads (count, scan, fill). Outputs are numbered in the order of R: the spline right-hand side, the band blocks, the
-// border (row-major over the spline rows and the calibration columns). An output nothing
+// per-iteration gather reads (count, scan, fill). Outputs are numbered: the spline right-hand side, the band blocks (by distance
+// from the diagonal, then in time), the border (row-major over the spline rows and the calibration columns). An output nothing
 // contributes to (a control point beyond the trajectory's end in the band's layout) gets one source, a word that is
 // always zero (`zero_slot`), so that every output has a list.
 // ---------------------------------------------------------------------------
@@ -65,10 +65,13 @@ DEVI StructOut struct_output(const GatherStruct& gs, int o) {
     q.a = q.b = ti / 6; q.r = ti % 6; q.rhs = 1;
     q.dst = size_t(gs.off_g) + size_t(ti);
   } else if (o < NS + n_b) {
-    const int e = o - NS, blk = e / 36, w = e - 36 * blk;
-    q.a = blk / gs.k; q.b = q.a + blk % gs.k;
+    // band blocks by distance from the diagonal first (d = b - a), then in time: the blocks of a distance share their list
+    // length ((k - d) segments per layout), so the short lists -- which the gather gives fewer lanes -- are one range
+    const int e = o - NS, bd = e / 36, w = e - 36 * bd;
+    const int d = bd / gs.n_cp;
+    q.a = bd - d * gs.n_cp; q.b = q.a + d;
     q.r = w / 6; q.c = w % 6;
-    q.dst = size_t(gs.off_B) + size_t(e);
+    q.dst = size_t(gs.off_B) + size_t(q.a * gs.k + d) * 36 + size_t(w);
   } else {
     const int e = o - NS - n_b, ti = e / gs.m;
     q.tc = e - ti * gs.m;
@@ -150,28 +153,33 @@ void launch_gather_lists(const GatherStruct& gs, int n_out, int* cnt, int* out_i
 
 // `tail`: the LM control stage rides in the workgroup that finishes last (see ControlTail).
 // U: sources per lane of a thin output (eight lanes): 6, or 12 for problems with outputs of 49..96 sources.
-// Thin outputs [n_thin8, n_thin) have at most EIGHT sources each (the border: one layout's cells over the k segments of
-// a control point) and take one lane instead of eight: an eighth of the threads for two thirds of the outputs.
+// Thin outputs [n_thin4, n_thin) have at most EIGHT sources each (the border: one layout's cells over the k segments of
+// a control point) and take one lane instead of eight: an eighth of the threads for two thirds of the outputs; outputs
+// [n_thin8, n_thin4) have at most 24 (the band's blocks away from the diagonal) and take four.
 template <int U>
 __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, const double* __restrict__ src,
                                                      const int* __restrict__ out_thin, const int64_t* __restrict__ ptr_thin,
-                                                     const int* __restrict__ idx_thin, int n_thin, int n_thin8,
+                                                     const int* __restrict__ idx_thin, int n_thin, int n_thin8, int n_thin4,
                                                      const int* __restrict__ out_fat, const int64_t* __restrict__ ptr_fat,
                                                      const int* __restrict__ idx_fat, int n_fat, int nb_fat,
                                                      const double* __restrict__ cost_src, int n_cost,
                                                      const LmState* st, int need_flag, size_t other_stride, ControlTail tail) {
   // (the list pointers of this thread's output do not depend on the state: requested before the flags are looked at)
   int64_t pre_q0 = 0, pre_q1 = 0;
-  const int nb_thin8 = (n_thin8 + 31) / 32;
+  const int nb_thin8 = (n_thin8 + 31) / 32, nb_thin4 = (n_thin4 - n_thin8 + 63) / 64;
   int o_thin = 0;
-  bool tiny = false;
+  int cls = 8;       // lanes per output of this workgroup's thin outputs
   {
     const int bidp = int(blockIdx.x) - 1;
     if (bidp >= nb_fat && n_thin > 0) {
       const int tb = bidp - nb_fat;
       int oc;
       if (tb < nb_thin8) { o_thin = (tb * int(blockDim.x) + int(threadIdx.x)) >> 3; oc = o_thin < n_thin8 ? o_thin : n_thin8 - 1; }
-      else { tiny = true; o_thin = n_thin8 + (tb - nb_thin8) * int(blockDim.x) + int(threadIdx.x); oc = o_thin < n_thin ? o_thin : n_thin - 1; }
+      else if (tb < nb_thin8 + nb_thin4) {
+        cls = 4; o_thin = n_thin8 + (((tb - nb_thin8) * int(blockDim.x) + int(threadIdx.x)) >> 2); oc = o_thin < n_thin4 ? o_thin : n_thin4 - 1;
+      } else {
+        cls = 1; o_thin = n_thin4 + (tb - nb_thin8 - nb_thin4) * int(blockDim.x) + int(threadIdx.x); oc = o_thin < n_thin ? o_thin : n_thin - 1;
+      }
       pre_q0 = ptr_thin[oc]; pre_q1 = ptr_thin[oc + 1];
     }
   }
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
     s = wave_sum(s);
     if (live && lane == 0) R[out_fat[wave]] = s;
   } else {
-    if (tiny) {      // one lane per output, at most eight sources, summed in list order
+    if (cls == 1) {      // one lane per output, at most eight sources, summed in list order
       const int o = o_thin;
       const int64_t q0 = pre_q0, q1 = pre_q1;
       int id[8];
@@ -250,6 +258,22 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += q0 + u < q1 ? v[u] : 0.0;
       if (o < n_thin) R[dst] = s;
+      return;
+    }
+    if (cls == 4) {      // four lanes per output, at most 24 sources
+      const int o = o_thin, sub = int(threadIdx.x) & 3;
+      const int64_t q0 = pre_q0, q1 = pre_q1;
+      int id[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) { const int64_t q = q0 + sub + 4 * u; id[u] = idx_thin[q < q1 ? q : q1 - 1]; }
+      double v[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) v[u] = src[id[u]];
+      double s = 0.0;
+#pragma unroll
+      for (int u = 0; u < 6; ++u) s += q0 + sub + 4 * u < q1 ? v[u] : 0.0;
+      s = row4_sum(s);
+      if (o < n_thin4 && sub == 0) R[out_thin[o]] = s;
       return;
     }
     const int o = o_thin, sub = int(threadIdx.x) & 7;
@@ -1767,18 +1791,18 @@ __global__ void init_state_kernel(LmState* st, double radius, double x_norm, con
 
 // ---- launch helpers ---------------------------------------------------------
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
-                   int n_thin, int n_thin8, int thin_per_lane, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
+                   int n_thin, int n_thin8, int n_thin4, int thin_per_lane, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
                    const double* cost_src, int n_cost,
                    const LmState* st, int need_flag, size_t other_stride, hipStream_t s, const ControlTail* tail) {
-  const int nb_thin = (n_thin8 + 31) / 32 + (n_thin - n_thin8 + 255) / 256, nb_fat = (n_fat + 3) / 4;
+  const int nb_thin = (n_thin8 + 31) / 32 + (n_thin4 - n_thin8 + 63) / 64 + (n_thin - n_thin4 + 255) / 256, nb_fat = (n_fat + 3) / 4;
   ControlTail t;
   if (tail) t = *tail; else { t = ControlTail(); t.enabled = 0; }
   // workgroup 0: cost / invalid count (+ control stage), then the fat outputs, then the thin ones
   if (thin_per_lane <= 6)
-    hipLaunchKernelGGL(gather_kernel<6>, dim3(1 + nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin, n_thin8,
+    hipLaunchKernelGGL(gather_kernel<6>, dim3(1 + nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin, n_thin8, n_thin4,
                        out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, cost_src, n_cost, st, need_flag, other_stride, t);
   else
-    hipLaunchKernelGGL(gather_kernel<12>, dim3(1 + nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin, n_thin8,
+    hipLaunchKernelGGL(gather_kernel<12>, dim3(1 + nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin, n_thin8, n_thin4,
                        out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, cost_src, n_cost, st, need_flag, other_stride, t);
 }
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
