@@ -340,15 +340,74 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     // reads them in this launch). At level 0 they are initialised from R(x) instead.
     const size_t aw = size_t(bid - n_nodes * per), naw = size_t(grid_l - n_nodes * per - (FROM_R && with_post ? 1 : 0));
     const size_t per_blk = size_t(BB) + fblk;
+    if (FROM_R) {
+      // four entries per thread and pass, their reads of R (and of the Jacobi scale, for the diagonal) requested together:
+      // one entry at a time the loop waited out two dependent round trips per entry, and with a long trajectory's sixty
+      // separators these workgroups, not the chains, ended the launch (1453 control points: level 0 45 us)
+      const size_t total = size_t(n_keep) * per_blk, stride = naw * kLevelThreads;
+      const int n_s = a.n_s();
+      for (size_t e0 = aw * kLevelThreads + tid; e0 < total; e0 += 4 * stride) {
+        size_t ridx[4], didx[4];
+        int trd[4], flags[4];          // flags: 1 entry exists, 2 value comes from R, 4 diagonal entry, 8 row exists in the trajectory, 16 goes to b.F
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const size_t e = e0 + u * stride;
+          const size_t ec = e < total ? e : total - 1;
+          const int kb = int(ec / per_blk);
+          const size_t rem = ec - size_t(kb) * per_blk;
+          const int blk = b.keep[2 * (keep0 + kb)];
+          int fl = e < total ? 1 : 0;
+          size_t ri = 0;
+          int tr_d = 0;
+          if (rem < size_t(BB)) {
+            const int r = int(rem) >> 5, c = int(rem) & 31;
+            const int tr = fr.trow(blk, r), tc = fr.trow(blk, c);
+            const int hi = max(tr, tc), lo = min(tr, tc);
+            const int lo_c = max(lo, 0), ic = lo_c / 6, cc = lo_c % 6, ir = max(hi, 0) / 6, rr = max(hi, 0) % 6, d = ir - ic;
+            const bool ok = lo >= 0 && d < a.k;
+            ri = a.off_B() + (size_t(ic) * a.k + (ok ? d : 0)) * 36 + cc * 6 + rr;
+            if (ok) fl |= 2;
+            if (r == c) { fl |= 4; const int t = FromR::RB * blk + r; if (r < FromR::RB && t < n_s) fl |= 8; tr_d = tr >= 0 ? tr : -1 - (t < n_s ? t : 0); }
+            didx[u] = size_t(blk) * BB + rem;
+          } else {
+            const size_t q = rem - BB;
+            const int r = int(q / m1p), j = int(q % m1p);
+            const int tr = fr.trow(blk, r), t = max(tr, 0), jc = min(j, a.mc);
+            ri = j < a.mc ? a.off_E() + size_t(t) * a.mc + jc : a.off_g() + t;
+            if (tr >= 0 && j <= a.mc) fl |= 2;
+            fl |= 16;
+            didx[u] = size_t(blk) * fblk + q;
+          }
+          ridx[u] = ri; trd[u] = tr_d; flags[u] = fl;
+        }
+        double rv[4], sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { rv[u] = a.R[ridx[u]]; sc[u] = a.scale[(flags[u] & 4) ? max(trd[u], 0) : 0]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int fl = flags[u];
+          if (!(fl & 1)) continue;
+          double v = (fl & 2) ? rv[u] : 0.0;
+          if (fl & 4) {        // diagonal: LM damping of an observed row, identity for padding / unobserved rows (see FromR::diag_block)
+            if (trd[u] >= 0) {
+              const double sv = sc[u];
+              const double dd = fmin(fmax(v * sv * sv, o.min_lm_diagonal), o.max_lm_diagonal) / (radius * sv * sv);     // FromR::damping
+              v += dd; a.dadd[trd[u]] = dd;
+            } else {
+              v = 1.0;
+              if (fl & 8) a.dadd[-1 - trd[u]] = 0.0;
+            }
+          }
+          if (fl & 16) b.F[didx[u]] = v; else b.D[didx[u]] = v;
+        }
+      }
+      if (pub) fanin_arrive(fan_word);
+      return;
+    }
     for (size_t e = aw * kLevelThreads + tid; e < size_t(n_keep) * per_blk; e += naw * kLevelThreads) {
       const int kb = int(e / per_blk);
       const size_t rem = e % per_blk;
       const int blk = b.keep[2 * (keep0 + kb)], mask = b.keep[2 * (keep0 + kb) + 1];
-      if (FROM_R) {
-        if (rem < size_t(BB)) b.D[size_t(blk) * BB + rem] = fr.diag_block(blk, int(rem) >> 5, int(rem) & 31, true);
-        else { const size_t q = rem - BB; b.F[size_t(blk) * fblk + q] = fr.border(blk, int(q / m1p), int(q % m1p)); }
-        continue;
-      }
       if (rem < size_t(BB)) {
         double v = b.D[size_t(blk) * BB + rem];
         if (mask & 1) v += pendD_r[(size_t(blk) * 2 + 0) * BB + rem];
