@@ -1859,7 +1859,7 @@ void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipSt
   const int m1 = a.m + 1;
   const bool blocked = reduced_is_blocked(a);
   // CALICO_DENSE=panel keeps the 16-column panel kernel for the in-LDS case (A/B switch)
-  static const bool use_block = [] { const char* e = std::getenv("CALICO_DENSE"); return !(e && std::string(e) == "panel"); }();
+  const bool use_block = [] { const char* e = std::getenv("CALICO_DENSE"); return !(e && std::string(e) == "panel"); }();      // (read per solve: A/B switches)
   if (m1 <= 128 && a.m >= 1 && use_block && ks <= 2) { launch_dense_block_solve(a, ks, s); return; }
   if (m1 <= 128) {
     const size_t lds = (size_t(m1) * ((16 * ((m1 + 15) / 16)) | 1) + m1 + 32 + 128 + 256) * sizeof(double);
@@ -1871,7 +1871,7 @@ void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipSt
     const int steps = (m1 - 128 + kRB - 1) / kRB, t0 = kRB * steps, mt1 = m1 - t0;
     // CALICO_BLOCK_STEP=valu: round 2's step kernel (in-wave column Cholesky on 64 rows, VALU tile update) and backward
     // sweep in a launch of its own -- A/B switch
-    static const bool step_mfma = [] { const char* e = std::getenv("CALICO_BLOCK_STEP"); return !(e && std::string(e) == "valu"); }();
+    const bool step_mfma = [] { const char* e = std::getenv("CALICO_BLOCK_STEP"); return !(e && std::string(e) == "valu"); }();
     for (int j = 0; j < steps; ++j) {
       const int rows = m1 - kRB * (j + 1), T = rows > 0 ? (rows + 63) / 64 : 0;
       if (step_mfma) launch_reduced_block_step(a, j, j == 0 ? ks : 1, T > 0 ? T * (T + 1) / 2 : 1, s);

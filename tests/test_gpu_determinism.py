@@ -187,3 +187,36 @@ def test_back_to_back_solves_behind_leftover_kernels():
         got = run(1)
         assert got[0] == ref[1][0] and got[2] == ref[1][2]
     assert run(30)[3] == ref[30][3]
+
+
+@pytest.mark.gpu
+def test_large_reduced_system_kernels_agree(monkeypatch):
+    """Rigs of many sensors have a reduced system of more than 128 columns (eight cameras + two IMUs: 220): it is factored
+    panel by panel over several workgroups (reduced_block_step_mfma_kernel: the tree nodes' parts on the matrix cores),
+    the remainder and the panels' backward sweep by the in-LDS 32-column-block solver. Round 2's kernels (64-row in-wave
+    column Cholesky, VALU tile update, backward sweep in a launch of its own) stay behind CALICO_BLOCK_STEP=valu, the
+    16-column panel solver for the remainder behind CALICO_DENSE=panel: the same algorithm in another order -- same
+    iterations, estimates equal to rounding; and the default path is reproducible bit for bit."""
+    api = helpers.hip_api()
+    scene = syn.make_scene(8, 1, True, 3, cam_rate=5.0, imu_rate=50.0, duration=4.0, chart="april", seed=31,
+                           pixel_noise=0.1, gyro_noise=1e-3, accel_noise=1e-2, robust=True, segment_duration=4.0 / 23.9,
+                           max_cam_obs=20000, n_imus=2)
+    runs = {}
+    for step, dense in (("", ""), ("valu", ""), ("", "panel")):
+        if step:
+            monkeypatch.setenv("CALICO_BLOCK_STEP", step)
+        else:
+            monkeypatch.delenv("CALICO_BLOCK_STEP", raising=False)
+        if dense:
+            monkeypatch.setenv("CALICO_DENSE", dense)
+        else:
+            monkeypatch.delenv("CALICO_DENSE", raising=False)
+        runs[(step, dense)] = _solve_repeatedly(api, scene, repeats=2, max_iter=20)
+    ref = runs[("", "")]
+    assert ref[0][0] > 3
+    assert ref[0][2] == ref[1][2] and np.array_equal(ref[0][3], ref[1][3]), "the default path is not reproducible"
+    for key, rr in runs.items():
+        for r in rr:
+            assert r[0] == ref[0][0] and r[1] == ref[0][1], key
+            np.testing.assert_allclose(r[2], ref[0][2], rtol=1e-9, err_msg=str(key))
+            np.testing.assert_allclose(r[3], ref[0][3], rtol=1e-7, atol=1e-9, err_msg=str(key))
