@@ -1923,8 +1923,8 @@ static size_t dense_back_lds(int q_max, int m1p) {
   const int qm = q_max <= 1 ? 1 : (q_max <= 2 ? 2 : 4);
   return std::max(std::max(dense_block_solve_lds_bytes(), bcr_back_lds_bytes(q_max, m1p)), bcr_back_pre_lds_doubles(qm) * sizeof(double));
 }
-hipError_t configure_dense_back(int q_max, int m1p) {
-  const size_t lds = dense_back_lds(q_max, m1p);
+size_t dense_back_lds_bytes(int q_max, int m1p) { return dense_back_lds(q_max, m1p); }
+hipError_t configure_dense_back_bytes(size_t lds) {
   for (const void* f : {reinterpret_cast<const void*>(&dense_back_kernel<1, 1, false>), reinterpret_cast<const void*>(&dense_back_kernel<2, 1, false>),
                         reinterpret_cast<const void*>(&dense_back_kernel<4, 1, false>), reinterpret_cast<const void*>(&dense_back_kernel<1, 2, false>),
                         reinterpret_cast<const void*>(&dense_back_kernel<2, 2, false>), reinterpret_cast<const void*>(&dense_back_kernel<4, 2, false>),

@@ -90,7 +90,8 @@ void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_node
 
 void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipStream_t s);
 bool dense_back_fusable(const SolveArgs& a, int ks, int q_max, bool border_rows);
-hipError_t configure_dense_back(int q_max, int m1p);
+size_t dense_back_lds_bytes(int q_max, int m1p);
+hipError_t configure_dense_back_bytes(size_t lds);
 void launch_dense_back(const SolveArgs& a, const BcrArgs& b, int ks, int node0, int n_nodes, int q_max, const double* x, double* x_cand,
                        const BlockDev* blocks, int n_blocks, const BcrTopSeps& ts, int* word, int seq, hipStream_t s);
 int reduced_schur_slices(const SolveArgs& a);
@@ -619,9 +620,12 @@ int build_plan(calico_problem* p) {
     d.intr_off = p->blocks[s.intr].amb_off; d.q_off = p->blocks[s.q].amb_off; d.t_off = p->blocks[s.t].amb_off;
     d.lat_off = p->blocks[s.lat].amb_off; d.grav_off = s.grav >= 0 ? p->blocks[s.grav].amb_off : 0; d.pad0 = 0;
     d.info = s.info; d.loss_scale = s.loss_scale;
+    std::array<int, 3> seen = {-2, -2, -2};       // (consecutive observations mostly share their layout: one compare instead of a map look-up)
     for (int64_t i = 0; i < s.n(); ++i) {
       const int body = s.kind == CALICO_SENSOR_CAMERA ? s.body[i] : -1;
       const std::array<int, 3> lkey = layout_key(si, s, i);
+      if (lkey == seen) continue;
+      seen = lkey;
       if (layout_of.count(lkey)) continue;
       LayoutDev L;
       L.sensor = int(si); L.c_pt = -1;
@@ -657,8 +661,12 @@ int build_plan(calico_problem* p) {
   for (size_t si = 0; si < p->sensors.size(); ++si) {
     HSensor& s = p->sensors[si];
     s.sorted_pos.assign(size_t(s.n()), 0);
+    std::array<int, 3> seen = {-2, -2, -2};
+    int seen_layout = -1;
     for (int64_t i = 0; i < s.n(); ++i) {
-      keys.push_back({layout_of[layout_key(si, s, i)], s.seg[i], int(si), i, s.stamps[size_t(i)]});
+      const std::array<int, 3> lkey = layout_key(si, s, i);
+      if (!(lkey == seen)) { seen = lkey; seen_layout = layout_of[lkey]; }
+      keys.push_back({seen_layout, s.seg[i], int(si), i, s.stamps[size_t(i)]});
     }
   }
   {
@@ -1302,17 +1310,30 @@ int upload_values(calico_problem* p) {
 }
 
 int configure_kernels(calico_problem* p) {
-  HIP_TRY(p, configure_eval_kernels(size_t(p->lds_cols) * p->row_pad * sizeof(double)));
   const SolveArgs sa = make_solve_args(p);
   const size_t reduced_lds = reduced_solve_lds_bytes(sa);
-  HIP_TRY(p, configure_solve_kernels(band_cholesky_lds_bytes(sa), p->dense_in_lds ? reduced_lds : 0, band_backsolve_lds_bytes(sa)));
+  // The kernels' dynamic-LDS limits depend on a handful of sizes. They are only ever RAISED on a device (two live handles
+  // of different shapes must not lower each other's limits), and the forty-odd hipFuncSetAttribute calls (0.3 ms) are
+  // skipped when the device already allows what this handle needs -- every handle of a known structure, and most others.
+  const bool db_fits = p->use_bcr && std::max(dense_block_solve_lds_bytes(), bcr_back_lds_bytes(std::min(p->bcr_q_max, 4), p->bcr_m1p)) + 1024 <= kMaxLds;
+  const std::array<size_t, 8> want = {size_t(p->lds_cols) * p->row_pad * sizeof(double), band_cholesky_lds_bytes(sa),
+                                      p->dense_in_lds ? reduced_lds : 0, band_backsolve_lds_bytes(sa), size_t(p->use_bcr ? 1 : 0),
+                                      size_t(p->use_bcr ? p->bcr_q_max : 0), size_t(p->use_bcr ? p->bcr_m1p : 0),
+                                      db_fits ? dense_back_lds_bytes(std::min(p->bcr_q_max, 4), p->bcr_m1p) : 0};
+  static std::mutex mu;
+  static std::map<int, std::array<size_t, 8>> allowed;
+  std::lock_guard<std::mutex> lock(mu);
+  std::array<size_t, 8>& cur = allowed[p->device];       // (zeros for a device seen for the first time)
+  std::array<size_t, 8> nw;
+  for (size_t i = 0; i < nw.size(); ++i) nw[i] = std::max(cur[i], want[i]);
+  if (nw == cur) return CALICO_OK;
+  HIP_TRY(p, configure_eval_kernels(nw[0]));
+  HIP_TRY(p, configure_solve_kernels(nw[1], nw[2], nw[3]));
   HIP_TRY(p, configure_dense_block_solve());
   HIP_TRY(p, configure_reduced_block_step());
-  if (p->use_bcr) {
-    HIP_TRY(p, configure_bcr_kernels(p->bcr_q_max, p->bcr_m1p));
-    if (std::max(dense_block_solve_lds_bytes(), bcr_back_lds_bytes(std::min(p->bcr_q_max, 4), p->bcr_m1p)) + 1024 <= kMaxLds)
-      HIP_TRY(p, configure_dense_back(std::min(p->bcr_q_max, 4), p->bcr_m1p));
-  }
+  if (nw[4]) HIP_TRY(p, configure_bcr_kernels(int(nw[5]), int(nw[6])));
+  if (nw[7]) HIP_TRY(p, configure_dense_back_bytes(nw[7]));
+  cur = nw;
   return CALICO_OK;
 }
 
