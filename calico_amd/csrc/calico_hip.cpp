@@ -362,7 +362,9 @@ struct calico_problem : PlanHost, PlanDev, Workspace {
   int rank = 0, world = 1;
   std::shared_ptr<PlanEntry> plan;    // the cached plan this handle's structure buffers are views of (null: it owns them)
 
-  std::vector<double> h_x, h_m0, h_m1, h_m2;     // staging of the values (alive until the uploads are through)
+  std::vector<double> h_x;     // staging of the parameter values (alive until the upload is through)
+  double* h_mpin = nullptr;    // pinned staging of the measurements in device order [m0 | m1 | m2], borrowed from the process-wide pool for the duration of finalize
+  size_t h_mpin_n = 0;
   bool active_dirty = true;
   bool any_tagged = false;       // some observation is tagged as an outlier: the kernels look at the tags only then
   bool xc_stale = true;       // the candidate buffer must be re-seeded with the constant blocks' values
@@ -1161,6 +1163,20 @@ struct Hasher {
   void bytes(const void* p, size_t n) {
     const unsigned char* c = static_cast<const unsigned char*>(p);
     size_t i = 0;
+    if (n >= 256) {
+      // long arrays (stamps, ids): four independent lanes of 64-bit words, folded into the two running mixes -- the
+      // single multiply chain above hashes at the latency of its multiplications, not at memory speed
+      uint64_t l0 = 0x243F6A8885A308D3ull, l1 = 0x13198A2E03707344ull, l2 = 0xA4093822299F31D0ull, l3 = 0x082EFA98EC4E6C89ull;
+      for (; i + 32 <= n; i += 32) {
+        uint64_t w[4];
+        std::memcpy(w, c + i, 32);
+        l0 = (l0 ^ w[0]) * 0xff51afd7ed558ccdull; l0 ^= l0 >> 32;
+        l1 = (l1 ^ w[1]) * 0xc4ceb9fe1a85ec53ull; l1 ^= l1 >> 29;
+        l2 = (l2 ^ w[2]) * 0x9E3779B97F4A7C15ull; l2 ^= l2 >> 31;
+        l3 = (l3 ^ w[3]) * 0xD6E8FEB86659FD93ull; l3 ^= l3 >> 30;
+      }
+      word(l0); word(l1); word(l2); word(l3);
+    }
     for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, c + i, 8); word(w); }
     if (i < n) { uint64_t w = 0; std::memcpy(&w, c + i, n - i); word(w ^ (uint64_t(n - i) << 56)); }
   }
@@ -1282,23 +1298,59 @@ int prepare_workspace(calico_problem* p) {
   return CALICO_OK;
 }
 
+// Pinned staging buffers for the measurement upload, shared by all handles of the process: a handle holds one from
+// upload_values to the synchronisation at the end of finalize (hipHostMalloc costs more than the upload it speeds up).
+struct PinnedPool {
+  std::mutex mu;
+  std::vector<std::pair<double*, size_t>> idle;
+  double* acquire(size_t n, size_t* cap) {
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      for (size_t i = 0; i < idle.size(); ++i)
+        if (idle[i].second >= n) { double* q = idle[i].first; *cap = idle[i].second; idle.erase(idle.begin() + long(i)); return q; }
+    }
+    double* q = nullptr;
+    const size_t c = n + n / 4;       // (some slack: the next structure is often a little larger)
+    if (hipHostMalloc(reinterpret_cast<void**>(&q), c * sizeof(double), hipHostMallocDefault) != hipSuccess) return nullptr;
+    *cap = c;
+    return q;
+  }
+  void release(double* q, size_t cap) {
+    if (!q) return;
+    std::lock_guard<std::mutex> lock(mu);
+    if (idle.size() < 2) { idle.emplace_back(q, cap); return; }
+    size_t small = 0;
+    for (size_t i = 1; i < idle.size(); ++i) if (idle[i].second < idle[small].second) small = i;
+    if (idle[small].second < cap) { (void)hipHostFree(idle[small].first); idle[small] = {q, cap}; }
+    else (void)hipHostFree(q);
+  }
+};
+PinnedPool& pinned_pool() { static PinnedPool* pp = new PinnedPool(); return *pp; }
+
 // The values: measurements in the device's (sorted) order, parameter vector.
 int upload_values(calico_problem* p) {
   hipStream_t s = p->stream;
   const size_t n = size_t(std::max<int64_t>(p->n_obs, 1));
-  p->h_m0.assign(n, 0.0); p->h_m1.assign(n, 0.0); p->h_m2.assign(n, 0.0);
+  // pinned staging (part of the workspace, so a pooled one brings it along): the three copies below are DMA transfers
+  // that return at once, where pageable vectors went through the runtime's bounce buffers synchronously
+  if (p->h_mpin && p->h_mpin_n < 3 * n) { pinned_pool().release(p->h_mpin, p->h_mpin_n); p->h_mpin = nullptr; p->h_mpin_n = 0; }
+  if (!p->h_mpin) {
+    p->h_mpin = pinned_pool().acquire(3 * n, &p->h_mpin_n);
+    if (!p->h_mpin) return p->set_error(CALICO_INTERNAL, "hipHostMalloc (measurement staging) failed");
+  }
+  double* m0 = p->h_mpin; double* m1 = m0 + n; double* m2 = m1 + n;
   for (const HSensor& sn : p->sensors) {
     const int dim = sn.dim();
     const int64_t ns = sn.n();
     const double* me = sn.meas.data();
     const int64_t* sp = sn.sorted_pos.data();
-    if (dim == 2) for (int64_t i = 0; i < ns; ++i) { const size_t q = size_t(sp[i]); p->h_m0[q] = me[2 * i]; p->h_m1[q] = me[2 * i + 1]; }
-    else for (int64_t i = 0; i < ns; ++i) { const size_t q = size_t(sp[i]); p->h_m0[q] = me[3 * i]; p->h_m1[q] = me[3 * i + 1]; p->h_m2[q] = me[3 * i + 2]; }
+    if (dim == 2) for (int64_t i = 0; i < ns; ++i) { const size_t q = size_t(sp[i]); m0[q] = me[2 * i]; m1[q] = me[2 * i + 1]; m2[q] = 0.0; }
+    else for (int64_t i = 0; i < ns; ++i) { const size_t q = size_t(sp[i]); m0[q] = me[3 * i]; m1[q] = me[3 * i + 1]; m2[q] = me[3 * i + 2]; }
   }
   if (p->n_obs > 0) {
-    HIP_TRY(p, hipMemcpyAsync(p->d_m0.p, p->h_m0.data(), size_t(p->n_obs) * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(p, hipMemcpyAsync(p->d_m1.p, p->h_m1.data(), size_t(p->n_obs) * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(p, hipMemcpyAsync(p->d_m2.p, p->h_m2.data(), size_t(p->n_obs) * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(p, hipMemcpyAsync(p->d_m0.p, m0, size_t(p->n_obs) * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(p, hipMemcpyAsync(p->d_m1.p, m1, size_t(p->n_obs) * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(p, hipMemcpyAsync(p->d_m2.p, m2, size_t(p->n_obs) * sizeof(double), hipMemcpyHostToDevice, s));
   }
   p->h_x.assign(size_t(p->n_amb), 0.0);
   for (const HBlock& b : p->blocks) std::copy(b.v.begin(), b.v.end(), p->h_x.begin() + b.amb_off);
@@ -1412,6 +1464,7 @@ int finalize(calico_problem* p) {
   rc = configure_kernels(p);
   if (rc != CALICO_OK) return rc;
   HIP_TRY(p, hipStreamSynchronize(p->stream));
+  pinned_pool().release(p->h_mpin, p->h_mpin_n); p->h_mpin = nullptr; p->h_mpin_n = 0;     // (the uploads are through)
   section("values + kernel attributes");
   p->dirty = false;
   return CALICO_OK;
@@ -1620,6 +1673,15 @@ const char* reason_message(int reason) {
 
 }  // namespace
 
+namespace {
+struct StreamPool {
+  std::mutex mu;
+  std::map<int, std::vector<hipStream_t>> idle;     // per device: streams of destroyed handles
+  static constexpr size_t kMaxIdle = 4;
+};
+StreamPool& stream_pool() { static StreamPool* sp = new StreamPool(); return *sp; }     // (never destroyed: the streams outlive static destruction)
+}  // namespace
+
 extern "C" {
 
 int32_t calico_problem_create(calico_problem** out, int32_t device) {
@@ -1630,7 +1692,14 @@ int32_t calico_problem_create(calico_problem** out, int32_t device) {
   if (hipSetDevice(device) != hipSuccess) return CALICO_INTERNAL;
   calico_problem* p = new calico_problem();
   p->device = device;
-  if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) { delete p; return CALICO_INTERNAL; }
+  // (a stream costs a few hundred microseconds to create: the handles of a create-solve-destroy loop pass theirs on)
+  {
+    StreamPool& sp = stream_pool();
+    std::lock_guard<std::mutex> lock(sp.mu);
+    std::vector<hipStream_t>& v = sp.idle[device];
+    if (!v.empty()) { p->stream = v.back(); v.pop_back(); }
+  }
+  if (!p->stream && hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) { delete p; return CALICO_INTERNAL; }
   p->own_stream = true;
   *out = p;
   return CALICO_OK;
@@ -1650,7 +1719,13 @@ void calico_problem_destroy(calico_problem* p) {
     std::lock_guard<std::mutex> lock(plan_cache().mu);
     if (p->plan->pool.size() < PlanCache::kMaxPool) p->plan->pool.push_back(std::move(w));
   }
-  if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+  pinned_pool().release(p->h_mpin, p->h_mpin_n); p->h_mpin = nullptr;      // (only set if a finalize failed half-way)
+  if (p->own_stream && p->stream) {      // (drained above)
+    StreamPool& sp = stream_pool();
+    std::lock_guard<std::mutex> lock(sp.mu);
+    std::vector<hipStream_t>& v = sp.idle[p->device];
+    if (v.size() < StreamPool::kMaxIdle) v.push_back(p->stream); else (void)hipStreamDestroy(p->stream);
+  }
   delete p;
 }
 
