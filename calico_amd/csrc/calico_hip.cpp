@@ -1883,8 +1883,11 @@ static int32_t add_obs(calico_problem* p, int32_t sid, int64_t n, const double* 
   const int dim = s.dim();
   // validate first so a failing call adds nothing
   std::vector<int> segs(static_cast<size_t>(n));
+  double last_t = 0.0;
+  int last_sg = -2;       // (the blocks of a camera frame share their stamp: one knot search per frame)
   for (int64_t i = 0; i < n; ++i) {
-    const int sg = spline_index(p, stamps[i]);
+    const int sg = (last_sg != -2 && stamps[i] == last_t) ? last_sg : spline_index(p, stamps[i]);
+    last_t = stamps[i]; last_sg = sg;
     if (sg < 0)
       return p->set_error(CALICO_INVALID_ARGUMENT, "measurement stamp is outside the spline's valid knots");
     segs[size_t(i)] = sg;
