@@ -368,6 +368,9 @@ struct calico_problem : PlanHost, PlanDev, Workspace {
   bool active_dirty = true;
   bool any_tagged = false;       // some observation is tagged as an outlier: the kernels look at the tags only then
   bool xc_stale = true;       // the candidate buffer must be re-seeded with the constant blocks' values
+  // residuals of ALL sensors at the parameter values `x` (calico_get_residuals / calico_project are per sensor, as
+  // Sensor::UpdateResiduals is: the second to last sensor of a write-back are served from here)
+  struct ResCache { bool valid = false, predict = false; std::vector<double> x, r; std::vector<uint8_t> v; } res_cache;
   std::vector<calico_iteration> iterations;
   PhaseTimer timer;
 
@@ -1392,6 +1395,7 @@ int configure_kernels(calico_problem* p) {
 // Plan (cached or built), workspace (pooled or allocated), values.
 int finalize(calico_problem* p) {
   if (!p->dirty) return CALICO_OK;
+  p->res_cache.valid = false;
   if (p->order <= 0) return p->set_error(CALICO_FAILED_PRECONDITION, "spline not set");
   if (p->order > 8) return p->set_error(CALICO_UNIMPLEMENTED, "spline order > 8 is not supported by the HIP kernels");
   HIP_TRY(p, hipSetDevice(p->device));
@@ -2240,19 +2244,29 @@ static int32_t residuals_or_prediction(calico_problem* p, int32_t sid, double* o
   int rc = finalize(p);
   if (rc != CALICO_OK) return rc;
   HIP_TRY(p, hipSetDevice(p->device));
-  rc = upload_x(p);
-  if (rc != CALICO_OK) return rc;
-  {
-    EvalArgs ea = make_eval_args(p, p->d_x.p, 0, true);
-    ea.items = p->d_items_all.p; ea.n_items = p->n_items_all;  // every rank re-evaluates all blocks here
-    ea.project = predict ? 1 : 0;
-    launch_eval(ea, false, p->stream);
+  // one evaluation and one download serve every sensor as long as no parameter value, measurement or tag has changed
+  calico_problem::ResCache& rc_ = p->res_cache;
+  std::vector<double> xnow(size_t(p->n_amb), 0.0);
+  for (const HBlock& b : p->blocks) std::copy(b.v.begin(), b.v.end(), xnow.begin() + b.amb_off);
+  if (!(rc_.valid && rc_.predict == predict && !p->active_dirty && rc_.x == xnow)) {
+    rc_.valid = false;
+    rc = upload_x(p);
+    if (rc != CALICO_OK) return rc;
+    {
+      EvalArgs ea = make_eval_args(p, p->d_x.p, 0, true);
+      ea.items = p->d_items_all.p; ea.n_items = p->n_items_all;  // every rank re-evaluates all blocks here
+      ea.project = predict ? 1 : 0;
+      launch_eval(ea, false, p->stream);
+    }
+    rc_.r.resize(size_t(p->n_obs) * 3);
+    rc_.v.resize(size_t(p->n_obs));
+    HIP_TRY(p, hipMemcpyAsync(rc_.r.data(), p->d_res.p, rc_.r.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(p, hipMemcpyAsync(rc_.v.data(), p->d_valid.p, rc_.v.size(), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    rc_.x.swap(xnow); rc_.predict = predict; rc_.valid = true;
   }
-  std::vector<double> r(size_t(p->n_obs) * 3);
-  std::vector<uint8_t> v(size_t(p->n_obs));
-  HIP_TRY(p, hipMemcpyAsync(r.data(), p->d_res.p, r.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  HIP_TRY(p, hipMemcpyAsync(v.data(), p->d_valid.p, v.size(), hipMemcpyDeviceToHost, p->stream));
-  HIP_TRY(p, hipStreamSynchronize(p->stream));
+  const std::vector<double>& r = rc_.r;
+  const std::vector<uint8_t>& v = rc_.v;
   const HSensor& s = p->sensors[sid];
   const int dim = s.dim();
   bool all = true;
@@ -2309,6 +2323,7 @@ int32_t calico_problem_set_outlier_mask(calico_problem* p, int32_t sid, const ui
   for (int64_t i = 0; i < s.n(); ++i) s.active[size_t(i)] = (is_outlier && is_outlier[i]) ? 0 : 1;
   s.n_active = -1;
   p->active_dirty = true;
+  p->res_cache.valid = false;
   return CALICO_OK;
 }
 
@@ -2338,6 +2353,7 @@ int32_t calico_mark_outliers(calico_problem* p, int32_t sid, double threshold, i
   HIP_TRY(p, hipStreamSynchronize(p->stream));
   for (int64_t i = 0; i < s.n(); ++i) s.active[size_t(i)] = act[size_t(s.sorted_pos[size_t(i)] - s.sorted_begin)];
   s.n_active = -1;
+  p->res_cache.valid = false;
   if (marked > 0) p->any_tagged = true;
   if (n_marked) *n_marked = marked;
   return CALICO_OK;
