@@ -114,7 +114,7 @@ def _i32(a):
 # Every symbol include/calico_hip.h declares (without prefix).
 ABI_SYMBOLS = [
     "problem_create", "problem_destroy", "last_error", "default_solver_options",
-    "problem_add_param_block", "problem_add_param_blocks", "get_param_block", "set_param_block", "set_param_blocks",
+    "problem_add_param_block", "problem_add_param_blocks", "get_param_block", "set_param_block", "set_param_blocks", "get_param_blocks",
     "problem_set_spline", "problem_add_rigid_body", "problem_add_sensor",
     "problem_add_camera_residuals", "problem_add_imu_residuals", "solve",
     "get_iterations", "get_residuals", "get_inlier_mask",
@@ -149,6 +149,7 @@ class CApi:
         g("get_param_block", C.c_int32, [P, C.c_int32, D])
         g("set_param_block", C.c_int32, [P, C.c_int32, D])
         g("set_param_blocks", C.c_int32, [P, C.c_int32, I, D])
+        g("get_param_blocks", C.c_int32, [P, C.c_int32, I, D])
         g("problem_set_spline", C.c_int32, [P, C.c_int32, C.c_int32, D, D, I])
         g("problem_add_rigid_body", C.c_int32, [P, C.c_int32, C.c_int32, I])
         g("problem_add_sensor", C.c_int32,
@@ -261,6 +262,14 @@ class Problem:
     def get_param_block(self, block_id, size):
         out = np.zeros(size)
         self._check(self.api.get_param_block(self.h, block_id, _dp(out)))
+        return out
+
+    def get_param_blocks(self, block_ids, sizes):
+        """Values of several blocks, concatenated (`sizes`: the blocks' sizes, or one size for all)."""
+        ids = _i32(block_ids)
+        total = int(np.sum(sizes)) if np.ndim(sizes) else int(sizes) * int(ids.size)
+        out = np.zeros(total)
+        self._check(self.api.get_param_blocks(self.h, ids.size, _ip(ids), _dp(out)))
         return out
 
     def set_param_block(self, block_id, values):

@@ -1811,6 +1811,19 @@ int32_t calico_set_param_block(calico_problem* p, int32_t id, const double* v) {
   return CALICO_OK;
 }
 
+int32_t calico_get_param_blocks(calico_problem* p, int32_t n, const int32_t* ids, double* out) {
+  if (!p) return CALICO_INVALID_ARGUMENT;
+  if (n < 0 || (n > 0 && (!ids || !out))) return p->set_error(CALICO_INVALID_ARGUMENT, "bad block list");
+  for (int32_t i = 0; i < n; ++i)
+    if (ids[i] < 0 || ids[i] >= int(p->blocks.size())) return p->set_error(CALICO_INVALID_ARGUMENT, "bad block id");
+  for (int32_t i = 0; i < n; ++i) {
+    const HBlock& b = p->blocks[size_t(ids[i])];
+    std::copy(b.v.begin(), b.v.end(), out);
+    out += b.size;
+  }
+  return CALICO_OK;
+}
+
 int32_t calico_set_param_blocks(calico_problem* p, int32_t n, const int32_t* ids, const double* v) {
   if (!p || n < 0 || (n > 0 && (!ids || !v))) return p ? p->set_error(CALICO_INVALID_ARGUMENT, "bad arguments") : CALICO_INVALID_ARGUMENT;
   for (int i = 0; i < n; ++i)

@@ -522,7 +522,7 @@ def read_back(built, scene):
         out.append(dict(intrinsics=P.get_param_block(b["intrinsics"], len(s.intrinsics)),
                         t=P.get_param_block(b["t"], 3), q=P.get_param_block(b["q"], 4),
                         latency=P.get_param_block(b["latency"], 1)[0]))
-    ctrl = np.stack([P.get_param_block(int(c), 6) for c in built.ctrl_blocks])
+    ctrl = P.get_param_blocks(np.asarray(built.ctrl_blocks, np.int32), 6).reshape(-1, 6)
     return out, ctrl
 
 

@@ -159,10 +159,14 @@ int32_t calico_get_param_block(calico_problem* p, int32_t block_id,
                                double* out);
 int32_t calico_set_param_block(calico_problem* p, int32_t block_id,
                                const double* values);
-/* Bulk form: n blocks, values concatenated in the order of block_ids. */
+/* Bulk forms: n blocks, values concatenated in the order of block_ids (the write-back of a spline's control points
+ * after Optimize(): one call instead of one per control point). */
 int32_t calico_set_param_blocks(calico_problem* p, int32_t n,
                                 const int32_t* block_ids,
                                 const double* values);
+int32_t calico_get_param_blocks(calico_problem* p, int32_t n,
+                                const int32_t* block_ids,
+                                double* values_out);
 
 /* Replaces Trajectory::AddParametersToProblem + GetEvaluationParams
  * (trajectory.cpp:51-79, bspline.hpp:138-161): the uniform knot vector

@@ -842,6 +842,14 @@ int32_t oracle_set_param_block(Problem* p, int32_t id, const double* v) {
   if (id < 0 || id >= int(p->blocks.size())) return p->set_error(CALICO_INVALID_ARGUMENT, "bad block id");
   std::copy(v, v + p->blocks[id].size, p->blocks[id].v.begin()); return CALICO_OK;
 }
+int32_t oracle_get_param_blocks(Problem* p, int32_t n, const int32_t* ids, double* out) {
+  for (int i = 0; i < n; ++i) {
+    if (ids[i] < 0 || ids[i] >= int(p->blocks.size())) return p->set_error(CALICO_INVALID_ARGUMENT, "bad block id");
+    std::copy(p->blocks[ids[i]].v.begin(), p->blocks[ids[i]].v.end(), out);
+    out += p->blocks[ids[i]].size;
+  }
+  return CALICO_OK;
+}
 int32_t oracle_set_param_blocks(Problem* p, int32_t n, const int32_t* ids, const double* v) {
   for (int i = 0; i < n; ++i) {
     if (ids[i] < 0 || ids[i] >= int(p->blocks.size())) return p->set_error(CALICO_INVALID_ARGUMENT, "bad block id");
