@@ -52,7 +52,8 @@ hipError_t configure_eval_kernels(size_t max_lds_bytes);
 void launch_gather(double* R, const double* src, const int* out_idx_thin, const int64_t* ptr_thin, const int* idx_thin,
                    int n_thin, int n_thin8, int n_thin4, int thin_per_lane, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
                    const double* cost_src, int n_cost, const LmState* st, int need_flag, size_t other_stride, hipStream_t s, const ControlTail* tail = nullptr);
-void launch_gather_lists(const GatherStruct& gs, int n_out, int* cnt, int* out_idx, int64_t* ptr, int* idx, int zero_slot, hipStream_t s);
+void launch_gather_lists(const GatherStruct& gs, int n_out, int* cnt, int* out_idx, int64_t* ptr, int* idx, int zero_slot, long long* scratch,
+                         hipStream_t s);
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s);
 size_t band_cholesky_lds_bytes(const SolveArgs& a);
@@ -1059,6 +1060,7 @@ int build_plan(calico_problem* p) {
   HIP_TRY(p, p->d_blocks.upload(p->h_blocks, s));
   HIP_TRY(p, p->d_cp_active.upload(cp_active, s));
   DevBuf<int> d_cnt;                    // (scratch of the device's list build; freed behind the synchronisation below)
+  DevBuf<long long> d_scan;
   const int zero_slot = int(comp_base + comp_off + row_store);      // a word of the partials nobody writes: allocated and cleared with them
   if (gs_ok) {
     if (size_t(zero_slot) + 2 >= size_t(0x7fffffff)) return p->set_error(CALICO_UNIMPLEMENTED, "problem too large for 32-bit gather indices");
@@ -1067,7 +1069,8 @@ int build_plan(calico_problem* p) {
     const int per_out = int(layouts.size()) * k;      // (<= 96)
     HIP_TRY(p, p->d_out_thin.alloc(size_t(gs_n_out))); HIP_TRY(p, p->d_ptr_thin.alloc(size_t(gs_n_out) + 1));
     HIP_TRY(p, p->d_idx_thin.alloc(size_t(gs_n_out) * per_out)); HIP_TRY(p, d_cnt.alloc(size_t(gs_n_out)));
-    launch_gather_lists(gsd, int(gs_n_out), d_cnt.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, zero_slot, s);
+    HIP_TRY(p, d_scan.alloc(size_t(gs_n_out) / 1024 + 2));      // block sums of the lists' prefix scan
+    launch_gather_lists(gsd, int(gs_n_out), d_cnt.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, zero_slot, d_scan.p, s);
     p->n_thin = int(gs_n_out);
     // the border's outputs (behind the right-hand side and the band) have one source per segment and layout that holds
     // their calibration column: at most k where every column belongs to ONE layout -- one lane each in the gather
