@@ -1487,12 +1487,34 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
       const int c = min(tid, m - 1);
       double acc = 0.0;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) acc += Sp[size_t(min(k, nsl - 1)) * mm + size_t(m) * M1 + c] * (k < nsl ? 1.0 : 0.0);
+      for (int k = 0; k < 8; ++k) acc += Sp[size_t(min(k, nsl - 1)) * mm + size_t(m) * M1 + c] * (k < nsl ? 1.0 : 0.0);
       gv[tid] = tid < m ? acc : 0.0;
       pend[tid] = 0.0;
     }
   }
   if (terminated) return;
+  if (nsl > 2) {
+    // long trajectories: up to eight K-slices (reduced_schur_slices). Slices 2.. are added in a pass of their own over the
+    // lower triangle, flat over the workgroup (the row-per-wave mapping above leaves most lanes on clamped duplicates)
+    const size_t mm = size_t(M1) * M1;
+    __syncthreads();
+    for (int e0 = tid; e0 < m * m; e0 += kDenseThreads * 4) {
+      double acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = min(e0 + kDenseThreads * u, m * m - 1), r = e / m, c = min(e - r * m, r);
+        double sacc = 0.0;
+#pragma unroll
+        for (int k = 2; k < 8; ++k) sacc += Sp[size_t(min(k, nsl - 1)) * mm + size_t(r) * M1 + c] * (k < nsl ? 1.0 : 0.0);
+        acc[u] = sacc;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + kDenseThreads * u, r = e / m, c = e - r * m;
+        if (e < m * m && c <= r) A[r * DNL + c] += acc[u];
+      }
+    }
+  }
   const bool dbg = CAL_DEV_TIMING(a.debug && (tid == 0 || tid == 64 * 5));
   long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define DTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }

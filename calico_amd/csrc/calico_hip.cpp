@@ -1285,7 +1285,7 @@ int prepare_workspace(calico_problem* p) {
   }
   const SolveArgs sa = make_solve_args(p);
   const size_t reduced_lds = reduced_solve_lds_bytes(sa);
-  HIP_TRY(p, p->d_Spart.alloc(4 * size_t(mw + 1) * (mw + 1) + 64));   // four K-slices of the Schur complement (+ slack: the blocked factorisation reads whole 32-column panels)
+  HIP_TRY(p, p->d_Spart.alloc(size_t(mw + 1 <= 128 ? 8 : 4) * size_t(mw + 1) * (mw + 1) + 64));   // up to eight K-slices of the Schur complement (long trajectories; four for the blocked path) (+ slack: the blocked factorisation reads whole 32-column panels)
   HIP_TRY(p, p->d_Swork.alloc(std::max<size_t>(reduced_lds / sizeof(double) + 8, size_t(mw + 1) * 16 * 13 + 8)));
   if (p->use_bcr) {
     const size_t N = size_t(p->bcr_N), bb = size_t(kBcrBP) * kBcrBP, fb = size_t(kBcrBP) * p->bcr_m1p;

@@ -1895,7 +1895,19 @@ static bool reduced_is_blocked(const SolveArgs& a) {
   return m1 >= reduced_blocked_from() && m1 > 128 && a.m <= 256 * kRBCols;
 }
 // K-slices of the Schur complement the reduced solve adds up on load
-int reduced_schur_slices(const SolveArgs& a) { return (a.m + 1 <= 128 || reduced_is_blocked(a)) ? kSchurSlices : 1; }
+int reduced_schur_slices(const SolveArgs& a) {
+  if (!(a.m + 1 <= 128 || reduced_is_blocked(a))) return 1;
+  // Long trajectories: the Schur complement's tiles walk all eliminated rows (6 n_cp · 32/30), a few tiles x K-slices
+  // workgroups in all -- at 1453 control points two slices meant 4.7k rows per workgroup, 12 us beside the last level.
+  // More slices there; the in-LDS 32-column-block solver adds up to eight on load (the 16-column panel solver two).
+  const char* e = std::getenv("CALICO_DENSE");
+  const bool panel = e && std::string(e) == "panel";
+  if (a.m + 1 <= 128 && !panel) {
+    if (a.n_cp >= 1280) return 8;
+    if (a.n_cp >= 640) return 4;
+  }
+  return kSchurSlices;
+}
 // Dense solve of the (m+1)x(m+1) augmented reduced system in a.Spart (ks K-slices) -> a.y[n_s ...]
 void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s, int t0 = 0, int outer_back = 0);     // bcr_kernels.hip
 void launch_reduced_block_step(const SolveArgs& a, int j, int nsl, int n_wg, hipStream_t s);     // bcr_kernels.hip
@@ -1904,7 +1916,7 @@ void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipSt
   const bool blocked = reduced_is_blocked(a);
   // CALICO_DENSE=panel keeps the 16-column panel kernel for the in-LDS case (A/B switch)
   const bool use_block = [] { const char* e = std::getenv("CALICO_DENSE"); return !(e && std::string(e) == "panel"); }();      // (read per solve: A/B switches)
-  if (m1 <= 128 && a.m >= 1 && use_block && ks <= 2) { launch_dense_block_solve(a, ks, s); return; }
+  if (m1 <= 128 && a.m >= 1 && use_block && ks <= 8) { launch_dense_block_solve(a, ks, s); return; }
   if (m1 <= 128) {
     const size_t lds = (size_t(m1) * ((16 * ((m1 + 15) / 16)) | 1) + m1 + 32 + 128 + 256) * sizeof(double);
     if (m1 <= 64) hipLaunchKernelGGL(reduced_solve_panel_kernel<1>, dim3(1), dim3(256), lds, s, a, 0, ks);
