@@ -69,6 +69,13 @@ struct FromR {
   const SolveArgs& a;
   const LmOptionsDev& o;
   double radius;
+  // 0: the Jacobi scale comes from a.scale. 1 / 2: the first linear solve of a solve, whose bookkeeping (post_eval_body
+  // with `first`: it computes a.scale from the diagonal of the first normal equations) rides in this very launch -- the
+  // scale of a diagonal entry is formed from the entry itself, as that bookkeeping does (1: Jacobi scaling on, 2: off)
+  int first_scale;
+  DEVI double scale_of(double v_diag, int t) const {
+    return first_scale == 0 ? a.scale[t] : (first_scale == 1 ? 1.0 / (1.0 + sqrt(v_diag)) : 1.0);
+  }
   static constexpr int RB = 6 * kBcrCps;   // real rows of a superblock
   // tangent row of (superblock I, local row r); -1: padding, beyond the trajectory, or an unobserved control point
   DEVI int trow(int I, int r) const {
@@ -87,7 +94,7 @@ struct FromR {
     return ok ? v : 0.0;
   }
   DEVI double damping(double v, int t) const {
-    const double s = a.scale[t];
+    const double s = scale_of(v, t);
     return fmin(fmax(v * s * s, o.min_lm_diagonal), o.max_lm_diagonal) / (radius * s * s);
   }
   // D(I)(r, c), damped; identity on padding / unobserved rows. `file`: this thread owns dadd of the row.
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   if (pub && int(blockIdx.x) >= int(gridDim.x) - n_schur_wg - n_root_wg) {
     if (terminated) return;
     use_current_R(a);
-    const FromR frs = {a, o, radius};
+    const FromR frs = {a, o, radius, 0};
     extern __shared__ double lds_s[];
     const int w = int(blockIdx.x) - (int(gridDim.x) - n_schur_wg - n_root_wg);
     if (w < n_schur_wg) {
@@ -306,12 +313,12 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     if (with_post && blockIdx.x == gridDim.x - 1) {
       if (terminated) return;
       if (threadIdx.x == 0 && a.st->commit_pending) a.st->commit_pending = 0;   // see commit_kernel (several ranks)
-      post_eval_body(a, x, blocks, n_blocks, o, log, log_cap, 0, jacobi_scaling);     // (all threads: it has barriers inside)
+      post_eval_body(a, x, blocks, n_blocks, o, log, log_cap, with_post == 2 ? 1 : 0, jacobi_scaling);     // (all threads: it has barriers inside)
       return;
     }
     use_current_R(a);
   }
-  const FromR fr = {a, o, radius};
+  const FromR fr = {a, o, radius, (FROM_R && with_post == 2) ? (jacobi_scaling ? 1 : 2) : 0};
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // Workgroup -> (node, role), XCD-aware: workgroup p runs on XCD p % 8, each XCD has its own L2, and all roles of a node
   // read the same spine blocks -- so node c takes the workgroups p = (c % 8) + 8·slot: one L2 serves its roles. The
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           double v = (fl & 2) ? rv[u] : 0.0;
           if (fl & 4) {        // diagonal: LM damping of an observed row, identity for padding / unobserved rows (see FromR::diag_block)
             if (trd[u] >= 0) {
-              const double sv = sc[u];
+              const double sv = fr.first_scale == 0 ? sc[u] : fr.scale_of(v, 0);
               const double dd = fmin(fmax(v * sv * sv, o.min_lm_diagonal), o.max_lm_diagonal) / (radius * sv * sv);     // FromR::damping
               v += dd; a.dadd[trd[u]] = dd;
             } else {
@@ -2000,14 +2007,14 @@ hipError_t configure_bcr_kernels(int q_max, int m1p) {
 // `schur_ks` > 0 (the LAST level of a tree of at least two): the Schur complement's tiles and the root's rows ride behind
 // this level's workgroups and take its results over the fan-in word; level 0 (`fan_word` given) resets the word.
 void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, int level, int keep0, int n_keep, const LmOptionsDev& o,
-                      const double* x, const BlockDev* blocks, int n_blocks, bool with_post_eval, IterLog* log, int log_cap, int jacobi,
+                      const double* x, const BlockDev* blocks, int n_blocks, int with_post_eval, IterLog* log, int log_cap, int jacobi,
                       hipStream_t s, int schur_ks, int* fan_word) {
   const int nfs = (a.mc + 1 + kBcrFS - 1) / kBcrFS;
   const int n_apply = n_keep > 0 ? std::min(64, std::max(1, n_keep * 4)) : 0;
   const int main_span = 8 * ((n_nodes + 7) / 8) * (1 + nfs);      // (node, role) workgroups laid out by XCD: see the kernel
   if (level == 0) {
     hipLaunchKernelGGL(bcr_level_kernel<true>, dim3(main_span + n_apply + (with_post_eval ? 1 : 0)), dim3(kLevelThreads),
-                       bcr_level_lds_bytes(), s, a, b, node0, n_nodes, nfs, level, keep0, n_keep, o, with_post_eval ? 1 : 0, x, blocks, n_blocks,
+                       bcr_level_lds_bytes(), s, a, b, node0, n_nodes, nfs, level, keep0, n_keep, o, with_post_eval, x, blocks, n_blocks,
                        log, log_cap, jacobi, 0, 0, 1, fan_word, 0);
   } else {
     const int nt = (a.mc + 1 + 15) / 16;

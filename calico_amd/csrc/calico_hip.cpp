@@ -82,7 +82,7 @@ hipError_t configure_dense_block_solve();
 hipError_t configure_reduced_block_step();
 size_t dense_block_solve_lds_bytes();
 void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, int level, int keep0, int n_keep, const LmOptionsDev& o,
-                      const double* x, const BlockDev* blocks, int n_blocks, bool with_post_eval, IterLog* log, int log_cap, int jacobi,
+                      const double* x, const BlockDev* blocks, int n_blocks, int with_post_eval, IterLog* log, int log_cap, int jacobi,
                       hipStream_t s, int schur_ks = 0, int* fan_word = nullptr);
 bool schur_rides_in_last_level(int n_levels, int n_last_nodes, int root);
 void launch_bcr_schur(const SolveArgs& a, const BcrArgs& b, int ks, const LmOptionsDev& o, hipStream_t s);
@@ -1553,11 +1553,13 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, c
 }
 
 // One linear solve + update of the candidate point: tree solver or sequential banded factorisation.
-void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOptionsDev& o, bool with_post_eval, int jacobi) {
+// with_post_eval: 0 none, 1 the bookkeeping of the step just accepted rides in the first launch, 2 the bookkeeping of the
+// solve's FIRST evaluation does (tree solver only: level 0 then forms the Jacobi scale of its diagonal entries itself)
+void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOptionsDev& o, int with_post_eval, int jacobi) {
   hipStream_t s = p->stream;
   const int n_blocks = int(p->h_blocks.size());
   if (!p->use_bcr) {
-    launch_solve(sa, o, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, p->dense_in_lds, s, with_post_eval, p->d_log.p, kLogCap, jacobi);
+    launch_solve(sa, o, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, p->dense_in_lds, s, with_post_eval == 1, p->d_log.p, kLogCap, jacobi);
     return;
   }
   const BcrArgs b = make_bcr_args(p);
@@ -1571,7 +1573,7 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
   int* const fan_word = p->d_handoff.p + 4;
   for (int l = 0; l < L; ++l) {
     const BcrLevel& lv = p->bcr_levels[size_t(l)];
-    launch_bcr_level(sa, b, lv.node0, lv.n_nodes, l, lv.keep0, lv.n_keep, o, p->d_x.p, p->d_blocks.p, n_blocks, l == 0 && with_post_eval,
+    launch_bcr_level(sa, b, lv.node0, lv.n_nodes, l, lv.keep0, lv.n_keep, o, p->d_x.p, p->d_blocks.p, n_blocks, l == 0 ? with_post_eval : 0,
                      p->d_log.p, kLogCap, jacobi, s, schur_rides && l == L - 1 ? ks : 0, schur_rides ? fan_word : nullptr);
   }
   if (!schur_rides) launch_bcr_schur(sa, b, ks, o, s);
@@ -2017,9 +2019,15 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   // iteration 0
   rc = enqueue_jacobian_eval(p, nullptr, 0);
   if (rc != CALICO_OK) return rc;
-  p->timer.begin(4, s);
-  launch_post_eval(sa, p->d_x.p, p->d_blocks.p, int(p->h_blocks.size()), o, p->d_log.p, kLogCap, 1, opt->jacobi_scaling, s);
-  p->timer.end(s);
+  // The bookkeeping of the first evaluation (initial cost, gradient norms, Jacobi scaling, log row 0) rides in the first
+  // linear solve's level-0 launch where the streaming loop and the tree solver run (CALICO_FOLD_FIRST=0: its own launch)
+  const bool fold_first = streaming && p->use_bcr && !p->has_exchange() && opt->max_num_iterations > 0 &&
+                          [] { const char* e = std::getenv("CALICO_FOLD_FIRST"); return !e || std::atoi(e) != 0; }();
+  if (!fold_first) {
+    p->timer.begin(4, s);
+    launch_post_eval(sa, p->d_x.p, p->d_blocks.p, int(p->h_blocks.size()), o, p->d_log.p, kLogCap, 1, opt->jacobi_scaling, s);
+    p->timer.end(s);
+  }
   const bool fused_control = [] { const char* e = std::getenv("CALICO_FUSED_CONTROL"); return !e || std::atoi(e) != 0; }();
   mark(2);
   if (streaming) {
@@ -2060,7 +2068,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
         continue;
       }
       p->timer.begin(2, s);
-      enqueue_linear_solve(p, sa, o, /*with_post_eval=*/enq > 0, opt->jacobi_scaling);
+      enqueue_linear_solve(p, sa, o, /*with_post_eval=*/enq > 0 ? 1 : (fold_first ? 2 : 0), opt->jacobi_scaling);
       p->timer.end(s);
       // the control stage rides in the last workgroup of the gather kernel
       ControlTail tail;
