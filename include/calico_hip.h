@@ -159,8 +159,10 @@ int32_t calico_get_param_block(calico_problem* p, int32_t block_id,
                                double* out);
 int32_t calico_set_param_block(calico_problem* p, int32_t block_id,
                                const double* values);
-/* Bulk forms: n blocks, values concatenated in the order of block_ids (the write-back of a spline's control points
- * after Optimize(): one call instead of one per control point). */
+/* Bulk forms: n blocks, values concatenated in the order of block_ids. Ceres reads and writes through the pointers
+ * Trajectory::AddParametersToProblem / WorldModel::AddParametersToProblem hand it (trajectory.cpp:51-60,
+ * world_model.cpp:52-61), so after Optimize() (batch_optimizer.cpp:72-78) the control points and model points are
+ * simply there; here they are fetched -- in one call instead of one per control point. */
 int32_t calico_set_param_blocks(calico_problem* p, int32_t n,
                                 const int32_t* block_ids,
                                 const double* values);
