@@ -224,6 +224,7 @@ class Problem:
         if st != OK:
             raise CalicoError(st, "calico_problem_create failed (no usable HIP device?)")
         self._keep = []
+        self._sizes = {}      # block id -> ambient size, of the blocks added through this object
 
     def close(self):
         if self.h:
@@ -245,11 +246,14 @@ class Problem:
         out = C.c_int32(-1)
         self._check(self.api.problem_add_param_block(self.h, _dp(v), v.size, manifold, int(bool(constant)),
                                                      C.byref(out)))
+        self._sizes[out.value] = v.size
         return out.value
 
     def add_param_blocks(self, values, manifold=MANIFOLD_EUCLIDEAN, constant=False):
         """n blocks of one size (rows of `values`); one ABI call where the library has the bulk form. Returns the ids."""
         v = _f64(values)
+        if len(v) == 0:
+            return np.zeros(0, np.int32)
         v = v.reshape(len(v), -1)
         n, size = v.shape
         const = np.ascontiguousarray(np.broadcast_to(np.asarray(constant, bool), (n,)), dtype=np.uint8)
@@ -257,6 +261,8 @@ class Problem:
             return np.array([self.add_param_block(v[i], manifold, bool(const[i])) for i in range(n)], np.int32)
         ids = np.zeros(n, np.int32)
         self._check(self.api.problem_add_param_blocks(self.h, n, size, manifold, const.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(v), _ip(ids)))
+        for i in ids:
+            self._sizes[int(i)] = size
         return ids
 
     def get_param_block(self, block_id, size):
@@ -267,7 +273,13 @@ class Problem:
     def get_param_blocks(self, block_ids, sizes):
         """Values of several blocks, concatenated (`sizes`: the blocks' sizes, or one size for all)."""
         ids = _i32(block_ids)
-        total = int(np.sum(sizes)) if np.ndim(sizes) else int(sizes) * int(ids.size)
+        per = np.broadcast_to(np.asarray(sizes, np.int64), (ids.size,))
+        # the C call writes every block's real size and takes no capacity: the caller's sizes must be the blocks' own
+        for i, n in zip(ids, per):
+            known = self._sizes.get(int(i))
+            if known is not None and known != int(n):
+                raise ValueError("block %d has %d values, not %d" % (int(i), known, int(n)))
+        total = int(per.sum())
         out = np.zeros(total)
         self._check(self.api.get_param_blocks(self.h, ids.size, _ip(ids), _dp(out)))
         return out
@@ -413,8 +425,10 @@ _hip_api = None
 
 
 def hip_library_path():
-    # CALICO_HIP_LIB: another build of the same library (development A/B runs); the product path is the in-tree one
-    return os.environ.get("CALICO_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), _HIP_LIB_NAME)
+    # CALICO_HIP_LIB (only with CALICO_DEV=1): another build of the same library, for development A/B runs
+    # (profiles/dev/ab.sh); the product path is the in-tree one
+    other = os.environ.get("CALICO_HIP_LIB") if os.environ.get("CALICO_DEV") == "1" else None
+    return other or os.path.join(os.path.dirname(os.path.abspath(__file__)), _HIP_LIB_NAME)
 
 
 def load_hip():

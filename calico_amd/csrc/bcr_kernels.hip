@@ -192,8 +192,8 @@ DEVI void schur_tile(const SolveArgs& a, const BcrArgs& b, const FromR& fr, int 
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int row = k0 + 4 * u + lk, sb = row >> 5;
-      const bool use = row < w_end && sb != f0 && sb != f1;      // (a select, not a product: a skipped row may hold anything)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(use ? va[u] : 0.0, vb[u], acc, 0, 0, 0);
+      const bool use = row < w_end && sb != f0 && sb != f1;      // (selects on BOTH operands: a skipped row may hold anything, NaN included -- it is being rewritten by this very launch -- and 0 x NaN is NaN)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(use ? va[u] : 0.0, use ? vb[u] : 0.0, acc, 0, 0, 0);
     }
   }
   if (LATE) {
@@ -206,7 +206,7 @@ DEVI void schur_tile(const SolveArgs& a, const BcrArgs& b, const FromR& fr, int 
       const bool use = sb >= 0 && wave < 8 && row >= r_begin && row < r_end;
       const size_t ro = size_t(min(row, n - 1)) * m1p;
       const double va = load_sc1(pa + ro), vb = load_sc1(pb + ro);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(use ? va : 0.0, vb, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(use ? va : 0.0, use ? vb : 0.0, acc, 0, 0, 0);
     }
   }
 #pragma unroll

@@ -1,0 +1,228 @@
+// block_elim.hpp — elimination of one 32x32 diagonal block on the matrix cores, spread over the SIMDs of a CU (round 4).
+//
+// What the tree levels, the dense reduced solve and the blocked reduced factorisation all do per step is
+//     D = L Lᵀ,   M = L⁻ᵀ,   Z = L⁻¹ X   (X: the columns that couple to the block; or Z = X L⁻ᵀ for the rows below it),
+// and rounds 1-3 did it as: two in-wave 16-column panels (one lane per row of [D; I], 31 instructions per column on ONE
+// wave) | barrier | MFMA tile update | barrier | panel | barrier | Z = MᵀX on the matrix cores | barrier: ~11.5k clocks
+// per block inside the kernels, the panels alone ~9.3k.
+//
+// Here the block is eliminated four columns per step, eight steps, with everything in MFMA accumulator tiles held
+// TRANSPOSED: tile (J, T) of a row tile T (sixteen rows of [D; I; Xᵀ]) and column tile J (sixteen columns of the block),
+//     acc[r] of lane (l16 = lane & 15, lk = lane >> 4)  =  -Aug[16T + l16][16J + lk + 4r]        (negated).
+// In this form
+//   * register u of a tile IS the operand "sixteen rows x the four columns of step u" of v_mfma_f64_16x16x4_f64 (lane
+//     (l16, lk) holds entry (l16, k = lk)) -- as A operand and as B operand alike;
+//   * the step's four columns of the factor for row tile T, L_T = Aug_T,step · L44⁻ᵀ, are ONE MFMA with -L44⁻¹ (the
+//     inverse of the 4x4 pivot block's Cholesky factor, rows 0..3 of a 16x4 A operand) against register u; result
+//     register 0 of lane (l16, lk) is L[16T + l16][step column lk] -- the operand layout again -- so the trailing update
+//     tile(J', T) += L_J' L_Tᵀ takes both operands straight from result registers. No LDS, no lane movement;
+//   * the only cross-lane traffic is the 4x4 pivot block (ten v_readlane pairs out of register u of the diagonal tile),
+//     factored redundantly by every lane: 4 x [v_rsq_f64 + one Newton step] on the chain; the lane's entry of -L44⁻¹ is
+//     the forward substitution of its own unit vector e_lk, selected by l16.
+// One wave cannot go faster than its chain (eight steps of ~75 VALU instructions + two dependent MFMAs) OR than its
+// flops (FP64 MFMA: 64 clocks per 16x16x4 on this part -- the whole augmented block is ~50 of them), so the work is split:
+//   * the CHIEF wave owns the spine (the block itself: tiles (0,0), (0,1), (1,1)) and nothing else -- five MFMAs per
+//     step -- and publishes per step, write-once in LDS: w (the pivot operand), l0 / l1 (the step's columns of L for
+//     rows 0..15 / 16..31), then a progress word;
+//   * FOLLOWER waves on the other SIMDs own the remaining row tiles (identity rows -> M, Xᵀ rows -> Zᵀ, rows below -> Z):
+//     per step and row tile one panel MFMA (whose result is final: four rows of Z, written out at once) and up to two
+//     trailing updates. They run behind the chief by a fraction of a step; nobody waits for them until the end.
+// Z therefore comes out of the factorisation itself: the separate "Z = MᵀX" phase and its barrier are gone, and M is
+// only formed where somebody files it.
+// Rows of a diagonal tile above the current pivot block carry rounding residue of entries that are zero in exact
+// arithmetic (A - L Lᵀ over the eliminated part); their products only land in entries nobody reads again.
+// A bad pivot is not patched: NaN propagates and is caught by the update stage.
+#pragma once
+#include "solve_dev.hpp"
+
+namespace cal {
+
+constexpr int kElimSlot = 64;                          // doubles per published vector (one per lane)
+constexpr int kElimStep = 3 * kElimSlot;               // w, l0, l1
+constexpr int kElimBufDoubles = 8 * kElimStep + 8;     // write-once per factorisation (+ the progress word)
+
+struct ElimChannel {
+  double* buf;       // LDS [8][3][64]
+  int* progress;     // LDS: `base` + number of steps published; monotonic over the factorisations of a launch
+};
+DEVI ElimChannel elim_channel(double* lds /* kElimBufDoubles */) { return ElimChannel{lds, reinterpret_cast<int*>(lds + 8 * kElimStep)}; }
+
+// The 4x4 pivot block of a step, factored by every lane, in seven short stages: the matrix pipe is in-order and a queued
+// MFMA blocks the wave's issue, so the chief's MFMAs that are off the chain are placed BETWEEN these stages, with
+// scheduling barriers -- left to the compiler they all land in front of the next step's critical panel MFMA.
+struct PivotChain {
+  double d;                 // register u of the (negated) diagonal tile
+  int b, l16;               // lane of the pivot block's entry (0, 0); the lane's l16
+  double e0, e1, e2, e3;    // -e_lk
+  double a10, a11, a20, a21, a22, a30, a31, a32, a33;
+  double r0, r1, r2, r3, l10, l20, l30, l21, l31, l32, x3a, x0, x1, x2;
+  DEVI void s0() { const double a00 = -readlane_f64(d, b); r0 = rsqrt_nr(a00); a10 = -readlane_f64(d, 16 + b); a11 = -readlane_f64(d, 17 + b); }
+  DEVI void s1() { l10 = a10 * r0; r1 = rsqrt_nr(__builtin_fma(-l10, l10, a11)); a20 = -readlane_f64(d, 32 + b); a21 = -readlane_f64(d, 33 + b); }
+  DEVI void s2() {
+    a22 = -readlane_f64(d, 34 + b);
+    l20 = a20 * r0; l21 = __builtin_fma(-l20, l10, a21) * r1;
+    r2 = rsqrt_nr(__builtin_fma(-l21, l21, __builtin_fma(-l20, l20, a22)));
+  }
+  DEVI void s3() {
+    a30 = -readlane_f64(d, 48 + b); a31 = -readlane_f64(d, 49 + b); a32 = -readlane_f64(d, 50 + b);
+    l30 = a30 * r0; l31 = __builtin_fma(-l30, l10, a31) * r1;
+    l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, a32)) * r2;
+  }
+  DEVI void s4() {
+    a33 = -readlane_f64(d, 51 + b);
+    r3 = rsqrt_nr(__builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, a33))));
+  }
+  DEVI void s5() {      // forward substitution L44 x = -e_lk (off the chain up to the last product)
+    x0 = e0 * r0; x1 = __builtin_fma(-l10, x0, e1) * r1;
+    x2 = __builtin_fma(-l21, x1, __builtin_fma(-l20, x0, e2)) * r2;
+    x3a = __builtin_fma(-l32, x2, __builtin_fma(-l31, x1, __builtin_fma(-l30, x0, e3)));
+  }
+  DEVI double s6() {    // the lane's entry of -L44⁻¹ in the A-operand layout (row l16 < 4, k = lk; zero elsewhere)
+    const double w012 = l16 == 0 ? x0 : (l16 == 1 ? x1 : (l16 == 2 ? x2 : 0.0));
+    return l16 == 3 ? x3a * r3 : w012;
+  }
+};
+
+#define CAL_SB() __builtin_amdgcn_sched_barrier(0)
+#define CAL_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0)
+// keeps all four result registers of a panel product allocated until here: only register 0 is used, and a dead register
+// the compiler hands to the next VALU instruction costs that instruction the MFMA's whole latency in hazard wait states
+#define CAL_KEEP(v) asm volatile("" : : "v"(v))
+
+DEVI void elim_publish(const ElimChannel& ch, int value) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __hip_atomic_store(ch.progress, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+DEVI void elim_wait(const ElimChannel& ch, int target) {
+  while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(ch.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - target < 0) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+
+// The chief. In: rows 0..31 of A (LDS, row stride LD): the block, lower triangle (the upper one is not read).
+// Out (WRITE_L): rows 0..31: L, lower triangle (above the diagonal undefined). `base`: value of the progress word before
+// this factorisation; it is base + 8 afterwards.
+template <bool WRITE_L, bool TS = false>
+DEVI void elim_chief(double* A, int LD, const ElimChannel ch, int base, int lane, long long* ts = nullptr) {
+  const int l16 = lane & 15, lk = lane >> 4;
+  const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+  f64x4 t00, t01, t11;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = lk + 4 * r;
+    const int hi = max(l16, c), lo = min(l16, c);
+    t00[r] = -A[hi * LD + lo];
+    t01[r] = -A[(16 + l16) * LD + c];
+    t11[r] = -A[(16 + hi) * LD + 16 + lo];
+  }
+  PivotChain pc;
+  pc.l16 = l16;
+  pc.e0 = lk == 0 ? -1.0 : 0.0; pc.e1 = lk == 1 ? -1.0 : 0.0; pc.e2 = lk == 2 ? -1.0 : 0.0; pc.e3 = lk == 3 ? -1.0 : 0.0;
+  double* const pub = ch.buf + lane;
+  f64x4 p0 = zero4, p1 = zero4;       // panel products (register 0: the step's columns of L for rows 0..15 / 16..31)
+  // ---- columns 0..15. Per step: pivot chain -> w; p0 = P(t00), p1 = P(t01) back to back (both only need w); then the
+  //      trailing updates t00 (what the next pivot block waits for), t01, t11. FP64 MFMAs and FP64 VALU work of one wave
+  //      do not overlap on this part (the matrix instruction runs on the SIMD's FP64 lanes: 64 clocks each), so there is
+  //      nothing to interleave -- the order just keeps dependent MFMAs apart. ----
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (TS) ts[u] = __builtin_readcyclecounter();
+    pc.d = t00[u]; pc.b = 4 * u;
+    pc.s0(); pc.s1(); pc.s2();
+    CAL_SB();
+    if (u > 0) elim_publish(ch, base + u);        // step u-1 is out (its LDS writes were issued a few hundred clocks ago: no wait)
+    CAL_SB();
+    pc.s3(); pc.s4(); pc.s5();
+    const double w = pc.s6();
+    CAL_SB();
+    pub[u * kElimStep] = w;
+    p0 = CAL_MFMA(w, t00[u], zero4);
+    p1 = CAL_MFMA(w, t01[u], zero4);
+    if (u < 3) t00 = CAL_MFMA(p0[0], p0[0], t00);
+    if (u < 3) t01 = CAL_MFMA(p0[0], p1[0], t01);
+    t11 = CAL_MFMA(p1[0], p1[0], t11);
+    pub[u * kElimStep + kElimSlot] = p0[0];
+    pub[u * kElimStep + 2 * kElimSlot] = p1[0];
+    if (WRITE_L) { A[l16 * LD + 4 * u + lk] = p0[0]; A[(16 + l16) * LD + 4 * u + lk] = p1[0]; }
+    CAL_SB();
+    CAL_KEEP(p0); CAL_KEEP(p1);
+  }
+  // ---- columns 16..31: the spine is t11 alone. Followers need w and l1 (slot 2) of these steps. ----
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (TS) ts[4 + u] = __builtin_readcyclecounter();
+    pc.d = t11[u]; pc.b = 4 * u;
+    pc.s0(); pc.s1(); pc.s2();
+    CAL_SB();
+    elim_publish(ch, base + 4 + u);               // step 3 + u is out
+    CAL_SB();
+    pc.s3(); pc.s4(); pc.s5();
+    const double w = pc.s6();
+    CAL_SB();
+    pub[(4 + u) * kElimStep] = w;
+    if (u == 3 && !WRITE_L) { elim_publish(ch, base + 8); break; }       // (the last step: the followers only need w)
+    p1 = CAL_MFMA(w, t11[u], zero4);
+    if (u < 3) t11 = CAL_MFMA(p1[0], p1[0], t11);
+    pub[(4 + u) * kElimStep + 2 * kElimSlot] = p1[0];
+    if (WRITE_L) A[(16 + l16) * LD + 16 + 4 * u + lk] = p1[0];
+    if (u == 3) elim_publish(ch, base + 8);
+    CAL_SB();
+    CAL_KEEP(p1);
+  }
+  CAL_KEEP(p0); CAL_KEEP(p1);
+  if (TS) ts[8] = __builtin_readcyclecounter();
+}
+
+// A row tile a follower owns: sixteen rows against the block's 32 columns.
+struct ElimTile {
+  const double* in;      // entry (row i of the tile, column c of the block) at in[i * in_row + c * in_col]
+  int in_row, in_col;
+  double* out;           // where the result entry (i, c) goes: out[i * out_row + c * out_col]
+  int out_row, out_col;
+  int kind;              // 0: loaded from `in`; 1 / 2: identity rows against the block's columns 0..15 / 16..31 (-> L⁻ᵀ)
+};
+
+// A follower with NT row tiles (compile-time unrolled; the descriptors are wave-uniform).
+template <int NT>
+DEVI void elim_follow(const ElimTile (&t)[NT], const ElimChannel ch, int base, int lane) {
+  const int l16 = lane & 15, lk = lane >> 4;
+  const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+  f64x4 x0[NT], x1[NT];
+#pragma unroll
+  for (int q = 0; q < NT; ++q) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = lk + 4 * r;
+      if (t[q].kind == 0) {
+        x0[q][r] = -t[q].in[l16 * t[q].in_row + c * t[q].in_col];
+        x1[q][r] = -t[q].in[l16 * t[q].in_row + (16 + c) * t[q].in_col];
+      } else {
+        const double id = l16 == c ? -1.0 : 0.0;
+        x0[q][r] = t[q].kind == 1 ? id : 0.0;
+        x1[q][r] = t[q].kind == 2 ? id : 0.0;
+      }
+    }
+  }
+  const double* const sub = ch.buf + lane;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int J = s >> 2, u = s & 3;
+    elim_wait(ch, base + s + 1);
+    const double w = sub[s * kElimStep];
+    const double l0 = (J == 0 && u < 3) ? sub[s * kElimStep + kElimSlot] : 0.0;
+    const double l1 = (s < 7) ? sub[s * kElimStep + 2 * kElimSlot] : 0.0;
+    double lp[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const f64x4 p = CAL_MFMA(w, (J == 0 ? x0[q][u] : x1[q][u]), zero4);
+      lp[q] = p[0];
+    }
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      t[q].out[l16 * t[q].out_row + (4 * s + lk) * t[q].out_col] = lp[q];
+      if (J == 0 && u < 3) x0[q] = CAL_MFMA(l0, lp[q], x0[q]);
+      if (s < 7 && !(J == 1 && u == 3)) x1[q] = CAL_MFMA(l1, lp[q], x1[q]);
+    }
+  }
+}
+
+}  // namespace cal

@@ -124,12 +124,22 @@ struct RcclApi {
 RcclApi& rccl() {
   static RcclApi api = [] {
     RcclApi a;
-    std::vector<std::string> names = {"librccl.so.1", "librccl.so"};
-    for (const char* env : {"ROCM_PATH", "ROCM_HOME"})
-      if (const char* r = std::getenv(env)) { names.push_back(std::string(r) + "/lib/librccl.so.1"); names.push_back(std::string(r) + "/lib/librccl.so"); }
-    names.push_back("/opt/rocm/lib/librccl.so.1"); names.push_back("/opt/rocm/lib/librccl.so");
-    for (const std::string& n : names) { a.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL); if (a.lib) break; }
-    if (!a.lib) { a.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return a; }
+    std::vector<std::string> names;
+    if (const char* one = std::getenv("CALICO_RCCL_LIB")) names.push_back(one);      // this library and no other (a particular RCCL build)
+    else {
+      names = {"librccl.so.1", "librccl.so"};
+      for (const char* env : {"ROCM_PATH", "ROCM_HOME"})
+        if (const char* r = std::getenv(env)) { names.push_back(std::string(r) + "/lib/librccl.so.1"); names.push_back(std::string(r) + "/lib/librccl.so"); }
+      names.push_back("/opt/rocm/lib/librccl.so.1"); names.push_back("/opt/rocm/lib/librccl.so");
+    }
+    std::string why;
+    for (const std::string& n : names) {
+      a.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
+      if (a.lib) break;
+      const char* e = dlerror();         // (dlerror() clears its state: one call per failure)
+      if (e) why = e;
+    }
+    if (!a.lib) { a.error = "librccl not found: " + why; return a; }
     auto sym = [&](const char* n) { void* f = dlsym(a.lib, n); if (!f && a.error.empty()) a.error = std::string("librccl lacks ") + n; return f; };
     a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
@@ -1080,7 +1090,7 @@ int build_plan(calico_problem* p) {
       for (int l = 0; l < gsd.n_lay; ++l) holders += gs_tab[size_t(gsd.n_lay) * gsd.nseg + size_t(l) * m + size_t(tc)] >= 0 ? 1 : 0;
       one_layout = holders <= 1;
     }
-    static const bool tiny_env = [] { const char* e = std::getenv("CALICO_GATHER_TINY"); return !e || std::atoi(e) != 0; }();
+    const bool tiny_env = [] { const char* e = std::getenv("CALICO_GATHER_TINY"); return !e || std::atoi(e) != 0; }();      // (per plan, like the key that hashes it)
     const int n_border0 = NS + n_cp * k * 36;          // first border output
     p->n_thin4 = (one_layout && tiny_env) ? n_border0 : p->n_thin;
     // band blocks at distance d from the diagonal have (k - d) segments per layout: four lanes where that is <= 24 sources
@@ -1155,7 +1165,8 @@ struct PlanCache {
   int64_t hits = 0, misses = 0;
   static constexpr size_t kMaxEntries = 8, kMaxPool = 2;
 };
-PlanCache& plan_cache() { static PlanCache c; return c; }
+// (never destroyed, like the stream and pinned pools: its buffers would be freed after the HIP runtime is gone)
+PlanCache& plan_cache() { static PlanCache* c = new PlanCache; return *c; }
 bool plan_cache_enabled() {
   static const bool on = [] { const char* e = std::getenv("CALICO_PLAN_CACHE"); return !e || std::atoi(e) != 0; }();
   return on;

@@ -2,6 +2,7 @@
 # usage: ab.sh <variant.so> [rounds]  -- alternates base / variant on the same box
 V=$1; R=${2:-3}
 cd /root/repo
+export CALICO_DEV=1      # (calico_amd/_capi.py honours CALICO_HIP_LIB only then)
 for i in $(seq $R); do
   for lib in base $V; do
     if [ "$lib" = base ]; then unset CALICO_HIP_LIB; else export CALICO_HIP_LIB=/root/repo/gpurun_ab/$lib; fi

@@ -82,3 +82,19 @@ def test_shard_windows_partition_rule():
         assert np.abs(sum(Hs) - H_full).max() <= 1e-10 * np.abs(H_full).max()
         share = np.array(costs) > 0
         assert share.all()
+
+
+def test_missing_rccl_is_a_clean_error():
+    """No librccl on the machine (CALICO_RCCL_LIB names the one library to load): calico_comm_get_unique_id returns
+    kInternal instead of crashing while it formats dlerror() (round-3 advice: dlerror() clears its state)."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from calico_amd import _capi; "
+            "lib = ctypes.CDLL(_capi.hip_library_path()); buf = (ctypes.c_uint8 * 128)(); "
+            "lib.calico_comm_get_unique_id.restype = ctypes.c_int32; "
+            "st = lib.calico_comm_get_unique_id(buf); st2 = lib.calico_comm_get_unique_id(buf); print('status', st, st2)"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, CALICO_RCCL_LIB="/nonexistent/librccl.so.1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "status 13 13" in r.stdout, r.stdout
