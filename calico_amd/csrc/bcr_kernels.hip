@@ -28,8 +28,11 @@
 
 #include "problem_dev.hpp"
 #include "solve_dev.hpp"
+#include "block_elim.hpp"
 
 namespace cal {
+
+bool block_elim_enabled();
 
 namespace {
 constexpr int BP = kBcrBP;              // 32
@@ -277,7 +280,10 @@ DEVI void schur_root_rows(const SolveArgs& a, const BcrArgs& b, int ks, int w0, 
 // FROM_R (level 0): the chain blocks come straight from the reduce buffer R(x) with the damping applied on the fly (no
 // staging pass); the extra workgroups initialise D and F of the level's separators from R, and the last of them does
 // the bookkeeping of the step just accepted when `with_post` is set (post_eval_body: it only reads R(x) and x).
-template <bool FROM_R>
+// ELIM (round 4): the block is eliminated by block_elim.hpp -- a chief wave on the spine, waves 1..3 as followers with the
+// identity rows (role 0: L⁻ᵀ) and the rows of Xᵀ, so that Z comes out of the factorisation -- instead of panel | tile |
+// panel | Z = MᵀX (CALICO_ELIM=panel keeps those).
+template <bool FROM_R, bool ELIM>
 __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, BcrArgs b, int node0, int n_nodes, int nfs, int level,
                                                                    int keep0, int n_keep, LmOptionsDev o, int with_post,
                                                                    const double* __restrict__ x, const BlockDev* __restrict__ blocks,
@@ -442,13 +448,18 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   double* const dinv = Zb + BP * XLD;              // [80]
   double* const bcast = dinv + 80;                 // [128]
   double* const dump = bcast + 128 + tid;          // [512]
+  const ElimChannel ech = elim_channel(bcast + 128 + kLevelThreads);      // [kElimBufDoubles] (ELIM)
+  if (ELIM) elim_reset(ech, tid, kLevelThreads);   // (the barrier behind the first block's commit orders it)
   const int l16 = lane & 15, lk = lane >> 4;
   // ---- global -> registers -> LDS of one chain block. Loaders are waves 1-3 and 5-7 (384 threads: three entries each
   // of D / B / A, two of the F slice); wave 0 goes straight to the factorisation, it is the critical path of every step. ----
-  constexpr int NL = kLevelThreads - 128, NU = 3;
-  const bool loader = wave != 0 && wave != 4;    // wave 4 shares the panel wave's SIMD: it stays out of the way, too
-  const int lt = tid - 64 - (wave > 4 ? 64 : 0);
-  struct Pre { double d[NU], bt[NU], at[NU], f[2]; };
+  // (ELIM: waves 1..3 are the chief's followers from the first clock of a step -- a follower that issues loads first starts
+  //  late and ends the step late --, so the loaders are waves 4..7: four entries each of D / B / A, two of the F slice.
+  //  Waves 5..7 alone take 8.3k clocks from request to commit, longer than the chief's chain.)
+  constexpr int NL = ELIM ? 256 : kLevelThreads - 128, NU = ELIM ? 4 : 3, NF = 2;
+  const bool loader = ELIM ? wave >= 4 : (wave != 0 && wave != 4);    // wave 4 shares the panel wave's SIMD: it stays out of the way, too
+  const int lt = ELIM ? tid - 256 : tid - 64 - (wave > 4 ? 64 : 0);
+  struct Pre { double d[NU], bt[NU], at[NU], f[NF]; };
   // level 0: positions in R of this thread's entries for superblock 0 (the band is uniform in time: superblock I adds
   // I·stride), and what does not depend on the superblock of their validity
   constexpr int RB = 6 * kBcrCps;
@@ -511,7 +522,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         pr.at[u] = vA ? ga : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < NF; ++u) {
         const int e = min(max(lt, 0) + NL * u, BP * kBcrFS - 1);
         const int r = e >> 4, col = role > 0 ? f0 + (e & 15) : 0;
         const int t = RB * blk + r;
@@ -538,7 +549,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       pr.at[u] = ga;
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NF; ++u) {
       const int e = min(max(lt, 0) + NL * u, BP * kBcrFS - 1);
       const int r = e >> 4, j = e & 15;
       const int col = role > 0 ? f0 + j : 0;
@@ -564,7 +575,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NF; ++u) {
       const int e = lt + NL * u;
       if (e < BP * kBcrFS) Xp[(e >> 4) * XLD + CF + (e & 15)] = pr.f[u];
     }
@@ -594,7 +605,30 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     const bool last = i + 1 == q;
     const int blk = blk0 + i;
     Pre pr;
+    const long long t_step = CAL_DEV_TIMING(a.debug != 0) ? __builtin_readcyclecounter() : 0;
     if (!last && loader) fetch(i + 1, pr);            // in flight while the block is factored
+    if (CAL_DEV_TIMING(a.debug && bid < 1 && lane == 0 && wave >= 4)) printf("level %d step %d wave %d: requests issued at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
+    if (ELIM) {
+      // ---- D = L Lᵀ, Z = L⁻¹X and (role 0) L⁻ᵀ in one pass: wave 0 the spine, waves 1..3 two row tiles each ----
+      if (wave == 0) elim_chief<0>(Dp, DLD, ech, lane);
+      else if (wave == 1) {
+        if (role == 0) {
+          const ElimTile t[2] = {{Zb, 0, 0, Dp + BP * DLD, DLD, 1, 1, nullptr}, {Zb, 0, 0, Dp + (BP + 16) * DLD, DLD, 1, 2, nullptr}};
+          elim_follow<2>(t, ech, lane);
+        } else {
+          const ElimTile t[1] = {{Xp + CF, 1, XLD, Zb + CF, 1, XLD, 0, nullptr}};
+          elim_follow<1>(t, ech, lane);
+        }
+      } else if (wave == 2 || wave == 3) {
+        const int c0 = wave == 2 ? CA : CB;
+        const ElimTile t[2] = {{Xp + c0, 1, XLD, Zb + c0, 1, XLD, 0, nullptr}, {Xp + c0 + 16, 1, XLD, Zb + c0 + 16, 1, XLD, 0, nullptr}};
+        elim_follow<2>(t, ech, lane);
+      }
+      if (CAL_DEV_TIMING(a.debug && bid < 1 && lane == 0 && wave < 4)) printf("level %d step %d wave %d: elimination done at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
+      if (!last && loader) commit(p ^ 1, pr);
+      if (CAL_DEV_TIMING(a.debug && bid < 1 && lane == 0 && wave >= 4)) printf("level %d step %d wave %d: committed at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
+      LTICK(3)
+    } else {
     // ---- D = L Lᵀ and L⁻ᵀ: two in-wave panels, one tile update between them ----
     if (wave == 0) panel_factor<1, false, false>(Dp, DLD, dinv, bcast, 0, 63, 16, lane, &pmin);
     lds_barrier();
@@ -620,8 +654,10 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       // (waves 0/4 and 2/6), not to those with two 8-MFMA jobs: 16 instead of 24 MFMAs on the busiest matrix pipe
       if (role > 0 && (wave == 0 || wave == 2)) zjob(4, wave == 0 ? 1 : 0);
     }
+    }
     lds_barrier();
     LTICK(4)
+    if (ELIM && !last) elim_reset(ech, tid, kLevelThreads);      // (the followers are through; the barrier at the end of the step orders it)
     // ---- file what the back-substitution needs ----
     if (role == 0) {
 #pragma unroll
@@ -1443,7 +1479,12 @@ constexpr int DNL = 129;     // row stride of the dense matrix in LDS
 //  runs them side by side, and the levels below then sweep their own border rows.)
 // t0 > 0: the system is what the blocked multi-launch factorisation (reduced_block_step_kernel) left of a larger one --
 // unknowns t0 .. a.m - 1, in place in slice 0 of a.Spart with the full system's row stride, right-hand side in its row a.m.
-DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const Handoff& ho, int t0 = 0, int outer_back = 0) {
+// elim (round 4): every 32-column block is eliminated by block_elim.hpp in place -- wave 0 the chief on the diagonal block (L
+// into the lower triangle), waves 1..3 the followers: the identity rows (L⁻ᵀ: strict upper triangle + dinvm), the row tiles
+// below (Z = A_ij L⁻ᵀ comes out of the factorisation, in place) and the right-hand side as a single-row tile (z = g L⁻ᵀ) --,
+// waves 4..7 beside them the trailing tiles of the block before that the current block does not touch; between two
+// blocks one phase: right-hand side of the rows below, and the trailing update of the NEXT block's two column tiles.
+DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const Handoff& ho, int t0 = 0, int outer_back = 0, int elim = 0) {
   LmState* st = a.st;
   const int terminated = st->terminated;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1576,6 +1617,75 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
       Daug[(BP + r) * DLD + c] = r == c ? 1.0 : 0.0;
     }
   };
+  if (elim) {
+    const ElimChannel ech = elim_channel(Daug);       // (the panel buffer is not used on this path)
+    elim_reset(ech, tid, kDenseThreads);
+    const int nt_all = mp / 16;
+    for (int jb = 0; jb < nb; ++jb) {
+      const int c0 = BP * jb;
+      const int t_first = 2 * (jb + 1), nT = nt_all - t_first;      // row tiles below the block
+      lds_barrier();
+      DTICK(1)
+      double* const blk = A + c0 * DNL + c0;
+      if (wave == 0) elim_chief<2>(blk, DNL, ech, lane);
+      else if (wave == 1) {
+        const ElimTile t[3] = {{gv, 0, 0, blk, DNL, 1, 1, dinvm + c0}, {gv, 0, 0, blk + 16 * DNL, DNL, 1, 2, dinvm + c0 + 16},
+                               {gv + c0, 0, 1, wv, 0, 1, 3, nullptr}};
+        elim_follow<3>(t, ech, lane);
+      } else if (wave == 2 || wave == 3) {
+        // the row tiles below, dealt in halves: wave 2 takes the first ceil(nT / 2), wave 3 the rest (at most three each)
+        const int h0 = (nT + 1) / 2;
+        const int first = wave == 2 ? 0 : h0, cnt = wave == 2 ? h0 : nT - h0;
+        double* const x0 = A + (16 * (t_first + first)) * DNL + c0;
+        if (cnt == 3) {
+          const ElimTile t[3] = {{x0, DNL, 1, x0, DNL, 1, 0, nullptr}, {x0 + 16 * DNL, DNL, 1, x0 + 16 * DNL, DNL, 1, 0, nullptr},
+                                 {x0 + 32 * DNL, DNL, 1, x0 + 32 * DNL, DNL, 1, 0, nullptr}};
+          elim_follow<3>(t, ech, lane);
+        } else if (cnt == 2) {
+          const ElimTile t[2] = {{x0, DNL, 1, x0, DNL, 1, 0, nullptr}, {x0 + 16 * DNL, DNL, 1, x0 + 16 * DNL, DNL, 1, 0, nullptr}};
+          elim_follow<2>(t, ech, lane);
+        } else if (cnt == 1) {
+          const ElimTile t[1] = {{x0, DNL, 1, x0, DNL, 1, 0, nullptr}};
+          elim_follow<1>(t, ech, lane);
+        }
+      } else if (jb > 0) {
+        // trailing tiles of block jb-1 outside the current block's two column tiles (those were updated before the
+        // barrier): tiles (I, c), c >= 2 relative to t_first - 2 ... i.e. column tiles >= t_first, rows I >= c; waves 5..7
+        // (wave 4 shares the chief's SIMD)
+        if (wave >= 5) {
+          const int Tn = nt_all - t_first;                  // row / column tiles behind the current block
+          const int ntile = Tn * (Tn + 1) / 2;
+          for (int q = wave - 5; q < ntile; q += 3) {
+            int I = 0, rem = q;
+            while (rem > I) { rem -= I + 1; ++I; }
+            trail_tile(t_first + I, t_first + rem, jb - 1);
+          }
+        }
+      }
+      lds_barrier();
+      DTICK(4)
+      // ---- between two blocks: the right-hand side, the channel, and the trailing update of the next block's columns ----
+      if (tid < BP) gv[c0 + tid] = wv[tid];
+      if (tid >= 256 && tid < 256 + mp - c0 - BP) {
+        const int prow = c0 + BP + (tid - 256);
+        const double* zr = A + prow * DNL + c0;
+        double a4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < BP; ++c) a4[c & 3] += zr[c] * wv[c];
+        gv[prow] -= (a4[0] + a4[1]) + (a4[2] + a4[3]);
+      }
+      if (jb + 1 < nb) {
+        elim_reset(ech, tid, kDenseThreads);
+        // tiles (I, c) with c in {t_first, t_first + 1}, I >= c: nT + (nT - 1) of them, over the eight waves
+        const int n_next = 2 * nT - 1;
+        for (int q = wave; q < n_next; q += 8) {
+          const int c = q < nT ? 0 : 1, I = q < nT ? q : q - nT + 1;
+          trail_tile(t_first + I, t_first + c, jb);
+        }
+      }
+      DTICK(6)
+    }
+  } else {
   stage_diag(0);
   for (int jb = 0; jb < nb; ++jb) {
     const int c0 = BP * jb;
@@ -1657,6 +1767,7 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
     lds_barrier();
     DTICK(6)
     if (jb + 1 < nb) stage_diag(jb + 1);
+  }
   }
   lds_barrier();
   // ---- backward: y_j = L_jj⁻ᵀ (z_j - pend_j), pend_k += L_jkᵀ y_j for the blocks before ----
@@ -1747,9 +1858,9 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
   } else if (tid < m) a.y[n + tid] = yv[tid];
   if (wave == 0 && lane == 0 && !(pmin > 0.0)) st->chol_failed = 1;
 }
-__global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveArgs a, int nsl, int t0, int outer_back) {
+__global__ __launch_bounds__(kDenseThreads) void dense_block_solve_kernel(SolveArgs a, int nsl, int t0, int outer_back, int elim) {
   extern __shared__ double lds[];
-  dense_block_solve_body(a, nsl, lds, Handoff{nullptr, 0}, t0, outer_back);
+  dense_block_solve_body(a, nsl, lds, Handoff{nullptr, 0}, t0, outer_back, elim);
 }
 // The dense reduced solve (workgroup 0) and the first back-substitution launch behind it (the other workgroups) in ONE
 // launch: the nodes request everything they need that the reduced solve does not produce -- L⁻ᵀ, Z^A, Z^B, border rows,
@@ -1760,11 +1871,11 @@ template <int QM, int MODE, bool PRE>
 __global__ __launch_bounds__(kDenseThreads) void dense_back_kernel(SolveArgs a, BcrArgs b, int nsl, int node0, int n_nodes, int q_max,
                                                                    const double* __restrict__ x, double* __restrict__ x_cand,
                                                                    const BlockDev* __restrict__ blocks, int n_blocks, BcrTopSeps ts,
-                                                                   int* word, int seq) {
+                                                                   int* word, int seq, int elim) {
   extern __shared__ double lds[];
   __shared__ double sh[64];
   const Handoff ho = {word, seq};
-  if (blockIdx.x == 0) { dense_block_solve_body(a, nsl, lds, ho); return; }
+  if (blockIdx.x == 0) { dense_block_solve_body(a, nsl, lds, ho, 0, 0, elim); return; }
   bcr_back_body<QM, MODE, true, PRE>(a, b, int(blockIdx.x) - 1, node0, n_nodes, 1, q_max, x, x_cand, blocks, n_blocks, ts, lds, sh, ho);
 }
 size_t dense_block_solve_lds_bytes() { return size_t(128 * DNL + 128 + 64 * DLD + 128 * 3 + 32 + 128 + kDenseThreads) * sizeof(double); }
@@ -1773,7 +1884,7 @@ hipError_t configure_dense_block_solve() {
                              int(dense_block_solve_lds_bytes()));
 }
 void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s, int t0, int outer_back) {
-  hipLaunchKernelGGL(dense_block_solve_kernel, dim3(1), dim3(kDenseThreads), dense_block_solve_lds_bytes(), s, a, ks, t0, outer_back);
+  hipLaunchKernelGGL(dense_block_solve_kernel, dim3(1), dim3(kDenseThreads), dense_block_solve_lds_bytes(), s, a, ks, t0, outer_back, block_elim_enabled() ? 1 : 0);
 }
 // ---------------------------------------------------------------------------
 // Large reduced systems (m + 1 > 128): one step of the blocked right-looking factorisation, 32 columns, over several
@@ -1969,7 +2080,8 @@ void launch_dense_back(const SolveArgs& a, const BcrArgs& b, int ks, int node0, 
                        const BlockDev* blocks, int n_blocks, const BcrTopSeps& ts, int* word, int seq, hipStream_t s) {
   const size_t lds = dense_back_lds(q_max, b.m1p);
   const dim3 grid(1 + n_nodes + 1), block(kDenseThreads);       // dense solve, the nodes, the calibration / root update
-#define LAUNCH_DB(QM, SD, PR) hipLaunchKernelGGL(HIP_KERNEL_NAME(dense_back_kernel<QM, SD, PR>), grid, block, lds, s, a, b, ks, node0, n_nodes, q_max, x, x_cand, blocks, n_blocks, ts, word, seq)
+  const int elim = block_elim_enabled() ? 1 : 0;
+#define LAUNCH_DB(QM, SD, PR) hipLaunchKernelGGL(HIP_KERNEL_NAME(dense_back_kernel<QM, SD, PR>), grid, block, lds, s, a, b, ks, node0, n_nodes, q_max, x, x_cand, blocks, n_blocks, ts, word, seq, elim)
   if (dense_back_pre(a)) {
     if (ts.n > 0) { if (q_max <= 1) LAUNCH_DB(1, 2, true); else if (q_max <= 2) LAUNCH_DB(2, 2, true); else LAUNCH_DB(4, 2, true); }
     else { if (q_max <= 1) LAUNCH_DB(1, 1, true); else if (q_max <= 2) LAUNCH_DB(2, 1, true); else LAUNCH_DB(4, 1, true); }
@@ -1981,17 +2093,19 @@ void launch_dense_back(const SolveArgs& a, const BcrArgs& b, int ks, int node0, 
 }
 
 // ---- launch helpers ---------------------------------------------------------
-size_t bcr_level_lds_bytes() { return size_t(2 * 64 * DLD + 3 * BP * XLD + 80 + 128 + kLevelThreads) * sizeof(double); }
+// CALICO_ELIM=panel: the block factorisation of rounds 1-3 (two in-wave panels + tile update + Z phase); read per solve (A/B switch)
+bool block_elim_enabled() { const char* e = std::getenv("CALICO_ELIM"); return !(e && std::string(e) == "panel"); }
+size_t bcr_level_lds_bytes() { return size_t(2 * 64 * DLD + 3 * BP * XLD + 80 + 128 + kLevelThreads + kElimBufDoubles) * sizeof(double); }
 size_t bcr_back_lds_bytes(int q_max, int m1p) {
   return (size_t(2) * q_max * BP * DLD + kBcrMaxChain * BP + 3 * BP + m1p + size_t(q_max) * BP + 4 * BP) * sizeof(double);
 }
 hipError_t configure_bcr_kernels(int q_max, int m1p) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bcr_level_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     int(bcr_level_lds_bytes()));
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bcr_level_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          int(bcr_level_lds_bytes()));
-  if (e != hipSuccess) return e;
+  hipError_t e = hipSuccess;
+  for (const void* f : {reinterpret_cast<const void*>(&bcr_level_kernel<true, true>), reinterpret_cast<const void*>(&bcr_level_kernel<false, true>),
+                        reinterpret_cast<const void*>(&bcr_level_kernel<true, false>), reinterpret_cast<const void*>(&bcr_level_kernel<false, false>)}) {
+    e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(bcr_level_lds_bytes()));
+    if (e != hipSuccess) return e;
+  }
   for (const void* f : {reinterpret_cast<const void*>(&bcr_back_kernel<1, 0>), reinterpret_cast<const void*>(&bcr_back_kernel<2, 0>),
                         reinterpret_cast<const void*>(&bcr_back_kernel<4, 0>), reinterpret_cast<const void*>(&bcr_back_kernel<8, 0>),
                         reinterpret_cast<const void*>(&bcr_back_kernel<1, 1>), reinterpret_cast<const void*>(&bcr_back_kernel<2, 1>),
@@ -2012,8 +2126,9 @@ void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nod
   const int nfs = (a.mc + 1 + kBcrFS - 1) / kBcrFS;
   const int n_apply = n_keep > 0 ? std::min(64, std::max(1, n_keep * 4)) : 0;
   const int main_span = 8 * ((n_nodes + 7) / 8) * (1 + nfs);      // (node, role) workgroups laid out by XCD: see the kernel
+  const bool elim = block_elim_enabled();
   if (level == 0) {
-    hipLaunchKernelGGL(bcr_level_kernel<true>, dim3(main_span + n_apply + (with_post_eval ? 1 : 0)), dim3(kLevelThreads),
+    hipLaunchKernelGGL((elim ? bcr_level_kernel<true, true> : bcr_level_kernel<true, false>), dim3(main_span + n_apply + (with_post_eval ? 1 : 0)), dim3(kLevelThreads),
                        bcr_level_lds_bytes(), s, a, b, node0, n_nodes, nfs, level, keep0, n_keep, o, with_post_eval, x, blocks, n_blocks,
                        log, log_cap, jacobi, 0, 0, 1, fan_word, 0);
   } else {
@@ -2023,7 +2138,7 @@ void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nod
     const int n_schur_wg = schur_ks > 0 ? nt * (nt + 1) / 2 * schur_ks : 0;
     const int n_root_wg = schur_ks > 0 ? std::max(1, (br * (a.mc + 1 + br) + kLevelThreads - 1) / kLevelThreads) : 0;
     const int n_prod = n_nodes * (1 + nfs) + n_apply;        // the workgroups of this level that really exist
-    hipLaunchKernelGGL(bcr_level_kernel<false>, dim3(main_span + n_apply + n_schur_wg + n_root_wg), dim3(kLevelThreads), bcr_level_lds_bytes(), s, a, b,
+    hipLaunchKernelGGL((elim ? bcr_level_kernel<false, true> : bcr_level_kernel<false, false>), dim3(main_span + n_apply + n_schur_wg + n_root_wg), dim3(kLevelThreads), bcr_level_lds_bytes(), s, a, b,
                        node0, n_nodes, nfs, level, keep0, n_keep, o, 0, x, blocks, n_blocks, log, log_cap, jacobi, n_schur_wg, n_root_wg,
                        std::max(1, schur_ks), schur_ks > 0 ? fan_word : nullptr, n_prod);
   }

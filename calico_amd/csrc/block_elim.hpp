@@ -39,13 +39,25 @@ namespace cal {
 
 constexpr int kElimSlot = 64;                          // doubles per published vector (one per lane)
 constexpr int kElimStep = 3 * kElimSlot;               // w, l0, l1
-constexpr int kElimBufDoubles = 8 * kElimStep + 8;     // write-once per factorisation (+ the progress word)
+constexpr int kElimBufDoubles = 8 * kElimStep;         // write-once per factorisation
+// No flag and no wait on the chief's side: the channel is filled with a sentinel (a NaN no arithmetic produces) before a
+// factorisation, the chief stores w, l0, l1 of a step in that order, and a follower requests l1, w, l0 in THAT order and
+// looks at its own lane's l1: LDS executes instructions in order, so once every lane has seen its l1 the reads behind it
+// have seen w and l0. (A progress word needed s_waitcnt lgkmcnt(0) in front of its store: the chief's stores queue behind
+// the followers' polling reads, and the wait cost it ~100 clocks per step inside the kernels.)
+constexpr unsigned long long kElimSentinel = 0x7FF8E11AE11AE11Aull;
 
-struct ElimChannel {
-  double* buf;       // LDS [8][3][64]
-  int* progress;     // LDS: `base` + number of steps published; monotonic over the factorisations of a launch
-};
-DEVI ElimChannel elim_channel(double* lds /* kElimBufDoubles */) { return ElimChannel{lds, reinterpret_cast<int*>(lds + 8 * kElimStep)}; }
+struct ElimChannel { double* buf; };      // LDS [8][3][64]
+DEVI ElimChannel elim_channel(double* lds /* kElimBufDoubles */) { return ElimChannel{lds}; }
+// all threads of the workgroup (any time after the followers of the last factorisation are through; a barrier follows)
+DEVI void elim_reset(const ElimChannel& ch, int tid, int nthreads) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(ch.buf);
+  for (int e = tid; e < kElimBufDoubles; e += nthreads) p[e] = kElimSentinel;
+}
+DEVI void elim_store(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");       // (the order of the stores of a step is part of the protocol)
+}
 
 // The 4x4 pivot block of a step, factored by every lane, in seven short stages: the matrix pipe is in-order and a queued
 // MFMA blocks the wave's issue, so the chief's MFMAs that are off the chain are placed BETWEEN these stages, with
@@ -89,20 +101,11 @@ struct PivotChain {
 // the compiler hands to the next VALU instruction costs that instruction the MFMA's whole latency in hazard wait states
 #define CAL_KEEP(v) asm volatile("" : : "v"(v))
 
-DEVI void elim_publish(const ElimChannel& ch, int value) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __hip_atomic_store(ch.progress, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-DEVI void elim_wait(const ElimChannel& ch, int target) {
-  while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(ch.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - target < 0) __builtin_amdgcn_s_sleep(1);
-  asm volatile("" ::: "memory");
-}
-
 // The chief. In: rows 0..31 of A (LDS, row stride LD): the block, lower triangle (the upper one is not read).
-// Out (WRITE_L): rows 0..31: L, lower triangle (above the diagonal undefined). `base`: value of the progress word before
-// this factorisation; it is base + 8 afterwards.
-template <bool WRITE_L, bool TS = false>
-DEVI void elim_chief(double* A, int LD, const ElimChannel ch, int base, int lane, long long* ts = nullptr) {
+// Out (WRITE_L = 1): rows 0..31: L, lower triangle (above the diagonal undefined); WRITE_L = 2: the lower triangle only --
+// in place in a matrix whose strict upper triangle belongs to somebody else (the dense solve keeps L⁻ᵀ there).
+template <int WRITE_L, bool TS = false>
+DEVI void elim_chief(double* A, int LD, const ElimChannel ch, int lane, long long* ts = nullptr) {
   const int l16 = lane & 15, lk = lane >> 4;
   const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
   f64x4 t00, t01, t11;
@@ -127,22 +130,21 @@ DEVI void elim_chief(double* A, int LD, const ElimChannel ch, int base, int lane
   for (int u = 0; u < 4; ++u) {
     if (TS) ts[u] = __builtin_readcyclecounter();
     pc.d = t00[u]; pc.b = 4 * u;
-    pc.s0(); pc.s1(); pc.s2();
-    CAL_SB();
-    if (u > 0) elim_publish(ch, base + u);        // step u-1 is out (its LDS writes were issued a few hundred clocks ago: no wait)
-    CAL_SB();
-    pc.s3(); pc.s4(); pc.s5();
+    pc.s0(); pc.s1(); pc.s2(); pc.s3(); pc.s4(); pc.s5();
     const double w = pc.s6();
     CAL_SB();
-    pub[u * kElimStep] = w;
+    elim_store(pub + u * kElimStep, w);
     p0 = CAL_MFMA(w, t00[u], zero4);
     p1 = CAL_MFMA(w, t01[u], zero4);
     if (u < 3) t00 = CAL_MFMA(p0[0], p0[0], t00);
     if (u < 3) t01 = CAL_MFMA(p0[0], p1[0], t01);
     t11 = CAL_MFMA(p1[0], p1[0], t11);
-    pub[u * kElimStep + kElimSlot] = p0[0];
-    pub[u * kElimStep + 2 * kElimSlot] = p1[0];
-    if (WRITE_L) { A[l16 * LD + 4 * u + lk] = p0[0]; A[(16 + l16) * LD + 4 * u + lk] = p1[0]; }
+    elim_store(pub + u * kElimStep + kElimSlot, p0[0]);
+    elim_store(pub + u * kElimStep + 2 * kElimSlot, p1[0]);
+    if (WRITE_L) {
+      if (WRITE_L == 1 || l16 >= 4 * u + lk) A[l16 * LD + 4 * u + lk] = p0[0];
+      A[(16 + l16) * LD + 4 * u + lk] = p1[0];
+    }
     CAL_SB();
     CAL_KEEP(p0); CAL_KEEP(p1);
   }
@@ -151,20 +153,15 @@ DEVI void elim_chief(double* A, int LD, const ElimChannel ch, int base, int lane
   for (int u = 0; u < 4; ++u) {
     if (TS) ts[4 + u] = __builtin_readcyclecounter();
     pc.d = t11[u]; pc.b = 4 * u;
-    pc.s0(); pc.s1(); pc.s2();
-    CAL_SB();
-    elim_publish(ch, base + 4 + u);               // step 3 + u is out
-    CAL_SB();
-    pc.s3(); pc.s4(); pc.s5();
+    pc.s0(); pc.s1(); pc.s2(); pc.s3(); pc.s4(); pc.s5();
     const double w = pc.s6();
     CAL_SB();
-    pub[(4 + u) * kElimStep] = w;
-    if (u == 3 && !WRITE_L) { elim_publish(ch, base + 8); break; }       // (the last step: the followers only need w)
+    elim_store(pub + (4 + u) * kElimStep, w);
+    if (u == 3 && !WRITE_L) break;                // (the last step: the followers only need w)
     p1 = CAL_MFMA(w, t11[u], zero4);
     if (u < 3) t11 = CAL_MFMA(p1[0], p1[0], t11);
-    pub[(4 + u) * kElimStep + 2 * kElimSlot] = p1[0];
-    if (WRITE_L) A[(16 + l16) * LD + 16 + 4 * u + lk] = p1[0];
-    if (u == 3) elim_publish(ch, base + 8);
+    if (u < 3) elim_store(pub + (4 + u) * kElimStep + 2 * kElimSlot, p1[0]);
+    if (WRITE_L == 1 || (WRITE_L == 2 && l16 >= 4 * u + lk)) A[(16 + l16) * LD + 16 + 4 * u + lk] = p1[0];
     CAL_SB();
     CAL_KEEP(p1);
   }
@@ -178,12 +175,14 @@ struct ElimTile {
   int in_row, in_col;
   double* out;           // where the result entry (i, c) goes: out[i * out_row + c * out_col]
   int out_row, out_col;
-  int kind;              // 0: loaded from `in`; 1 / 2: identity rows against the block's columns 0..15 / 16..31 (-> L⁻ᵀ)
+  int kind;              // 0: loaded from `in`; 1 / 2: identity rows against the block's columns 0..15 / 16..31 (-> L⁻ᵀ);
+                         // 3: a single row (i = 0) loaded from `in`, the other fifteen are zero and nothing of them is stored
+  double* diag;          // kinds 1 / 2, if not null: only the strict upper triangle of L⁻ᵀ goes to `out`, its diagonal to diag[i]
 };
 
 // A follower with NT row tiles (compile-time unrolled; the descriptors are wave-uniform).
 template <int NT>
-DEVI void elim_follow(const ElimTile (&t)[NT], const ElimChannel ch, int base, int lane) {
+DEVI void elim_follow(const ElimTile (&t)[NT], const ElimChannel ch, int lane) {
   const int l16 = lane & 15, lk = lane >> 4;
   const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
   f64x4 x0[NT], x1[NT];
@@ -192,24 +191,35 @@ DEVI void elim_follow(const ElimTile (&t)[NT], const ElimChannel ch, int base, i
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int c = lk + 4 * r;
-      if (t[q].kind == 0) {
-        x0[q][r] = -t[q].in[l16 * t[q].in_row + c * t[q].in_col];
-        x1[q][r] = -t[q].in[l16 * t[q].in_row + (16 + c) * t[q].in_col];
-      } else {
-        const double id = l16 == c ? -1.0 : 0.0;
-        x0[q][r] = t[q].kind == 1 ? id : 0.0;
-        x1[q][r] = t[q].kind == 2 ? id : 0.0;
-      }
+      const double v0 = t[q].in[l16 * t[q].in_row + c * t[q].in_col], v1 = t[q].in[l16 * t[q].in_row + (16 + c) * t[q].in_col];
+      const double id = l16 == c ? -1.0 : 0.0;
+      const bool ld = t[q].kind == 0 || (t[q].kind == 3 && l16 == 0);
+      x0[q][r] = ld ? -v0 : (t[q].kind == 1 ? id : 0.0);
+      x1[q][r] = ld ? -v1 : (t[q].kind == 2 ? id : 0.0);
     }
   }
-  const double* const sub = ch.buf + lane;
+  const unsigned long long* const sub = reinterpret_cast<const unsigned long long*>(ch.buf) + lane;
+  // what step s needs, the last-stored vector first (see ElimChannel); step s + 1 is requested before step s is worked
+  // on, so that the LDS round trip runs beside the step's MFMAs (a request that came too early is repeated)
+  unsigned long long v[3] = {0, 0, 0}, nv[3] = {0, 0, 0};
+  auto request = [&](int s, unsigned long long (&d)[3]) {
+    const bool need_l0 = s < 3, need_l1 = s < 7;
+    if (need_l1) d[2] = __hip_atomic_load(sub + s * kElimStep + 2 * kElimSlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    d[0] = __hip_atomic_load(sub + s * kElimStep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (need_l0) d[1] = __hip_atomic_load(sub + s * kElimStep + kElimSlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+  };
+  request(0, v);
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     const int J = s >> 2, u = s & 3;
-    elim_wait(ch, base + s + 1);
-    const double w = sub[s * kElimStep];
-    const double l0 = (J == 0 && u < 3) ? sub[s * kElimStep + kElimSlot] : 0.0;
-    const double l1 = (s < 7) ? sub[s * kElimStep + 2 * kElimSlot] : 0.0;
+    const bool need_l0 = s < 3, need_l1 = s < 7;
+    while (__builtin_amdgcn_ballot_w64((need_l1 ? v[2] : v[0]) == kElimSentinel) != 0) { __builtin_amdgcn_s_sleep(1); request(s, v); }
+    const double w = __longlong_as_double((long long)v[0]);
+    const double l0 = need_l0 ? __longlong_as_double((long long)v[1]) : 0.0;
+    const double l1 = need_l1 ? __longlong_as_double((long long)v[2]) : 0.0;
+    if (s < 7) request(s + 1, nv);
     double lp[NT];
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
@@ -218,10 +228,17 @@ DEVI void elim_follow(const ElimTile (&t)[NT], const ElimChannel ch, int base, i
     }
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
-      t[q].out[l16 * t[q].out_row + (4 * s + lk) * t[q].out_col] = lp[q];
-      if (J == 0 && u < 3) x0[q] = CAL_MFMA(l0, lp[q], x0[q]);
-      if (s < 7 && !(J == 1 && u == 3)) x1[q] = CAL_MFMA(l1, lp[q], x1[q]);
+      {
+        const int col = 4 * s + lk, row = l16 + (t[q].kind == 2 ? 16 : 0);      // (row: of L⁻ᵀ, for the identity tiles)
+        double* dst = t[q].out + l16 * t[q].out_row + col * t[q].out_col;
+        if (t[q].kind == 3) { if (l16 == 0) *dst = lp[q]; }
+        else if ((t[q].kind == 1 || t[q].kind == 2) && t[q].diag) { if (col > row) *dst = lp[q]; else if (col == row) t[q].diag[l16] = lp[q]; }
+        else *dst = lp[q];
+      }
+      if (need_l0) x0[q] = CAL_MFMA(l0, lp[q], x0[q]);
+      if (need_l1 && !(J == 1 && u == 3)) x1[q] = CAL_MFMA(l1, lp[q], x1[q]);
     }
+    v[0] = nv[0]; v[1] = nv[1]; v[2] = nv[2];
   }
 }
 

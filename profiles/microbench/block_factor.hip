@@ -39,7 +39,6 @@ __global__ __launch_bounds__(512) void bench(const double* D, const double* X, d
   double pmin = 1.0, x = 1.0 + lane * 1e-3;
   long long t0, t1;
   const ElimChannel ch = elim_channel(chbuf);
-  if (tid == 0) *ch.progress = 0;
   auto init = [&]() {
     for (int e = tid; e < 1024; e += blockDim.x) {
       const int r = e >> 5, c = e & 31;
@@ -54,6 +53,7 @@ __global__ __launch_bounds__(512) void bench(const double* D, const double* X, d
     for (int rep = 0; rep < 4; ++rep) {
       init();
       if (MODE == 2) { split_reset(cbuf, tid, blockDim.x); __syncthreads(); }
+      if (MODE == 1) { elim_reset(ch, tid, blockDim.x); __syncthreads(); }
       PIN(x); t0 = __builtin_readcyclecounter(); PIN(x);
       if (MODE == 0) {
         if (wave == 0) panel_factor<1, false, false>(A, DLD, dinv, bcast, 0, 63, 16, lane, &pmin);
@@ -74,17 +74,17 @@ __global__ __launch_bounds__(512) void bench(const double* D, const double* X, d
       } else if (MODE == 1) {
         if (wave == 0) {
           long long ts[9];
-          elim_chief<true, true>(A, DLD, ch, base, lane, ts);
+          elim_chief<1, true>(A, DLD, ch, lane, ts);
           if (lane == 0 && rep == 3) { for (int i = 0; i < 9; ++i) cyc[16 + i] = ts[i] - t0; }
         }
         else if (wave == 1) {
-          const ElimTile t[3] = {{nullptr, 0, 0, A + 32 * DLD, DLD, 1, 1}, {nullptr, 0, 0, A + 48 * DLD, DLD, 1, 2},
-                                 {Xs + 64, 1, XLD, Zb + 64, 1, XLD, 0}};
-          elim_follow<3>(t, ch, base, lane);
+          const ElimTile t[3] = {{Zb, 0, 0, A + 32 * DLD, DLD, 1, 1, nullptr}, {Zb, 0, 0, A + 48 * DLD, DLD, 1, 2, nullptr},
+                                 {Xs + 64, 1, XLD, Zb + 64, 1, XLD, 0, nullptr}};
+          elim_follow<3>(t, ch, lane);
         } else if (wave == 2 || wave == 3) {
           const int c0 = 32 * (wave - 2);
-          const ElimTile t[2] = {{Xs + c0, 1, XLD, Zb + c0, 1, XLD, 0}, {Xs + c0 + 16, 1, XLD, Zb + c0 + 16, 1, XLD, 0}};
-          elim_follow<2>(t, ch, base, lane);
+          const ElimTile t[2] = {{Xs + c0, 1, XLD, Zb + c0, 1, XLD, 0, nullptr}, {Xs + c0 + 16, 1, XLD, Zb + c0 + 16, 1, XLD, 0, nullptr}};
+          elim_follow<2>(t, ch, lane);
         }
         base += 8;
         lds_barrier();
