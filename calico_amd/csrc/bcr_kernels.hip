@@ -289,6 +289,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
                                                                    const double* __restrict__ x, const BlockDev* __restrict__ blocks,
                                                                    int n_blocks, IterLog* log, int log_cap, int jacobi_scaling,
                                                                    int n_schur_wg, int n_root_wg, int schur_ks, int* fan_word, int n_prod) {
+  const long long t_kernel = CAL_DEV_TIMING(a.debug != 0) ? __builtin_readcyclecounter() : 0;
   LmState* st = a.st;
   const int terminated = st->terminated;     // tested after the first loads are on their way (they are harmless)
   const double radius = st->radius;
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       if (terminated) return;
       if (threadIdx.x == 0 && a.st->commit_pending) a.st->commit_pending = 0;   // see commit_kernel (several ranks)
       post_eval_body(a, x, blocks, n_blocks, o, log, log_cap, with_post == 2 ? 1 : 0, jacobi_scaling);     // (all threads: it has barriers inside)
+      if (CAL_DEV_TIMING(a.debug == 4 && threadIdx.x == 0)) printf("bcr_level 0: the bookkeeping workgroup lived %lld clocks\n", (long long)(__builtin_readcyclecounter() - t_kernel));
       return;
     }
     use_current_R(a);
@@ -414,6 +416,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           if (fl & 16) b.F[didx[u]] = v; else b.D[didx[u]] = v;
         }
       }
+      if (CAL_DEV_TIMING(a.debug == 4 && threadIdx.x == 0 && aw == 0)) printf("bcr_level 0: a separator-initialisation workgroup lived %lld clocks\n", (long long)(__builtin_readcyclecounter() - t_kernel));
       if (pub) fanin_arrive(fan_word);
       return;
     }
@@ -466,6 +469,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   int iD[NU], iB[NU];
   bool okD[NU], okB[NU];
   const int strideB = kBcrCps * a.k * 36;
+  const double inv_radius = 1.0 / radius;
   if (FROM_R) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -505,12 +509,24 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         const bool vD = okD[u] && r < nreal && c < nreal && act_r && act_c;
         double v = RBnd[vD ? iD[u] : 0];
         v = vD ? v : 0.0;
-        if (r == c) {
+        {
+          // LM damping of a diagonal entry (FromR::damping), for every entry and selected afterwards: as a branch around a
+          // division (with the scale's load inside it) this piece alone kept Z 2k clocks per step behind the chief -- the
+          // loads of the step's other entries queued behind it. 1 / (radius s^2) as a product of 1 / radius (once per
+          // thread) and the filed 1 / s^2; only a solve's first linear solve, which forms the scale itself, divides.
+          const bool dg = r == c;
           const int t = RB * blk + r;
           const bool real_row = r < RB && r < nreal;
-          const double d = fr.damping(v, real_row ? t : 0);
-          if (vD) { v += d; if (role == 0) a.dadd[t] = d; }
-          else { v = 1.0; if (role == 0 && real_row) a.dadd[t] = 0.0; }
+          const int ts = (dg && real_row) ? t : 0;
+          double d;
+          if (fr.first_scale == 0) {
+            const double sv = a.scale[ts], q2 = a.scale[a.NT() + ts];
+            d = fmin(fmax(v * sv * sv, o.min_lm_diagonal), o.max_lm_diagonal) * (inv_radius * q2);
+          } else d = fr.damping(v, ts);
+          if (dg) {
+            if (vD) { v += d; if (role == 0) a.dadd[t] = d; }
+            else { v = 1.0; if (role == 0 && real_row) a.dadd[t] = 0.0; }
+          }
         }
         pr.d[u] = v;
         const bool vB = okB[u] && has_next && r < nreal_n && act_rn && act_c;
@@ -580,8 +596,10 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       if (e < BP * kBcrFS) Xp[(e >> 4) * XLD + CF + (e & 15)] = pr.f[u];
     }
   };
-  const bool dbg = CAL_DEV_TIMING(a.debug && bid < 2 && lane == 0 && (wave == 0 || wave == 5));
+  const bool dbg = CAL_DEV_TIMING(a.debug && a.debug < 4 && bid < 2 && lane == 0 && (wave == 0 || wave == 5));
   long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
+  const long long t_setup = CAL_DEV_TIMING(a.debug >= 4) ? __builtin_readcyclecounter() - t_kernel : 0;
+  long long t_first = 0, t_loop = 0, t_top[4] = {0, 0, 0, 0}, t_elim[4] = {0, 0, 0, 0}, t_bara[4] = {0, 0, 0, 0};
 #define LTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   double pmin = 1.0;
   // U_aa (role 0: waves 0..3, tile (wave >> 1, wave & 1)) or U_aF (border roles: waves 2, 3, row tile wave - 2)
@@ -594,6 +612,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   }
   __syncthreads();
   LTICK(0)
+  if (CAL_DEV_TIMING(a.debug >= 4)) t_first = __builtin_readcyclecounter() - t_kernel;
   // (the barriers of the step loop order LDS traffic only: __syncthreads() would also drain the global loads of the
   //  next block, which are meant to stay in flight while this one is factored)
   for (int i = 0; i < q; ++i) {
@@ -606,8 +625,12 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     const int blk = blk0 + i;
     Pre pr;
     const long long t_step = CAL_DEV_TIMING(a.debug != 0) ? __builtin_readcyclecounter() : 0;
+    if (CAL_DEV_TIMING(a.debug >= 4)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (k == i) t_top[k] = t_step - t_kernel;
+    }
     if (!last && loader) fetch(i + 1, pr);            // in flight while the block is factored
-    if (CAL_DEV_TIMING(a.debug && bid < 1 && lane == 0 && wave >= 4)) printf("level %d step %d wave %d: requests issued at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
+    if (CAL_DEV_TIMING(a.debug == 2 && bid < 1 && lane == 0 && wave >= 4)) printf("level %d step %d wave %d: requests issued at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
     if (ELIM) {
       // ---- D = L Lᵀ, Z = L⁻¹X and (role 0) L⁻ᵀ in one pass: wave 0 the spine, waves 1..3 two row tiles each ----
       if (wave == 0) elim_chief<0>(Dp, DLD, ech, lane);
@@ -624,9 +647,9 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         const ElimTile t[2] = {{Xp + c0, 1, XLD, Zb + c0, 1, XLD, 0, nullptr}, {Xp + c0 + 16, 1, XLD, Zb + c0 + 16, 1, XLD, 0, nullptr}};
         elim_follow<2>(t, ech, lane);
       }
-      if (CAL_DEV_TIMING(a.debug && bid < 1 && lane == 0 && wave < 4)) printf("level %d step %d wave %d: elimination done at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
+      if (CAL_DEV_TIMING(a.debug == 2 && bid < 1 && lane == 0 && wave < 4)) printf("level %d step %d wave %d: elimination done at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
       if (!last && loader) commit(p ^ 1, pr);
-      if (CAL_DEV_TIMING(a.debug && bid < 1 && lane == 0 && wave >= 4)) printf("level %d step %d wave %d: committed at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
+      if (CAL_DEV_TIMING(a.debug == 2 && bid < 1 && lane == 0 && wave >= 4)) printf("level %d step %d wave %d: committed at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
       LTICK(3)
     } else {
     // ---- D = L Lᵀ and L⁻ᵀ: two in-wave panels, one tile update between them ----
@@ -655,8 +678,16 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       if (role > 0 && (wave == 0 || wave == 2)) zjob(4, wave == 0 ? 1 : 0);
     }
     }
+    if (CAL_DEV_TIMING(a.debug >= 4)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (k == i) t_elim[k] = __builtin_readcyclecounter() - t_kernel;
+    }
     lds_barrier();
     LTICK(4)
+    if (CAL_DEV_TIMING(a.debug >= 4)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (k == i) t_bara[k] = __builtin_readcyclecounter() - t_kernel;
+    }
     if (ELIM && !last) elim_reset(ech, tid, kLevelThreads);      // (the followers are through; the barrier at the end of the step orders it)
     // ---- file what the back-substitution needs ----
     if (role == 0) {
@@ -736,6 +767,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     lds_barrier();
     LTICK(6)
   }
+  if (CAL_DEV_TIMING(a.debug >= 4)) t_loop = __builtin_readcyclecounter() - t_kernel;
   if (dbg) printf("bcr_level %d wg %d wave %d (q %d) cycles: load %lld | per step: panel0 %lld  tile %lld  panel1+commit %lld  Z %lld  stores+U %lld  barrier %lld\n",
                   level, bid, wave, q, tph[0], tph[1] / q, tph[2] / q, tph[3] / q, tph[4] / q, tph[5] / q, tph[6] / q);
 #undef LTICK
@@ -753,6 +785,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       for (int r = 0; r < 4; ++r) put(dst + size_t(16 * (wave - 2) + lk + 4 * r) * m1p, acc_a[r]);
     }
   }
+  if (CAL_DEV_TIMING(a.debug >= 4 && tid == 0 && (bid < 9 || bid % 7 == 0))) printf("bcr_level %d: chain workgroup %d (role %d) lived %lld clocks: set-up done at %lld, first block in LDS at %lld, chain done at %lld | steps begin %lld %lld %lld %lld | wave 0 through with its part %lld %lld %lld %lld | Z there %lld %lld %lld %lld\n", level, bid, role, (long long)(__builtin_readcyclecounter() - t_kernel), t_setup, t_first, t_loop, t_top[0], t_top[1], t_top[2], t_top[3], t_elim[0], t_elim[1], t_elim[2], t_elim[3], t_bara[0], t_bara[1], t_bara[2], t_bara[3]);
   if (role == 0 && wave == 0 && lane == 0 && !(pmin > 0.0)) st->chol_failed = 1;
   if (pub) fanin_arrive(fan_word);
 }
@@ -929,7 +962,7 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
   // update of the candidate point reads (gradient, damping, the control points' current values): a dependent global
   // load costs about a microsecond here, the arithmetic next to nothing. Chain indices are clamped, not predicated,
   // so that the loads stay unconditional.
-  const bool bdbg = CAL_DEV_TIMING(a.debug && dbg_first && tid == 0);
+  const bool bdbg = CAL_DEV_TIMING(a.debug == 1 && dbg_first && tid == 0);
   long long bt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, btk = bdbg ? __builtin_readcyclecounter() : 0;
 #define BTICK(i) if (bdbg) { const long long t_ = __builtin_readcyclecounter(); bt[i] += t_ - btk; btk = t_; }
   // update stage: thread e < 32q owns row e of the chain (gradient, damping), thread e < 5q control point e. The offset
@@ -1014,7 +1047,7 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
     if (side) yroot_v = (b.root >= 0 && (tid & 31) < RB) ? load_sc1(a.y + n_s + mc + (tid & 31)) : 0.0;
   }
   BTICK(0)
-  if (CAL_DEV_TIMING(a.debug > 1)) {     // development aid: which input of the node is not finite?
+  if (CAL_DEV_TIMING(a.debug == 2)) {     // development aid: which input of the node is not finite?
     bool bz = false, bm = false, ba = false, bt = false;
 #pragma unroll
     for (int i = 0; i < QM; ++i) {
@@ -1243,7 +1276,7 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* 
   const bool my_cp_in = (tid < q * kBcrCps || sep_cp) && my_cp < a.n_cp;
   const int my_cp_c = my_cp_in ? my_cp : 0;
   const int my_off = b.ctrl_off[my_cp_c];
-  const bool pdbg = CAL_DEV_TIMING(a.debug && nd_slot == ndp->slot && blk0 == 0 && tid == 0);
+  const bool pdbg = CAL_DEV_TIMING(a.debug == 1 && nd_slot == ndp->slot && blk0 == 0 && tid == 0);
   long long pt[6] = {0, 0, 0, 0, 0, 0}, ptk = pdbg ? __builtin_readcyclecounter() : 0;
 #define PTICK(i) if (pdbg) { const long long t_ = __builtin_readcyclecounter(); pt[i] += t_ - ptk; ptk = t_; }
   // ---- requests: operands for LDS (thread (r16, sub): two entries of a row) ----
@@ -1485,6 +1518,7 @@ constexpr int DNL = 129;     // row stride of the dense matrix in LDS
 // waves 4..7 beside them the trailing tiles of the block before that the current block does not touch; between two
 // blocks one phase: right-hand side of the rows below, and the trailing update of the NEXT block's two column tiles.
 DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const Handoff& ho, int t0 = 0, int outer_back = 0, int elim = 0) {
+  const long long t_entry = CAL_DEV_TIMING(a.debug != 0) ? __builtin_readcyclecounter() : 0;
   LmState* st = a.st;
   const int terminated = st->terminated;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1563,11 +1597,12 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
       }
     }
   }
-  const bool dbg = CAL_DEV_TIMING(a.debug && (tid == 0 || tid == 64 * 5));
+  const bool dbg = CAL_DEV_TIMING(a.debug == 1 && (tid == 0 || tid == 64 * 5));
   long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define DTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
   __syncthreads();
   DTICK(0)
+  if (dbg) printf("dense_block_solve wave %d: %lld clocks from the kernel's first instruction to the loaded system\n", wave, (long long)(tk - t_entry));
   double pmin = 1.0;
   // 16x16 tile (I, c) of the trailing matrix minus the contribution of block jb's two panels, all sixteen operands
   // read before the first MFMA

@@ -1271,7 +1271,7 @@ int prepare_workspace(calico_problem* p) {
   HIP_TRY(p, p->d_Lb.alloc(size_t(NS) * 6 * k)); HIP_TRY(p, p->d_Linv.alloc(size_t(n_cp) * 36));
   HIP_TRY(p, p->d_Y.alloc(size_t(NS) * (mw + 1)));
   HIP_TRY(p, p->d_S.alloc(size_t(mw + 1) * (mw + 1)));
-  HIP_TRY(p, p->d_y.alloc(size_t(NT) + p->border_extra() + 64)); HIP_TRY(p, p->d_zbuf.alloc(size_t(NS) + 64)); HIP_TRY(p, p->d_dadd.alloc(NT)); HIP_TRY(p, p->d_scale.alloc(NT));
+  HIP_TRY(p, p->d_y.alloc(size_t(NT) + p->border_extra() + 64)); HIP_TRY(p, p->d_zbuf.alloc(size_t(NS) + 64)); HIP_TRY(p, p->d_dadd.alloc(NT)); HIP_TRY(p, p->d_scale.alloc(2 * size_t(NT)));      // [Jacobi scale s | 1 / s^2]
   HIP_TRY(p, p->d_res.alloc(size_t(n_obs) * 3)); HIP_TRY(p, p->d_valid.alloc(size_t(n_obs)));
   HIP_TRY(p, p->d_active.alloc(size_t(n_obs))); HIP_TRY(p, p->d_counter.alloc(1));
   p->active_dirty = true; p->xc_stale = true;

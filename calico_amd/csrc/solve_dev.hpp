@@ -86,7 +86,12 @@ DEVI void post_eval_body(SolveArgs a, const double* __restrict__ x, const BlockD
   const bool act = tid < 256;
   const int NT = a.NT();
   if (first && act) {
-    for (int j = tid; j < NT; j += 256) a.scale[j] = jacobi_scaling ? 1.0 / (1.0 + sqrt(diag_entry(a, j))) : 1.0;
+    // (behind the scale, 1 / s^2 = (1 + sqrt(diag))^2: the tree levels' chains damp their diagonal entries with products only)
+    for (int j = tid; j < NT; j += 256) {
+      const double q = 1.0 + sqrt(diag_entry(a, j));
+      a.scale[j] = jacobi_scaling ? 1.0 / q : 1.0;
+      a.scale[NT + j] = jacobi_scaling ? q * q : 1.0;
+    }
   }
   double mx = 0.0, sm = 0.0;
   for (int b = act ? tid : n_blocks; b < n_blocks; b += 256) {

@@ -31,8 +31,8 @@ __device__ __forceinline__ f64x4 atb_tile_n(const double* P, int ldp, int pc0, c
   return acc;
 }
 // out_*: [64][32] (L, then L⁻ᵀ) followed by Z [32][80]
-template <int MODE>
-__global__ __launch_bounds__(512) void bench(const double* D, const double* X, double* out_old, double* out_new, double* out_split, long long* cyc) {
+template <int MODE, int NOISE = 0>
+__global__ __launch_bounds__(512) void bench(const double* D, const double* X, double* out_old, double* out_new, double* out_split, long long* cyc, const double* noise = nullptr) {
   __shared__ double A[64 * DLD], Xs[32 * XLD], Zb[32 * XLD], bcast[128], dinv[80], dumpb[512], chbuf[kElimBufDoubles], cbuf[kSplitDoubles];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lk = lane >> 4;
   double* dump = dumpb + tid;
@@ -72,6 +72,27 @@ __global__ __launch_bounds__(512) void bench(const double* D, const double* X, d
         if (blockDim.x == 512) { zjob(wave >> 1, wave & 1); if (wave == 0 || wave == 2) zjob(4, wave == 0 ? 1 : 0); }
         lds_barrier();
       } else if (MODE == 1) {
+        if (NOISE && wave >= 4) {      // what a tree level's loader waves do beside the elimination: scattered 8-byte loads, then LDS writes
+          double v[14];
+          const size_t base = size_t(rep) * 65536 + size_t(tid - 256) * 7;
+#pragma unroll
+          for (int u = 0; u < 14; ++u) v[u] = noise[(base + size_t(u) * 4099) & 0x3ffff];
+          double sacc = 0.0;
+#pragma unroll
+          for (int u = 0; u < 14; ++u) { sacc += v[u]; dumpb[tid] = sacc; }
+          if (NOISE >= 2) {           // ... and their arithmetic: integer index work and a few FP64 divisions per entry
+            int k2 = tid;
+            double q2 = 1.0 + sacc;
+#pragma unroll 1
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+              for (int j = 0; j < 24; ++j) k2 = (k2 * 33 + j) / 6 + (k2 % 7);
+              q2 = fmin(fmax(q2 * 1.25, 1e-6), 1e32) / (3.0 + q2 * q2);
+            }
+            sacc += q2 + k2;
+          }
+          x += sacc * 1e-300;
+        }
         if (wave == 0) {
           long long ts[9];
           elim_chief<1, true>(A, DLD, ch, lane, ts);
@@ -170,6 +191,9 @@ int main() {
   double *dD, *dX, *oo, *on, *os; long long* cyc;
   hipMalloc(&dD, n * n * sizeof(double)); hipMalloc(&dX, 32 * 80 * sizeof(double)); hipMalloc(&oo, NO * sizeof(double)); hipMalloc(&on, NO * sizeof(double)); hipMalloc(&os, NO * sizeof(double));
   hipMalloc(&cyc, 64 * sizeof(long long));
+  long long* cyc3; hipMalloc(&cyc3, 64 * sizeof(long long)); hipMemset(cyc3, 0, 64 * sizeof(long long));
+  long long* cyc2; hipMalloc(&cyc2, 64 * sizeof(long long)); hipMemset(cyc2, 0, 64 * sizeof(long long));
+  double* dN; hipMalloc(&dN, 0x40000 * sizeof(double)); hipMemset(dN, 0, 0x40000 * sizeof(double));
   hipMemcpy(dD, D.data(), n * n * sizeof(double), hipMemcpyHostToDevice);
   hipMemcpy(dX, X.data(), 32 * 80 * sizeof(double), hipMemcpyHostToDevice);
   for (int threads : {512}) {
@@ -177,6 +201,8 @@ int main() {
     for (int rep = 0; rep < 2; ++rep) {
       hipLaunchKernelGGL(bench<0>, dim3(1), dim3(threads), 0, 0, dD, dX, oo, on, os, cyc);
       hipLaunchKernelGGL(bench<1>, dim3(1), dim3(threads), 0, 0, dD, dX, oo, on, os, cyc);
+      hipLaunchKernelGGL((bench<1, 1>), dim3(1), dim3(threads), 0, 0, dD, dX, oo, on, os, cyc2, dN);
+      hipLaunchKernelGGL((bench<1, 2>), dim3(1), dim3(threads), 0, 0, dD, dX, oo, on, os, cyc3, dN);
       hipLaunchKernelGGL(bench<2>, dim3(1), dim3(threads), 0, 0, dD, dX, oo, on, os, cyc);
     }
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
@@ -205,6 +231,14 @@ int main() {
     printf("column split, waves 0..3 [enter own panel, leave]: ");
     for (int i = 0; i < 8; ++i) printf("%lld ", h[40 + i]);
     printf("\n");
+    { std::vector<long long> h2(64); hipMemcpy(h2.data(), cyc2, 64 * sizeof(long long), hipMemcpyDeviceToHost);
+      printf("chief + followers with four loader waves beside them: %lld %lld %lld %lld clk; chief, from the start: ", h2[4], h2[5], h2[6], h2[7]);
+      for (int i = 0; i < 9; ++i) printf("%lld ", h2[16 + i]);
+      printf("\n"); }
+    { std::vector<long long> h2(64); hipMemcpy(h2.data(), cyc3, 64 * sizeof(long long), hipMemcpyDeviceToHost);
+      printf("... loader waves with their arithmetic, too:                %lld %lld %lld %lld clk; chief, from the start: ", h2[4], h2[5], h2[6], h2[7]);
+      for (int i = 0; i < 9; ++i) printf("%lld ", h2[16 + i]);
+      printf("\n"); }
     printf("chief, clocks from the start: ");
     for (int i = 0; i < 9; ++i) printf("%lld ", h[16 + i]);
     printf("\n");
