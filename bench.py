@@ -160,6 +160,121 @@ def spawn_ranks(n):
     return rc
 
 
+def _profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
+
+
+def dominant_kernel_from_profiles():
+    """(kernel name, share of the kernel time of the run, average working launch in us, file) of the kernel with the largest
+    total duration in the newest committed profiles/rNN_kernel_stats.csv."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernel_stats.csv")))
+    if not files:
+        return None
+    rows = list(csv.DictReader(open(files[-1])))
+    solver = [r for r in rows if "cal" in r["Name"] and "gather_lists" not in r["Name"]]
+    if not solver:
+        return None
+    top = max(solver, key=lambda r: float(r["TotalDurationNs"]))
+    return top["Name"], float(top["Percentage"]) / 100.0, float(top["AverageWorkingNs"]) / 1e3, os.path.basename(files[-1])
+
+
+def expected_scaling_bound(config, world):
+    """Upper bound on the speed-up of `world` ranks (all-reduce free), measured on one GPU by profiles/shard_scaling_model.py:
+    every rank solves the whole linear system, only the evaluation shrinks with the shard."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_shard_scaling_model.json")))
+    if not files:
+        return None
+    try:
+        rows = json.load(open(files[-1])).get("configs[%d]" % config, {}).get("per_rank", [])
+        for r in rows:
+            if r.get("world") == world:
+                return {"speedup_over_one_rank_at_most": r["speedup_bound_without_all_reduce"], "source": "profiles/" + os.path.basename(files[-1]),
+                        "note": "every rank solves the whole linear system (DESIGN.md 8): only the evaluation shrinks with the shard, and the "
+                                "all-reduce of R comes on top"}
+    except Exception:
+        pass
+    return None
+
+
+def roofline_object(scene, world, args, ms_per_step, iter_bytes, dense_ms, dense_ms_raw, phase_n, jac_ms, jac_ms_raw, jac, bracket_ms,
+                    n_skipped, alg_bytes, achieved, wu_ms, wu_n):
+    not_this_run = "profiles/ (committed rocprofv3 passes on the default workload, one rank; NOT measured in this run)"
+    use_profiles = args.config == 3 and world == 1
+    traffic_js = _profile_json("hbm_traffic.json") if use_profiles else None
+    fp64_js = _profile_json("fp64_utilisation.json") if use_profiles else None
+
+    def counters(match):
+        out = {"source": not_this_run}
+        if traffic_js:
+            for k, v in (traffic_js.get("by_kernel") or {}).items():
+                if match in k:
+                    out["hbm_bytes_per_launch"] = v
+                    out["hbm_kernel"] = k
+                    break
+        if fp64_js:
+            for k, v in (fp64_js.get("kernels") or {}).items():
+                if match in k:
+                    out["fp64_frac_of_78.6_tflops"] = v.get("fp64_frac")
+                    out["mfma_util"] = v.get("mfma_util")
+                    out["profiled_launch_us"] = v.get("us")
+                    break
+        return out
+
+    dom = dominant_kernel_from_profiles()
+    dense_c = counters("dense_back_kernel")
+    eval_c = counters("eval_jacobian_kernel")
+    lin_ms = max(0.0, wu_ms[2] / max(1, wu_n[2]) - bracket_ms)      # one linear solve (its launches back to back), warmup solves
+    dominant = {
+        "kernel": "dense_back_kernel (dense reduced solve of the calibration + root block, first back-substitution launch behind an in-launch hand-off)"
+                  if phase_n[8] else "n/a (no reduced-system launch bracketed)",
+        "by_profile": {"kernel": dom[0], "share_of_kernel_time": dom[1], "avg_working_launch_us": dom[2], "file": "profiles/" + dom[3]} if dom else None,
+        "avg_launch_ms": dense_ms if phase_n[8] else None, "launches_bracketed": phase_n[8],
+        "avg_launch_ms_with_event_bracket": dense_ms_raw if phase_n[8] else None,
+        "share_of_step": (dense_ms / ms_per_step) if phase_n[8] else None,
+        "limited_by": "latency: one workgroup factors the reduced system block by block (a chain of dependent 4-column steps on one wave), "
+                      "six more wait for its solution; neither HBM nor FP64 throughput is the bound (see counters)",
+        "measured_frac_of_hbm_peak": (dense_c["hbm_bytes_per_launch"] / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                     if phase_n[8] and "hbm_bytes_per_launch" in dense_c else None,
+        "counters": dense_c,
+    }
+    evaluation = {
+        "kernel": "eval_jacobian_kernel (fused residual + analytic Jacobian + JtJ partials: IMU items + camera frames)",
+        "avg_launch_ms": jac_ms, "launches": jac, "launches_bracketed": phase_n[7],
+        "avg_launch_ms_with_event_bracket": jac_ms_raw, "bracketed_launches_that_exited_early": n_skipped,
+        "share_of_step": jac_ms / ms_per_step,
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "measured_frac_of_hbm_peak": (eval_c["hbm_bytes_per_launch"] / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if "hbm_bytes_per_launch" in eval_c else None,
+        "fused_paper_ratio": achieved / HBM_PEAK_GBS,
+        "fused_paper_ratio_note": "algorithmic bytes of the UNFUSED data flow of one Jacobian launch over its time: a paper figure, "
+                                  "the kernel does not move those bytes",
+        "counters": eval_c,
+    }
+    return {
+        "bound": "hbm", "limited_by": "latency (dependent FP64 chains of single waves and six kernel boundaries per iteration; DESIGN.md 4)",
+        "achieved": iter_bytes / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": iter_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "algorithmic_bytes_per_iteration": iter_bytes,
+        # `traffic`: HBM bytes per launch of the dominant kernel (PMC, per the guide's corrections); null when there is no committed pass for this run's shape
+        "traffic": dense_c.get("hbm_bytes_per_launch"), "traffic_source": not_this_run,
+        "kernel": dominant["kernel"], "kernel_avg_launch_ms": dominant["avg_launch_ms"], "event_bracket_ms": bracket_ms,
+        "linear_solve_share_of_step": lin_ms / ms_per_step if wu_n[2] else None,
+        "linear_solve_ms": lin_ms if wu_n[2] else None,
+        "dominant_kernel": dominant,
+        "evaluation_kernel": evaluation,
+        "mfma_utilisation": {"kernel": "dense_back_kernel", "mfma_util": dense_c.get("mfma_util"), "fp64_frac": dense_c.get("fp64_frac_of_78.6_tflops"),
+                             "source": not_this_run,
+                             "definition": "SQ_VALU_MFMA_BUSY_CYCLES (sum over SIMDs) / (kernel duration x 2.4 GHz x 1024 SIMDs); fp64_frac: FP64 flops / duration / 78.6 TFLOP/s"},
+        "fp64_by_kernel": ({"source": not_this_run, "kernels": fp64_js.get("kernels")} if fp64_js else None),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,7 +287,7 @@ def main():
                     help="exercise the sharding + all-reduce path even with one rank (validation)")
     ap.add_argument("--repeats", type=int, default=0,
                     help="timed samples of --steps iterations each (default: 25 when --steps <= 50, else 5); the median is reported")
-    ap.add_argument("--min-seconds", type=float, default=4.0,
+    ap.add_argument("--min-seconds", type=float, default=10.5,
                     help="without --repeats: as many samples as it takes to keep the GPU busy this long")
     ap.add_argument("--poor-start", type=float, default=0.0,
                     help="move the start away from the truth: focal lengths x (1 + F/100), translations + F cm, control "
@@ -305,11 +420,12 @@ def main():
     def read_phases(phases=range(6)):
         """HIP-event phase times accumulated since the last set_phase_timing (waits for the stream: a solve returns as soon
         as the device reports its end, the early-exit kernels of the iterations enqueued ahead drain afterwards)."""
-        phase_ms = [0.0] * 7
-        phase_n = [0] * 7
+        phase_ms = [0.0] * 9
+        phase_n = [0] * 9
         for i in phases:
             phase_ms[i], phase_n[i] = P.phase_time(i)
-        phase_ms[6], phase_n[6] = P.phase_time(0 | 0x100)   # Jacobian launches that did work (not the early exits after termination)
+        phase_ms[7], phase_n[7] = P.phase_time(0 | 0x100)   # Jacobian launches that did work (not the early exits after termination)
+        phase_ms[8], phase_n[8] = P.phase_time(6 | 0x100)   # the same for the launch that solves the reduced system
         return phase_ms, phase_n
 
     # Optimize() end to end on a fresh handle: the reference rebuilds its ceres::Problem on every call
@@ -380,10 +496,11 @@ def main():
     P.set_phase_timing(0x3f)   # all phases + the bracket calibration (phase 5)
     timed_solves(max(1, args.warmup))
     wu_ms, wu_n = read_phases()
-    # timed region: only the dominant kernel (phase 0) carries events, and only every 16th of its launches -- an event
+    # timed region: only the Jacobian kernel (phase 0) and the reduced-system launch (phase 6: the longest kernel of an
+    # iteration) carry events, and only every 16th of their launches -- an event
     # pair costs ~6 us of stream time on either side of the kernel. The K-step sample is a few milliseconds long, so it is
     # repeated and the MEDIAN sample is the one reported (box-to-box and run-to-run spread is several per cent).
-    # By default the samples add up to >= 3 s of GPU work (4 s are aimed at: the first, estimating sample runs slower) (a 20-iteration sample is ~3 ms: the driver's utilisation
+    # By default the samples add up to >= 8 s of contiguous GPU work (9 s are aimed at: the first, estimating sample runs slower) (a 20-iteration sample is ~3 ms: the driver's 5-second utilisation
     # sampler would otherwise never see the device busy); --repeats N fixes the count.
     if args.repeats > 0:
         repeats = args.repeats
@@ -400,13 +517,13 @@ def main():
             repeats = int(t.item())
     samples = []
     for _ in range(repeats):
-        P.set_phase_timing(0x01 | (16 << 8))             # (restarts the accumulated phase times)
+        P.set_phase_timing(0x41 | (16 << 8))             # (restarts the accumulated phase times)
         barrier()
         t0 = time.perf_counter()
         rec = timed_solves(args.steps)
         barrier()
         elapsed = time.perf_counter() - t0
-        rec = rec + read_phases((0,))                    # only the Jacobian kernel carries events in the timed region
+        rec = rec + read_phases((0, 6))                  # only the Jacobian kernel and the reduced-system launch carry events in the timed region
         if dist is not None:
             t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -433,19 +550,13 @@ def main():
         # HIP-event time of the sampled Jacobian launches that did work (a launch enqueued ahead of a solve that has
         # terminated exits at once), minus what the same event bracket measures around a ~2 us kernel
         bracket_ms = max(0.0, wu_ms[5] / max(1, wu_n[5]) - 0.002)     # calibrated during the warmup solves
-        n_skipped = max(0, phase_n[0] - phase_n[6])
-        jac_ms_raw = phase_ms[6] / max(1, phase_n[6])
+        n_skipped = max(0, phase_n[0] - phase_n[7])
+        jac_ms_raw = phase_ms[7] / max(1, phase_n[7])
         jac_ms = max(1e-6, jac_ms_raw - bracket_ms)
+        dense_ms_raw = phase_ms[8] / max(1, phase_n[8])
+        dense_ms = max(1e-6, dense_ms_raw - bracket_ms)
         alg_bytes = algorithmic_bytes_per_jacobian_launch(scene) / world
         achieved = alg_bytes / (jac_ms * 1e-3) / 1e9 if jac_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        # the PMC figure was collected on the default workload with one rank: it does not describe other runs
-        if os.path.exists(tpath) and args.config == 3 and world == 1:
-            try:
-                traffic = json.load(open(tpath)).get("eval_jacobian_kernel_bytes_per_launch")
-            except Exception:
-                traffic = None
         ms_per_step = 1e3 * elapsed / done
         iter_bytes = algorithmic_bytes_per_iteration(scene)      # whole job: all ranks together
         out = {
@@ -514,33 +625,17 @@ def main():
             # `frac` is SURVEY.md 8(d)'s own definition: the ALGORITHMIC bytes of one LM iteration (per block: observation read
             # twice, residual written, Jacobian written and read back for assembly, residual of the cost-only pass) over the
             # measured time of an iteration, against the HBM peak. The fused kernels keep the Jacobian on chip, so the bytes
-            # the hardware really moves are far fewer (`traffic`, from the PMC counters, per launch of the dominant kernel);
-            # the per-launch paper ratio of that kernel alone (it can exceed 1) is kept as `fused_paper_ratio`.
-            "roofline": {
-                "bound": "hbm", "limited_by": "latency (dependent FP64 chains of single waves; see DESIGN.md 4)",
-                "achieved": iter_bytes / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": iter_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_iteration": iter_bytes,
-                "traffic": traffic,
-                "kernel": "eval_jacobian_kernel (fused residual + analytic Jacobian + JtJ partials: IMU items + camera frames)",
-                "kernel_avg_launch_ms": jac_ms, "kernel_launches": jac, "kernel_launches_bracketed": phase_n[6],
-                "kernel_avg_launch_ms_with_event_bracket": jac_ms_raw, "event_bracket_ms": bracket_ms,
-                "kernel_bracketed_launches_that_exited_early": n_skipped,
-                "kernel_algorithmic_bytes_per_launch": alg_bytes,
-                "kernel_measured_frac": (traffic / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "fused_paper_ratio": achieved / HBM_PEAK_GBS,
-                "fused_paper_ratio_note": "algorithmic bytes of the UNFUSED data flow of one Jacobian launch over its time: a paper "
-                                          "figure, the kernel does not move those bytes",
-            },
+            # the hardware really moves are far fewer (PMC figures under `dominant_kernel` / `evaluation_kernel`).
+            # `dominant_kernel` is the kernel with the largest share of the step in profiles/<round>_kernel_stats.csv -- the
+            # launch that solves the reduced system; it and the Jacobian kernel are timed live (HIP events on the library's
+            # stream); counters (`traffic`, FP64 / MFMA utilisation) come from the committed rocprofv3 passes, not from this run.
+            "roofline": roofline_object(scene, world, args, ms_per_step, iter_bytes, dense_ms, dense_ms_raw, phase_n, jac_ms, jac_ms_raw,
+                                        jac, bracket_ms, n_skipped, alg_bytes, achieved, wu_ms, wu_n),
         }
-        fp64 = os.path.join(ROOT, "profiles", "fp64_utilisation.json")
-        if os.path.exists(fp64) and args.config == 3 and world == 1:
-            try:
-                fj = json.load(open(fp64))
-                out["roofline"]["fp64_by_kernel"] = fj
-                out["roofline"]["mfma_utilisation"] = fj.get("mfma_utilisation_dominant_kernel")
-            except Exception:
-                pass
+        if world > 1:
+            bound = expected_scaling_bound(args.config, world)
+            if bound is not None:
+                out["expected_strong_scaling_bound"] = bound
         if tagging is not None:
             out["config"]["outlier_tagging_passes"] = tagging
         if not args.no_cpu_baseline and world == 1:

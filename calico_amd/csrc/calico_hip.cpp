@@ -105,7 +105,7 @@ namespace {
 
 constexpr size_t kMaxLds = 160 * 1024;
 constexpr int kLogCap = 4096;
-constexpr int kNumPhases = 6;   // 5 = calibration: the same event bracket around a trivial kernel
+constexpr int kNumPhases = 7;   // 5 = calibration: the same event bracket around a trivial kernel; 6 = the reduced-system launch inside phase 2
 
 // RCCL is loaded when the first communicator is asked for (calico_comm_get_unique_id / calico_comm_init_rccl), not at
 // link time: a single-GPU user needs no librccl on the machine. An already loaded librccl (e.g. the one torch ships) is
@@ -224,13 +224,15 @@ struct PhaseTimer {
   int every = 1;            // bracket only every `every`-th launch of a phase (an event pair costs ~6 us of stream time)
   int64_t seen[kNumPhases] = {0, 0, 0, 0, 0, 0};
   bool open_rec = false;
+  int nested = 0;           // phase 6 sits inside phase 2: a bracket inside an open bracket is not recorded
   void begin(int phase, hipStream_t s) {
+    if (open_rec) { ++nested; return; }
     open_rec = (mask >> phase) & 1;
     if (open_rec && phase != 5 && every > 1) open_rec = (seen[phase]++ % every) == 0;
     if (!open_rec) return;
     Rec r; r.phase = phase; r.a = get(); r.b = nullptr; (void)hipEventRecord(r.a, s); pending.push_back(r);
   }
-  void end(hipStream_t s) { if (!open_rec) return; Rec& r = pending.back(); r.b = get(); (void)hipEventRecord(r.b, s); open_rec = false; }
+  void end(hipStream_t s) { if (nested) { --nested; return; } if (!open_rec) return; Rec& r = pending.back(); r.b = get(); (void)hipEventRecord(r.b, s); open_rec = false; }
   void resolve() {  // call after a stream sync
     for (const Rec& r : pending) {
       float t = 0;
@@ -1608,12 +1610,14 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
   const BcrLevel& lf = p->bcr_levels[size_t(l_first)];
   const bool fused = l_first == 0 && dense_back_fusable(sa, ks, lf.q_max, /*border_rows=*/l_first > 0) &&
                      std::max(dense_block_solve_lds_bytes(), bcr_back_lds_bytes(lf.q_max, p->bcr_m1p)) + 1024 <= kMaxLds;
+  p->timer.begin(6, s);       // the launch that solves the reduced system: the longest kernel of an iteration at configs[3]
   if (fused) {
     p->handoff_seq = p->handoff_seq % 0x3fffffff + 1;
     launch_dense_back(sa, b, ks, lf.node0, lf.n_nodes, lf.q_max, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, ts, p->d_handoff.p, p->handoff_seq, s);
   } else {
     launch_reduced_solve(sa, p->dense_in_lds, ks, s);
   }
+  p->timer.end(s);
   for (int l = L - 1; l >= 0; --l) {
     const BcrLevel& lv = p->bcr_levels[size_t(l)];
     if (ts.n > 0 && l == L - 1) continue;

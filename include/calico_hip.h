@@ -350,13 +350,15 @@ int32_t calico_problem_set_stream(calico_problem* p, void* stream);
  * Jacobian + JᵀJ partials), 1 reduction of partials, 2 linear solve,
  * 3 cost-only evaluation, 4 LM control + update, 5 calibration: the same
  * event bracket around a trivial (~2 us) kernel, i.e. the overhead contained
- * in every per-launch figure of the other phases. `phase | 0x100` restricts the
+ * in every per-launch figure of the other phases, 6 the launch inside phase 2
+ * that solves the reduced system (dense reduced solve + first back-substitution
+ * where they share a launch; not recorded while phase 2's bracket is open). `phase | 0x100` restricts the
  * sums to working launches: kernels of iterations enqueued ahead return at once
  * when the solve has terminated, and brackets shorter than a quarter of the
  * phase's longest one are left out. */
 int32_t calico_get_phase_time(calico_problem* p, int32_t phase, double* ms,
                               int64_t* launches);
-/* Which phases are bracketed by HIP events (bits 0..5: bit i = phase i; default: none) and, in bits 8..15, a sampling
+/* Which phases are bracketed by HIP events (bits 0..6: bit i = phase i; default: none) and, in bits 8..15, a sampling
  * interval N: only every N-th launch of a phase is bracketed (0 or 1: every launch). An event pair costs about 6 us of
  * stream time, so a throughput measurement brackets a sample of the launches, not all of them. The call resets the
  * accumulated times. */

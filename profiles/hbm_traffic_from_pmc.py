@@ -50,7 +50,9 @@ def main():
     js = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; FETCH_SIZE doubled (gfx950), see hbm_traffic_from_pmc.py",
           "eval_jacobian_kernel_bytes_per_launch": jac[0][4] if jac else None,
           "eval_jacobian_kernel_fetch_bytes_x2": jac[0][2] if jac else None,
-          "eval_jacobian_kernel_write_bytes": jac[0][3] if jac else None}
+          "eval_jacobian_kernel_write_bytes": jac[0][3] if jac else None,
+          # every kernel, by the name in front of its argument list: HBM bytes per launch (fetch x2 + write)
+          "by_kernel": {r[0].split("(")[0].replace("void ", ""): r[4] for r in rows}}
     json.dump(js, open(out_json, "w"), indent=1)
     for r in rows[:12]:
         print("%-70s fetch(x2) %10.0f  write %10.0f  total %10.0f B/launch" % (r[0][:70], r[2], r[3], r[4]))

@@ -77,7 +77,8 @@ def test_solver_variants_agree(monkeypatch):
     monkeypatch.setenv("CALICO_SPECULATIVE", "1")
     for name, value in [("CALICO_STREAM_DEPTH", "0"), ("CALICO_FUSED_CONTROL", "0"), ("CALICO_ROW_CELLS", "0"),
                         ("CALICO_IMU_CHUNK", "7"), ("CALICO_STREAM_DEPTH", "1"), ("CALICO_BCR_MERGE_TOP", "0"),
-                        ("CALICO_FUSE_SCHUR", "0"), ("CALICO_FUSE_BACK", "0"), ("CALICO_GATHER_STRUCT", "0"), ("CALICO_GATHER_TINY", "0"), ("CALICO_FOLD_FIRST", "0")]:
+                        ("CALICO_FUSE_SCHUR", "0"), ("CALICO_FUSE_BACK", "0"), ("CALICO_GATHER_STRUCT", "0"), ("CALICO_GATHER_TINY", "0"), ("CALICO_FOLD_FIRST", "0"),
+                        ("CALICO_ELIM", "panel")]:       # round 4: the block factorisation of rounds 1-3 instead of block_elim.hpp
         monkeypatch.setenv(name, value)
         results[(name, value)] = _solve_repeatedly(api, scene, repeats=1, max_iter=50)[0]
         monkeypatch.delenv(name)
@@ -220,3 +221,39 @@ def test_large_reduced_system_kernels_agree(monkeypatch):
             assert r[0] == ref[0][0] and r[1] == ref[0][1], key
             np.testing.assert_allclose(r[2], ref[0][2], rtol=1e-9, err_msg=str(key))
             np.testing.assert_allclose(r[3], ref[0][3], rtol=1e-7, atol=1e-9, err_msg=str(key))
+
+
+@pytest.mark.gpu
+def test_block_elimination_agrees_with_the_panel_factorisation(monkeypatch):
+    """Round 4: every 32-column block of the tree levels and of the dense reduced solve is eliminated on the matrix cores
+    (block_elim.hpp: a chief wave on the spine, follower waves with the identity rows and the rows of X, hand-over through a
+    sentinel-filled LDS channel). Against the in-wave panel factorisation of rounds 1-3 (CALICO_ELIM=panel) -- a different
+    order of the same sums -- the solve must take the same iterations with costs equal to 1e-9 and estimates to 1e-7, with
+    and without the dense solve's launch fusion, for several chain lengths; and the default path must repeat bit for bit
+    (a follower that read a channel entry too early would show as a run-to-run difference)."""
+    api = helpers.hip_api()
+    scene = syn.make_scene(4, 1, True, 3, cam_rate=10.0, imu_rate=100.0, duration=8.7, chart="april", seed=23,
+                           pixel_noise=0.1, gyro_noise=1e-3, accel_noise=1e-2, robust=True, segment_duration=8.7 / 23.9,
+                           max_cam_obs=6000)
+    for leaf in ("", "2", "8"):
+        if leaf:
+            monkeypatch.setenv("CALICO_BCR_LEAF", leaf)
+        else:
+            monkeypatch.delenv("CALICO_BCR_LEAF", raising=False)
+        runs = {}
+        for elim, fuse in (("mfma", "1"), ("panel", "1"), ("mfma", "0")):
+            monkeypatch.setenv("CALICO_ELIM", elim)
+            monkeypatch.setenv("CALICO_FUSE_BACK", fuse)
+            runs[(elim, fuse)] = _solve_repeatedly(api, scene, repeats=3 if elim == "mfma" else 1, max_iter=30)
+        for reps in runs.values():
+            for r in reps[1:]:
+                assert r[0] == reps[0][0] and r[1] == reps[0][1]
+                assert np.array_equal(r[2], reps[0][2]) and np.array_equal(r[3], reps[0][3])
+        ref = runs[("panel", "1")][0]
+        for key, reps in runs.items():
+            r = reps[0]
+            assert r[0] == ref[0] and r[1] == ref[1], (leaf, key)
+            np.testing.assert_allclose(r[2], ref[2], rtol=1e-9, atol=0, err_msg=str((leaf, key)))
+            np.testing.assert_allclose(r[3], ref[3], rtol=1e-7, atol=1e-10, err_msg=str((leaf, key)))
+    monkeypatch.delenv("CALICO_ELIM")
+    monkeypatch.delenv("CALICO_FUSE_BACK")
