@@ -494,6 +494,12 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       const int nreal = a.n_s() - RB * blk, nreal_n = nreal - RB;     // real rows of this superblock / of the next one
       const double* RBnd = a.R + a.off_B() + size_t(blk) * strideB;
       const double* RBndA = a.R + a.off_B() + size_t(max(blk - 1, 0)) * strideB;
+      // Two passes: every load of the block is REQUESTED before the first store. The damping of a diagonal entry is filed
+      // (a.dadd) as it is formed, and as far as the compiler knows that store may alias a.R -- with the store inside the
+      // loop over the entries every entry's loads waited for the entry before it: NU dependent round trips per block
+      // instead of one (the head of the launch and every step's loads were that much longer).
+      double vraw[NU], graw[NU], garaw[NU], svv[NU], q2v[NU], fraw[NF];
+      bool vDs[NU], vBs[NU], vAs[NU], vFs[NF];
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         const int e = min(max(lt, 0) + NL * u, BB - 1);
@@ -506,36 +512,15 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           act_rn = a.cp_active[min(kBcrCps * (blk + 1) + r / 6, n_cp - 1)] != 0;
           act_cl = a.cp_active[min(max(kBcrCps * (blk - 1) + c / 6, 0), n_cp - 1)] != 0;
         }
-        const bool vD = okD[u] && r < nreal && c < nreal && act_r && act_c;
-        double v = RBnd[vD ? iD[u] : 0];
-        v = vD ? v : 0.0;
-        {
-          // LM damping of a diagonal entry (FromR::damping), for every entry and selected afterwards: as a branch around a
-          // division (with the scale's load inside it) this piece alone kept Z 2k clocks per step behind the chief -- the
-          // loads of the step's other entries queued behind it. 1 / (radius s^2) as a product of 1 / radius (once per
-          // thread) and the filed 1 / s^2; only a solve's first linear solve, which forms the scale itself, divides.
-          const bool dg = r == c;
-          const int t = RB * blk + r;
-          const bool real_row = r < RB && r < nreal;
-          const int ts = (dg && real_row) ? t : 0;
-          double d;
-          if (fr.first_scale == 0) {
-            const double sv = a.scale[ts], q2 = a.scale[a.NT() + ts];
-            d = fmin(fmax(v * sv * sv, o.min_lm_diagonal), o.max_lm_diagonal) * (inv_radius * q2);
-          } else d = fr.damping(v, ts);
-          if (dg) {
-            if (vD) { v += d; if (role == 0) a.dadd[t] = d; }
-            else { v = 1.0; if (role == 0 && real_row) a.dadd[t] = 0.0; }
-          }
-        }
-        pr.d[u] = v;
-        const bool vB = okB[u] && has_next && r < nreal_n && act_rn && act_c;
-        const double g = RBnd[vB ? iB[u] : 0];
-        pr.bt[u] = vB ? g : 0.0;
-        const bool vA = okB[u] && has_a && r < nreal && act_r && act_cl;
-        double ga = 0.0;
-        if (has_a) ga = RBndA[vA ? iB[u] : 0];      // (only the first block of a chain touches the left separator)
-        pr.at[u] = vA ? ga : 0.0;
+        vDs[u] = okD[u] && r < nreal && c < nreal && act_r && act_c;
+        vraw[u] = RBnd[vDs[u] ? iD[u] : 0];
+        const int ts = (r == c && r < RB && r < nreal) ? RB * blk + r : 0;
+        svv[u] = a.scale[ts]; q2v[u] = a.scale[a.NT() + ts];        // (harmless during a solve's first linear solve, which does not use them)
+        vBs[u] = okB[u] && has_next && r < nreal_n && act_rn && act_c;
+        graw[u] = RBnd[vBs[u] ? iB[u] : 0];
+        vAs[u] = okB[u] && has_a && r < nreal && act_r && act_cl;
+        garaw[u] = 0.0;
+        if (has_a) garaw[u] = RBndA[vAs[u] ? iB[u] : 0];      // (only the first block of a chain touches the left separator)
       }
 #pragma unroll
       for (int u = 0; u < NF; ++u) {
@@ -544,11 +529,36 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         const int t = RB * blk + r;
         bool act_r = true;
         if (!b.all_active) act_r = a.cp_active[min(kBcrCps * blk + r / 6, a.n_cp - 1)] != 0;
-        const bool vF = role > 0 && r < RB && r < nreal && col <= a.mc && act_r;
-        const size_t idx = vF ? (col < a.mc ? a.off_E() + size_t(t) * a.mc + col : a.off_g() + t) : a.off_g();
-        const double f = a.R[idx];
-        pr.f[u] = vF ? f : 0.0;
+        vFs[u] = role > 0 && r < RB && r < nreal && col <= a.mc && act_r;
+        const size_t idx = vFs[u] ? (col < a.mc ? a.off_E() + size_t(t) * a.mc + col : a.off_g() + t) : a.off_g();
+        fraw[u] = a.R[idx];
       }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int e = min(max(lt, 0) + NL * u, BB - 1);
+        const int r = e >> 5, c = e & 31;
+        double v = vDs[u] ? vraw[u] : 0.0;
+        {
+          // LM damping of a diagonal entry (FromR::damping), for every entry and selected afterwards (no branch around
+          // loads). 1 / (radius s^2) as a product of 1 / radius (once per thread) and the filed 1 / s^2; only a solve's
+          // first linear solve, which forms the scale itself, divides.
+          const bool dg = r == c;
+          const int t = RB * blk + r;
+          const bool real_row = r < RB && r < nreal;
+          double d;
+          if (fr.first_scale == 0) d = fmin(fmax(v * svv[u] * svv[u], o.min_lm_diagonal), o.max_lm_diagonal) * (inv_radius * q2v[u]);
+          else d = fr.damping(v, (dg && real_row) ? t : 0);
+          if (dg) {
+            if (vDs[u]) { v += d; if (role == 0) a.dadd[t] = d; }
+            else { v = 1.0; if (role == 0 && real_row) a.dadd[t] = 0.0; }
+          }
+        }
+        pr.d[u] = v;
+        pr.bt[u] = vBs[u] ? graw[u] : 0.0;
+        pr.at[u] = vAs[u] ? garaw[u] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < NF; ++u) pr.f[u] = vFs[u] ? fraw[u] : 0.0;
       return;
     }
 #pragma unroll
