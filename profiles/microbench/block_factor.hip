@@ -75,8 +75,10 @@ __global__ __launch_bounds__(512) void bench(const double* D, const double* X, d
         if (NOISE && wave >= 4) {      // what a tree level's loader waves do beside the elimination: scattered 8-byte loads, then LDS writes
           double v[14];
           const size_t base = size_t(rep) * 65536 + size_t(tid - 256) * 7;
+          // NOISE 3: the loads miss every cache (a 1 GiB buffer, one line per load, never the same line twice)
+          const size_t far = (size_t(rep) * 0x2000000 + size_t(tid - 256) * 0x20000 + size_t(blockIdx.x)) ;
 #pragma unroll
-          for (int u = 0; u < 14; ++u) v[u] = noise[(base + size_t(u) * 4099) & 0x3ffff];
+          for (int u = 0; u < 14; ++u) v[u] = NOISE == 3 ? noise[(far + size_t(u) * 0x2000 + 0x40000) & 0x7ffffff] : noise[(base + size_t(u) * 4099) & 0x3ffff];
           double sacc = 0.0;
 #pragma unroll
           for (int u = 0; u < 14; ++u) { sacc += v[u]; dumpb[tid] = sacc; }
@@ -191,9 +193,10 @@ int main() {
   double *dD, *dX, *oo, *on, *os; long long* cyc;
   hipMalloc(&dD, n * n * sizeof(double)); hipMalloc(&dX, 32 * 80 * sizeof(double)); hipMalloc(&oo, NO * sizeof(double)); hipMalloc(&on, NO * sizeof(double)); hipMalloc(&os, NO * sizeof(double));
   hipMalloc(&cyc, 64 * sizeof(long long));
+  long long* cyc4; hipMalloc(&cyc4, 64 * sizeof(long long)); hipMemset(cyc4, 0, 64 * sizeof(long long));
   long long* cyc3; hipMalloc(&cyc3, 64 * sizeof(long long)); hipMemset(cyc3, 0, 64 * sizeof(long long));
   long long* cyc2; hipMalloc(&cyc2, 64 * sizeof(long long)); hipMemset(cyc2, 0, 64 * sizeof(long long));
-  double* dN; hipMalloc(&dN, 0x40000 * sizeof(double)); hipMemset(dN, 0, 0x40000 * sizeof(double));
+  double* dN; hipMalloc(&dN, size_t(0x8000000) * sizeof(double)); hipMemset(dN, 0, size_t(0x8000000) * sizeof(double));
   hipMemcpy(dD, D.data(), n * n * sizeof(double), hipMemcpyHostToDevice);
   hipMemcpy(dX, X.data(), 32 * 80 * sizeof(double), hipMemcpyHostToDevice);
   for (int threads : {512}) {
@@ -203,6 +206,7 @@ int main() {
       hipLaunchKernelGGL(bench<1>, dim3(1), dim3(threads), 0, 0, dD, dX, oo, on, os, cyc);
       hipLaunchKernelGGL((bench<1, 1>), dim3(1), dim3(threads), 0, 0, dD, dX, oo, on, os, cyc2, dN);
       hipLaunchKernelGGL((bench<1, 2>), dim3(1), dim3(threads), 0, 0, dD, dX, oo, on, os, cyc3, dN);
+      hipLaunchKernelGGL((bench<1, 3>), dim3(1), dim3(threads), 0, 0, dD, dX, oo, on, os, cyc4, dN);
       hipLaunchKernelGGL(bench<2>, dim3(1), dim3(threads), 0, 0, dD, dX, oo, on, os, cyc);
     }
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
@@ -237,6 +241,10 @@ int main() {
       printf("\n"); }
     { std::vector<long long> h2(64); hipMemcpy(h2.data(), cyc3, 64 * sizeof(long long), hipMemcpyDeviceToHost);
       printf("... loader waves with their arithmetic, too:                %lld %lld %lld %lld clk; chief, from the start: ", h2[4], h2[5], h2[6], h2[7]);
+      for (int i = 0; i < 9; ++i) printf("%lld ", h2[16 + i]);
+      printf("\n"); }
+    { std::vector<long long> h2(64); hipMemcpy(h2.data(), cyc4, 64 * sizeof(long long), hipMemcpyDeviceToHost);
+      printf("... loader waves whose loads miss every cache:               %lld %lld %lld %lld clk; chief, from the start: ", h2[4], h2[5], h2[6], h2[7]);
       for (int i = 0; i < 9; ++i) printf("%lld ", h2[16 + i]);
       printf("\n"); }
     printf("chief, clocks from the start: ");
