@@ -939,7 +939,7 @@ DEVI void back_calib(const SolveArgs& a, const BcrArgs& b, const double* __restr
 // workgroup of kBackThreads threads. `top`: the node forms L⁻¹g - Z^F y_c itself (sweeping its border rows) instead of
 // reading b.zb. QM bounds the unrolled load batches (longest chain of the level).
 template <int QM, int MODE, bool HO>      // MODE 0: reads b.zb; 1: `top`; 2: top + the top separators beside the chain (BcrTopSeps)
-DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __restrict__ ndp, int /*top*/, int q_max, int terminated,
+DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev nd, int /*top*/, int q_max, int terminated,
                     bool dbg_first, const double* __restrict__ x, double* __restrict__ x_cand, double* lds, double* sh,
                     const BcrTopSeps& ts, const Handoff& ho) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -949,7 +949,7 @@ DEVI void back_node(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __re
   constexpr bool SIDE = MODE == 2;
   constexpr int top = MODE >= 1 ? 1 : 0;       // compile-time: the border rows' registers exist only where they are used
   UpdSums s = {0.0, 0.0, 0.0, 0};
-  const int q = ndp->q, nd_left = ndp->left, nd_right = ndp->right, nd_slot = ndp->slot, blk0 = ndp->blk0;
+  const int q = nd.q, nd_left = nd.left, nd_right = nd.right, nd_slot = nd.slot, blk0 = nd.blk0;
   double* ZBs = lds;                                   // [q][32][33]
   double* Ms = ZBs + size_t(q_max) * BP * DLD;         // [q][32][33]
   double* tv = Ms + size_t(q_max) * BP * DLD;          // [8][32]
@@ -1257,7 +1257,7 @@ DEVI void mat_times_tile_both(const double* Z, const f64x4& b0, const f64x4& b1,
 }
 size_t bcr_back_pre_lds_doubles(int q_max) { return size_t(3 * q_max + 2) * BP * DLD + 128 + size_t(8) * (q_max + 1) * BP + size_t(q_max + 1) * BP; }
 template <int QM, bool SIDE>
-DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* __restrict__ ndp, int terminated,
+DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev nd, int terminated,
                         const double* __restrict__ x, double* __restrict__ x_cand, double* lds, double* sh,
                         const BcrTopSeps& ts, const Handoff& ho) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lk = lane >> 4;
@@ -1265,7 +1265,7 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* 
   const size_t fblk = size_t(BP) * m1p;
   constexpr int RB = 6 * kBcrCps;
   UpdSums s = {0.0, 0.0, 0.0, 0};
-  const int q = ndp->q, nd_left = ndp->left, nd_right = ndp->right, nd_slot = ndp->slot, blk0 = ndp->blk0;
+  const int q = nd.q, nd_left = nd.left, nd_right = nd.right, nd_slot = nd.slot, blk0 = nd.blk0;
   double* ZAs = lds;                                   // [QM][32][33]
   double* ZBs = ZAs + size_t(QM) * BP * DLD;           // [QM][32][33]
   double* Ms = ZBs + size_t(QM) * BP * DLD;            // [QM][32][33]
@@ -1286,7 +1286,7 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* 
   const bool my_cp_in = (tid < q * kBcrCps || sep_cp) && my_cp < a.n_cp;
   const int my_cp_c = my_cp_in ? my_cp : 0;
   const int my_off = b.ctrl_off[my_cp_c];
-  const bool pdbg = CAL_DEV_TIMING(a.debug == 1 && nd_slot == ndp->slot && blk0 == 0 && tid == 0);
+  const bool pdbg = CAL_DEV_TIMING(a.debug == 1 && blk0 == 0 && tid == 0);
   long long pt[6] = {0, 0, 0, 0, 0, 0}, ptk = pdbg ? __builtin_readcyclecounter() : 0;
 #define PTICK(i) if (pdbg) { const long long t_ = __builtin_readcyclecounter(); pt[i] += t_ - ptk; ptk = t_; }
   // ---- requests: operands for LDS (thread (r16, sub): two entries of a row) ----
@@ -1470,7 +1470,7 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev* 
 template <int QM, int MODE, bool HO, bool PRE = false>     // longest chain of the level; MODE: see back_node; HO: rides in the dense solve's launch; PRE: back_node_pre
 DEVI void bcr_back_body(SolveArgs a, const BcrArgs& b, int wg, int node0, int n_nodes, int top, int q_max,
                         const double* __restrict__ x, double* __restrict__ x_cand,
-                        const BlockDev* __restrict__ blocks, int n_blocks, const BcrTopSeps& ts, double* lds, double* sh, const Handoff& ho) {
+                        const BlockDev* __restrict__ blocks, int n_blocks, const BcrTopSeps& ts, double* lds, double* sh, const Handoff& ho, int q0 = 0) {
   LmState* st = a.st;
   const int terminated = st->terminated;     // tested after the loads are on their way
   use_current_R(a);
@@ -1491,8 +1491,16 @@ DEVI void bcr_back_body(SolveArgs a, const BcrArgs& b, int wg, int node0, int n_
     return;
   }
   if (wg == n_nodes) { back_calib<HO>(a, b, x, x_cand, blocks, n_blocks, sh, lds, ho); return; }
-  if (PRE) back_node_pre<QM, MODE == 2>(a, b, b.nodes + node0 + wg, terminated, x, x_cand, lds, sh, ts, ho);
-  else back_node<QM, MODE, HO>(a, b, b.nodes + node0 + wg, top, q_max, terminated, wg == 0, x, x_cand, lds, sh, ts, ho);
+  // (q0 > 0: the nodes are level 0's, which are regular -- [chain of q0] [separator] [chain] ... in time order, slot = number --,
+  //  so the descriptor is arithmetic on the node's number: no load in front of the node's requests, one dependent round trip
+  //  (~1.9 us behind a kernel boundary) less at the head of the dense solve's launch. The host's table says the same.)
+  BcrNodeDev nd;
+  if (q0 > 0) {
+    nd.blk0 = wg * (q0 + 1); nd.q = min(q0, b.N - nd.blk0);
+    nd.left = wg > 0 ? nd.blk0 - 1 : -1; nd.right = nd.blk0 + nd.q < b.N ? nd.blk0 + nd.q : -1; nd.slot = node0 + wg; nd.pend = 0;
+  } else nd = b.nodes[node0 + wg];
+  if (PRE) back_node_pre<QM, MODE == 2>(a, b, nd, terminated, x, x_cand, lds, sh, ts, ho);
+  else back_node<QM, MODE, HO>(a, b, nd, top, q_max, terminated, wg == 0, x, x_cand, lds, sh, ts, ho);
 }
 template <int QM, int MODE>
 __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, BcrArgs b, int node0, int n_nodes, int top, int extras, int q_max,
@@ -1549,6 +1557,13 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
   // ---- load: lower triangle (K-slices summed), right-hand side = row m; identity beyond m ----
   {
     const size_t mm = size_t(M1) * M1;
+    // (the right-hand side's loads go first, with the matrix's: requested behind the matrix's wait they were a second round trip)
+    double rhs_acc = 0.0;
+    if (tid < 128) {
+      const int c = min(tid, m - 1);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) rhs_acc += Sp[size_t(min(k, nsl - 1)) * mm + size_t(m) * M1 + c] * (k < nsl ? 1.0 : 0.0);
+    }
     // thread (wave w, lane): rows w, w+8, ...; columns lane, lane+64 -- sixteen rows in flight per pass
     for (int r0 = wave; r0 < mp; r0 += 8 * 16) {
       double v[16][2];
@@ -1576,11 +1591,7 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
       }
     }
     if (tid < 128) {
-      const int c = min(tid, m - 1);
-      double acc = 0.0;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) acc += Sp[size_t(min(k, nsl - 1)) * mm + size_t(m) * M1 + c] * (k < nsl ? 1.0 : 0.0);
-      gv[tid] = tid < m ? acc : 0.0;
+      gv[tid] = tid < m ? rhs_acc : 0.0;
       pend[tid] = 0.0;
     }
   }
@@ -1921,7 +1932,8 @@ __global__ __launch_bounds__(kDenseThreads) void dense_back_kernel(SolveArgs a, 
   __shared__ double sh[64];
   const Handoff ho = {word, seq};
   if (blockIdx.x == 0) { dense_block_solve_body(a, nsl, lds, ho, 0, 0, elim); return; }
-  bcr_back_body<QM, MODE, true, PRE>(a, b, int(blockIdx.x) - 1, node0, n_nodes, 1, q_max, x, x_cand, blocks, n_blocks, ts, lds, sh, ho);
+  bcr_back_body<QM, MODE, true, PRE>(a, b, int(blockIdx.x) - 1, node0, n_nodes, 1, q_max, x, x_cand, blocks, n_blocks, ts, lds, sh, ho,
+                                     node0 == 0 ? q_max : 0);      // (the nodes of this launch are level 0's: launch_dense_back)
 }
 size_t dense_block_solve_lds_bytes() { return size_t(128 * DNL + 128 + 64 * DLD + 128 * 3 + 32 + 128 + kDenseThreads) * sizeof(double); }
 hipError_t configure_dense_block_solve() {
