@@ -54,6 +54,9 @@ void launch_gather(double* R, const double* src, const int* out_idx_thin, const 
                    const double* cost_src, int n_cost, const LmState* st, int need_flag, size_t other_stride, hipStream_t s, const ControlTail* tail = nullptr);
 void launch_gather_lists(const GatherStruct& gs, int n_out, int* cnt, int* out_idx, int64_t* ptr, int* idx, int zero_slot, long long* scratch,
                          hipStream_t s);
+size_t gather_fixed_entries(int n_thin, int n_thin8, int n_thin4, int thin_per_lane);
+void launch_gather_pack_fixed(const int64_t* ptr, const int* idx, int n_thin, int n_thin8, int n_thin4, int thin_per_lane, int zero_slot, int* out,
+                              hipStream_t s);
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s);
 size_t band_cholesky_lds_bytes(const SolveArgs& a);
@@ -280,13 +283,14 @@ struct PlanHost {
   int n_thin = 0, n_fat = 0;
   int n_thin8 = 0, n_thin4 = 0;  // thin outputs [0, n_thin8) take eight lanes, [n_thin8, n_thin4) four (<= 24 sources), [n_thin4, n_thin) one (<= 8)
   int thin_per_lane = 6;       // sources per lane of a thin output's eight lanes (6: up to 48 sources, 12: up to 96)
+  bool gather_fixed = false;   // the thin lists at a fixed stride (d_idx_fixed) instead of CSR
   bool dense_in_lds = true;
   int gather_owner_block = 0;
   bool gs_lists_on_device = false;   // the band / border / spline right-hand side lists were built by the device (launch_gather_lists)
 };
 struct PlanDev {      // structure on the device: immutable once uploaded
   DevBuf<double> d_knots, d_basis, d_stamp;
-  DevBuf<int> d_ctrl_off, d_point_off, d_out_thin, d_idx_thin, d_out_fat, d_idx_fat, d_prim_tab, d_bkeep, d_cp_block, d_gs_tab;
+  DevBuf<int> d_ctrl_off, d_point_off, d_out_thin, d_idx_thin, d_idx_fixed, d_out_fat, d_idx_fat, d_prim_tab, d_bkeep, d_cp_block, d_gs_tab;
   DevBuf<int64_t> d_ptr_thin, d_ptr_fat;
   DevBuf<uint8_t> d_cp_active;
   DevBuf<SensorDev> d_sensors;
@@ -296,7 +300,7 @@ struct PlanDev {      // structure on the device: immutable once uploaded
   DevBuf<CellDev> d_cells;
   DevBuf<BlockDev> d_blocks;
   DevBuf<BcrNodeDev> d_bnodes;
-#define PLAN_DEV_BUFS(X) X(d_knots) X(d_basis) X(d_stamp) X(d_ctrl_off) X(d_point_off) X(d_out_thin) X(d_idx_thin) X(d_out_fat) X(d_idx_fat) \
+#define PLAN_DEV_BUFS(X) X(d_knots) X(d_basis) X(d_stamp) X(d_ctrl_off) X(d_point_off) X(d_out_thin) X(d_idx_thin) X(d_idx_fixed) X(d_out_fat) X(d_idx_fat) \
   X(d_prim_tab) X(d_bkeep) X(d_cp_block) X(d_gs_tab) X(d_ptr_thin) X(d_ptr_fat) X(d_cp_active) X(d_sensors) X(d_layouts) X(d_items) X(d_items_all)     \
   X(d_jac_items) X(d_fitems) X(d_cells) X(d_blocks) X(d_bnodes)
   void take_from(PlanDev& o) {
@@ -1105,6 +1109,13 @@ int build_plan(calico_problem* p) {
   }
   HIP_TRY(p, p->d_out_fat.upload(out_fat, s)); HIP_TRY(p, p->d_idx_fat.upload(idx_fat, s));
   HIP_TRY(p, p->d_ptr_fat.upload(ptr_fat, s));
+  // the thin outputs' lists at a fixed stride per lane class: the gather then needs no pointer load in front of its index
+  // loads (CALICO_GATHER_FIXED=0: the CSR form; read per plan and part of its key)
+  p->gather_fixed = [] { const char* e = std::getenv("CALICO_GATHER_FIXED"); return !e || std::atoi(e) != 0; }() && p->n_thin > 0;
+  if (p->gather_fixed) {
+    HIP_TRY(p, p->d_idx_fixed.alloc(gather_fixed_entries(p->n_thin, p->n_thin8, p->n_thin4, p->thin_per_lane) + 8));
+    launch_gather_pack_fixed(p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->n_thin8, p->n_thin4, p->thin_per_lane, zero_slot, p->d_idx_fixed.p, s);
+  }
   HIP_TRY(p, p->d_cells.upload(p->h_cells, s)); HIP_TRY(p, p->d_prim_tab.upload(prim_tab, s));
   p->partials_alloc = comp_base + comp_off + row_store + 2;      // (+ the word that is always zero, see zero_slot)
   p->r_size = r_size;
@@ -1222,7 +1233,7 @@ PlanKey structure_key(const calico_problem* p) {
   }
   // the switches finalize reads from the environment
   for (const char* name : {"CALICO_SOLVER", "CALICO_SPECULATIVE", "CALICO_BAND_SPLIT", "CALICO_BCR_LEAF", "CALICO_BCR_MERGE_TOP", "CALICO_IMU_CHUNK",
-                           "CALICO_ROW_CELLS", "CALICO_GATHER_STRUCT", "CALICO_GATHER_TINY"}) {
+                           "CALICO_ROW_CELLS", "CALICO_GATHER_STRUCT", "CALICO_GATHER_TINY", "CALICO_GATHER_FIXED"}) {
     const char* e = std::getenv(name);
     h.word(e ? 1 : 0);
     if (e) h.bytes(e, std::strlen(e));
@@ -1557,7 +1568,7 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, c
     HIP_TRY(p, hipMemsetAsync(target, 0, p->r_size * sizeof(double), p->stream));
   }
   launch_expand_cells(ea, p->stream);                     // compact frame records -> one expanded block per cell
-  launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->n_thin8, p->n_thin4, p->thin_per_lane, p->d_out_fat.p,
+  launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->gather_fixed ? nullptr : p->d_ptr_thin.p, p->gather_fixed ? p->d_idx_fixed.p : p->d_idx_thin.p, p->n_thin, p->n_thin8, p->n_thin4, p->thin_per_lane, p->d_out_fat.p,
                 p->d_ptr_fat.p, p->d_idx_fat.p, p->n_fat, p->d_partials.p + p->partial_doubles, p->n_fitems + p->n_jac_items, st, need_flag,
                 spec ? p->r_size : 0, p->stream, tail);
   p->timer.end(p->stream);

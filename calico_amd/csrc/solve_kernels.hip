@@ -200,7 +200,11 @@ void launch_gather_lists(const GatherStruct& gs, int n_out, int* cnt, int* out_i
 // Thin outputs [n_thin4, n_thin) have at most EIGHT sources each (the border: one layout's cells over the k segments of
 // a control point) and take one lane instead of eight: an eighth of the threads for two thirds of the outputs; outputs
 // [n_thin8, n_thin4) have at most 24 (the band's blocks away from the diagonal) and take four.
-template <int U>
+// FIXED (round 4): the thin outputs' source lists at a fixed stride per class (8·U / 24 / 8 entries, padded with the index of
+// the word of the partials that is always zero) instead of CSR: a lane's indices follow from its output number alone, so the
+// pointer load in front of them -- one of the three dependent round trips of this launch, ~1.9 us each behind a kernel
+// boundary -- is gone, and so are the per-source bounds tests. Same sources in the same order: the sums are bit-identical.
+template <int U, bool FIXED>
 __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, const double* __restrict__ src,
                                                      const int* __restrict__ out_thin, const int64_t* __restrict__ ptr_thin,
                                                      const int* __restrict__ idx_thin, int n_thin, int n_thin8, int n_thin4,
@@ -224,7 +228,25 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
       } else {
         cls = 1; o_thin = n_thin4 + (tb - nb_thin8 - nb_thin4) * int(blockDim.x) + int(threadIdx.x); oc = o_thin < n_thin ? o_thin : n_thin - 1;
       }
-      pre_q0 = ptr_thin[oc]; pre_q1 = ptr_thin[oc + 1];
+      if (!FIXED) { pre_q0 = ptr_thin[oc]; pre_q1 = ptr_thin[oc + 1]; }
+    }
+  }
+  // FIXED: idx_thin is the fixed-stride table [n_thin8][8U | n_thin4 - n_thin8][24 | n_thin - n_thin4][8]
+  const size_t fbase4 = size_t(n_thin8) * (8 * U), fbase1 = fbase4 + size_t(n_thin4 - n_thin8) * 24;
+  int fid[U > 8 ? U : 8];
+  if (FIXED && int(blockIdx.x) - 1 >= nb_fat && n_thin > 0) {      // (requested before the state is looked at, like the pointers were)
+    if (cls == 1) {
+      const int oc = o_thin < n_thin ? o_thin : n_thin - 1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) fid[u] = idx_thin[fbase1 + size_t(oc - n_thin4) * 8 + u];
+    } else if (cls == 4) {
+      const int oc = o_thin < n_thin4 ? o_thin : n_thin4 - 1, sub = int(threadIdx.x) & 3;
+#pragma unroll
+      for (int u = 0; u < 6; ++u) fid[u] = idx_thin[fbase4 + size_t(oc - n_thin8) * 24 + sub + 4 * u];
+    } else {
+      const int oc = o_thin < n_thin8 ? o_thin : n_thin8 - 1, sub = int(threadIdx.x) & 7;
+#pragma unroll
+      for (int u = 0; u < U; ++u) fid[u] = idx_thin[size_t(oc) * (8 * U) + sub + 8 * u];
     }
   }
   if (st && (st->terminated || (need_flag && !st->need_jacobian))) {
@@ -288,6 +310,46 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
     s = wave_sum(s);
     if (live && lane == 0) R[out_fat[wave]] = s;
   } else {
+    if (FIXED) {
+      if (cls == 1) {
+        const int o = o_thin;
+        const int dst = out_thin[o < n_thin ? o : n_thin - 1];
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[fid[u]];
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+        if (o < n_thin) R[dst] = s;
+        return;
+      }
+      if (cls == 4) {
+        const int o = o_thin, sub = int(threadIdx.x) & 3;
+        double v[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) v[u] = src[fid[u]];
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) s += v[u];
+        s = row4_sum(s);
+        if (o < n_thin4 && sub == 0) R[out_thin[o]] = s;
+        return;
+      }
+      const int o = o_thin, sub = int(threadIdx.x) & 7;
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = src[fid[u]];
+      // (the order of the CSR form: the first six per lane, then the others, added behind them)
+      double s = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int u = 0; u < 6; ++u) s += v[u];
+#pragma unroll
+      for (int u = 6; u < U; ++u) s2 += v[u];
+      s += s2;
+      s = row8_sum(s);
+      if (o < n_thin8 && sub == 0) R[out_thin[o]] = s;
+      return;
+    }
     if (cls == 1) {      // one lane per output, at most eight sources, summed in list order
       const int o = o_thin;
       const int64_t q0 = pre_q0, q1 = pre_q1;
@@ -1842,12 +1904,31 @@ void launch_gather(double* R, const double* src, const int* out_idx_thin, const 
   ControlTail t;
   if (tail) t = *tail; else { t = ControlTail(); t.enabled = 0; }
   // workgroup 0: cost / invalid count (+ control stage), then the fat outputs, then the thin ones
-  if (thin_per_lane <= 6)
-    hipLaunchKernelGGL(gather_kernel<6>, dim3(1 + nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin, n_thin8, n_thin4,
-                       out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, cost_src, n_cost, st, need_flag, other_stride, t);
-  else
-    hipLaunchKernelGGL(gather_kernel<12>, dim3(1 + nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin, n_thin8, n_thin4,
-                       out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, cost_src, n_cost, st, need_flag, other_stride, t);
+  // ptr_thin == nullptr: idx_thin is the fixed-stride table (gather_pack_fixed)
+#define LAUNCH_GATHER(UU, FX) hipLaunchKernelGGL((gather_kernel<UU, FX>), dim3(1 + nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin, n_thin8, n_thin4, \
+                       out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, cost_src, n_cost, st, need_flag, other_stride, t)
+  if (thin_per_lane <= 6) { if (ptr_thin) LAUNCH_GATHER(6, false); else LAUNCH_GATHER(6, true); }
+  else { if (ptr_thin) LAUNCH_GATHER(12, false); else LAUNCH_GATHER(12, true); }
+#undef LAUNCH_GATHER
+}
+// The thin outputs' CSR lists repacked at a fixed stride per lane class (see gather_kernel, FIXED); once per plan.
+__global__ __launch_bounds__(256) void gather_pack_fixed_kernel(const int64_t* __restrict__ ptr, const int* __restrict__ idx, int n_thin, int n_thin8,
+                                                               int n_thin4, int s8, int zero_slot, int* __restrict__ out) {
+  const int o = int(blockIdx.x) * 256 + int(threadIdx.x);
+  if (o >= n_thin) return;
+  const size_t base4 = size_t(n_thin8) * s8, base1 = base4 + size_t(n_thin4 - n_thin8) * 24;
+  const int stride = o < n_thin8 ? s8 : (o < n_thin4 ? 24 : 8);
+  const size_t base = o < n_thin8 ? size_t(o) * s8 : (o < n_thin4 ? base4 + size_t(o - n_thin8) * 24 : base1 + size_t(o - n_thin4) * 8);
+  const int64_t q0 = ptr[o], q1 = ptr[o + 1];
+  for (int k = 0; k < stride; ++k) out[base + k] = q0 + k < q1 ? idx[q0 + k] : zero_slot;
+}
+size_t gather_fixed_entries(int n_thin, int n_thin8, int n_thin4, int thin_per_lane) {
+  return size_t(n_thin8) * (8 * thin_per_lane) + size_t(n_thin4 - n_thin8) * 24 + size_t(n_thin - n_thin4) * 8;
+}
+void launch_gather_pack_fixed(const int64_t* ptr, const int* idx, int n_thin, int n_thin8, int n_thin4, int thin_per_lane, int zero_slot, int* out,
+                              hipStream_t s) {
+  if (n_thin <= 0) return;
+  hipLaunchKernelGGL(gather_pack_fixed_kernel, dim3((n_thin + 255) / 256), dim3(256), 0, s, ptr, idx, n_thin, n_thin8, n_thin4, 8 * thin_per_lane, zero_slot, out);
 }
 void launch_post_eval(const SolveArgs& a, const double* x, const BlockDev* blocks, int n_blocks, const LmOptionsDev& o,
                       IterLog* log, int log_cap, int first, int jacobi, hipStream_t s) {
