@@ -716,8 +716,12 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     // ---- Schur updates of the next block of the chain (in LDS) or of the right separator (pending slots) ----
     const int it = (wave & 3) >> 1, jt = wave & 1;
     const int row0 = 16 * it + lk, col0 = 16 * jt + l16;
+    // (ELIM: nobody reads the upper right 16x16 tile of a diagonal block -- the chief takes the lower triangle and the lower left
+    //  tile, the reduced system the lower triangle of the root --, so wave 1's tile of the three symmetric updates is left out)
+    const bool sym_skip = ELIM && wave == 1;
     if (!last) {
-      if (wave < 4) {          // next.D -= Z^BᵀZ^B
+      if (sym_skip) {
+      } else if (wave < 4) {          // next.D -= Z^BᵀZ^B
         f64x4 acc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = Dn[(row0 + 4 * r) * DLD + col0];
@@ -743,7 +747,8 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       }
     } else if (right >= 0) {
       if (role == 0) {
-        if (wave < 4) {        // pending D of the right separator, from its left (side 0)
+        if (sym_skip) {
+        } else if (wave < 4) {        // pending D of the right separator, from its left (side 0)
           f64x4 acc = {0.0, 0.0, 0.0, 0.0};
           acc = atb_tile<true>(Zb, XLD, CB + 16 * it, Zb, XLD, CB + 16 * jt, 0, BP, acc, lane);
           double* dst = pendD_w + (size_t(right) * 2 + 0) * BB;
@@ -768,7 +773,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     // ---- what the left separator collects over the chain ----
     if (left >= 0) {
       if (role == 0) {
-        if (wave < 4) acc_a = atb_tile<true>(Zb, XLD, CA + 16 * it, Zb, XLD, CA + 16 * jt, 0, BP, acc_a, lane);
+        if (wave < 4 && !sym_skip) acc_a = atb_tile<true>(Zb, XLD, CA + 16 * it, Zb, XLD, CA + 16 * jt, 0, BP, acc_a, lane);
       } else if (wave == 2 || wave == 3) {
         acc_a = atb_tile<true>(Zb, XLD, CA + 16 * (wave - 2), Zb, XLD, CF, 0, BP, acc_a, lane);
       }
@@ -783,7 +788,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
 #undef LTICK
   if (left >= 0) {
     if (role == 0) {
-      if (wave < 4) {
+      if (wave < 4 && !(ELIM && wave == 1)) {
         const int it = wave >> 1, jt = wave & 1;
         double* dst = pendD_w + (size_t(left) * 2 + 1) * BB;
 #pragma unroll
