@@ -1936,9 +1936,15 @@ __global__ __launch_bounds__(kDenseThreads) void dense_back_kernel(SolveArgs a, 
   extern __shared__ double lds[];
   __shared__ double sh[64];
   const Handoff ho = {word, seq};
-  if (blockIdx.x == 0) { dense_block_solve_body(a, nsl, lds, ho, 0, 0, elim); return; }
+  const long long t_db = CAL_DEV_TIMING(a.debug == 4) ? __builtin_readcyclecounter() : 0;
+  if (blockIdx.x == 0) {
+    dense_block_solve_body(a, nsl, lds, ho, 0, 0, elim);
+    if (CAL_DEV_TIMING(a.debug == 4 && threadIdx.x == 0)) printf("dense_back: the solve's workgroup lived %lld clocks (terminated %d)\n", (long long)(__builtin_readcyclecounter() - t_db), a.st->terminated);
+    return;
+  }
   bcr_back_body<QM, MODE, true, PRE>(a, b, int(blockIdx.x) - 1, node0, n_nodes, 1, q_max, x, x_cand, blocks, n_blocks, ts, lds, sh, ho,
                                      node0 == 0 ? q_max : 0);      // (the nodes of this launch are level 0's: launch_dense_back)
+  if (CAL_DEV_TIMING(a.debug == 4 && threadIdx.x == 0)) printf("dense_back: workgroup %d lived %lld clocks (terminated %d)\n", int(blockIdx.x), (long long)(__builtin_readcyclecounter() - t_db), a.st->terminated);
 }
 size_t dense_block_solve_lds_bytes() { return size_t(128 * DNL + 128 + 64 * DLD + 128 * 3 + 32 + 128 + kDenseThreads) * sizeof(double); }
 hipError_t configure_dense_block_solve() {
