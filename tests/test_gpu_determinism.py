@@ -78,7 +78,7 @@ def test_solver_variants_agree(monkeypatch):
     for name, value in [("CALICO_STREAM_DEPTH", "0"), ("CALICO_FUSED_CONTROL", "0"), ("CALICO_ROW_CELLS", "0"),
                         ("CALICO_IMU_CHUNK", "7"), ("CALICO_STREAM_DEPTH", "1"), ("CALICO_BCR_MERGE_TOP", "0"),
                         ("CALICO_FUSE_SCHUR", "0"), ("CALICO_FUSE_BACK", "0"), ("CALICO_GATHER_STRUCT", "0"), ("CALICO_GATHER_TINY", "0"), ("CALICO_FOLD_FIRST", "0"),
-                        ("CALICO_ELIM", "panel")]:       # round 4: the block factorisation of rounds 1-3 instead of block_elim.hpp
+                        ("CALICO_GATHER_FIXED", "0"), ("CALICO_ELIM", "panel")]:       # round 4: the block factorisation of rounds 1-3 instead of block_elim.hpp
         monkeypatch.setenv(name, value)
         results[(name, value)] = _solve_repeatedly(api, scene, repeats=1, max_iter=50)[0]
         monkeypatch.delenv(name)
