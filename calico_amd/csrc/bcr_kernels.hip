@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 #include "problem_dev.hpp"
 #include "solve_dev.hpp"
@@ -288,11 +289,15 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
                                                                    int keep0, int n_keep, LmOptionsDev o, int with_post,
                                                                    const double* __restrict__ x, const BlockDev* __restrict__ blocks,
                                                                    int n_blocks, IterLog* log, int log_cap, int jacobi_scaling,
-                                                                   int n_schur_wg, int n_root_wg, int schur_ks, int* fan_word, int n_prod) {
+                                                                   int n_schur_wg, int n_root_wg, int schur_ks, int* fan_word, int n_prod,
+                                                                   BcrInlineNodes inl) {
   const long long t_kernel = CAL_DEV_TIMING(a.debug != 0) ? __builtin_readcyclecounter() : 0;
   LmState* st = a.st;
-  const int terminated = st->terminated;     // tested after the first loads are on their way (they are harmless)
-  const double radius = st->radius;
+  // (vector loads: see vector_ptr. `terminated` is tested after the first loads are on their way -- they are harmless)
+  const LmState* const stv = vector_ptr(const_cast<const LmState*>(st));
+  const int terminated_v = stv->terminated;
+  const double radius = stv->radius;          // (stays in a VGPR: only arithmetic uses it)
+  const int r_cur_v = FROM_R ? stv->rcur : 0;
   // `pub` (the last level's launch when the Schur complement rides in it): this level's workgroups are the PRODUCERS of
   // an in-launch fan-in -- what the riders read (Y rows, the root's pending slots, separators updated in place) leaves
   // with write-through stores, and every producing workgroup arrives at `fan_word` once, terminated or not; the riders
@@ -300,14 +305,14 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   const bool pub = !FROM_R && fan_word != nullptr;
   if (FROM_R && fan_word != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *fan_word = 0;     // (the next fan-in counts from zero)
   if (pub && int(blockIdx.x) >= int(gridDim.x) - n_schur_wg - n_root_wg) {
-    if (terminated) return;
+    if (uniform(terminated_v)) return;
     use_current_R(a);
     const FromR frs = {a, o, radius, 0};
     extern __shared__ double lds_s[];
     const int w = int(blockIdx.x) - (int(gridDim.x) - n_schur_wg - n_root_wg);
     if (w < n_schur_wg) {
       // (the last level has one or two nodes of one superblock each)
-      const int lb0 = b.nodes[node0].blk0, lb1 = n_nodes > 1 ? b.nodes[node0 + 1].blk0 : -1;
+      const int lb0 = inl.n > 0 ? inl.nd[0].blk0 : b.nodes[node0].blk0, lb1 = n_nodes > 1 ? (inl.n > 0 ? inl.nd[1].blk0 : b.nodes[node0 + 1].blk0) : -1;
       schur_tile<kLevelThreads / 64, true>(a, b, frs, w / schur_ks, w % schur_ks, schur_ks, lds_s, fan_word, n_prod, lb0, lb1);
     } else {
       fanin_wait(fan_word, n_prod);
@@ -318,14 +323,18 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   auto put = [&](double* dst, double v) { if (pub) store_sc1(dst, v); else *dst = v; };
   if (FROM_R) {
     if (with_post && blockIdx.x == gridDim.x - 1) {
-      if (terminated) return;
+      if (uniform(terminated_v)) return;
       if (threadIdx.x == 0 && a.st->commit_pending) a.st->commit_pending = 0;   // see commit_kernel (several ranks)
       post_eval_body(a, x, blocks, n_blocks, o, log, log_cap, with_post == 2 ? 1 : 0, jacobi_scaling);     // (all threads: it has barriers inside)
       if (CAL_DEV_TIMING(a.debug == 4 && threadIdx.x == 0)) printf("bcr_level 0: the bookkeeping workgroup lived %lld clocks\n", (long long)(__builtin_readcyclecounter() - t_kernel));
       return;
     }
-    use_current_R(a);
   }
+  // Which reduce buffer holds R(x) is a word of the LM state (speculative evaluation): the chains' first block is requested
+  // from BOTH buffers at once and selected when the state has arrived -- with the buffer chosen first, every load of the
+  // launch's head waited out the state's round trip before it was even issued (two dependent round trips instead of one).
+  const double* const R_buf0 = a.R;
+  const double* const R_buf1 = a.R + a.r_stride;
   const FromR fr = {a, o, radius, (FROM_R && with_post == 2) ? (jacobi_scaling ? 1 : 2) : 0};
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // Workgroup -> (node, role), XCD-aware: workgroup p runs on XCD p % 8, each XCD has its own L2, and all roles of a node
@@ -350,7 +359,8 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   const double* const Gr = b.G + size_t(par) * NB * BB;
   double* const Gw = b.G + size_t(par ^ 1) * NB * BB;
   if (bid >= n_nodes * per) {
-    if (terminated) { if (pub) fanin_arrive(fan_word); return; }
+    if (uniform(terminated_v)) { if (pub) fanin_arrive(fan_word); return; }
+    if (FROM_R) use_current_R(a);
     // surviving separators that are not eliminated at this level: D += pending, F += pending (in place; nobody else
     // reads them in this launch). At level 0 they are initialised from R(x) instead.
     const size_t aw = size_t(bid - n_nodes * per), naw = size_t(grid_l - n_nodes * per - (FROM_R && with_post ? 1 : 0));
@@ -440,10 +450,26 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     if (pub) fanin_arrive(fan_word);
     return;
   }
-  const BcrNodeDev* __restrict__ ndp = b.nodes + node0 + bid / per;
+  // The node's descriptor without a load in front of the node's requests (a dependent round trip behind a kernel boundary is
+  // ~1.9 us): level 0 is regular -- [chain of q] [separator] [chain] ... in time order --, so its descriptors are arithmetic on
+  // the node's number (inl.q_regular; the host's table says the same); the few nodes of the levels near the top come with
+  // the kernel arguments (inl.n); only the wide middle levels of a long trajectory read the table.
+  BcrNodeDev nd_;
+  {
+    const int c = bid / per;
+    if (FROM_R && inl.q_regular > 0) {
+      nd_.blk0 = c * (inl.q_regular + 1); nd_.q = min(inl.q_regular, b.N - nd_.blk0);
+      nd_.left = c > 0 ? nd_.blk0 - 1 : -1; nd_.right = nd_.blk0 + nd_.q < b.N ? nd_.blk0 + nd_.q : -1; nd_.slot = node0 + c; nd_.pend = 0;
+    } else if (!FROM_R && inl.n > 0) {
+      nd_ = inl.nd[0];
+      if (c == 1) nd_ = inl.nd[1];
+      if (c == 2) nd_ = inl.nd[2];
+      if (c == 3) nd_ = inl.nd[3];
+    } else nd_ = b.nodes[node0 + c];
+  }
   const int role = bid % per;
   const int f0 = (role - 1) * kBcrFS;        // first border column of this role (role >= 1)
-  const int q = ndp->q, left = ndp->left, right = ndp->right, blk0 = ndp->blk0, pend_mask = ndp->pend;
+  const int q = nd_.q, left = nd_.left, right = nd_.right, blk0 = nd_.blk0, pend_mask = nd_.pend;
   extern __shared__ double lds[];
   double* const Daug = lds;                        // [2][64·DLD]
   double* const Xb = Daug + 2 * 64 * DLD;          // [2][32·XLD]
@@ -469,7 +495,6 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   int iD[NU], iB[NU];
   bool okD[NU], okB[NU];
   const int strideB = kBcrCps * a.k * 36;
-  const double inv_radius = 1.0 / radius;
   if (FROM_R) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -484,7 +509,8 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       iB[u] = okB[u] ? ((c / 6) * a.k + dB) * 36 + (c % 6) * 6 + r % 6 : 0;
     }
   }
-  auto fetch = [&](int i, Pre& pr) {
+  auto fetch = [&](int i, Pre& pr, auto both_tag) {
+    constexpr bool BOTH = decltype(both_tag)::value;      // (FROM_R, first block of the launch: see R_buf0 / R_buf1)
     const int blk = blk0 + i, mask = pend_mask;
     const bool has_next = (i + 1 < q) || right >= 0;
     const bool has_a = (i == 0) && left >= 0;
@@ -492,13 +518,16 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     if (FROM_R) {
       // neighbours in the tree are neighbours in time at level 0 (next = blk + 1, left separator = blk - 1)
       const int nreal = a.n_s() - RB * blk, nreal_n = nreal - RB;     // real rows of this superblock / of the next one
-      const double* RBnd = a.R + a.off_B() + size_t(blk) * strideB;
-      const double* RBndA = a.R + a.off_B() + size_t(max(blk - 1, 0)) * strideB;
+      const double* const Rsel = BOTH ? R_buf0 : a.R;
+      const double* RBnd = Rsel + a.off_B() + size_t(blk) * strideB;
+      const double* RBndA = Rsel + a.off_B() + size_t(max(blk - 1, 0)) * strideB;
+      const size_t alt = BOTH ? a.r_stride : 0;      // the same entry of the other buffer
       // Two passes: every load of the block is REQUESTED before the first store. The damping of a diagonal entry is filed
       // (a.dadd) as it is formed, and as far as the compiler knows that store may alias a.R -- with the store inside the
       // loop over the entries every entry's loads waited for the entry before it: NU dependent round trips per block
       // instead of one (the head of the launch and every step's loads were that much longer).
       double vraw[NU], graw[NU], garaw[NU], svv[NU], q2v[NU], fraw[NF];
+      double vraw1[NU], graw1[NU], garaw1[NU], fraw1[NF];
       bool vDs[NU], vBs[NU], vAs[NU], vFs[NF];
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
@@ -514,13 +543,17 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         }
         vDs[u] = okD[u] && r < nreal && c < nreal && act_r && act_c;
         vraw[u] = RBnd[vDs[u] ? iD[u] : 0];
+        if (BOTH) vraw1[u] = RBnd[alt + (vDs[u] ? iD[u] : 0)];
         const int ts = (r == c && r < RB && r < nreal) ? RB * blk + r : 0;
         svv[u] = a.scale[ts]; q2v[u] = a.scale[a.NT() + ts];        // (harmless during a solve's first linear solve, which does not use them)
         vBs[u] = okB[u] && has_next && r < nreal_n && act_rn && act_c;
         graw[u] = RBnd[vBs[u] ? iB[u] : 0];
+        if (BOTH) graw1[u] = RBnd[alt + (vBs[u] ? iB[u] : 0)];
         vAs[u] = okB[u] && has_a && r < nreal && act_r && act_cl;
         garaw[u] = 0.0;
         if (has_a) garaw[u] = RBndA[vAs[u] ? iB[u] : 0];      // (only the first block of a chain touches the left separator)
+        garaw1[u] = 0.0;
+        if (BOTH && has_a) garaw1[u] = RBndA[alt + (vAs[u] ? iB[u] : 0)];
       }
 #pragma unroll
       for (int u = 0; u < NF; ++u) {
@@ -531,7 +564,15 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         if (!b.all_active) act_r = a.cp_active[min(kBcrCps * blk + r / 6, a.n_cp - 1)] != 0;
         vFs[u] = role > 0 && r < RB && r < nreal && col <= a.mc && act_r;
         const size_t idx = vFs[u] ? (col < a.mc ? a.off_E() + size_t(t) * a.mc + col : a.off_g() + t) : a.off_g();
-        fraw[u] = a.R[idx];
+        fraw[u] = Rsel[idx];
+        if (BOTH) fraw1[u] = Rsel[alt + idx];
+      }
+      if (BOTH) {
+        const bool second = r_cur_v != 0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) { vraw[u] = second ? vraw1[u] : vraw[u]; graw[u] = second ? graw1[u] : graw[u]; garaw[u] = second ? garaw1[u] : garaw[u]; }
+#pragma unroll
+        for (int u = 0; u < NF; ++u) fraw[u] = second ? fraw1[u] : fraw[u];
       }
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
@@ -546,6 +587,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           const int t = RB * blk + r;
           const bool real_row = r < RB && r < nreal;
           double d;
+          const double inv_radius = 1.0 / radius;       // (once per thread: the same value in every entry)
           if (fr.first_scale == 0) d = fmin(fmax(v * svv[u] * svv[u], o.min_lm_diagonal), o.max_lm_diagonal) * (inv_radius * q2v[u]);
           else d = fr.damping(v, (dg && real_row) ? t : 0);
           if (dg) {
@@ -616,8 +658,9 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   f64x4 acc_a = {0.0, 0.0, 0.0, 0.0};
   {
     Pre pr;
-    if (loader) fetch(0, pr);
-    if (terminated) { if (pub) fanin_arrive(fan_word); return; }
+    if (loader) fetch(0, pr, std::integral_constant<bool, FROM_R>());
+    if (FROM_R) a.R = uniform(r_cur_v) ? R_buf1 : R_buf0;        // (use_current_R; the later blocks' requests come behind the state anyway)
+    if (uniform(terminated_v)) { if (pub) fanin_arrive(fan_word); return; }
     if (loader) commit(0, pr);
   }
   __syncthreads();
@@ -639,7 +682,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
 #pragma unroll
       for (int k = 0; k < 4; ++k) if (k == i) t_top[k] = t_step - t_kernel;
     }
-    if (!last && loader) fetch(i + 1, pr);            // in flight while the block is factored
+    if (!last && loader) fetch(i + 1, pr, std::false_type());            // in flight while the block is factored
     if (CAL_DEV_TIMING(a.debug == 2 && bid < 1 && lane == 0 && wave >= 4)) printf("level %d step %d wave %d: requests issued at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
     if (ELIM) {
       // ---- D = L Lᵀ, Z = L⁻¹X and (role 0) L⁻ᵀ in one pass: wave 0 the spine, waves 1..3 two row tiles each ----
@@ -2190,7 +2233,7 @@ hipError_t configure_bcr_kernels(int q_max, int m1p) {
 // this level's workgroups and take its results over the fan-in word; level 0 (`fan_word` given) resets the word.
 void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, int level, int keep0, int n_keep, const LmOptionsDev& o,
                       const double* x, const BlockDev* blocks, int n_blocks, int with_post_eval, IterLog* log, int log_cap, int jacobi,
-                      hipStream_t s, int schur_ks, int* fan_word) {
+                      hipStream_t s, int schur_ks, int* fan_word, const BcrInlineNodes& inl) {
   const int nfs = (a.mc + 1 + kBcrFS - 1) / kBcrFS;
   const int n_apply = n_keep > 0 ? std::min(64, std::max(1, n_keep * 4)) : 0;
   const int main_span = 8 * ((n_nodes + 7) / 8) * (1 + nfs);      // (node, role) workgroups laid out by XCD: see the kernel
@@ -2198,7 +2241,7 @@ void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nod
   if (level == 0) {
     hipLaunchKernelGGL((elim ? bcr_level_kernel<true, true> : bcr_level_kernel<true, false>), dim3(main_span + n_apply + (with_post_eval ? 1 : 0)), dim3(kLevelThreads),
                        bcr_level_lds_bytes(), s, a, b, node0, n_nodes, nfs, level, keep0, n_keep, o, with_post_eval, x, blocks, n_blocks,
-                       log, log_cap, jacobi, 0, 0, 1, fan_word, 0);
+                       log, log_cap, jacobi, 0, 0, 1, fan_word, 0, inl);
   } else {
     const int nt = (a.mc + 1 + 15) / 16;
     const int br = a.m - a.mc;
@@ -2208,7 +2251,7 @@ void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nod
     const int n_prod = n_nodes * (1 + nfs) + n_apply;        // the workgroups of this level that really exist
     hipLaunchKernelGGL((elim ? bcr_level_kernel<false, true> : bcr_level_kernel<false, false>), dim3(main_span + n_apply + n_schur_wg + n_root_wg), dim3(kLevelThreads), bcr_level_lds_bytes(), s, a, b,
                        node0, n_nodes, nfs, level, keep0, n_keep, o, 0, x, blocks, n_blocks, log, log_cap, jacobi, n_schur_wg, n_root_wg,
-                       std::max(1, schur_ks), schur_ks > 0 ? fan_word : nullptr, n_prod);
+                       std::max(1, schur_ks), schur_ks > 0 ? fan_word : nullptr, n_prod, inl);
   }
 }
 void launch_bcr_schur(const SolveArgs& a, const BcrArgs& b, int ks, const LmOptionsDev& o, hipStream_t s) {

@@ -26,6 +26,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/calico_hip.h"
@@ -86,7 +87,7 @@ hipError_t configure_reduced_block_step();
 size_t dense_block_solve_lds_bytes();
 void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, int level, int keep0, int n_keep, const LmOptionsDev& o,
                       const double* x, const BlockDev* blocks, int n_blocks, int with_post_eval, IterLog* log, int log_cap, int jacobi,
-                      hipStream_t s, int schur_ks = 0, int* fan_word = nullptr);
+                      hipStream_t s, int schur_ks, int* fan_word, const BcrInlineNodes& inl);
 bool schur_rides_in_last_level(int n_levels, int n_last_nodes, int root);
 void launch_bcr_schur(const SolveArgs& a, const BcrArgs& b, int ks, const LmOptionsDev& o, hipStream_t s);
 void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, bool top, bool extras, bool border_rows, int q_max,
@@ -181,6 +182,83 @@ struct HSensor {
   int64_t n() const { return int64_t(stamps.size()); }
 };
 
+// Device memory of plans and workspaces comes out of a few large slabs instead of one hipMalloc per buffer: a handle
+// has some forty buffers, most of them a few KB, and a buffer of its own sits on pages of its own -- every kernel's
+// first touch of each (state, descriptors, index lists, ...) then costs an address translation of its own behind the
+// kernel boundary. One slab is one allocation of >= 64 MB: contiguous, mapped with the largest fragments the driver
+// has. First fit over a free list ordered by address, neighbours merged on release; a request no slab can serve opens
+// a new slab (a multiple of 64 MB), and if that fails the request goes to hipMalloc as before. The slabs are never
+// returned (like the stream and pinned pools: no HIP calls during static destruction). CALICO_ARENA=0: hipMalloc per
+// buffer (rounds 1-4).
+class DeviceArena {
+ public:
+  static DeviceArena& get() { static DeviceArena* a = new DeviceArena; return *a; }
+  hipError_t alloc(void** out, size_t bytes) {
+    if (!enabled_) return hipMalloc(out, bytes);
+    bytes = (bytes + kAlign - 1) / kAlign * kAlign;
+    std::lock_guard<std::mutex> g(mu_);
+    int dev = 0; (void)hipGetDevice(&dev);
+    for (int pass = 0; pass < 2; ++pass) {
+      for (Slab& sl : slabs_) {
+        if (sl.device != dev) continue;
+        for (auto it = sl.free.begin(); it != sl.free.end(); ++it) {
+          if (it->second < bytes) continue;
+          const size_t off = it->first, len = it->second;
+          sl.free.erase(it);
+          if (len > bytes) sl.free.emplace(off + bytes, len - bytes);
+          *out = sl.base + off;
+          used_[*out] = bytes;
+          return hipSuccess;
+        }
+      }
+      if (pass == 1) break;
+      const size_t want = (bytes + kSlab - 1) / kSlab * kSlab;
+      void* base = nullptr;
+      if (hipMalloc(&base, want) != hipSuccess) { (void)hipGetLastError(); break; }
+      Slab sl; sl.base = static_cast<char*>(base); sl.size = want; sl.device = dev; sl.free.emplace(0, want);
+      slabs_.push_back(std::move(sl));
+    }
+    return hipMalloc(out, bytes);      // (not in used_: release() hands it to hipFree)
+  }
+  void release(void* p) {
+    if (!p) return;
+    // hipFree waits for the device; a block that goes back to the free list must do the same (a solve returns while the
+    // early-exit kernels of the iterations enqueued ahead are still on its stream)
+    if (enabled_) (void)hipDeviceSynchronize();
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      auto u = used_.find(p);
+      if (u != used_.end()) {
+        const size_t bytes = u->second;
+        used_.erase(u);
+        for (Slab& sl : slabs_) {
+          char* c = static_cast<char*>(p);
+          if (c < sl.base || c >= sl.base + sl.size) continue;
+          size_t off = size_t(c - sl.base), len = bytes;
+          auto next = sl.free.lower_bound(off);
+          if (next != sl.free.end() && next->first == off + len) { len += next->second; next = sl.free.erase(next); }
+          if (next != sl.free.begin()) {
+            auto prev = std::prev(next);
+            if (prev->first + prev->second == off) { off = prev->first; len += prev->second; sl.free.erase(prev); }
+          }
+          sl.free.emplace(off, len);
+          return;
+        }
+        return;
+      }
+    }
+    (void)hipFree(p);
+  }
+ private:
+  static constexpr size_t kAlign = 4096, kSlab = size_t(64) << 20;
+  struct Slab { char* base = nullptr; size_t size = 0; int device = 0; std::map<size_t, size_t> free; };
+  DeviceArena() { const char* e = std::getenv("CALICO_ARENA"); enabled_ = !e || std::atoi(e) != 0; }
+  std::mutex mu_;
+  std::vector<Slab> slabs_;
+  std::unordered_map<void*, size_t> used_;
+  bool enabled_ = true;
+};
+
 template <class T> struct DevBuf {
   T* p = nullptr; size_t n = 0;
   bool owner = true;        // false: a view of a buffer the plan cache owns (structure shared between handles)
@@ -188,7 +266,7 @@ template <class T> struct DevBuf {
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
-  void release() { if (p && owner) (void)hipFree(p); p = nullptr; n = 0; owner = true; }
+  void release() { if (p && owner) DeviceArena::get().release(p); p = nullptr; n = 0; owner = true; }
   void alias(const DevBuf& o) { release(); p = o.p; n = o.n; owner = false; }
   void take(DevBuf& o) { release(); p = o.p; n = o.n; owner = o.owner; o.p = nullptr; o.n = 0; o.owner = true; }
   void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(owner, o.owner); }
@@ -196,7 +274,7 @@ template <class T> struct DevBuf {
     if (count == 0) count = 1;
     if (count == n && p && owner) return hipSuccess;
     release();        // (a view is dropped, never written through)
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    hipError_t e = DeviceArena::get().alloc(reinterpret_cast<void**>(&p), count * sizeof(T));
     if (e == hipSuccess) n = count;
     return e;
   }
@@ -263,7 +341,7 @@ struct PlanHost {
   int sep_s = 0, sep_n = 0;   // separator control points of the nested-dissection split (sep_n = 0: none)
   // tree solver (bcr_kernels.hip): elimination plan, level after level
   bool use_bcr = false, bcr_all_active = false;
-  int bcr_N = 0, bcr_m1p = 16, bcr_root = -1, bcr_root_pend = 0, bcr_root_par = 0, bcr_br = 0, bcr_q_max = 1, bcr_slots = 1;
+  int bcr_N = 0, bcr_m1p = 16, bcr_root = -1, bcr_root_pend = 0, bcr_root_par = 0, bcr_br = 0, bcr_q_max = 1, bcr_slots = 1, bcr_q0 = 1;
   std::vector<BcrLevel> bcr_levels;
   std::vector<BcrNodeDev> h_bcr_nodes;
   std::vector<int> h_bcr_keep, h_cp_block;
@@ -513,6 +591,7 @@ void build_bcr_plan(calico_problem* p) {
   p->bcr_root_par = (level - 1) & 1;
   p->bcr_br = alive.empty() ? 0 : 6 * kBcrCps;
   p->bcr_q_max = q_max_all;
+  p->bcr_q0 = q;       // level 0's chain length: its node table is arithmetic on the node's number (BcrInlineNodes)
   p->bcr_slots = int(p->h_bcr_nodes.size()) + 1;
   { const char* e = std::getenv("CALICO_BCR_MERGE_TOP"); p->bcr_merge_top = !e || std::atoi(e) != 0; }   // (A/B switch, see enqueue_linear_solve)
 }
@@ -530,6 +609,7 @@ EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool
   a.cell_chunk = p->cell_chunk; a.cell_rec_max = p->cell_rec_max; a.project = 0; a.row_cell_chunk = p->row_cell_chunk; a.frame_lds_doubles = p->frame_lds_doubles; a.pad5 = 0; a.wave_log = p->d_wave_log.p; a.active = p->any_tagged ? p->d_active.p : nullptr; a.apply_loss = apply_loss;
   a.st = nullptr; a.need_flag = 0; a.cost_index_base = 0;
   a.fitems = p->d_fitems.p; a.n_fitems = p->n_fitems;
+  a.hint_progress = nullptr; a.hint_seq = 0; a.hint_pad = 0; a.hint_ftol = a.hint_ptol = 0.0;
   return a;
 }
 
@@ -1545,11 +1625,18 @@ int do_allreduce(calico_problem* p, double* buf, int64_t n) {
 // the last step was rejected, so whole iterations can be enqueued without a host round trip.
 // `spec`: evaluation at the candidate point x_at = x_cand into the reduce buffer that does NOT hold R(x) (chosen on
 // the device from LmState.rcur); otherwise evaluation at x into buffer 0.
+// `end_hint` (streaming solve loop, fused Jacobian launch only: end_hint_available): the launch tells the host whether the
+// control stage behind it is about to end the solve (eval_kernels.hip, end_hint_body).
+static bool end_hint_available(const calico_problem* p) { return p->order == 6 && p->n_fitems > 0; }
 int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, const double* x_at = nullptr, bool spec = false,
-                          const ControlTail* tail = nullptr) {
+                          const ControlTail* tail = nullptr, bool end_hint = false) {
   p->timer.begin(0, p->stream);
   EvalArgs ea = make_eval_args(p, x_at ? x_at : p->d_x.p, 1, false);
   ea.st = st; ea.need_flag = need_flag;
+  if (end_hint && tail && st && end_hint_available(p)) {
+    ea.hint_progress = tail->progress; ea.hint_seq = tail->seq;
+    ea.hint_ftol = tail->o.function_tolerance; ea.hint_ptol = tail->o.parameter_tolerance;
+  }
   ea.items = p->d_jac_items.p; ea.n_items = p->n_jac_items; ea.cost_index_base = p->n_fitems;
   if (p->order == 6 && p->n_fitems > 0) {
     launch_eval_jacobian(ea, p->stream);                  // camera frames (item-cost slots [0, n_fitems)) + everything else
@@ -1595,10 +1682,17 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
   for (int i = 0; schur_rides && i < p->bcr_levels[size_t(L - 1)].n_nodes; ++i)
     schur_rides = p->h_bcr_nodes[size_t(p->bcr_levels[size_t(L - 1)].node0 + i)].q == 1;
   int* const fan_word = p->d_handoff.p + 4;
+  // (A/B switch, read per solve: 0 = every level reads its node descriptors from the table)
+  const bool inline_nodes = [] { const char* e = std::getenv("CALICO_INLINE_NODES"); return !e || std::atoi(e) != 0; }();
   for (int l = 0; l < L; ++l) {
     const BcrLevel& lv = p->bcr_levels[size_t(l)];
+    BcrInlineNodes inl = {};
+    if (inline_nodes) {
+      if (l == 0) inl.q_regular = p->bcr_q0;
+      else if (lv.n_nodes <= 4) { inl.n = lv.n_nodes; for (int i = 0; i < lv.n_nodes; ++i) inl.nd[i] = p->h_bcr_nodes[size_t(lv.node0 + i)]; }
+    }
     launch_bcr_level(sa, b, lv.node0, lv.n_nodes, l, lv.keep0, lv.n_keep, o, p->d_x.p, p->d_blocks.p, n_blocks, l == 0 ? with_post_eval : 0,
-                     p->d_log.p, kLogCap, jacobi, s, schur_rides && l == L - 1 ? ks : 0, schur_rides ? fan_word : nullptr);
+                     p->d_log.p, kLogCap, jacobi, s, schur_rides && l == L - 1 ? ks : 0, schur_rides ? fan_word : nullptr, inl);
   }
   if (!schur_rides) launch_bcr_schur(sa, b, ks, o, s);
   // The top level of the tree is one or two single superblocks next to the root: their back-substitution rides in the
@@ -2055,8 +2149,17 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
     p->timer.end(s);
   }
   const bool fused_control = [] { const char* e = std::getenv("CALICO_FUSED_CONTROL"); return !e || std::atoi(e) != 0; }();
+  // The iteration enqueued ahead of the device is wasted when the one in front of it ends the solve (six early-exit kernels,
+  // 40 us at configs[3], in front of the caller's next solve). With the end hint the Jacobian launch of iteration i says, from
+  // what the linear solve left, whether iteration i's control stage will end the solve; iteration i + 1 is enqueued on its
+  // "go" (progress word 2) -- the evaluation chain is still running then, so the device does not wait -- or, without one,
+  // once iteration i has ended without terminating (CALICO_PREDICT_END=0: always one iteration ahead, rounds 2-3).
+  const bool predict_end = streaming && fused_control && end_hint_available(p) &&
+                           [] { const char* e = std::getenv("CALICO_PREDICT_END"); return !e || std::atoi(e) != 0; }();
   mark(2);
+  int dbg_enq = 0, dbg_go = 0, dbg_wait = 0;      // CALICO_SOLVE_TIMING: iterations enqueued, on a go word, behind a finished iteration
   if (streaming) {
+    __atomic_store_n(p->h_progress + 2, 0, __ATOMIC_RELEASE);     // (a go word of the same epoch, 2047 solves ago)
     int enq = 0;
     auto t_progress = std::chrono::steady_clock::now();     // when the device last reported a finished iteration
     int last_seen = 0;
@@ -2069,7 +2172,11 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
         const int word = __atomic_load_n(p->h_progress, __ATOMIC_ACQUIRE);
         const int seen = (word >> 20) == epoch ? (word & 0xfffff) : 0;    // words of another epoch: early-exit kernels of the previous solve
         if (seen != last_seen) { last_seen = seen; t_progress = std::chrono::steady_clock::now(); spins = 0; }
-        if (!budget_spent && enq - seen < stream_depth) {
+        const bool room = predict_end
+                              ? (seen >= enq || __atomic_load_n(p->h_progress + 2, __ATOMIC_ACQUIRE) == ((epoch << 20) | enq))
+                              : enq - seen < stream_depth;
+        if (!budget_spent && room) {
+          if (solve_timing) { ++dbg_enq; if (seen >= enq) ++dbg_wait; else ++dbg_go; }
           // the device raises the termination word BEFORE the iteration count: having seen the count move, look at the
           // flag once more, or one solve in two enqueues a whole iteration of early-exit kernels for nothing
           if (__atomic_load_n(p->h_progress + 1, __ATOMIC_ACQUIRE) == epoch) done = true;
@@ -2101,7 +2208,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
       tail.enabled = 1; tail.n_amb = p->n_amb; tail.log_cap = kLogCap; tail.seq = ++enq; tail.o = o; tail.x = p->d_x.p;
       tail.x_cand = p->d_xc.p; tail.log = p->d_log.p; tail.Rbase = p->d_R.p; tail.r_stride = p->r_size;
       tail.progress = p->d_progress; tail.owner_block = p->gather_owner_block;
-      rc = enqueue_jacobian_eval(p, p->d_state.p, 0, p->d_xc.p, true, fused_control ? &tail : nullptr);
+      rc = enqueue_jacobian_eval(p, p->d_state.p, 0, p->d_xc.p, true, fused_control ? &tail : nullptr, predict_end);
       if (rc != CALICO_OK) return rc;
       if (!fused_control) {
         p->timer.begin(4, s);
@@ -2240,9 +2347,11 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
   sm->total_time_in_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   if (solve_timing) {
     mark(4);
-    std::fprintf(stderr, "solve host us: since last return %.1f | prep %.1f | begin launch %.1f | first evaluation enqueued %.1f | loop %.1f | results %.1f\n",
+    std::fprintf(stderr, "solve host us: since last return %.1f | prep %.1f | begin launch %.1f | first evaluation enqueued %.1f | loop %.1f | results %.1f"
+                 " | iterations: device %d, enqueued %d (ahead of the device %d, behind a finished iteration %d), reason %d\n",
                  std::chrono::duration<double, std::micro>(t_start - t_last_return).count(), t_mark[0], t_mark[1] - t_mark[0],
-                 t_mark[2] - t_mark[1], t_mark[3] - t_mark[2], t_mark[4] - t_mark[3]);
+                 t_mark[2] - t_mark[1], t_mark[3] - t_mark[2], t_mark[4] - t_mark[3], st.iteration, dbg_enq, dbg_go, dbg_wait,
+                 st.termination_reason);
     t_last_return = std::chrono::steady_clock::now();
   }
   return CALICO_OK;

@@ -1043,8 +1043,38 @@ __global__ __launch_bounds__(64) void eval_frames_kernel(EvalArgs a) {
 
 // Whole Jacobian pass in one launch (spline order 6): the generic items (IMU cells; they are few and each is a long
 // single-wave computation, so they go first) and the camera frames run side by side instead of back to back.
+// The extra workgroup of the Jacobian launch in the streaming solve loop (EvalArgs.hint_progress): will the control stage
+// behind this evaluation end the solve? By the parameter tolerance: the very test of control_body on the very sums. By the
+// function tolerance: the model's cost change stands in for the candidate's (they agree to a few per cent where a solve
+// converges). "Go" -> the host enqueues the next iteration now, while this evaluation runs; otherwise it waits for the
+// control stage's word, and a solve that does end leaves nothing behind it on the stream. A wrong "hold" costs the host's
+// reaction time once, a wrong "go" what every solve cost before; the results do not depend on either.
+DEV void end_hint_body(const EvalArgs& a) {
+  const LmState* st = a.st;
+  const int lane = threadIdx.x;
+  if (st->terminated) return;
+  const int parts = st->upd_parts;
+  const double* upd = st->upd_ext;
+  const int n = st->upd_ext_n;
+  const double x_cost = st->x_cost, x_norm = st->x_norm;
+  const int chol_failed = st->chol_failed, epoch = st->sink.epoch;
+  double mcc = 0.0, sn = 0.0, bad = 0.0;
+  if (parts == 0 && upd) {
+    for (int i = lane; i < n; i += 64) { mcc += upd[4 * i]; sn += upd[4 * i + 1]; bad += upd[4 * i + 3]; }
+  } else if (lane < parts) {
+    mcc = st->upd_mcc[lane]; sn = st->upd_sn[lane]; bad = st->upd_bad[lane] ? 1.0 : 0.0;
+  }
+  mcc = wave_sum(mcc); sn = wave_sum(sn); bad = wave_sum(bad);
+  bool end = false;
+  if (!(bad > 0.0) && !chol_failed && mcc > 0.0)
+    end = sqrt(sn) <= a.hint_ptol * (x_norm + a.hint_ptol) || mcc <= 1.25 * a.hint_ftol * x_cost;
+  if (!end && lane == 0)
+    __hip_atomic_store(a.hint_progress + 2, (epoch << 20) | a.hint_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(64) void eval_jacobian_kernel(EvalArgs a) {
   extern __shared__ double lds[];
+  if (int(blockIdx.x) == a.n_items + a.n_fitems) { end_hint_body(a); return; }
   const unsigned long long t0 = CAL_DEV_TIMING(a.debug >= 3) ? __builtin_amdgcn_s_memrealtime() : 0;
   if (int(blockIdx.x) < a.n_items) eval_items_body<true, 6>(a, blockIdx.x, lds);
   else eval_frames_body(a, blockIdx.x - a.n_items, lds);
@@ -1310,7 +1340,8 @@ void launch_eval_jacobian(const EvalArgs& a, hipStream_t stream) {
   if (a.n_items + a.n_fitems == 0) return;
   size_t lds = size_t(a.lds_cols) * a.row_pad * sizeof(double);
   if (a.n_fitems > 0 && lds < frame_launch_bytes(a)) lds = frame_launch_bytes(a);
-  hipLaunchKernelGGL(eval_jacobian_kernel, dim3(a.n_items + a.n_fitems), dim3(64), lds, stream, a);
+  const int hint = a.hint_progress && a.st ? 1 : 0;      // one more workgroup: end_hint_body
+  hipLaunchKernelGGL(eval_jacobian_kernel, dim3(a.n_items + a.n_fitems + hint), dim3(64), lds, stream, a);
 }
 
 void launch_eval(const EvalArgs& a, bool jac, hipStream_t stream) {

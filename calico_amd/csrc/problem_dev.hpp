@@ -111,6 +111,13 @@ struct EvalArgs {
   const uint8_t* active; // per observation (sorted order): 0 = tagged as outlier, left out; nullptr = all in
   int frame_lds_doubles, pad5;   // LDS of a frame workgroup for the widest frame layout of the problem (0: worst case)
   unsigned long long* wave_log;  // CALICO_KERNEL_TIMING=3: [start, end] of every workgroup of the Jacobian launch (100 MHz clock)
+  // Streaming solve loop: one more workgroup of the Jacobian launch looks at what the linear solve in front of it left
+  // (model cost change, step norm) and tells the host whether the control stage of this iteration is going to end the solve;
+  // the host enqueues the next iteration only on "go" (progress word 2), so that a solve that ends leaves no iteration of
+  // early-exit kernels behind on the stream. nullptr: no hint.
+  int* hint_progress;
+  int hint_seq, hint_pad;
+  double hint_ftol, hint_ptol;
 };
 
 // Where the stage that terminates a solve leaves its results for the host (pinned, host-mapped memory: final state,
@@ -271,6 +278,13 @@ struct BcrNodeDev {
   int pend;                  // bit 0 / 1: the (single) superblock carries a pending update from the chain on its left / right (previous level)
 };
 
+// Node descriptors that reach a level's launch without a load (bcr_level_kernel): q_regular > 0 -- level 0, whose nodes are
+// regular ([chain of q] [separator] ...), described by the chain length alone; n > 0 -- a level of at most four nodes, by value.
+struct BcrInlineNodes {
+  int q_regular, n;
+  BcrNodeDev nd[4];
+};
+
 // The top level's nodes (single superblocks between the root and the ends) when their back-substitution rides in the
 // launch of the level below: every node there solves the top separators next to it itself (n = 0: separate launch).
 struct BcrTopSeps {
@@ -300,6 +314,18 @@ struct BcrArgs {
   int root, root_pend, root_par;   // surviving superblock (-1: none), its pending mask and the parity of those slots
   int n_slots;
 };
+
+// Words of the LM state read at the head of a kernel, by VECTOR loads. A wave-uniform address normally becomes a scalar
+// load, and scalar loads return out of order: the first later use of ANY scalar load's result -- a kernel argument the
+// compiler fetches late, a descriptor -- is an s_waitcnt lgkmcnt(0), i.e. it waits for the state's round trip as well,
+// and every request behind it is issued a round trip late (~2k clocks behind a kernel boundary; ISA of the tree levels).
+// Vector loads return in order: a load issued first is waited for with vmcnt(N), whatever was requested behind it.
+// `vector_ptr` hides the pointer's uniformity from the compiler; `uniform` brings a loaded word back into an SGPR.
+template <class T> __device__ __forceinline__ const T* vector_ptr(const T* p) { asm volatile("" : "+v"(p)); return p; }
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uniform(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 
 // Sums across lanes without the LDS crossbar. `__shfl_xor` compiles to ds_bpermute_b32 (two per double, an LDS round
 // trip per step of a dependent chain); inside a row of 16 lanes the DPP modifiers exchange lanes in two v_mov_b32_dpp,

@@ -78,7 +78,8 @@ def test_solver_variants_agree(monkeypatch):
     for name, value in [("CALICO_STREAM_DEPTH", "0"), ("CALICO_FUSED_CONTROL", "0"), ("CALICO_ROW_CELLS", "0"),
                         ("CALICO_IMU_CHUNK", "7"), ("CALICO_STREAM_DEPTH", "1"), ("CALICO_BCR_MERGE_TOP", "0"),
                         ("CALICO_FUSE_SCHUR", "0"), ("CALICO_FUSE_BACK", "0"), ("CALICO_GATHER_STRUCT", "0"), ("CALICO_GATHER_TINY", "0"), ("CALICO_FOLD_FIRST", "0"),
-                        ("CALICO_GATHER_FIXED", "0"), ("CALICO_ELIM", "panel")]:       # round 4: the block factorisation of rounds 1-3 instead of block_elim.hpp
+                        ("CALICO_GATHER_FIXED", "0"), ("CALICO_ELIM", "panel"),       # round 4: the block factorisation of rounds 1-3 instead of block_elim.hpp
+                        ("CALICO_PREDICT_END", "0"), ("CALICO_INLINE_NODES", "0")]:
         monkeypatch.setenv(name, value)
         results[(name, value)] = _solve_repeatedly(api, scene, repeats=1, max_iter=50)[0]
         monkeypatch.delenv(name)
@@ -257,3 +258,35 @@ def test_block_elimination_agrees_with_the_panel_factorisation(monkeypatch):
             np.testing.assert_allclose(r[3], ref[3], rtol=1e-7, atol=1e-10, err_msg=str((leaf, key)))
     monkeypatch.delenv("CALICO_ELIM")
     monkeypatch.delenv("CALICO_FUSE_BACK")
+
+
+@pytest.mark.gpu
+def test_end_prediction_and_inline_descriptors_change_nothing(monkeypatch):
+    """Round 4 (second half): (a) the Jacobian launch of every iteration tells the host whether the control stage behind
+    it is about to end the solve, and the host enqueues the next iteration on that word instead of always one ahead
+    (CALICO_PREDICT_END); (b) the tree levels get their node descriptors without a load -- level 0's by arithmetic, the
+    top levels' with the kernel arguments --, request their first block from both reduce buffers before the LM state has
+    arrived, and read the state with vector loads (CALICO_INLINE_NODES=0 restores the table look-up). Neither touches
+    the arithmetic: solves of every length -- converged, cut by the budget at every iteration count, restarted back to
+    back -- must be bit-identical with the switches off. A wrong hint shows as a hang or a lost iteration, a wrong
+    descriptor or buffer as different numbers."""
+    api = helpers.hip_api()
+    scene = syn.make_scene(4, 1, True, 3, cam_rate=10.0, imu_rate=100.0, duration=8.7, chart="april", seed=21,
+                           pixel_noise=0.1, gyro_noise=1e-3, accel_noise=1e-2, robust=True, segment_duration=8.7 / 23.9,
+                           max_cam_obs=6000)
+    long_scene = syn.make_scene(2, 1, True, 2, seed=4)       # 185 control points: several tree levels, the middle ones read the table
+    for sc, budgets in ((scene, (50, 1, 2, 3, 5, 8)), (long_scene, (50, 4))):
+        runs = {}
+        for pe, inl in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+            monkeypatch.setenv("CALICO_PREDICT_END", pe)
+            monkeypatch.setenv("CALICO_INLINE_NODES", inl)
+            runs[(pe, inl)] = [_solve_repeatedly(api, sc, repeats=2, max_iter=b) for b in budgets]
+        monkeypatch.delenv("CALICO_PREDICT_END")
+        monkeypatch.delenv("CALICO_INLINE_NODES")
+        ref = runs[("0", "0")]
+        assert ref[0][0][1] == _capi.CONVERGENCE and ref[0][0][0] > 3
+        for key, per_budget in runs.items():
+            for rb, r in zip(ref, per_budget):
+                for a, b in zip(rb, r):
+                    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2], key
+                    assert np.array_equal(a[3], b[3]), key
