@@ -358,6 +358,8 @@ struct PlanHost {
   int cell_chunk = 1, cell_rec_max = 1, row_cell_chunk = 1;
   int frame_lds_doubles = 0;
   int n_fitems = 0, n_jac_items = 0;
+  bool fuse_expand = false;    // cell workgroups (EvalArgs.pair_mode): camera cells expanded inside the Jacobian launch, IMU items form their own blocks
+  int pair_wave_lds_doubles = 0;
   int n_thin = 0, n_fat = 0;
   int n_thin8 = 0, n_thin4 = 0;  // thin outputs [0, n_thin8) take eight lanes, [n_thin8, n_thin4) four (<= 24 sources), [n_thin4, n_thin) one (<= 8)
   int thin_per_lane = 6;       // sources per lane of a thin output's eight lanes (6: up to 48 sources, 12: up to 96)
@@ -610,6 +612,7 @@ EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool
   a.st = nullptr; a.need_flag = 0; a.cost_index_base = 0;
   a.fitems = p->d_fitems.p; a.n_fitems = p->n_fitems;
   a.hint_progress = nullptr; a.hint_seq = 0; a.hint_pad = 0; a.hint_ftol = a.hint_ptol = 0.0;
+  a.pair_mode = 0; a.wave_lds_doubles = 0;
   return a;
 }
 
@@ -870,6 +873,7 @@ int build_plan(calico_problem* p) {
             p->h_cells.push_back(c);
           }
           p->h_cells.back().frame_count += 1;
+          f.cell = int(p->h_cells.size()) - 1; f.cell_frames = 0; f.cell_prim_off = 0; f.cell_pad = 0; f.cell_partial_off = 0; f.cell_src_off = 0;   // (filled below)
           p->h_fitems.push_back(f);
         }
       } else {
@@ -879,13 +883,71 @@ int build_plan(calico_problem* p) {
     }
     // IMU work items hand their staged rows to the cell kernel ("row cells": one expanded block per (layout, segment)
     // instead of one per item); everything else forms its own block
-    const bool row_cells_ok = [] { const char* e = std::getenv("CALICO_ROW_CELLS"); return !e || std::atoi(e) != 0; }();
+    // fuse_expand (CALICO_FUSE_EXPAND=0: off): no launch for the cell expansion -- a camera cell is expanded by the last of its
+    // frames inside the Jacobian launch (eval_kernels.hip), and the other work items form their blocks themselves, each
+    // registered as a cell of its own so that the gather's device-built lists see it. Needs every such (layout, segment) to
+    // be ONE work item (an IMU cell of at most imu_chunk_items blocks: the usual case).
+    bool fuse = !p->h_fitems.empty() && [] { const char* e = std::getenv("CALICO_FUSE_EXPAND"); return !e || std::atoi(e) != 0; }();
+    for (const CellDev& c : p->h_cells) if (c.frame_count > 2) fuse = false;       // (a workgroup is two waves: one frame each)
+    {
+      // ... and two waves' staging areas must fit the CU's LDS
+      size_t need = 0;
+      for (size_t l = 0; l < layouts.size(); ++l) {
+        const LayoutDev& L = layouts[l];
+        const HSensor& hs = p->sensors[size_t(L.sensor)];
+        if (layout_uses_frames[l]) {
+          const int P1 = 7 + (L.c_intr >= 0 ? hs.K : 0) + 3 * (L.c_q >= 0) + 3 * (L.c_t >= 0) + 3 * (L.c_bq >= 0) + 3 * (L.c_bt >= 0);
+          const int Ps = 7 + (L.c_intr >= 0 ? hs.K : 0) + 3 * (L.c_bq >= 0);
+          need = std::max(need, frame_lds_doubles(Ps, P1, L.ncols + 1));
+        } else {
+          need = std::max(need, size_t((L.ncols + 1 + 3) & ~3) * size_t((3 * imu_chunk_items + 1) | 1));
+        }
+      }
+      need = (need + 1) & ~size_t(1);
+      if (2 * need * sizeof(double) + 2048 > kMaxLds) fuse = false;
+      p->pair_wave_lds_doubles = int(need);
+    }
+    {
+      int prev_layout = -1, prev_seg = -1;
+      for (const ItemDev& it : p->h_items) {
+        if (layout_uses_frames[size_t(it.layout)]) continue;
+        if (it.layout == prev_layout && it.seg == prev_seg) fuse = false;
+        if (p->sensors[size_t(layouts[size_t(it.layout)].sensor)].kind == CALICO_SENSOR_CAMERA) fuse = false;     // (camera blocks outside the frame path)
+        prev_layout = it.layout; prev_seg = it.seg;
+      }
+    }
+    p->fuse_expand = fuse;
+    if (fuse) {
+      // two frame entries per camera cell, so that wave w of the cell's workgroup finds its frame at 2 * cell + w without
+      // reading the cell descriptor first; a cell of one frame gets an empty second entry (obs_count = 0: the wave only helps
+      // with the expansion)
+      std::vector<FrameItemDev> padded;
+      padded.reserve(2 * p->h_cells.size());
+      for (CellDev& c : p->h_cells) {
+        const FrameItemDev f0 = p->h_fitems[size_t(c.frame_begin)];
+        FrameItemDev f1 = f0;
+        if (c.frame_count > 1) f1 = p->h_fitems[size_t(c.frame_begin) + 1]; else f1.obs_count = 0;
+        c.frame_begin = int(padded.size());
+        padded.push_back(f0); padded.push_back(f1);
+      }
+      p->h_fitems.swap(padded);
+    }
+    const bool row_cells_ok = !fuse && [] { const char* e = std::getenv("CALICO_ROW_CELLS"); return !e || std::atoi(e) != 0; }();
     for (ItemDev it : p->h_items) {
       if (layout_uses_frames[size_t(it.layout)]) continue;
       const LayoutDev& L = layouts[size_t(it.layout)];
       const HSensor& hs = p->sensors[size_t(L.sensor)];
       const int n1 = L.ncols + 1;
-      if (row_cells_ok && hs.kind != CALICO_SENSOR_CAMERA && n1 <= 112) {
+      if (fuse) {
+        // a cell of one work item that writes the cell's block itself (prim_off = -2: nothing for expand_cells_kernel to do)
+        CellDev c;
+        c.layout = it.layout; c.seg = it.seg; c.frame_begin = int(p->h_jac_items.size()); c.frame_count = 1;
+        c.partial_off = int64_t(poff); c.src_off = 0; c.n1 = n1; c.PE = 0; c.prim_off = -2; c.pad0 = 0;
+        p->h_cells.push_back(c);
+        it.rows_off = -2;            // (< 0: the item forms its own block; -2: that block is listed as a cell's)
+        it.partial_off = int64_t(poff);
+        poff += size_t(n1) * n1;
+      } else if (row_cells_ok && hs.kind != CALICO_SENSOR_CAMERA && n1 <= 112) {
         it.partial_off = 0; it.rows_off = 0;   // row store offset assigned below, once the staging dimensions are known
         if (p->h_cells.empty() || p->h_cells.back().prim_off >= 0 || p->h_cells.back().layout != it.layout ||
             p->h_cells.back().seg != it.seg) {
@@ -968,6 +1030,10 @@ int build_plan(calico_problem* p) {
       c.prim_off = tab_off[size_t(c.layout)]; c.pad0 = 0;
       c.n1 = L.ncols + 1; c.PE = PT + 1;
       c.src_off = p->h_fitems[size_t(c.frame_begin)].partial_off;
+      for (int f = c.frame_begin; f < c.frame_begin + (p->fuse_expand ? 2 : c.frame_count); ++f) {      // (copies for the cell's workgroup: fuse_expand)
+        FrameItemDev& fi = p->h_fitems[size_t(f)];
+        fi.cell_frames = c.frame_count; fi.cell_prim_off = c.prim_off; fi.cell_partial_off = c.partial_off; fi.cell_src_off = c.src_off;
+      }
     }
   }
   for (HSensor& s : p->sensors) { s.sorted_begin = n_obs; s.sorted_end = 0; }
@@ -1010,10 +1076,10 @@ int build_plan(calico_problem* p) {
       row_store += stride;
     }
     for (CellDev& c : p->h_cells)
-      if (c.prim_off < 0) c.src_off = p->h_jac_items[size_t(c.frame_begin)].rows_off;
+      if (c.prim_off == -1) c.src_off = p->h_jac_items[size_t(c.frame_begin)].rows_off;
     p->row_cell_chunk = std::max(1, int((56 * 1024 / sizeof(double)) / std::max<size_t>(1, stride)));
     int most = 1;
-    for (const CellDev& c : p->h_cells) if (c.prim_off < 0) most = std::max(most, c.frame_count);
+    for (const CellDev& c : p->h_cells) if (c.prim_off == -1) most = std::max(most, c.frame_count);
     p->row_cell_chunk = std::min(p->row_cell_chunk, most);
   }
   section("sort + work items");
@@ -1034,7 +1100,10 @@ int build_plan(calico_problem* p) {
   // other spline orders' generic items).
   bool gs_ok = [] { const char* e = std::getenv("CALICO_GATHER_STRUCT"); return !e || std::atoi(e) != 0; }();
   gs_ok = gs_ok && int(layouts.size()) * k <= 96 && int(layouts.size()) >= 1 && m >= 1 && n_cells > 0;
-  for (int itn = n_cells; gs_ok && itn < n_part; ++itn) gs_ok = p->h_jac_items[size_t(itn - n_cells)].rows_off >= 0;   // no block of its own
+  for (int itn = n_cells; gs_ok && itn < n_part; ++itn) {   // no block of its own, or one that is listed as a cell's (fuse_expand)
+    const int64_t ro = p->h_jac_items[size_t(itn - n_cells)].rows_off;
+    gs_ok = ro >= 0 || ro == -2;
+  }
   const int64_t gs_n_out = int64_t(NS) * m + int64_t(n_cp) * k * 36 + NS;
   gs_ok = gs_ok && gs_n_out * 96 < int64_t(0x7fffffff);
   p->gs_lists_on_device = gs_ok;
@@ -1055,7 +1124,7 @@ int build_plan(calico_problem* p) {
   pairs.reserve(gs_ok ? size_t(n_part) * 256 : poff / 2 + 4 * size_t(p->n_items));
   for (int itn = 0; itn < n_part; ++itn) {
     const bool is_cell = itn < n_cells;
-    if (!is_cell && p->h_jac_items[size_t(itn - n_cells)].rows_off >= 0) continue;   // its block is the row cell's
+    if (!is_cell && (p->h_jac_items[size_t(itn - n_cells)].rows_off >= 0 || p->h_jac_items[size_t(itn - n_cells)].rows_off == -2)) continue;   // its block is a cell's
     const int it_layout = is_cell ? p->h_cells[size_t(itn)].layout : p->h_jac_items[size_t(itn - n_cells)].layout;
     const int it_seg = is_cell ? p->h_cells[size_t(itn)].seg : p->h_jac_items[size_t(itn - n_cells)].seg;
     const int64_t it_poff = is_cell ? p->h_cells[size_t(itn)].partial_off : p->h_jac_items[size_t(itn - n_cells)].partial_off;
@@ -1313,7 +1382,7 @@ PlanKey structure_key(const calico_problem* p) {
   }
   // the switches finalize reads from the environment
   for (const char* name : {"CALICO_SOLVER", "CALICO_SPECULATIVE", "CALICO_BAND_SPLIT", "CALICO_BCR_LEAF", "CALICO_BCR_MERGE_TOP", "CALICO_IMU_CHUNK",
-                           "CALICO_ROW_CELLS", "CALICO_GATHER_STRUCT", "CALICO_GATHER_TINY", "CALICO_GATHER_FIXED"}) {
+                           "CALICO_ROW_CELLS", "CALICO_FUSE_EXPAND", "CALICO_GATHER_STRUCT", "CALICO_GATHER_TINY", "CALICO_GATHER_FIXED"}) {
     const char* e = std::getenv(name);
     h.word(e ? 1 : 0);
     if (e) h.bytes(e, std::strlen(e));
@@ -1638,6 +1707,7 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, c
     ea.hint_ftol = tail->o.function_tolerance; ea.hint_ptol = tail->o.parameter_tolerance;
   }
   ea.items = p->d_jac_items.p; ea.n_items = p->n_jac_items; ea.cost_index_base = p->n_fitems;
+  if (p->fuse_expand) { ea.pair_mode = 1; ea.wave_lds_doubles = p->pair_wave_lds_doubles; }      // (the plan has frames and order 6 then)
   if (p->order == 6 && p->n_fitems > 0) {
     launch_eval_jacobian(ea, p->stream);                  // camera frames (item-cost slots [0, n_fitems)) + everything else
   } else {
@@ -1654,7 +1724,7 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, c
     // as zeros, not as what the previous reduction left there
     HIP_TRY(p, hipMemsetAsync(target, 0, p->r_size * sizeof(double), p->stream));
   }
-  launch_expand_cells(ea, p->stream);                     // compact frame records -> one expanded block per cell
+  if (!p->fuse_expand) launch_expand_cells(ea, p->stream);   // compact frame records -> one expanded block per cell
   launch_gather(p->d_R.p, p->d_partials.p, p->d_out_thin.p, p->gather_fixed ? nullptr : p->d_ptr_thin.p, p->gather_fixed ? p->d_idx_fixed.p : p->d_idx_thin.p, p->n_thin, p->n_thin8, p->n_thin4, p->thin_per_lane, p->d_out_fat.p,
                 p->d_ptr_fat.p, p->d_idx_fat.p, p->n_fat, p->d_partials.p + p->partial_doubles, p->n_fitems + p->n_jac_items, st, need_flag,
                 spec ? p->r_size : 0, p->stream, tail);

@@ -506,7 +506,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // [J r]ᵀ[J r] of the staged rows (column-major, stride pad) -> upper triangle of the n1×n1 item block, NT = ceil(n1/16).
 template <int NT>
 __device__ __attribute__((noinline)) void stage_b_mfma(const double* lds, int pad, int nrows, int n1, double* out) {
-  const int lane = threadIdx.x, lc16 = lane & 15, lk = lane >> 4;
+  const int lane = threadIdx.x & 63, lc16 = lane & 15, lk = lane >> 4;
   f64x4 acc[NT][NT];
 #pragma unroll
   for (int I = 0; I < NT; ++I)
@@ -555,6 +555,7 @@ DEV void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+
 // ---------------------------------------------------------------------------
 // The evaluation kernel. JAC: stage Jacobian rows and form the item's
 // [JᵀJ | Jᵀr] block; !JAC: residuals / cost only.
@@ -563,7 +564,7 @@ DEV void wave_lds_sync() {
 template <bool JAC, int KT>
 DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds) {
   if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;        // (one wave per item; a workgroup of eval_cells_kernel has two)
   const int row_pad = a.row_pad;
   const bool dbg = CAL_DEV_TIMING(JAC && a.debug && (item_id == 3 || item_id == a.n_items - 2) && lane == 0);
   long long tph[4] = {0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
@@ -785,9 +786,17 @@ DEV double lane_value(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
+// What a frame's wave hands to its cell's workgroup (eval_cells_kernel) instead of writing a compact record: where M_ext and
+// the expansion coefficients lie in its LDS area, and its share of the cell's pair table (requested behind the blocks' loop).
+constexpr int kPairQ = 16;          // pairs per thread of a 128-thread workgroup: 2048 >= 63 * 64 / 2 (frame layouts: <= 60 columns)
+struct FramePair {
+  const double* Me; const double* coef;
+  int PE, n1;
+  int e[kPairQ];
+};
+DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds, FramePair* fp = nullptr) {
   if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const bool dbg = CAL_DEV_TIMING(a.debug && fidx == 7 && lane == 0);
   long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define FTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
@@ -933,6 +942,12 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   const double item_cost = wave_sum(cost);
   const double n_invalid = wave_sum(n_bad);
   if (lane == 0) { a.item_cost[2 * fidx] = item_cost; a.item_cost[2 * fidx + 1] = n_invalid; }
+  if (fp) {      // this thread's pairs of the cell's expansion: on their way while the per-frame steps run
+    const int n_pairs = n1 * (n1 + 1) / 2, tid = threadIdx.x;
+    const int* __restrict__ ptab = a.prim_tab + it.cell_prim_off;
+#pragma unroll
+    for (int q = 0; q < kPairQ; ++q) fp->e[q] = ptab[min(tid + 128 * q, n_pairs - 1)];
+  }
   FTICK(6)
   // ---- M_s to LDS (full symmetric; C/D layout: col = lane & 15, row = (lane >> 4) + 4·reg) ----
   wave_lds_sync();
@@ -1020,6 +1035,7 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds) {
   // ---- compact record: M_ext (PE×PE) then coef (n1). The expansion TᵀMT -- out(i, j) = coef_i coef_j M_ext(prim_i, prim_j)
   //      -- is done once per CELL by expand_cells_kernel over all its frames. Only prim rows / columns < P1e and the
   //      latency row / column PT are read there; the others are written as they lie. ----
+  if (fp) { fp->Me = Me; fp->coef = coef; fp->PE = PE; fp->n1 = n1; return; }      // (the cell's workgroup expands out of LDS: no record)
   double* out = a.partials + it.partial_off;
   const int nme = PE * PE;
   for (int i = lane; i < nme; i += 64) out[i] = Me[i];
@@ -1081,6 +1097,64 @@ __global__ __launch_bounds__(64) void eval_jacobian_kernel(EvalArgs a) {
   if (CAL_DEV_TIMING(a.debug >= 3) && a.wave_log && threadIdx.x == 0) {   // CALICO_KERNEL_TIMING=3: life span of every wave (100 MHz clock)
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
     if (t1 - t0 > 200) { a.wave_log[2 * blockIdx.x] = t0; a.wave_log[2 * blockIdx.x + 1] = t1; }   // not the early exits after termination
+  }
+}
+
+// Cell workgroups (EvalArgs.pair_mode): the Jacobian pass in workgroups of TWO waves, one per SIMD pair of a CU.
+//   workgroups [0, n_item_wg): two work items (IMU cells), each wave its own -- they form their blocks themselves;
+//   workgroups [n_item_wg, n_item_wg + n_cells): a camera cell -- wave w evaluates frame 2 * cell + w (a.fitems holds two
+//     entries per cell; an empty second one: the wave goes straight to the barrier), M_ext and the expansion coefficients stay
+//     in the wave's LDS area, and behind ONE workgroup barrier both waves expand the cell's block, pair by pair, frame 0 then
+//     frame 1 -- the sums of expand_cells_kernel in the same order (bit-identical) without the compact record's trip through
+//     memory, without that kernel's launch and without its dependent loads (cell descriptor -> records);
+//   one more workgroup for the end hint.
+// 2 x (cells + item pairs) waves: what the one-wave launch had, in the same single round of one wave per SIMD.
+__global__ __launch_bounds__(128) void eval_cells_kernel(EvalArgs a) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  double* const lds_w = lds + size_t(wave) * a.wave_lds_doubles;
+  const int n_item_wg = (a.n_items + 1) >> 1, n_cell_wg = a.n_fitems >> 1;
+  const int g = blockIdx.x;
+  if (g < n_item_wg) {
+    const int item = 2 * g + wave;
+    if (item < a.n_items) eval_items_body<true, 6>(a, item, lds_w);
+    return;
+  }
+  if (g >= n_item_wg + n_cell_wg) { if (wave == 0 && a.hint_progress) end_hint_body(a); return; }
+  if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;      // (both waves alike: nobody is left at the barrier)
+  const int fidx = 2 * (g - n_item_wg) + wave;
+  const FrameItemDev* ip = a.fitems + fidx;
+  const int nf = ip->cell_frames;
+  FramePair fp;
+  fp.Me = nullptr; fp.coef = nullptr; fp.PE = 0; fp.n1 = 0;
+  if (wave < nf) eval_frames_body(a, fidx, lds_w, &fp);
+  else {
+    // the empty second entry of a one-frame cell: the layout's sizes from the descriptor, the pairs, a zero in the cost slots
+    const PrimMap pm = prim_map(ip->L, ip->S);
+    const SmallMap sm = small_map(ip->L, ip->S);
+    fp.PE = pm.PE; fp.n1 = ip->L.ncols + 1;
+    fp.Me = lds_w + frame_area_a(sm.P, sm.PT, pm.P1); fp.coef = fp.Me + ((fp.PE * fp.PE + 1) & ~1);
+    const int n_pairs = fp.n1 * (fp.n1 + 1) / 2;
+    const int* __restrict__ ptab = a.prim_tab + ip->cell_prim_off;
+#pragma unroll
+    for (int q = 0; q < kPairQ; ++q) fp.e[q] = ptab[min(tid + 128 * q, n_pairs - 1)];
+    if ((tid & 63) == 0) { a.item_cost[2 * fidx] = 0.0; a.item_cost[2 * fidx + 1] = 0.0; }
+  }
+  __syncthreads();
+  const int n1 = fp.n1, n_pairs = n1 * (n1 + 1) / 2;
+  // frame f's M_ext / coefficients: in wave f's area, at the offsets this wave's own have in its area (one layout per cell)
+  const long long shift = (long long)a.wave_lds_doubles;
+  const double* const me0 = fp.Me - size_t(wave) * shift;
+  const double* const cf0 = fp.coef - size_t(wave) * shift;
+  double* out = a.partials + ip->cell_partial_off;
+#pragma unroll
+  for (int q = 0; q < kPairQ; ++q) {
+    if (tid + 128 * q >= n_pairs) continue;
+    const int pi = fp.e[q] & 255, pj = (fp.e[q] >> 8) & 255, pm_off = fp.e[q] >> 16;
+    double acc = 0.0;
+    acc += cf0[pi] * cf0[pj] * me0[pm_off];
+    if (nf > 1) acc += cf0[shift + pi] * cf0[shift + pj] * me0[shift + pm_off];
+    out[size_t(pi) * n1 + pj] = acc;
   }
 }
 
@@ -1338,6 +1412,12 @@ void launch_eval_frames(const EvalArgs& a, hipStream_t stream) {
 // items (a.items / a.n_items, cost slots from a.cost_index_base) and frames (a.fitems / a.n_fitems) together
 void launch_eval_jacobian(const EvalArgs& a, hipStream_t stream) {
   if (a.n_items + a.n_fitems == 0) return;
+  if (a.pair_mode) {
+    const int hint = a.hint_progress && a.st ? 1 : 0;
+    hipLaunchKernelGGL(eval_cells_kernel, dim3(((a.n_items + 1) >> 1) + (a.n_fitems >> 1) + hint), dim3(128),
+                       2 * size_t(a.wave_lds_doubles) * sizeof(double), stream, a);
+    return;
+  }
   size_t lds = size_t(a.lds_cols) * a.row_pad * sizeof(double);
   if (a.n_fitems > 0 && lds < frame_launch_bytes(a)) lds = frame_launch_bytes(a);
   const int hint = a.hint_progress && a.st ? 1 : 0;      // one more workgroup: end_hint_body
@@ -1361,6 +1441,8 @@ hipError_t configure_eval_kernels(size_t max_lds_bytes) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(frame_lds_bytes()));
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&expand_cells_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_cells_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_jacobian_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           int(std::max<size_t>(std::max(max_lds_bytes, frame_lds_bytes()), 80 * 1024)));

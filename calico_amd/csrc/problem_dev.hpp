@@ -68,6 +68,10 @@ struct FrameItemDev {
   LayoutDev L;           // copies, as in ItemDev
   SensorDev S;
   int ctrl_off[8];
+  // the frame's cell (cell workgroups, EvalArgs.pair_mode): copies of the cell descriptor's fields (no load of it in front of
+  // the expansion)
+  int cell, cell_frames, cell_prim_off, cell_pad;
+  int64_t cell_partial_off, cell_src_off;
 };
 
 // All frames of one cell = (layout, segment): the cell kernel expands and sums their compact records
@@ -118,6 +122,11 @@ struct EvalArgs {
   int* hint_progress;
   int hint_seq, hint_pad;
   double hint_ftol, hint_ptol;
+  // Cell workgroups (plans with `fuse_expand`; eval_cells_kernel): the Jacobian launch runs workgroups of TWO waves -- the
+  // (at most two) frames of one camera cell, which then expand the cell's block together out of LDS: no compact record
+  // leaves the CU and expand_cells_kernel has no launch --, or two work items that form their blocks themselves.
+  int pair_mode;             // a.fitems holds two entries per camera cell (the second one may be empty: obs_count = 0)
+  int wave_lds_doubles;      // LDS of one wave of such a workgroup
 };
 
 // Where the stage that terminates a solve leaves its results for the host (pinned, host-mapped memory: final state,

@@ -79,7 +79,8 @@ def test_solver_variants_agree(monkeypatch):
                         ("CALICO_IMU_CHUNK", "7"), ("CALICO_STREAM_DEPTH", "1"), ("CALICO_BCR_MERGE_TOP", "0"),
                         ("CALICO_FUSE_SCHUR", "0"), ("CALICO_FUSE_BACK", "0"), ("CALICO_GATHER_STRUCT", "0"), ("CALICO_GATHER_TINY", "0"), ("CALICO_FOLD_FIRST", "0"),
                         ("CALICO_GATHER_FIXED", "0"), ("CALICO_ELIM", "panel"),       # round 4: the block factorisation of rounds 1-3 instead of block_elim.hpp
-                        ("CALICO_PREDICT_END", "0"), ("CALICO_INLINE_NODES", "0")]:
+                        ("CALICO_PREDICT_END", "0"), ("CALICO_INLINE_NODES", "0"),
+                        ("CALICO_FUSE_EXPAND", "0")]:       # the cell expansion in a launch of its own, IMU cells as row cells
         monkeypatch.setenv(name, value)
         results[(name, value)] = _solve_repeatedly(api, scene, repeats=1, max_iter=50)[0]
         monkeypatch.delenv(name)
@@ -290,3 +291,32 @@ def test_end_prediction_and_inline_descriptors_change_nothing(monkeypatch):
                 for a, b in zip(rb, r):
                     assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2], key
                     assert np.array_equal(a[3], b[3]), key
+
+
+@pytest.mark.gpu
+def test_cell_workgroups_equal_the_expansion_launch(monkeypatch):
+    """Round 4: where every camera cell has at most two frames and every IMU cell is one work item, the Jacobian launch
+    runs workgroups of two waves (eval_cells_kernel): the frames of a cell leave M_ext and the expansion coefficients in
+    LDS and expand the cell's block together behind one workgroup barrier -- no compact record, no expand_cells_kernel
+    launch --, and IMU items form their blocks themselves. The sums are those of the separate expansion launch in the same
+    order: with CALICO_FUSE_EXPAND=0 (records + expansion launch + row cells) the solve must walk the same iterations BIT FOR
+    BIT. Scenes: two frames per cell; one frame per cell (10 Hz camera: the second wave of a cell's workgroup only helps
+    with the expansion); a scene with three frames in some cells (the plan must fall back to the launch of its own)."""
+    api = helpers.hip_api()
+    common = dict(chart="april", pixel_noise=0.1, gyro_noise=1e-3, accel_noise=1e-2, robust=True, max_cam_obs=6000)
+    scenes = [
+        syn.make_scene(4, 1, True, 3, cam_rate=20.0, imu_rate=100.0, duration=4.0, seed=31, segment_duration=4.0 / 23.9, **common),
+        syn.make_scene(2, 3, True, 2, cam_rate=10.0, imu_rate=100.0, duration=4.0, seed=32, segment_duration=4.0 / 23.9, **common),
+        syn.make_scene(2, 1, True, 3, cam_rate=30.0, imu_rate=100.0, duration=3.0, seed=33, segment_duration=3.0 / 23.9, **common),
+    ]
+    for sc in scenes:
+        runs = {}
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("CALICO_FUSE_EXPAND", fuse)
+            runs[fuse] = _solve_repeatedly(api, sc, repeats=2, max_iter=20)
+        monkeypatch.delenv("CALICO_FUSE_EXPAND")
+        ref = runs["0"][0]
+        assert ref[0] > 3
+        for r in runs["1"] + runs["0"]:
+            assert r[0] == ref[0] and r[1] == ref[1] and r[2] == ref[2]
+            assert np.array_equal(r[3], ref[3])
