@@ -889,6 +889,9 @@ int build_plan(calico_problem* p) {
     // be ONE work item (an IMU cell of at most imu_chunk_items blocks: the usual case).
     bool fuse = !p->h_fitems.empty() && [] { const char* e = std::getenv("CALICO_FUSE_EXPAND"); return !e || std::atoi(e) != 0; }();
     for (const CellDev& c : p->h_cells) if (c.frame_count > 2) fuse = false;       // (a workgroup is two waves: one frame each)
+    // ... and most cells should have both: the second wave of a one-frame cell only waits for the first (configs[3] at 50 Hz
+    // knots -- 0.4 frames per cell -- lost 3 % to the cell workgroups, the notebook run's shape -- 0.9 -- 0.5 %)
+    if (2 * p->h_fitems.size() < 3 * p->h_cells.size()) fuse = false;
     {
       // ... and two waves' staging areas must fit the CU's LDS
       size_t need = 0;
@@ -1425,7 +1428,7 @@ int prepare_workspace(calico_problem* p) {
   HIP_TRY(p, p->d_m0.alloc(size_t(n_obs))); HIP_TRY(p, p->d_m1.alloc(size_t(n_obs))); HIP_TRY(p, p->d_m2.alloc(size_t(n_obs)));
   HIP_TRY(p, p->d_partials.alloc(p->partials_alloc));
   HIP_TRY(p, hipMemsetAsync(p->d_partials.p + (p->partials_alloc - 2), 0, 2 * sizeof(double), s));      // the word the lists point to for "nothing"
-  if (std::getenv("CALICO_KERNEL_TIMING") && std::atoi(std::getenv("CALICO_KERNEL_TIMING")) >= 3) HIP_TRY(p, p->d_wave_log.alloc(2 * size_t(p->n_jac_items + p->n_fitems)));
+  if (std::getenv("CALICO_KERNEL_TIMING") && std::atoi(std::getenv("CALICO_KERNEL_TIMING")) >= 3) HIP_TRY(p, p->d_wave_log.alloc(2 * size_t(p->n_jac_items + p->n_fitems) + 8));
   HIP_TRY(p, p->d_R.alloc(2 * r_size)); HIP_TRY(p, hipMemsetAsync(p->d_R.p, 0, 2 * r_size * sizeof(double), s));
   HIP_TRY(p, p->d_R2.alloc(2));
   const int NT = 6 * n_cp + m;
@@ -2405,7 +2408,7 @@ int32_t calico_solve(calico_problem* p, const calico_solver_options* opt, calico
     std::vector<unsigned long long> wl(p->d_wave_log.n);
     HIP_TRY(p, hipMemcpy(wl.data(), p->d_wave_log.p, wl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (size_t i = 0; i + 1 < wl.size(); i += 2)
-      std::fprintf(stderr, "WAVE %zu %s t0 %llu t1 %llu\n", i / 2, int(i / 2) < p->n_jac_items ? "item" : "frame", wl[i], wl[i + 1]);
+      std::fprintf(stderr, "WAVE %zu %s t0 %llu t1 %llu\n", i / 2, int(i / 2) < ((p->n_jac_items + 1) & ~1) ? "item" : "frame", wl[i], wl[i + 1]);
   }
   sm->termination_type = st.termination_type;
   sm->num_successful_steps = st.num_successful; sm->num_unsuccessful_steps = st.num_unsuccessful;

@@ -504,40 +504,54 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 // [J r]ᵀ[J r] of the staged rows (column-major, stride pad) -> upper triangle of the n1×n1 item block, NT = ceil(n1/16).
-template <int NT>
-__device__ __attribute__((noinline)) void stage_b_mfma(const double* lds, int pad, int nrows, int n1, double* out) {
+// ROW0 / ROW1: tile rows [ROW0, ROW1) of the upper triangle only -- two waves of a workgroup sharing one item's tiles
+// (eval_cells_kernel); a tile's k-steps stay in one wave, in the same order.
+// (The staged rows are named as LDS: through a generic pointer -- what a function that is not inlined gets -- every operand
+//  was a flat_load.)
+typedef const double __attribute__((address_space(3))) * LdsRows;
+template <int NT, int ROW0 = 0, int ROW1 = NT>
+__device__ __attribute__((noinline)) void stage_b_mfma(LdsRows lds, int pad, int nrows, int n1, double* out) {
   const int lane = threadIdx.x & 63, lc16 = lane & 15, lk = lane >> 4;
   f64x4 acc[NT][NT];
 #pragma unroll
-  for (int I = 0; I < NT; ++I)
+  for (int I = ROW0; I < ROW1; ++I)
 #pragma unroll
     for (int J = I; J < NT; ++J) acc[I][J] = f64x4{0.0, 0.0, 0.0, 0.0};
   // Loads are unconditional on clamped (row, column) -- always a valid staged value -- and masked by a 0/1 factor:
   // a conditional load splits the loop body into blocks, and the accumulators then bounce between VGPRs and AGPRs
   // (8 copies per tile and k-step).
-  const double* cp[NT];
+  LdsRows cp[NT];
   double cm[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
+  for (int t = ROW0; t < NT; ++t) {
     const int c = 16 * t + lc16;
     cm[t] = c < n1 ? 1.0 : 0.0;
     cp[t] = lds + (c < n1 ? c : n1 - 1) * pad;
   }
+  // (the next k-step's operands are requested before this one's MFMAs are issued: an LDS round trip and the masking per
+  //  k-step were ~450 clocks in front of 64 x tiles of matrix pipe)
+  double nx[NT];
+  {
+    const int rc = min(lk, nrows - 1);
+#pragma unroll
+    for (int t = ROW0; t < NT; ++t) nx[t] = cp[t][rc];
+  }
   for (int r0 = 0; r0 < nrows; r0 += 4) {
-    const int r = r0 + lk;
-    const int rc = r < nrows ? r : nrows - 1;
-    const double rm = r < nrows ? 1.0 : 0.0;
+    const double rm = r0 + lk < nrows ? 1.0 : 0.0;
     double op[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) op[t] = cp[t][rc] * (cm[t] * rm);
+    for (int t = ROW0; t < NT; ++t) op[t] = nx[t] * (cm[t] * rm);
+    const int rn = min(r0 + 4 + lk, nrows - 1);
 #pragma unroll
-    for (int I = 0; I < NT; ++I)
+    for (int t = ROW0; t < NT; ++t) nx[t] = cp[t][rn];
+#pragma unroll
+    for (int I = ROW0; I < ROW1; ++I)
 #pragma unroll
       for (int J = I; J < NT; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I], op[J], acc[I][J], 0, 0, 0);
   }
   // C/D layout: col = lane & 15, row = (lane >> 4) + 4·reg
 #pragma unroll
-  for (int I = 0; I < NT; ++I)
+  for (int I = ROW0; I < ROW1; ++I)
 #pragma unroll
     for (int J = I; J < NT; ++J)
 #pragma unroll
@@ -545,6 +559,21 @@ __device__ __attribute__((noinline)) void stage_b_mfma(const double* lds, int pa
         const int gi = 16 * I + lk + 4 * r, gj = 16 * J + lc16;
         if (gi <= gj && gj < n1) out[size_t(gi) * n1 + gj] = acc[I][J][r];
       }
+}
+// PART 0: all tiles; 1: the top tile row (the late wave's share: it has just staged the rows); 2: the other rows (the early wave's)
+// PART 0: all tiles; 1: the top tile row (the late wave's share: it has just staged the rows); 2: the other rows (the early wave's).
+// (Every call costs ~4k clocks on top of its MFMAs -- fifteen k-steps of a not quite hidden LDS round trip --, so the shares are
+//  one call each: splitting the early wave's own tiles around the barrier as well measured slower.)
+template <int PART>
+DEV void stage_b_dispatch(const double* lds_generic, int pad, int nrows, int n1, double* out) {
+  LdsRows lds = (LdsRows)lds_generic;
+  switch ((n1 + 15) >> 4) {
+    case 1: if (PART != 2) stage_b_mfma<1>(lds, pad, nrows, n1, out); break;
+    case 2: if (PART == 0) stage_b_mfma<2>(lds, pad, nrows, n1, out); else if (PART == 1) stage_b_mfma<2, 0, 1>(lds, pad, nrows, n1, out); else stage_b_mfma<2, 1, 2>(lds, pad, nrows, n1, out); break;
+    case 3: if (PART == 0) stage_b_mfma<3>(lds, pad, nrows, n1, out); else if (PART == 1) stage_b_mfma<3, 0, 1>(lds, pad, nrows, n1, out); else stage_b_mfma<3, 1, 3>(lds, pad, nrows, n1, out); break;
+    case 4: if (PART == 0) stage_b_mfma<4>(lds, pad, nrows, n1, out); else if (PART == 1) stage_b_mfma<4, 0, 1>(lds, pad, nrows, n1, out); else stage_b_mfma<4, 1, 4>(lds, pad, nrows, n1, out); break;
+    default: if (PART == 0) stage_b_mfma<5>(lds, pad, nrows, n1, out); else if (PART == 1) stage_b_mfma<5, 0, 1>(lds, pad, nrows, n1, out); else stage_b_mfma<5, 1, 5>(lds, pad, nrows, n1, out); break;
+  }
 }
 
 // LDS traffic inside ONE wave (the frame and work-item kernels run one wave per workgroup): the wave's own LDS stores
@@ -561,8 +590,9 @@ DEV void wave_lds_sync() {
 // [JᵀJ | Jᵀr] block; !JAC: residuals / cost only.
 // grid = n_items, block = 64 (one wave).
 // ---------------------------------------------------------------------------
+struct ItemStage { int nrows, n1; double* out; };      // a work item whose rows are staged, [J r]ᵀ[J r] still to be formed
 template <bool JAC, int KT>
-DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds) {
+DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds, ItemStage* stage_only = nullptr) {
   if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
   const int lane = threadIdx.x & 63;        // (one wave per item; a workgroup of eval_cells_kernel has two)
   const int row_pad = a.row_pad;
@@ -654,13 +684,8 @@ DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds) {
       return;
     }
     double* out = a.partials + it.partial_off;
-    switch ((n1 + 15) >> 4) {
-      case 1: stage_b_mfma<1>(lds, row_pad, nrows, n1, out); break;
-      case 2: stage_b_mfma<2>(lds, row_pad, nrows, n1, out); break;
-      case 3: stage_b_mfma<3>(lds, row_pad, nrows, n1, out); break;
-      case 4: stage_b_mfma<4>(lds, row_pad, nrows, n1, out); break;
-      default: stage_b_mfma<5>(lds, row_pad, nrows, n1, out); break;
-    }
+    if (stage_only) { stage_only->nrows = nrows; stage_only->n1 = n1; stage_only->out = out; return; }     // (the workgroup shares the tiles out: eval_cells_kernel)
+    stage_b_dispatch<0>(lds, row_pad, nrows, n1, out);
     ITICK(2)
     if (dbg) printf("eval_items cycles (kind %d, %d obs, %d cols, pad %d): setup+zero %lld  stage A %lld  stage B %lld\n", S.kind, it.obs_count, ncols, row_pad, tph[0], tph[1], tph[2]);
   }
@@ -1109,15 +1134,56 @@ __global__ __launch_bounds__(64) void eval_jacobian_kernel(EvalArgs a) {
 //     memory, without that kernel's launch and without its dependent loads (cell descriptor -> records);
 //   one more workgroup for the end hint.
 // 2 x (cells + item pairs) waves: what the one-wave launch had, in the same single round of one wave per SIMD.
+DEV void eval_cells_body(const EvalArgs& a, double* lds);
 __global__ __launch_bounds__(128) void eval_cells_kernel(EvalArgs a) {
   extern __shared__ double lds[];
+  const unsigned long long t0 = CAL_DEV_TIMING(a.debug >= 3) ? __builtin_amdgcn_s_memrealtime() : 0;
+  eval_cells_body(a, lds);
+  if (CAL_DEV_TIMING(a.debug >= 3) && a.wave_log && (threadIdx.x & 63) == 0) {   // CALICO_KERNEL_TIMING=3: life span of every wave (100 MHz clock)
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    const int w = 2 * blockIdx.x + (threadIdx.x >> 6);
+    if (t1 - t0 > 200) { a.wave_log[2 * w] = t0; a.wave_log[2 * w + 1] = t1; }
+  }
+}
+DEV void eval_cells_body(const EvalArgs& a, double* lds) {
   const int tid = threadIdx.x, wave = tid >> 6;
   double* const lds_w = lds + size_t(wave) * a.wave_lds_doubles;
   const int n_item_wg = (a.n_items + 1) >> 1, n_cell_wg = a.n_fitems >> 1;
   const int g = blockIdx.x;
   if (g < n_item_wg) {
-    const int item = 2 * g + wave;
-    if (item < a.n_items) eval_items_body<true, 6>(a, item, lds_w);
+    // items g and g + n_item_wg: a gyroscope cell and an accelerometer cell where the problem has both (the items come sorted
+    // by sensor). The accelerometer's rows are staged ~4 us after the gyroscope's and [J r]ᵀ[J r] is 10 tiles x 16 MFMAs for
+    // either: the early wave forms all of its own tiles, then -- behind the workgroup's barrier -- the lower tile rows of the late
+    // item's (six tiles of ten), while the late wave forms the top row (a tile's k-steps stay in one wave: the sums do not change).
+    if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
+    const int i0 = g, i1 = g + n_item_wg;
+    const bool both = i1 < a.n_items;
+    const int mine = wave == 0 ? i0 : i1, other = wave == 0 ? i1 : i0;
+    if (!both) { if (wave == 0) eval_items_body<true, 6>(a, i0, lds_w); return; }
+    const bool late_m = a.items[mine].S.kind == 2, late_o = a.items[other].S.kind == 2;      // (CALICO_SENSOR_ACCELEROMETER)
+    const bool shared = late_m != late_o && a.items[mine].rows_off < 0 && a.items[other].rows_off < 0;
+    if (!shared) { eval_items_body<true, 6>(a, mine, lds_w); return; }
+    const bool dbg = CAL_DEV_TIMING(a.debug == 1 && g == 3 && (tid & 63) == 0);
+    const long long tq0 = dbg ? __builtin_readcyclecounter() : 0;
+    long long tq1 = 0, tq2 = 0, tq3 = 0;
+    ItemStage st;
+    eval_items_body<true, 6>(a, mine, lds_w, &st);
+    if (dbg) tq1 = __builtin_readcyclecounter();
+    if (!late_m) {
+      stage_b_dispatch<0>(lds_w, a.row_pad, st.nrows, st.n1, st.out);
+      if (dbg) tq2 = __builtin_readcyclecounter();
+      __syncthreads();
+      if (dbg) tq3 = __builtin_readcyclecounter();
+      const ItemDev* op = a.items + other;
+      const int n1o = op->L.ncols + 1, nro = (op->S.kind == 0 ? 2 : 3) * op->obs_count;
+      stage_b_dispatch<2>(lds + size_t(wave ^ 1) * a.wave_lds_doubles, a.row_pad, nro, n1o, a.partials + op->partial_off);
+    } else {
+      if (dbg) tq2 = __builtin_readcyclecounter();
+      __syncthreads();
+      if (dbg) tq3 = __builtin_readcyclecounter();
+      stage_b_dispatch<1>(lds_w, a.row_pad, st.nrows, st.n1, st.out);
+    }
+    if (dbg) printf("item pair wave %d (late %d): rows staged after %lld clocks, own tiles %lld, barrier %lld, shared tiles %lld\n", wave, int(late_m), tq1 - tq0, tq2 - tq1, tq3 - tq2, (long long)__builtin_readcyclecounter() - tq3);
     return;
   }
   if (g >= n_item_wg + n_cell_wg) { if (wave == 0 && a.hint_progress) end_hint_body(a); return; }
