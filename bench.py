@@ -229,7 +229,9 @@ def roofline_object(scene, world, args, ms_per_step, iter_bytes, dense_ms, dense
 
     dom = dominant_kernel_from_profiles()
     dense_c = counters("dense_back_kernel")
-    eval_c = counters("eval_jacobian_kernel")
+    eval_c = counters("eval_cells_kernel")
+    if "hbm_bytes_per_launch" not in eval_c and "mfma_util" not in eval_c:
+        eval_c = counters("eval_jacobian_kernel")        # (profiles of a plan without cell workgroups)
     lin_ms = max(0.0, wu_ms[2] / max(1, wu_n[2]) - bracket_ms)      # one linear solve (its launches back to back), warmup solves
     dominant = {
         "kernel": "dense_back_kernel (dense reduced solve of the calibration + root block, first back-substitution launch behind an in-launch hand-off)"
@@ -245,7 +247,8 @@ def roofline_object(scene, world, args, ms_per_step, iter_bytes, dense_ms, dense
         "counters": dense_c,
     }
     evaluation = {
-        "kernel": "eval_jacobian_kernel (fused residual + analytic Jacobian + JtJ partials: IMU items + camera frames)",
+        "kernel": "eval_cells_kernel (fused residual + analytic Jacobian + JtJ blocks of whole cells: two-wave workgroups, a camera cell's "
+                  "frames expand their block out of LDS; eval_jacobian_kernel + expand_cells_kernel where a plan has no cell workgroups)",
         "avg_launch_ms": jac_ms, "launches": jac, "launches_bracketed": phase_n[7],
         "avg_launch_ms_with_event_bracket": jac_ms_raw, "bracketed_launches_that_exited_early": n_skipped,
         "share_of_step": jac_ms / ms_per_step,
@@ -257,7 +260,7 @@ def roofline_object(scene, world, args, ms_per_step, iter_bytes, dense_ms, dense
         "counters": eval_c,
     }
     return {
-        "bound": "hbm", "limited_by": "latency (dependent FP64 chains of single waves and six kernel boundaries per iteration; DESIGN.md 4)",
+        "bound": "hbm", "limited_by": "latency (dependent FP64 chains of single waves and five kernel boundaries per iteration; DESIGN.md 4)",
         "achieved": iter_bytes / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": iter_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "algorithmic_bytes_per_iteration": iter_bytes,

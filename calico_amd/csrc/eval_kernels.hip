@@ -544,6 +544,7 @@ __device__ __attribute__((noinline)) void stage_b_mfma(LdsRows lds, int pad, int
     const int rn = min(r0 + 4 + lk, nrows - 1);
 #pragma unroll
     for (int t = ROW0; t < NT; ++t) nx[t] = cp[t][rn];
+    __builtin_amdgcn_sched_barrier(0);      // (left to itself the scheduler sinks these requests into the next trip, right in front of their use)
 #pragma unroll
     for (int I = ROW0; I < ROW1; ++I)
 #pragma unroll
@@ -561,7 +562,8 @@ __device__ __attribute__((noinline)) void stage_b_mfma(LdsRows lds, int pad, int
       }
 }
 // PART 0: all tiles; 1: the top tile row (the late wave's share: it has just staged the rows); 2: the other rows (the early wave's)
-// PART 0: all tiles; 1: the top tile row (the late wave's share: it has just staged the rows); 2: the other rows (the early wave's).
+// PART 0: all tiles; 1: the top tile rows (the late wave's share, seven tiles of ten: it starts on them the moment its rows are
+// staged); 2: the other rows (the early wave's, behind its own block).
 // (Every call costs ~4k clocks on top of its MFMAs -- fifteen k-steps of a not quite hidden LDS round trip --, so the shares are
 //  one call each: splitting the early wave's own tiles around the barrier as well measured slower.)
 template <int PART>
@@ -571,8 +573,8 @@ DEV void stage_b_dispatch(const double* lds_generic, int pad, int nrows, int n1,
     case 1: if (PART != 2) stage_b_mfma<1>(lds, pad, nrows, n1, out); break;
     case 2: if (PART == 0) stage_b_mfma<2>(lds, pad, nrows, n1, out); else if (PART == 1) stage_b_mfma<2, 0, 1>(lds, pad, nrows, n1, out); else stage_b_mfma<2, 1, 2>(lds, pad, nrows, n1, out); break;
     case 3: if (PART == 0) stage_b_mfma<3>(lds, pad, nrows, n1, out); else if (PART == 1) stage_b_mfma<3, 0, 1>(lds, pad, nrows, n1, out); else stage_b_mfma<3, 1, 3>(lds, pad, nrows, n1, out); break;
-    case 4: if (PART == 0) stage_b_mfma<4>(lds, pad, nrows, n1, out); else if (PART == 1) stage_b_mfma<4, 0, 1>(lds, pad, nrows, n1, out); else stage_b_mfma<4, 1, 4>(lds, pad, nrows, n1, out); break;
-    default: if (PART == 0) stage_b_mfma<5>(lds, pad, nrows, n1, out); else if (PART == 1) stage_b_mfma<5, 0, 1>(lds, pad, nrows, n1, out); else stage_b_mfma<5, 1, 5>(lds, pad, nrows, n1, out); break;
+    case 4: if (PART == 0) stage_b_mfma<4>(lds, pad, nrows, n1, out); else if (PART == 1) stage_b_mfma<4, 0, 2>(lds, pad, nrows, n1, out); else stage_b_mfma<4, 2, 4>(lds, pad, nrows, n1, out); break;
+    default: if (PART == 0) stage_b_mfma<5>(lds, pad, nrows, n1, out); else if (PART == 1) stage_b_mfma<5, 0, 2>(lds, pad, nrows, n1, out); else stage_b_mfma<5, 2, 5>(lds, pad, nrows, n1, out); break;
   }
 }
 
@@ -1153,8 +1155,8 @@ DEV void eval_cells_body(const EvalArgs& a, double* lds) {
   if (g < n_item_wg) {
     // items g and g + n_item_wg: a gyroscope cell and an accelerometer cell where the problem has both (the items come sorted
     // by sensor). The accelerometer's rows are staged ~4 us after the gyroscope's and [J r]ᵀ[J r] is 10 tiles x 16 MFMAs for
-    // either: the early wave forms all of its own tiles, then -- behind the workgroup's barrier -- the lower tile rows of the late
-    // item's (six tiles of ten), while the late wave forms the top row (a tile's k-steps stay in one wave: the sums do not change).
+    // either: the early wave forms all of its own tiles, then the lower tile rows of the late item's (three tiles of ten), while
+    // the late wave forms the upper rows (a tile's k-steps stay in one wave: the sums do not change).
     if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
     const int i0 = g, i1 = g + n_item_wg;
     const bool both = i1 < a.n_items;
@@ -1166,20 +1168,27 @@ DEV void eval_cells_body(const EvalArgs& a, double* lds) {
     const bool dbg = CAL_DEV_TIMING(a.debug == 1 && g == 3 && (tid & 63) == 0);
     const long long tq0 = dbg ? __builtin_readcyclecounter() : 0;
     long long tq1 = 0, tq2 = 0, tq3 = 0;
+    // (the late wave does not wait for the early one: it raises a word in LDS when its rows are staged -- the word is cleared
+    //  in front of a barrier both waves pass at once -- and goes on with its share; the early wave looks at the word when its own
+    //  block is done)
+    volatile int* const staged = reinterpret_cast<volatile int*>(lds + 2 * size_t(a.wave_lds_doubles));
+    if (tid == 0) *staged = 0;
+    __syncthreads();
     ItemStage st;
     eval_items_body<true, 6>(a, mine, lds_w, &st);
     if (dbg) tq1 = __builtin_readcyclecounter();
     if (!late_m) {
       stage_b_dispatch<0>(lds_w, a.row_pad, st.nrows, st.n1, st.out);
       if (dbg) tq2 = __builtin_readcyclecounter();
-      __syncthreads();
+      while (*staged == 0) __builtin_amdgcn_s_sleep(1);
       if (dbg) tq3 = __builtin_readcyclecounter();
       const ItemDev* op = a.items + other;
       const int n1o = op->L.ncols + 1, nro = (op->S.kind == 0 ? 2 : 3) * op->obs_count;
       stage_b_dispatch<2>(lds + size_t(wave ^ 1) * a.wave_lds_doubles, a.row_pad, nro, n1o, a.partials + op->partial_off);
     } else {
       if (dbg) tq2 = __builtin_readcyclecounter();
-      __syncthreads();
+      wave_lds_sync();                       // (the rows are in LDS)
+      if ((tid & 63) == 0) *staged = 1;
       if (dbg) tq3 = __builtin_readcyclecounter();
       stage_b_dispatch<1>(lds_w, a.row_pad, st.nrows, st.n1, st.out);
     }
@@ -1481,7 +1490,7 @@ void launch_eval_jacobian(const EvalArgs& a, hipStream_t stream) {
   if (a.pair_mode) {
     const int hint = a.hint_progress && a.st ? 1 : 0;
     hipLaunchKernelGGL(eval_cells_kernel, dim3(((a.n_items + 1) >> 1) + (a.n_fitems >> 1) + hint), dim3(128),
-                       2 * size_t(a.wave_lds_doubles) * sizeof(double), stream, a);
+                       (2 * size_t(a.wave_lds_doubles) + 2) * sizeof(double), stream, a);
     return;
   }
   size_t lds = size_t(a.lds_cols) * a.row_pad * sizeof(double);

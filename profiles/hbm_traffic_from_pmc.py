@@ -46,7 +46,7 @@ def main():
                      "launches_counted", "launches_total"])
         for r in rows:
             cw.writerow([r[0]] + ["%.0f" % x for x in r[1:5]] + [r[5], r[6]])
-    jac = [r for r in rows if "eval_jacobian_kernel" in r[0]]
+    jac = [r for r in rows if "eval_cells_kernel" in r[0] or "eval_jacobian_kernel" in r[0]]
     js = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; FETCH_SIZE doubled (gfx950), see hbm_traffic_from_pmc.py",
           "eval_jacobian_kernel_bytes_per_launch": jac[0][4] if jac else None,
           "eval_jacobian_kernel_fetch_bytes_x2": jac[0][2] if jac else None,
