@@ -504,77 +504,90 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 // [J r]ᵀ[J r] of the staged rows (column-major, stride pad) -> upper triangle of the n1×n1 item block, NT = ceil(n1/16).
-// ROW0 / ROW1: tile rows [ROW0, ROW1) of the upper triangle only -- two waves of a workgroup sharing one item's tiles
+// T0 / T1: tiles [T0, T1) of the upper triangle in row-major order only -- two waves of a workgroup sharing one item's tiles
 // (eval_cells_kernel); a tile's k-steps stay in one wave, in the same order.
 // (The staged rows are named as LDS: through a generic pointer -- what a function that is not inlined gets -- every operand
-//  was a flat_load.)
+//  was a flat_load. The file is compiled with -amdgpu-mfma-vgpr-form: see __graft_entry__.py.)
+template <int NT> struct StageBTiles {      // tile t of the row-major upper triangle -> (row[t], col[t]), at compile time
+  int row[NT * (NT + 1) / 2], col[NT * (NT + 1) / 2];
+  constexpr StageBTiles() : row(), col() {
+    int k = 0;
+    for (int I = 0; I < NT; ++I)
+      for (int J = I; J < NT; ++J) { row[k] = I; col[k] = J; ++k; }
+  }
+};
 typedef const double __attribute__((address_space(3))) * LdsRows;
-template <int NT, int ROW0 = 0, int ROW1 = NT>
+template <int NT, int T0 = 0, int T1 = NT * (NT + 1) / 2>
 __device__ __attribute__((noinline)) void stage_b_mfma(LdsRows lds, int pad, int nrows, int n1, double* out) {
   const int lane = threadIdx.x & 63, lc16 = lane & 15, lk = lane >> 4;
-  f64x4 acc[NT][NT];
+  constexpr int NP = T1 - T0;
+  constexpr StageBTiles<NT> tiles{};
+  constexpr int G0 = tiles.row[T0];      // the first column group any of the tiles reads
+  f64x4 acc[NP];
 #pragma unroll
-  for (int I = ROW0; I < ROW1; ++I)
-#pragma unroll
-    for (int J = I; J < NT; ++J) acc[I][J] = f64x4{0.0, 0.0, 0.0, 0.0};
+  for (int t = 0; t < NP; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
   // Loads are unconditional on clamped (row, column) -- always a valid staged value -- and masked by a 0/1 factor:
-  // a conditional load splits the loop body into blocks, and the accumulators then bounce between VGPRs and AGPRs
-  // (8 copies per tile and k-step).
+  // a conditional load splits the loop body into blocks.
   LdsRows cp[NT];
   double cm[NT];
 #pragma unroll
-  for (int t = ROW0; t < NT; ++t) {
+  for (int t = G0; t < NT; ++t) {
     const int c = 16 * t + lc16;
     cm[t] = c < n1 ? 1.0 : 0.0;
     cp[t] = lds + (c < n1 ? c : n1 - 1) * pad;
   }
-  // (the next k-step's operands are requested before this one's MFMAs are issued: an LDS round trip and the masking per
-  //  k-step were ~450 clocks in front of 64 x tiles of matrix pipe)
+  // (the next k-step's operands are requested before this one's MFMAs are issued: an LDS round trip per k-step in front of
+  //  64 x tiles of matrix pipe otherwise)
   double nx[NT];
   {
     const int rc = min(lk, nrows - 1);
 #pragma unroll
-    for (int t = ROW0; t < NT; ++t) nx[t] = cp[t][rc];
+    for (int t = G0; t < NT; ++t) nx[t] = cp[t][rc];
   }
   for (int r0 = 0; r0 < nrows; r0 += 4) {
     const double rm = r0 + lk < nrows ? 1.0 : 0.0;
     double op[NT];
 #pragma unroll
-    for (int t = ROW0; t < NT; ++t) op[t] = nx[t] * (cm[t] * rm);
+    for (int t = G0; t < NT; ++t) op[t] = nx[t] * (cm[t] * rm);
     const int rn = min(r0 + 4 + lk, nrows - 1);
 #pragma unroll
-    for (int t = ROW0; t < NT; ++t) nx[t] = cp[t][rn];
+    for (int t = G0; t < NT; ++t) nx[t] = cp[t][rn];
     __builtin_amdgcn_sched_barrier(0);      // (left to itself the scheduler sinks these requests into the next trip, right in front of their use)
 #pragma unroll
-    for (int I = ROW0; I < ROW1; ++I)
-#pragma unroll
-      for (int J = I; J < NT; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I], op[J], acc[I][J], 0, 0, 0);
+    for (int t = 0; t < NP; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[tiles.row[T0 + t]], op[tiles.col[T0 + t]], acc[t], 0, 0, 0);
   }
   // C/D layout: col = lane & 15, row = (lane >> 4) + 4·reg
 #pragma unroll
-  for (int I = ROW0; I < ROW1; ++I)
+  for (int t = 0; t < NP; ++t) {
+    const int I = tiles.row[T0 + t], J = tiles.col[T0 + t];
 #pragma unroll
-    for (int J = I; J < NT; ++J)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int gi = 16 * I + lk + 4 * r, gj = 16 * J + lc16;
-        if (gi <= gj && gj < n1) out[size_t(gi) * n1 + gj] = acc[I][J][r];
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int gi = 16 * I + lk + 4 * r, gj = 16 * J + lc16;
+      if (gi <= gj && gj < n1) out[size_t(gi) * n1 + gj] = acc[t][r];
+    }
+  }
 }
-// PART 0: all tiles; 1: the top tile row (the late wave's share: it has just staged the rows); 2: the other rows (the early wave's)
-// PART 0: all tiles; 1: the top tile rows (the late wave's share, seven tiles of ten: it starts on them the moment its rows are
-// staged); 2: the other rows (the early wave's, behind its own block).
-// (Every call costs ~4k clocks on top of its MFMAs -- fifteen k-steps of a not quite hidden LDS round trip --, so the shares are
-//  one call each: splitting the early wave's own tiles around the barrier as well measured slower.)
+// PART 0: all tiles; 1: the first 60 % of the upper triangle's tiles in row-major order (the late wave's share: it starts on
+// them the moment its rows are staged); 2: the rest (the early wave's, behind its own block).
+// (Every call costs ~4k clocks on top of its MFMAs, so a share is one call: splitting the early wave's own tiles around the
+//  hand-over as well measured slower.)
+template <int NT, int PART>
+DEV void stage_b_part(LdsRows lds, int pad, int nrows, int n1, double* out) {
+  constexpr int T = NT * (NT + 1) / 2, n_main = (3 * T + 2) / 5;
+  if constexpr (PART == 0) stage_b_mfma<NT>(lds, pad, nrows, n1, out);
+  else if constexpr (PART == 1) { if constexpr (n_main > 0) stage_b_mfma<NT, 0, n_main>(lds, pad, nrows, n1, out); }
+  else { if constexpr (n_main < T) stage_b_mfma<NT, n_main, T>(lds, pad, nrows, n1, out); }
+}
 template <int PART>
 DEV void stage_b_dispatch(const double* lds_generic, int pad, int nrows, int n1, double* out) {
   LdsRows lds = (LdsRows)lds_generic;
   switch ((n1 + 15) >> 4) {
-    case 1: if (PART != 2) stage_b_mfma<1>(lds, pad, nrows, n1, out); break;
-    case 2: if (PART == 0) stage_b_mfma<2>(lds, pad, nrows, n1, out); else if (PART == 1) stage_b_mfma<2, 0, 1>(lds, pad, nrows, n1, out); else stage_b_mfma<2, 1, 2>(lds, pad, nrows, n1, out); break;
-    case 3: if (PART == 0) stage_b_mfma<3>(lds, pad, nrows, n1, out); else if (PART == 1) stage_b_mfma<3, 0, 1>(lds, pad, nrows, n1, out); else stage_b_mfma<3, 1, 3>(lds, pad, nrows, n1, out); break;
-    case 4: if (PART == 0) stage_b_mfma<4>(lds, pad, nrows, n1, out); else if (PART == 1) stage_b_mfma<4, 0, 2>(lds, pad, nrows, n1, out); else stage_b_mfma<4, 2, 4>(lds, pad, nrows, n1, out); break;
-    default: if (PART == 0) stage_b_mfma<5>(lds, pad, nrows, n1, out); else if (PART == 1) stage_b_mfma<5, 0, 2>(lds, pad, nrows, n1, out); else stage_b_mfma<5, 2, 5>(lds, pad, nrows, n1, out); break;
+    case 1: stage_b_part<1, PART>(lds, pad, nrows, n1, out); break;
+    case 2: stage_b_part<2, PART>(lds, pad, nrows, n1, out); break;
+    case 3: stage_b_part<3, PART>(lds, pad, nrows, n1, out); break;
+    case 4: stage_b_part<4, PART>(lds, pad, nrows, n1, out); break;
+    default: stage_b_part<5, PART>(lds, pad, nrows, n1, out); break;
   }
 }
 
@@ -1155,8 +1168,8 @@ DEV void eval_cells_body(const EvalArgs& a, double* lds) {
   if (g < n_item_wg) {
     // items g and g + n_item_wg: a gyroscope cell and an accelerometer cell where the problem has both (the items come sorted
     // by sensor). The accelerometer's rows are staged ~4 us after the gyroscope's and [J r]ᵀ[J r] is 10 tiles x 16 MFMAs for
-    // either: the early wave forms all of its own tiles, then the lower tile rows of the late item's (three tiles of ten), while
-    // the late wave forms the upper rows (a tile's k-steps stay in one wave: the sums do not change).
+    // either: the early wave forms all of its own tiles, then the last four of the late item's ten, while the late wave forms the
+    // first six (a tile's k-steps stay in one wave: the sums do not change).
     if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;
     const int i0 = g, i1 = g + n_item_wg;
     const bool both = i1 < a.n_items;
