@@ -508,6 +508,15 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // (eval_cells_kernel); a tile's k-steps stay in one wave, in the same order.
 // (The staged rows are named as LDS: through a generic pointer -- what a function that is not inlined gets -- every operand
 //  was a flat_load. The file is compiled with -amdgpu-mfma-vgpr-form: see __graft_entry__.py.)
+// A cell's block leaves with write-through stores: 6 MB of blocks written at the very end of the launch's workgroups would
+// otherwise sit dirty in the XCDs' L2s and be written back behind the last wave, inside the launch's duration.
+DEV void block_store(double* p, double v) {
+#ifdef CALICO_BLOCK_STORE_PLAIN
+  *p = v;
+#else
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 template <int NT> struct StageBTiles {      // tile t of the row-major upper triangle -> (row[t], col[t]), at compile time
   int row[NT * (NT + 1) / 2], col[NT * (NT + 1) / 2];
   constexpr StageBTiles() : row(), col() {
@@ -564,7 +573,7 @@ __device__ __attribute__((noinline)) void stage_b_mfma(LdsRows lds, int pad, int
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gi = 16 * I + lk + 4 * r, gj = 16 * J + lc16;
-      if (gi <= gj && gj < n1) out[size_t(gi) * n1 + gj] = acc[t][r];
+      if (gi <= gj && gj < n1) block_store(out + size_t(gi) * n1 + gj, acc[t][r]);
     }
   }
 }
@@ -1242,7 +1251,7 @@ DEV void eval_cells_body(const EvalArgs& a, double* lds) {
     double acc = 0.0;
     acc += cf0[pi] * cf0[pj] * me0[pm_off];
     if (nf > 1) acc += cf0[shift + pi] * cf0[shift + pj] * me0[shift + pm_off];
-    out[size_t(pi) * n1 + pj] = acc;
+    block_store(out + size_t(pi) * n1 + pj, acc);
   }
 }
 

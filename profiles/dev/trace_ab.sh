@@ -11,7 +11,7 @@ for i in $(seq $R); do for lib in base $V; do
   python $REPO/profiles/summarize_rocpd.py /tmp/prof_ab/*.db | python -c "
 import sys, csv
 rows = list(csv.DictReader(sys.stdin))
-want = ['bcr_level_kernelILb1', 'bcr_level_kernelILb0', 'dense_back', 'eval_jacobian', 'expand_cells', 'gather_kernel']
+want = ['bcr_level_kernelILb1', 'bcr_level_kernelILb0', 'dense_back', 'eval_cells', 'eval_jacobian', 'expand_cells', 'gather_kernel']
 out, tot = [], 0.0
 for w in want:
     r = [x for x in rows if w in x['Name']]
