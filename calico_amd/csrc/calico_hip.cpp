@@ -889,9 +889,6 @@ int build_plan(calico_problem* p) {
     // be ONE work item (an IMU cell of at most imu_chunk_items blocks: the usual case).
     bool fuse = !p->h_fitems.empty() && [] { const char* e = std::getenv("CALICO_FUSE_EXPAND"); return !e || std::atoi(e) != 0; }();
     for (const CellDev& c : p->h_cells) if (c.frame_count > 2) fuse = false;       // (a workgroup is two waves: one frame each)
-    // ... and most cells should have both: the second wave of a one-frame cell only waits for the first (configs[3] at 50 Hz
-    // knots -- 0.4 frames per cell -- lost 3 % to the cell workgroups, the notebook run's shape -- 0.9 -- 0.5 %)
-    if (2 * p->h_fitems.size() < 3 * p->h_cells.size()) fuse = false;
     {
       // ... and two waves' staging areas must fit the CU's LDS
       size_t need = 0;
@@ -921,19 +918,31 @@ int build_plan(calico_problem* p) {
     }
     p->fuse_expand = fuse;
     if (fuse) {
-      // two frame entries per camera cell, so that wave w of the cell's workgroup finds its frame at 2 * cell + w without
-      // reading the cell descriptor first; a cell of one frame gets an empty second entry (obs_count = 0: the wave only helps
-      // with the expansion)
-      std::vector<FrameItemDev> padded;
-      padded.reserve(2 * p->h_cells.size());
+      // two frame entries per workgroup, so that wave w of workgroup g finds its frame at 2 g + w without reading a descriptor
+      // first: the two frames of a cell (they expand the cell's block together), or two one-frame cells (`cell_pad` = 1, "solo":
+      // each wave expands its own cell alone, no barrier), or a solo frame and an empty entry (obs_count = 0)
+      std::vector<FrameItemDev> packed;
+      packed.reserve(2 * p->h_cells.size());
+      std::vector<FrameItemDev> solos;
       for (CellDev& c : p->h_cells) {
-        const FrameItemDev f0 = p->h_fitems[size_t(c.frame_begin)];
-        FrameItemDev f1 = f0;
-        if (c.frame_count > 1) f1 = p->h_fitems[size_t(c.frame_begin) + 1]; else f1.obs_count = 0;
-        c.frame_begin = int(padded.size());
-        padded.push_back(f0); padded.push_back(f1);
+        if (c.frame_count > 1) {
+          FrameItemDev f0 = p->h_fitems[size_t(c.frame_begin)], f1 = p->h_fitems[size_t(c.frame_begin) + 1];
+          f0.cell_pad = f1.cell_pad = 0;
+          packed.push_back(f0); packed.push_back(f1);
+        } else {
+          FrameItemDev f0 = p->h_fitems[size_t(c.frame_begin)];
+          f0.cell_pad = 1;
+          solos.push_back(f0);
+        }
       }
-      p->h_fitems.swap(padded);
+      for (size_t i = 0; i < solos.size(); i += 2) {
+        packed.push_back(solos[i]);
+        FrameItemDev f1 = solos[i];
+        if (i + 1 < solos.size()) f1 = solos[i + 1]; else f1.obs_count = 0;
+        packed.push_back(f1);
+      }
+      p->h_fitems.swap(packed);
+      for (CellDev& c : p->h_cells) c.frame_begin = -1;      // (the frames are no longer contiguous by cell: FrameItemDev.cell says whose they are)
     }
     const bool row_cells_ok = !fuse && [] { const char* e = std::getenv("CALICO_ROW_CELLS"); return !e || std::atoi(e) != 0; }();
     for (ItemDev it : p->h_items) {
@@ -1032,11 +1041,11 @@ int build_plan(calico_problem* p) {
       }
       c.prim_off = tab_off[size_t(c.layout)]; c.pad0 = 0;
       c.n1 = L.ncols + 1; c.PE = PT + 1;
-      c.src_off = p->h_fitems[size_t(c.frame_begin)].partial_off;
-      for (int f = c.frame_begin; f < c.frame_begin + (p->fuse_expand ? 2 : c.frame_count); ++f) {      // (copies for the cell's workgroup: fuse_expand)
-        FrameItemDev& fi = p->h_fitems[size_t(f)];
-        fi.cell_frames = c.frame_count; fi.cell_prim_off = c.prim_off; fi.cell_partial_off = c.partial_off; fi.cell_src_off = c.src_off;
-      }
+      c.src_off = c.frame_begin >= 0 ? p->h_fitems[size_t(c.frame_begin)].partial_off : 0;      // (no compact records with cell workgroups)
+    }
+    for (FrameItemDev& fi : p->h_fitems) {      // (copies of the cell's fields for the cell's workgroup: fuse_expand)
+      const CellDev& c = p->h_cells[size_t(fi.cell)];
+      fi.cell_frames = c.frame_count; fi.cell_prim_off = c.prim_off; fi.cell_partial_off = c.partial_off; fi.cell_src_off = c.src_off;
     }
   }
   for (HSensor& s : p->sensors) { s.sorted_begin = n_obs; s.sorted_end = 0; }

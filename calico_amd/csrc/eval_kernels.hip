@@ -841,6 +841,7 @@ constexpr int kPairQ = 16;          // pairs per thread of a 128-thread workgrou
 struct FramePair {
   const double* Me; const double* coef;
   int PE, n1;
+  int t0, stride;       // this thread's pairs: t0 + stride * q (128 threads of a two-frame cell's workgroup, or the 64 lanes of a solo frame)
   int e[kPairQ];
 };
 DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds, FramePair* fp = nullptr) {
@@ -992,10 +993,10 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds, FrameP
   const double n_invalid = wave_sum(n_bad);
   if (lane == 0) { a.item_cost[2 * fidx] = item_cost; a.item_cost[2 * fidx + 1] = n_invalid; }
   if (fp) {      // this thread's pairs of the cell's expansion: on their way while the per-frame steps run
-    const int n_pairs = n1 * (n1 + 1) / 2, tid = threadIdx.x;
+    const int n_pairs = n1 * (n1 + 1) / 2;
     const int* __restrict__ ptab = a.prim_tab + it.cell_prim_off;
 #pragma unroll
-    for (int q = 0; q < kPairQ; ++q) fp->e[q] = ptab[min(tid + 128 * q, n_pairs - 1)];
+    for (int q = 0; q < kPairQ; ++q) fp->e[q] = ptab[min(fp->t0 + fp->stride * q, n_pairs - 1)];
   }
   FTICK(6)
   // ---- M_s to LDS (full symmetric; C/D layout: col = lane & 15, row = (lane >> 4) + 4·reg) ----
@@ -1151,11 +1152,11 @@ __global__ __launch_bounds__(64) void eval_jacobian_kernel(EvalArgs a) {
 
 // Cell workgroups (EvalArgs.pair_mode): the Jacobian pass in workgroups of TWO waves, one per SIMD pair of a CU.
 //   workgroups [0, n_item_wg): two work items (IMU cells), each wave its own -- they form their blocks themselves;
-//   workgroups [n_item_wg, n_item_wg + n_cells): a camera cell -- wave w evaluates frame 2 * cell + w (a.fitems holds two
-//     entries per cell; an empty second one: the wave goes straight to the barrier), M_ext and the expansion coefficients stay
-//     in the wave's LDS area, and behind ONE workgroup barrier both waves expand the cell's block, pair by pair, frame 0 then
-//     frame 1 -- the sums of expand_cells_kernel in the same order (bit-identical) without the compact record's trip through
-//     memory, without that kernel's launch and without its dependent loads (cell descriptor -> records);
+//   workgroups behind them: wave w evaluates frame 2 g + w (a.fitems holds two entries per workgroup). The two frames of ONE
+//     cell: M_ext and the expansion coefficients stay in the waves' LDS areas, and behind ONE workgroup barrier both waves expand
+//     the cell's block, pair by pair, frame 0 then frame 1 -- the sums of expand_cells_kernel in the same order (bit-identical)
+//     without the compact record's trip through memory, without that kernel's launch and without its dependent loads (cell
+//     descriptor -> records). Or two one-frame cells ("solo"): each wave expands its own block out of its own LDS area;
 //   one more workgroup for the end hint.
 // 2 x (cells + item pairs) waves: what the one-wave launch had, in the same single round of one wave per SIMD.
 DEV void eval_cells_body(const EvalArgs& a, double* lds);
@@ -1221,21 +1222,40 @@ DEV void eval_cells_body(const EvalArgs& a, double* lds) {
   if (a.st && (a.st->terminated || (a.need_flag && !a.st->need_jacobian))) return;      // (both waves alike: nobody is left at the barrier)
   const int fidx = 2 * (g - n_item_wg) + wave;
   const FrameItemDev* ip = a.fitems + fidx;
-  const int nf = ip->cell_frames;
+  const bool solo = ip->cell_pad != 0;       // (both entries of a workgroup are of one kind: build_plan)
   FramePair fp;
   fp.Me = nullptr; fp.coef = nullptr; fp.PE = 0; fp.n1 = 0;
-  if (wave < nf) eval_frames_body(a, fidx, lds_w, &fp);
-  else {
-    // the empty second entry of a one-frame cell: the layout's sizes from the descriptor, the pairs, a zero in the cost slots
-    const PrimMap pm = prim_map(ip->L, ip->S);
-    const SmallMap sm = small_map(ip->L, ip->S);
-    fp.PE = pm.PE; fp.n1 = ip->L.ncols + 1;
-    fp.Me = lds_w + frame_area_a(sm.P, sm.PT, pm.P1); fp.coef = fp.Me + ((fp.PE * fp.PE + 1) & ~1);
-    const int n_pairs = fp.n1 * (fp.n1 + 1) / 2;
+  if (solo && ip->obs_count == 0) { if ((tid & 63) == 0) { a.item_cost[2 * fidx] = 0.0; a.item_cost[2 * fidx + 1] = 0.0; } return; }
+  fp.t0 = solo ? (tid & 63) : tid; fp.stride = solo ? 64 : 128;
+  eval_frames_body(a, fidx, lds_w, &fp);       // (one call site: inlined twice, the kernel spilled twice as much)
+  if (solo) {
+    // a one-frame cell: the wave expands its own block, straight out of its LDS area (the same products as expand_cells_kernel
+    // forms for a cell of one frame); the other wave of the workgroup does the same for another cell, or has nothing to do
+    const int lane = tid & 63;
+    wave_lds_sync();
+    const int n1 = fp.n1, n_pairs = n1 * (n1 + 1) / 2;
     const int* __restrict__ ptab = a.prim_tab + ip->cell_prim_off;
+    int e2[kPairQ];
 #pragma unroll
-    for (int q = 0; q < kPairQ; ++q) fp.e[q] = ptab[min(tid + 128 * q, n_pairs - 1)];
-    if ((tid & 63) == 0) { a.item_cost[2 * fidx] = 0.0; a.item_cost[2 * fidx + 1] = 0.0; }
+    for (int q = 0; q < kPairQ; ++q) e2[q] = ptab[min(lane + 64 * (kPairQ + q), n_pairs - 1)];      // (the second half of the lane's pairs)
+    double* out = a.partials + ip->cell_partial_off;
+#pragma unroll
+    for (int q = 0; q < kPairQ; ++q) {
+      if (lane + 64 * q >= n_pairs) continue;
+      const int pi = fp.e[q] & 255, pj = (fp.e[q] >> 8) & 255, pm_off = fp.e[q] >> 16;
+      double acc = 0.0;
+      acc += fp.coef[pi] * fp.coef[pj] * fp.Me[pm_off];
+      block_store(out + size_t(pi) * n1 + pj, acc);
+    }
+#pragma unroll
+    for (int q = 0; q < kPairQ; ++q) {
+      if (lane + 64 * (kPairQ + q) >= n_pairs) continue;
+      const int pi = e2[q] & 255, pj = (e2[q] >> 8) & 255, pm_off = e2[q] >> 16;
+      double acc = 0.0;
+      acc += fp.coef[pi] * fp.coef[pj] * fp.Me[pm_off];
+      block_store(out + size_t(pi) * n1 + pj, acc);
+    }
+    return;
   }
   __syncthreads();
   const int n1 = fp.n1, n_pairs = n1 * (n1 + 1) / 2;
@@ -1250,7 +1270,7 @@ DEV void eval_cells_body(const EvalArgs& a, double* lds) {
     const int pi = fp.e[q] & 255, pj = (fp.e[q] >> 8) & 255, pm_off = fp.e[q] >> 16;
     double acc = 0.0;
     acc += cf0[pi] * cf0[pj] * me0[pm_off];
-    if (nf > 1) acc += cf0[shift + pi] * cf0[shift + pj] * me0[shift + pm_off];
+    acc += cf0[shift + pi] * cf0[shift + pj] * me0[shift + pm_off];
     block_store(out + size_t(pi) * n1 + pj, acc);
   }
 }

@@ -299,12 +299,12 @@ def test_cell_workgroups_equal_the_expansion_launch(monkeypatch):
     runs workgroups of two waves (eval_cells_kernel): the frames of a cell leave M_ext and the expansion coefficients in
     LDS and expand the cell's block together behind one workgroup barrier -- no compact record, no expand_cells_kernel
     launch --, and IMU items form their blocks themselves. Every block is the sum the separate expansion launch forms, in
-    the same order (configs[1..3], where every cell has two frames, come out bit for bit: profiles/dev/bitwise.py); where
-    a cell has one frame its workgroup carries an empty second entry, whose zero cost slot regroups the sum of the costs --
-    so against CALICO_FUSE_EXPAND=0 (records + expansion launch + row cells) the iterations must agree to rounding, and
-    each variant must reproduce itself bit for bit. Scenes: two frames per cell; one frame per cell (10 Hz camera: the
-    second wave of a cell's workgroup only helps with the expansion); three frames in some cells (the plan falls back to
-    the launch of its own)."""
+    the same order (configs[1..3], where every cell has two frames, come out bit for bit: profiles/dev/bitwise.py); one-frame
+    cells are packed two to a workgroup (each wave expands its own), which reorders the frames' cost slots and so regroups
+    the sum of the costs -- so against CALICO_FUSE_EXPAND=0 (records + expansion launch + row cells) the iterations must
+    agree to rounding, and each variant must reproduce itself bit for bit. Scenes: two frames per cell (and a few with
+    one at the ends); one frame per cell (10 Hz camera); three frames in some cells (the plan falls back to the launch of
+    its own)."""
     api = helpers.hip_api()
     common = dict(chart="april", pixel_noise=0.1, gyro_noise=1e-3, accel_noise=1e-2, robust=True, max_cam_obs=6000)
     scenes = [
