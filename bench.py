@@ -601,7 +601,7 @@ def main():
                 # evaluation at the candidate point): the blocks are counted once per pass
                 "residual_blocks_evaluated_per_s": n_blocks * max(jac, cost) / elapsed,
                 "parallelism": "obs-shard x%d + native RCCL all-reduce(JtJ,Jtr,cost)" % world if world > 1 else "single GPU",
-                "host_loop": "non-blocking: device-published progress, two iterations enqueued ahead" if world == 1 and not args.force_collective else "batches of %d iterations per host read-back" % args.sync_every,
+                "host_loop": "non-blocking: device-published progress; iteration i + 1 enqueued when the Jacobian launch of iteration i reports that its control stage will not end the solve (CALICO_PREDICT_END=0: always one iteration ahead)" if world == 1 and not args.force_collective else "batches of %d iterations per host read-back" % args.sync_every,
                 "poor_start": args.poor_start,
                 "successful_steps_last_solve": last.num_successful_steps, "unsuccessful_steps_last_solve": last.num_unsuccessful_steps,
                 "linear_solver": os.environ.get("CALICO_SOLVER", "tree (block cyclic reduction over 5-control-point superblocks)"),
