@@ -1131,6 +1131,11 @@ int build_plan(calico_problem* p) {
       gs_tab[size_t(n_lay) * nsg + size_t(n_lay) * m + size_t(l)] = layouts[size_t(l)].ncols + 1;
     }
     gsd.n_lay = n_lay; gsd.nseg = nsg; gsd.n_cp = n_cp; gsd.k = k; gsd.m = m;
+    {   // band blocks at distance d from the diagonal have (k - d) segments per layout: four lanes in the gather where that is <= 24 sources
+      int d4 = k;
+      while (d4 > 0 && (k - (d4 - 1)) * n_lay <= 24) --d4;
+      gsd.d_split = d4;
+    }
     gsd.off_g = sa.off_g(); gsd.off_B = sa.off_B(); gsd.off_E = sa.off_E();
   }
   pairs.reserve(gs_ok ? size_t(n_part) * 256 : poff / 2 + 4 * size_t(p->n_items));
@@ -1261,8 +1266,7 @@ int build_plan(calico_problem* p) {
     const int n_border0 = NS + n_cp * k * 36;          // first border output
     p->n_thin4 = (one_layout && tiny_env) ? n_border0 : p->n_thin;
     // band blocks at distance d from the diagonal have (k - d) segments per layout: four lanes where that is <= 24 sources
-    int d4 = k;
-    while (d4 > 0 && (k - (d4 - 1)) * gsd.n_lay <= 24) --d4;
+    const int d4 = gsd.d_split;
     p->n_thin8 = (one_layout && tiny_env) ? std::min(n_border0, NS + d4 * n_cp * 36) : p->n_thin;     // (the classes are ranges: [8 | 4 | 1])
   } else {
     HIP_TRY(p, p->d_out_thin.upload(out_thin, s)); HIP_TRY(p, p->d_idx_thin.upload(idx_thin, s));

@@ -198,7 +198,7 @@ struct BlockDev {  // one reduced (free, used) parameter block
 struct GatherStruct {
   const int* tab;
   int n_lay, nseg, n_cp, k, m;      // m: calibration tangent columns (SolveArgs.mc)
-  int pad0;
+  int d_split;                       // band blocks at distance < d_split from the diagonal are numbered first (struct_output)
   unsigned long long off_g, off_B, off_E;
 };
 

@@ -65,11 +65,16 @@ DEVI StructOut struct_output(const GatherStruct& gs, int o) {
     q.a = q.b = ti / 6; q.r = ti % 6; q.rhs = 1;
     q.dst = size_t(gs.off_g) + size_t(ti);
   } else if (o < NS + n_b) {
-    // band blocks by distance from the diagonal first (d = b - a), then in time: the blocks of a distance share their list
-    // length ((k - d) segments per layout), so the short lists -- which the gather gives fewer lanes -- are one range
-    const int e = o - NS, bd = e / 36, w = e - 36 * bd;
-    const int d = bd / gs.n_cp;
-    q.a = bd - d * gs.n_cp; q.b = q.a + d;
+    // band blocks in two ranges -- distances d < d_split from the diagonal (long lists: eight lanes per output in the gather),
+    // then the others (four lanes) --, and IN TIME inside a range: the gather deals contiguous pieces of a range to the XCDs,
+    // and the outputs of one stretch of the trajectory read the same cells' blocks -- dealt by distance first, every XCD's L2
+    // fetched every cell block (29 MB of fetches for 6 MB of blocks)
+    const int e = o - NS, ds = gs.d_split, n_a = gs.n_cp * ds * 36;
+    int bd, d;
+    if (e < n_a) { bd = e / 36; q.a = bd / ds; d = bd - q.a * ds; }
+    else { const int dr = gs.k - ds; bd = (e - n_a) / 36; q.a = bd / dr; d = ds + (bd - q.a * dr); }
+    const int w = e - 36 * (e / 36);
+    q.b = q.a + d;
     q.r = w / 6; q.c = w % 6;
     q.dst = size_t(gs.off_B) + size_t(q.a * gs.k + d) * 36 + size_t(w);
   } else {
@@ -211,16 +216,33 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
                                                      const int* __restrict__ out_fat, const int64_t* __restrict__ ptr_fat,
                                                      const int* __restrict__ idx_fat, int n_fat, int nb_fat,
                                                      const double* __restrict__ cost_src, int n_cost,
-                                                     const LmState* st, int need_flag, size_t other_stride, ControlTail tail) {
+                                                     const LmState* st, int need_flag, size_t other_stride, ControlTail tail, int xcd_map) {
   // (the list pointers of this thread's output do not depend on the state: requested before the flags are looked at)
   int64_t pre_q0 = 0, pre_q1 = 0;
   const int nb_thin8 = (n_thin8 + 31) / 32, nb_thin4 = (n_thin4 - n_thin8 + 63) / 64;
   int o_thin = 0;
   int cls = 8;       // lanes per output of this workgroup's thin outputs
+  // xcd_map: workgroup p runs on XCD p % 8, each XCD has an L2 of its own, and the outputs are numbered in time inside a lane
+  // class -- so every class is cut into eight contiguous pieces, one per XCD (the class's workgroups, padded to a multiple of
+  // eight and starting at a multiple of eight, are dealt piece x = p % 8, position p / 8): the cells' blocks of one stretch of
+  // the trajectory are then fetched by one L2 instead of by all eight.
+  int tb_map = int(blockIdx.x) - 1 - nb_fat;
+  bool idle = false;
+  if (xcd_map && int(blockIdx.x) - 1 >= nb_fat) {
+    const int pb = int(blockIdx.x) - ((1 + nb_fat + 7) & ~7);
+    const int nb_thin1 = (n_thin - n_thin4 + 255) / 256;
+    const int nbp8 = (nb_thin8 + 7) & ~7, nbp4 = (nb_thin4 + 7) & ~7;
+    int pbc = pb, nbc = nb_thin8, base_l = 0;
+    if (pb >= nbp8 + nbp4) { pbc = pb - nbp8 - nbp4; nbc = nb_thin1; base_l = nb_thin8 + nb_thin4; }
+    else if (pb >= nbp8) { pbc = pb - nbp8; nbc = nb_thin4; base_l = nb_thin8; }
+    const int j = (pbc & 7) * ((nbc + 7) >> 3) + (pbc >> 3);
+    idle = pb < 0 || j >= nbc;
+    tb_map = base_l + (idle ? 0 : j);
+  }
   {
     const int bidp = int(blockIdx.x) - 1;
     if (bidp >= nb_fat && n_thin > 0) {
-      const int tb = bidp - nb_fat;
+      const int tb = tb_map;
       int oc;
       if (tb < nb_thin8) { o_thin = (tb * int(blockDim.x) + int(threadIdx.x)) >> 3; oc = o_thin < n_thin8 ? o_thin : n_thin8 - 1; }
       else if (tb < nb_thin8 + nb_thin4) {
@@ -253,6 +275,7 @@ __global__ __launch_bounds__(256) void gather_kernel(double* __restrict__ R, con
     if (tail.enabled && tail.progress && st->terminated && blockIdx.x == 0 && threadIdx.x == 0) publish_progress(tail.progress, st, tail.seq);
     return;
   }
+  if (idle) return;        // (padding of the XCD-aware dealing)
   __shared__ LmState s_st;
   __shared__ double s_c01[2];
   ControlStage pf;
@@ -1900,13 +1923,17 @@ void launch_gather(double* R, const double* src, const int* out_idx_thin, const 
                    int n_thin, int n_thin8, int n_thin4, int thin_per_lane, const int* out_idx_fat, const int64_t* ptr_fat, const int* idx_fat, int n_fat,
                    const double* cost_src, int n_cost,
                    const LmState* st, int need_flag, size_t other_stride, hipStream_t s, const ControlTail* tail) {
-  const int nb_thin = (n_thin8 + 31) / 32 + (n_thin4 - n_thin8 + 63) / 64 + (n_thin - n_thin4 + 255) / 256, nb_fat = (n_fat + 3) / 4;
+  const int nb_fat = (n_fat + 3) / 4;
+  const int nb8 = (n_thin8 + 31) / 32, nb4 = (n_thin4 - n_thin8 + 63) / 64, nb1 = (n_thin - n_thin4 + 255) / 256;
+  // (A/B switch, read per launch: CALICO_GATHER_XCD=0 = the thin workgroups in output order, rounds 1-4)
+  const int xcd_map = [] { const char* e = std::getenv("CALICO_GATHER_XCD"); return !e || std::atoi(e) != 0; }() ? 1 : 0;
+  const int n_blocks = xcd_map ? ((1 + nb_fat + 7) & ~7) + ((nb8 + 7) & ~7) + ((nb4 + 7) & ~7) + ((nb1 + 7) & ~7) : 1 + nb_fat + nb8 + nb4 + nb1;
   ControlTail t;
   if (tail) t = *tail; else { t = ControlTail(); t.enabled = 0; }
   // workgroup 0: cost / invalid count (+ control stage), then the fat outputs, then the thin ones
   // ptr_thin == nullptr: idx_thin is the fixed-stride table (gather_pack_fixed)
-#define LAUNCH_GATHER(UU, FX) hipLaunchKernelGGL((gather_kernel<UU, FX>), dim3(1 + nb_thin + nb_fat), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin, n_thin8, n_thin4, \
-                       out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, cost_src, n_cost, st, need_flag, other_stride, t)
+#define LAUNCH_GATHER(UU, FX) hipLaunchKernelGGL((gather_kernel<UU, FX>), dim3(n_blocks), dim3(256), 0, s, R, src, out_idx_thin, ptr_thin, idx_thin, n_thin, n_thin8, n_thin4, \
+                       out_idx_fat, ptr_fat, idx_fat, n_fat, nb_fat, cost_src, n_cost, st, need_flag, other_stride, t, xcd_map)
   if (thin_per_lane <= 6) { if (ptr_thin) LAUNCH_GATHER(6, false); else LAUNCH_GATHER(6, true); }
   else { if (ptr_thin) LAUNCH_GATHER(12, false); else LAUNCH_GATHER(12, true); }
 #undef LAUNCH_GATHER
