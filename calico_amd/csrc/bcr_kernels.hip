@@ -284,6 +284,21 @@ DEVI void schur_root_rows(const SolveArgs& a, const BcrArgs& b, int ks, int w0, 
 // ELIM (round 4): the block is eliminated by block_elim.hpp -- a chief wave on the spine, waves 1..3 as followers with the
 // identity rows (role 0: L⁻ᵀ) and the rows of Xᵀ, so that Z comes out of the factorisation -- instead of panel | tile |
 // panel | Z = MᵀX (CALICO_ELIM=panel keeps those).
+// A thread's share of a block's entries on the way from memory to LDS (bcr_level_kernel's fetch / commit): NL threads
+// take NU entries of D / B / A and NF of the F slice each, thread lt the entries lt, lt + NL, ...
+template <int NL_, int NU_, int NF_>
+struct BcrLoadMap {
+  static constexpr int NL = NL_, NU = NU_, NF = NF_;
+  int lt;
+  int iD[NU_], iB[NU_];        // level 0: positions in R of the entries for superblock 0
+  bool okD[NU_], okB[NU_];
+};
+template <int NU, int NF>
+struct BcrPre { double d[NU], bt[NU], at[NU], f[NF]; };
+#ifndef BCR_FIRST_BLOCK_ALL_WAVES
+#define BCR_FIRST_BLOCK_ALL_WAVES 1
+#endif
+
 template <bool FROM_R, bool ELIM>
 __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, BcrArgs b, int node0, int n_nodes, int nfs, int level,
                                                                    int keep0, int n_keep, LmOptionsDev o, int with_post,
@@ -488,28 +503,35 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   constexpr int NL = ELIM ? 256 : kLevelThreads - 128, NU = ELIM ? 4 : 3, NF = 2;
   const bool loader = ELIM ? wave >= 4 : (wave != 0 && wave != 4);    // wave 4 shares the panel wave's SIMD: it stays out of the way, too
   const int lt = ELIM ? tid - 256 : tid - 64 - (wave > 4 ? 64 : 0);
-  struct Pre { double d[NU], bt[NU], at[NU], f[NF]; };
+  typedef BcrPre<NU, NF> Pre;
   // level 0: positions in R of this thread's entries for superblock 0 (the band is uniform in time: superblock I adds
   // I·stride), and what does not depend on the superblock of their validity
   constexpr int RB = 6 * kBcrCps;
-  int iD[NU], iB[NU];
-  bool okD[NU], okB[NU];
   const int strideB = kBcrCps * a.k * 36;
-  if (FROM_R) {
+  auto fill_map = [&](auto& m) {
+    typedef typename std::remove_reference<decltype(m)>::type M;
+    if (FROM_R) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const int e = min(max(lt, 0) + NL * u, BB - 1);
-      const int r = e >> 5, c = e & 31;
-      const int hi = max(r, c), lo = min(r, c);
-      const int dD = hi / 6 - lo / 6;
-      okD[u] = r < RB && c < RB && dD < a.k;
-      iD[u] = okD[u] ? ((lo / 6) * a.k + dD) * 36 + (lo % 6) * 6 + hi % 6 : 0;
-      const int dB = kBcrCps + r / 6 - c / 6;       // row r of the next superblock against column c of this one
-      okB[u] = r < RB && c < RB && dB < a.k;
-      iB[u] = okB[u] ? ((c / 6) * a.k + dB) * 36 + (c % 6) * 6 + r % 6 : 0;
+      for (int u = 0; u < M::NU; ++u) {
+        const int e = min(max(m.lt, 0) + M::NL * u, BB - 1);
+        const int r = e >> 5, c = e & 31;
+        const int hi = max(r, c), lo = min(r, c);
+        const int dD = hi / 6 - lo / 6;
+        m.okD[u] = r < RB && c < RB && dD < a.k;
+        m.iD[u] = m.okD[u] ? ((lo / 6) * a.k + dD) * 36 + (lo % 6) * 6 + hi % 6 : 0;
+        const int dB = kBcrCps + r / 6 - c / 6;       // row r of the next superblock against column c of this one
+        m.okB[u] = r < RB && c < RB && dB < a.k;
+        m.iB[u] = m.okB[u] ? ((c / 6) * a.k + dB) * 36 + (c % 6) * 6 + r % 6 : 0;
+      }
     }
-  }
-  auto fetch = [&](int i, Pre& pr, auto both_tag) {
+  };
+  BcrLoadMap<NL, NU, NF> lmap;
+  lmap.lt = lt;
+  fill_map(lmap);
+  auto fetch = [&](int i, auto& pr, auto both_tag, const auto& m) {
+    typedef typename std::remove_reference<decltype(m)>::type M;
+    constexpr int NL = M::NL, NU = M::NU, NF = M::NF;
+    const int lt = m.lt;
     constexpr bool BOTH = decltype(both_tag)::value;      // (FROM_R, first block of the launch: see R_buf0 / R_buf1)
     const int blk = blk0 + i, mask = pend_mask;
     const bool has_next = (i + 1 < q) || right >= 0;
@@ -541,19 +563,19 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           act_rn = a.cp_active[min(kBcrCps * (blk + 1) + r / 6, n_cp - 1)] != 0;
           act_cl = a.cp_active[min(max(kBcrCps * (blk - 1) + c / 6, 0), n_cp - 1)] != 0;
         }
-        vDs[u] = okD[u] && r < nreal && c < nreal && act_r && act_c;
-        vraw[u] = RBnd[vDs[u] ? iD[u] : 0];
-        if (BOTH) vraw1[u] = RBnd[alt + (vDs[u] ? iD[u] : 0)];
+        vDs[u] = m.okD[u] && r < nreal && c < nreal && act_r && act_c;
+        vraw[u] = RBnd[vDs[u] ? m.iD[u] : 0];
+        if (BOTH) vraw1[u] = RBnd[alt + (vDs[u] ? m.iD[u] : 0)];
         const int ts = (r == c && r < RB && r < nreal) ? RB * blk + r : 0;
         svv[u] = a.scale[ts]; q2v[u] = a.scale[a.NT() + ts];        // (harmless during a solve's first linear solve, which does not use them)
-        vBs[u] = okB[u] && has_next && r < nreal_n && act_rn && act_c;
-        graw[u] = RBnd[vBs[u] ? iB[u] : 0];
-        if (BOTH) graw1[u] = RBnd[alt + (vBs[u] ? iB[u] : 0)];
-        vAs[u] = okB[u] && has_a && r < nreal && act_r && act_cl;
+        vBs[u] = m.okB[u] && has_next && r < nreal_n && act_rn && act_c;
+        graw[u] = RBnd[vBs[u] ? m.iB[u] : 0];
+        if (BOTH) graw1[u] = RBnd[alt + (vBs[u] ? m.iB[u] : 0)];
+        vAs[u] = m.okB[u] && has_a && r < nreal && act_r && act_cl;
         garaw[u] = 0.0;
-        if (has_a) garaw[u] = RBndA[vAs[u] ? iB[u] : 0];      // (only the first block of a chain touches the left separator)
+        if (has_a) garaw[u] = RBndA[vAs[u] ? m.iB[u] : 0];      // (only the first block of a chain touches the left separator)
         garaw1[u] = 0.0;
-        if (BOTH && has_a) garaw1[u] = RBndA[alt + (vAs[u] ? iB[u] : 0)];
+        if (BOTH && has_a) garaw1[u] = RBndA[alt + (vAs[u] ? m.iB[u] : 0)];
       }
 #pragma unroll
       for (int u = 0; u < NF; ++u) {
@@ -628,7 +650,10 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       pr.f[u] = role > 0 ? (v0 + ((mask & 1) ? v1 : 0.0)) + ((mask & 2) ? v2 : 0.0) : 0.0;
     }
   };
-  auto commit = [&](int p, const Pre& pr) {
+  auto commit = [&](int p, const auto& pr, const auto& m) {
+    typedef typename std::remove_reference<decltype(m)>::type M;
+    constexpr int NL = M::NL, NU = M::NU, NF = M::NF;
+    const int lt = m.lt;
     double* Dp = Daug + p * 64 * DLD;
     double* Xp = Xb + p * BP * XLD;
 #pragma unroll
@@ -657,11 +682,18 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   // U_aa (role 0: waves 0..3, tile (wave >> 1, wave & 1)) or U_aF (border roles: waves 2, 3, row tile wave - 2)
   f64x4 acc_a = {0.0, 0.0, 0.0, 0.0};
   {
-    Pre pr;
-    if (loader) fetch(0, pr, std::integral_constant<bool, FROM_R>());
+    // ELIM: nobody has anything else to do before the first block is in LDS -- all eight waves fetch it, two entries of
+    // D / B / A and one of the F slice each (half the instructions per thread of the loaders' share of a later block)
+    constexpr bool kAllFetchFirst = ELIM && BCR_FIRST_BLOCK_ALL_WAVES;
+    typedef typename std::conditional<kAllFetchFirst, BcrLoadMap<kLevelThreads, BB / kLevelThreads, 1>, BcrLoadMap<NL, NU, NF>>::type Map0;
+    Map0 m0;
+    if constexpr (kAllFetchFirst) { m0.lt = tid; fill_map(m0); } else { m0 = lmap; }
+    BcrPre<Map0::NU, Map0::NF> pr;
+    const bool load0 = kAllFetchFirst || loader;
+    if (load0) fetch(0, pr, std::integral_constant<bool, FROM_R>(), m0);
     if (FROM_R) a.R = uniform(r_cur_v) ? R_buf1 : R_buf0;        // (use_current_R; the later blocks' requests come behind the state anyway)
     if (uniform(terminated_v)) { if (pub) fanin_arrive(fan_word); return; }
-    if (loader) commit(0, pr);
+    if (load0) commit(0, pr, m0);
   }
   __syncthreads();
   LTICK(0)
@@ -682,7 +714,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
 #pragma unroll
       for (int k = 0; k < 4; ++k) if (k == i) t_top[k] = t_step - t_kernel;
     }
-    if (!last && loader) fetch(i + 1, pr, std::false_type());            // in flight while the block is factored
+    if (!last && loader) fetch(i + 1, pr, std::false_type(), lmap);            // in flight while the block is factored
     if (CAL_DEV_TIMING(a.debug == 2 && bid < 1 && lane == 0 && wave >= 4)) printf("level %d step %d wave %d: requests issued at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
     if (ELIM) {
       // ---- D = L Lᵀ, Z = L⁻¹X and (role 0) L⁻ᵀ in one pass: wave 0 the spine, waves 1..3 two row tiles each ----
@@ -701,7 +733,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         elim_follow<2>(t, ech, lane);
       }
       if (CAL_DEV_TIMING(a.debug == 2 && bid < 1 && lane == 0 && wave < 4)) printf("level %d step %d wave %d: elimination done at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
-      if (!last && loader) commit(p ^ 1, pr);
+      if (!last && loader) commit(p ^ 1, pr, lmap);
       if (CAL_DEV_TIMING(a.debug == 2 && bid < 1 && lane == 0 && wave >= 4)) printf("level %d step %d wave %d: committed at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
       LTICK(3)
     } else {
@@ -713,7 +745,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     lds_barrier();
     LTICK(2)
     if (wave == 0) panel_factor<1, false, false>(Dp, DLD, dinv, bcast, 16, 63, 16, lane, &pmin);
-    else if (!last && loader) commit(p ^ 1, pr);
+    else if (!last && loader) commit(p ^ 1, pr, lmap);
     lds_barrier();
     LTICK(3)
     // ---- Z = L⁻¹ X = MᵀX, M = L⁻ᵀ in rows 32..63 (upper triangular: row tile it needs k < 16(it+1)) ----

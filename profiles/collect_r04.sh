@@ -41,8 +41,8 @@ timeout 300 python $REPO/bench.py --force-collective --no-cpu-baseline --repeats
 for v in panel mfma panel mfma panel mfma; do CALICO_ELIM=$v timeout 300 python $REPO/bench.py --no-cpu-baseline --repeats 60 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('CALICO_ELIM=$v', round(d['value'],1), 'it/s', d['ms_per_step'], 'ms/iteration')"; done > $OUT/r04_elim_ab.txt
 for c in 1 2 4; do for v in panel mfma; do CALICO_ELIM=$v timeout 300 python $REPO/bench.py --config $c --no-cpu-baseline --repeats 30 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('configs[$c] CALICO_ELIM=$v', round(d['value'],1), 'it/s')"; done; done >> $OUT/r04_elim_ab.txt
 # 6b. A/B of the round's second half (same box): cell workgroups (CALICO_FUSE_EXPAND=0: records + expansion launch + row cells),
-#     the end-of-solve hint (CALICO_PREDICT_END=0), the device arena (CALICO_ARENA=0)
-for sw in CALICO_FUSE_EXPAND CALICO_PREDICT_END CALICO_ARENA; do for r in 1 2 3; do for v in 0 1; do env $sw=$v timeout 300 python $REPO/bench.py --no-cpu-baseline --repeats 60 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$sw=$v', round(d['value'],1), 'it/s', d['ms_per_step'], 'ms/iteration')"; done; done; done > $OUT/r04_second_half_ab.txt
+#     the end-of-solve hint (CALICO_PREDICT_END=0), the device arena (CALICO_ARENA=0), the XCD-aware gather (CALICO_GATHER_XCD=0)
+for sw in CALICO_FUSE_EXPAND CALICO_PREDICT_END CALICO_ARENA CALICO_GATHER_XCD; do for r in 1 2 3; do for v in 0 1; do env $sw=$v timeout 300 python $REPO/bench.py --no-cpu-baseline --repeats 60 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$sw=$v', round(d['value'],1), 'it/s', d['ms_per_step'], 'ms/iteration')"; done; done; done > $OUT/r04_second_half_ab.txt
 for c in 1 2 4; do for v in 0 1; do CALICO_FUSE_EXPAND=$v timeout 300 python $REPO/bench.py --config $c --no-cpu-baseline --repeats 30 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('configs[$c] CALICO_FUSE_EXPAND=$v', round(d['value'],1), 'it/s')"; done; done >> $OUT/r04_second_half_ab.txt
 if [ -x $REPO/profiles/microbench/bin/any_order ]; then timeout 90 $REPO/profiles/microbench/bin/any_order > $OUT/r04_any_order_launch_microbench.txt 2>&1; fi
 # 7. the 32x32 block elimination alone on a CU (microbenchmark; built by profiles/microbench/run_block_factor.sh)
