@@ -527,7 +527,8 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   };
   BcrLoadMap<NL, NU, NF> lmap;
   lmap.lt = lt;
-  fill_map(lmap);
+  constexpr bool kAllFetchFirst = ELIM && BCR_FIRST_BLOCK_ALL_WAVES;
+  if (!kAllFetchFirst) fill_map(lmap);       // (otherwise behind the first block's requests: the loaders' map is for the later blocks)
   auto fetch = [&](int i, auto& pr, auto both_tag, const auto& m) {
     typedef typename std::remove_reference<decltype(m)>::type M;
     constexpr int NL = M::NL, NU = M::NU, NF = M::NF;
@@ -684,13 +685,13 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   {
     // ELIM: nobody has anything else to do before the first block is in LDS -- all eight waves fetch it, two entries of
     // D / B / A and one of the F slice each (half the instructions per thread of the loaders' share of a later block)
-    constexpr bool kAllFetchFirst = ELIM && BCR_FIRST_BLOCK_ALL_WAVES;
     typedef typename std::conditional<kAllFetchFirst, BcrLoadMap<kLevelThreads, BB / kLevelThreads, 1>, BcrLoadMap<NL, NU, NF>>::type Map0;
     Map0 m0;
     if constexpr (kAllFetchFirst) { m0.lt = tid; fill_map(m0); } else { m0 = lmap; }
     BcrPre<Map0::NU, Map0::NF> pr;
     const bool load0 = kAllFetchFirst || loader;
     if (load0) fetch(0, pr, std::integral_constant<bool, FROM_R>(), m0);
+    if (kAllFetchFirst) fill_map(lmap);
     if (FROM_R) a.R = uniform(r_cur_v) ? R_buf1 : R_buf0;        // (use_current_R; the later blocks' requests come behind the state anyway)
     if (uniform(terminated_v)) { if (pub) fanin_arrive(fan_word); return; }
     if (load0) commit(0, pr, m0);
@@ -1390,12 +1391,20 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev n
   const int cy = min(col, mc);                          // column of Y to read (mc: the right-hand side z = L⁻¹g)
   const bool is_y = col < mc, is_z = col == mc + BP, is_r = col >= mc && col < mc + BP;
   const int cr = min(max(col - mc, 0), BP - 1);
+  // (wave-uniform: a wave requests only what one of its sixteen columns selects below -- the requests of the eight waves of
+  //  a node, not their round trip, are what this phase takes)
+  const bool w_yz = uniform(int(16 * wave < mc || ((mc + BP) >> 4) == wave)) != 0;          // a column of Y, or z
+  const bool w_r = uniform(int(16 * wave + 15 >= mc && 16 * wave < mc + BP)) != 0;          // a column of the root part
   double rh[QM][8], ws[2][8];
 #pragma unroll
   for (int i = 0; i < QM; ++i) {
     const double* yb = b.Y + size_t(blk0 + min(i, q - 1)) * fblk;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) rh[i][e] = yb[size_t(lk + 4 * (e & 3) + 16 * (e >> 2)) * m1p + (is_z ? mc : cy)];
+    for (int e = 0; e < 8; ++e) rh[i][e] = 0.0;
+    if (w_yz) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rh[i][e] = yb[size_t(lk + 4 * (e & 3) + 16 * (e >> 2)) * m1p + (is_z ? mc : cy)];
+    }
   }
   if (SIDE) {
 #pragma unroll
@@ -1405,13 +1414,24 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev n
       const double* yb = b.Y + size_t(eb) * fblk;
       const double* za = b.ZA + size_t(eb) * BB;
       const double* zb = b.ZB + size_t(eb) * BB;
+      double vy[8], va[8], vb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { vy[e] = 0.0; va[e] = 0.0; vb[e] = 0.0; }
+      if (w_yz) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vy[e] = yb[size_t(lk + 4 * (e & 3) + 16 * (e >> 2)) * m1p + (is_z ? mc : cy)];
+      }
+      if (w_r) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int row = lk + 4 * (e & 3) + 16 * (e >> 2);
+          va[e] = za[row * BP + cr]; vb[e] = zb[row * BP + cr];
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int row = lk + 4 * (e & 3) + 16 * (e >> 2);
-        const double vy = yb[size_t(row) * m1p + (is_z ? mc : cy)];
-        const double va = za[row * BP + cr], vb = zb[row * BP + cr];
-        const double vr = (ts.left[k] >= 0 ? va : 0.0) + (ts.right[k] >= 0 ? vb : 0.0);
-        ws[sd][e] = is_y ? -vy : (is_r ? -vr : (is_z ? vy : 0.0));
+        const double vr = (ts.left[k] >= 0 ? va[e] : 0.0) + (ts.right[k] >= 0 ? vb[e] : 0.0);
+        ws[sd][e] = is_y ? -vy[e] : (is_r ? -vr : (is_z ? vy[e] : 0.0));
       }
     }
   }
@@ -1644,32 +1664,51 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
 #pragma unroll
       for (int k = 0; k < 8; ++k) rhs_acc += Sp[size_t(min(k, nsl - 1)) * mm + size_t(m) * M1 + c] * (k < nsl ? 1.0 : 0.0);
     }
-    // thread (wave w, lane): rows w, w+8, ...; columns lane, lane+64 -- sixteen rows in flight per pass
-    for (int r0 = wave; r0 < mp; r0 += 8 * 16) {
-      double v[16][2];
+    // The lower triangle FOLDED into a rectangle of mp/2 rows of mp entries, dealt flat over the workgroup (sixteen entries per
+    // thread at mp = 128): folded row f is row f with its diagonal (f + 1 entries) followed by the strict lower part of row
+    // mp-1-f (mp-1-f entries); the diagonal of the rows mp/2.. is one more entry for threads 128.. . (A row per wave and
+    // two columns per lane took twice the load instructions, half of them on clamped duplicates above the diagonal --
+    // and the head of this launch is bound by the eight waves' load instructions, not by the round trip.)
+    const int half_rows = mp >> 1, n_fold = half_rows * mp;
+    auto fold_entry = [&](int e, int& r, int& c) {
+      const int e5 = e >> 5;                       // mp = 32 nb: f = (e / 32) / nb
+      const int f = nb == 4 ? e5 >> 2 : (nb == 3 ? e5 / 3 : (nb == 2 ? e5 >> 1 : e5));
+      const int p = e - f * mp;
+      const bool low = p <= f;
+      r = low ? f : mp - 1 - f;
+      c = low ? p : p - f - 1;
+    };
+    const bool diag_thread = tid >= 128 && tid < 128 + half_rows;
+    const int rd = half_rows + (diag_thread ? tid - 128 : 0);
+    double vdiag = 0.0;
+    {
+      const int rl = min(rd, m - 1);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) vdiag += Sp[size_t(min(k, nsl - 1)) * mm + size_t(rl) * M1 + rl] * (k < nsl ? 1.0 : 0.0);
+    }
+    for (int e0 = tid; e0 < n_fold; e0 += kDenseThreads * 16) {
+      double v[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
-        const int r = min(r0 + 8 * u, m - 1);
+        int r, c;
+        fold_entry(min(e0 + kDenseThreads * u, n_fold - 1), r, c);
+        const int rl = min(r, m - 1), cl = min(c, rl);
+        double acc = 0.0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int c = min(lane + 64 * h, r);
-          double acc = 0.0;
-#pragma unroll
-          for (int k = 0; k < 2; ++k) acc += Sp[size_t(min(k, nsl - 1)) * mm + size_t(r) * M1 + c] * (k < nsl ? 1.0 : 0.0);
-          v[u][h] = acc;
-        }
+        for (int k = 0; k < 2; ++k) acc += Sp[size_t(min(k, nsl - 1)) * mm + size_t(rl) * M1 + cl] * (k < nsl ? 1.0 : 0.0);
+        v[u] = acc;
       }
       if (terminated) return;
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
-        const int r = r0 + 8 * u;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int c = lane + 64 * h;
-          if (r < mp && c <= r) A[r * DNL + c] = (r < m) ? v[u][h] : (r == c ? 1.0 : 0.0);
-        }
+        const int e = e0 + kDenseThreads * u;
+        int r, c;
+        fold_entry(min(e, n_fold - 1), r, c);
+        if (e < n_fold) A[r * DNL + c] = (r < m) ? v[u] : (r == c ? 1.0 : 0.0);
       }
     }
+    if (terminated) return;
+    if (diag_thread) A[rd * DNL + rd] = rd < m ? vdiag : 1.0;
     if (tid < 128) {
       gv[tid] = tid < m ? rhs_acc : 0.0;
       pend[tid] = 0.0;
