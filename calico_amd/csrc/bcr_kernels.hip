@@ -1669,44 +1669,45 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
     // mp-1-f (mp-1-f entries); the diagonal of the rows mp/2.. is one more entry for threads 128.. . (A row per wave and
     // two columns per lane took twice the load instructions, half of them on clamped duplicates above the diagonal --
     // and the head of this launch is bound by the eight waves' load instructions, not by the round trip.)
+    // (32-bit offsets, the second slice at a fixed distance, (row, column) kept packed between request and store: the
+    //  instructions of this phase, two waves per SIMD, are what it takes -- not the round trip)
     const int half_rows = mp >> 1, n_fold = half_rows * mp;
-    auto fold_entry = [&](int e, int& r, int& c) {
-      const int e5 = e >> 5;                       // mp = 32 nb: f = (e / 32) / nb
-      const int f = nb == 4 ? e5 >> 2 : (nb == 3 ? e5 / 3 : (nb == 2 ? e5 >> 1 : e5));
-      const int p = e - f * mp;
-      const bool low = p <= f;
-      r = low ? f : mp - 1 - f;
-      c = low ? p : p - f - 1;
-    };
+    const int slice1 = nsl > 1 ? int(mm) : 0;       // (one slice: the same entry again, times zero)
+    const double w1 = nsl > 1 ? 1.0 : 0.0;
     const bool diag_thread = tid >= 128 && tid < 128 + half_rows;
     const int rd = half_rows + (diag_thread ? tid - 128 : 0);
     double vdiag = 0.0;
     {
-      const int rl = min(rd, m - 1);
-#pragma unroll
-      for (int k = 0; k < 2; ++k) vdiag += Sp[size_t(min(k, nsl - 1)) * mm + size_t(rl) * M1 + rl] * (k < nsl ? 1.0 : 0.0);
+      const int rl = min(rd, m - 1), off = rl * M1 + rl;
+      vdiag = (0.0 + Sp[off] * 1.0) + Sp[off + slice1] * w1;
     }
-    for (int e0 = tid; e0 < n_fold; e0 += kDenseThreads * 16) {
-      double v[16];
+    // (the block count as a compile-time constant: thread tid's entries tid + 512 u then sit at folded row f0 + (16 / NB) u
+    //  and a fixed position -- no division, and most of the index arithmetic folds)
+    auto load_fold = [&](auto nb_tag) {
+      constexpr int NB = decltype(nb_tag)::value, MP = 32 * NB, NFOLD = MP / 2 * MP, NU = (NFOLD + kDenseThreads - 1) / kDenseThreads;
+      double v[NU];
+      int rc[NU];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        int r, c;
-        fold_entry(min(e0 + kDenseThreads * u, n_fold - 1), r, c);
-        const int rl = min(r, m - 1), cl = min(c, rl);
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) acc += Sp[size_t(min(k, nsl - 1)) * mm + size_t(rl) * M1 + cl] * (k < nsl ? 1.0 : 0.0);
-        v[u] = acc;
+      for (int u = 0; u < NU; ++u) {
+        const int e = min(tid + kDenseThreads * u, NFOLD - 1);
+        const int f = (e >> 5) / NB, p = e - f * MP;
+        const bool low = p <= f;
+        const int r = low ? f : MP - 1 - f, c = low ? p : p - f - 1;
+        rc[u] = r << 8 | c;
+        const int rl = min(r, m - 1), cl = min(c, rl), off = rl * M1 + cl;
+        v[u] = (0.0 + Sp[off] * 1.0) + Sp[off + slice1] * w1;
       }
       if (terminated) return;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int e = e0 + kDenseThreads * u;
-        int r, c;
-        fold_entry(min(e, n_fold - 1), r, c);
-        if (e < n_fold) A[r * DNL + c] = (r < m) ? v[u] : (r == c ? 1.0 : 0.0);
+      for (int u = 0; u < NU; ++u) {
+        const int r = rc[u] >> 8, c = rc[u] & 255;
+        if (tid + kDenseThreads * u < NFOLD) A[r * DNL + c] = (r < m) ? v[u] : (r == c ? 1.0 : 0.0);
       }
-    }
+    };
+    if (nb == 4) load_fold(std::integral_constant<int, 4>());
+    else if (nb == 3) load_fold(std::integral_constant<int, 3>());
+    else if (nb == 2) load_fold(std::integral_constant<int, 2>());
+    else load_fold(std::integral_constant<int, 1>());
     if (terminated) return;
     if (diag_thread) A[rd * DNL + rd] = rd < m ? vdiag : 1.0;
     if (tid < 128) {
