@@ -611,7 +611,7 @@ EvalArgs make_eval_args(calico_problem* p, const double* x, int apply_loss, bool
   a.cell_chunk = p->cell_chunk; a.cell_rec_max = p->cell_rec_max; a.project = 0; a.row_cell_chunk = p->row_cell_chunk; a.frame_lds_doubles = p->frame_lds_doubles; a.pad5 = 0; a.wave_log = p->d_wave_log.p; a.active = p->any_tagged ? p->d_active.p : nullptr; a.apply_loss = apply_loss;
   a.st = nullptr; a.need_flag = 0; a.cost_index_base = 0;
   a.fitems = p->d_fitems.p; a.n_fitems = p->n_fitems;
-  a.hint_progress = nullptr; a.hint_seq = 0; a.hint_pad = 0; a.hint_ftol = a.hint_ptol = 0.0;
+  a.hint_progress = nullptr; a.hint_seq = 0; a.hint_first = 0; a.hint_ftol = a.hint_ptol = 0.0;
   a.pair_mode = 0; a.wave_lds_doubles = 0;
   return a;
 }
@@ -1720,6 +1720,9 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, c
   ea.st = st; ea.need_flag = need_flag;
   if (end_hint && tail && st && end_hint_available(p)) {
     ea.hint_progress = tail->progress; ea.hint_seq = tail->seq;
+    // (the hint's workgroup first in the grid: it is dispatched with the launch, not behind the first workgroups that end
+    //  -- the host has the whole evaluation to enqueue the next iteration. CALICO_HINT_FIRST=0: last, A/B switch read per solve)
+    ea.hint_first = [] { const char* e = std::getenv("CALICO_HINT_FIRST"); return !e || std::atoi(e) != 0; }() ? 1 : 0;
     ea.hint_ftol = tail->o.function_tolerance; ea.hint_ptol = tail->o.parameter_tolerance;
   }
   ea.items = p->d_jac_items.p; ea.n_items = p->n_jac_items; ea.cost_index_base = p->n_fitems;

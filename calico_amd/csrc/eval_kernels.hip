@@ -1174,7 +1174,9 @@ DEV void eval_cells_body(const EvalArgs& a, double* lds) {
   const int tid = threadIdx.x, wave = tid >> 6;
   double* const lds_w = lds + size_t(wave) * a.wave_lds_doubles;
   const int n_item_wg = (a.n_items + 1) >> 1, n_cell_wg = a.n_fitems >> 1;
-  const int g = blockIdx.x;
+  const int hint_wg = a.hint_progress && a.st && a.hint_first ? 1 : 0;       // (launch_eval_jacobian: one more workgroup)
+  if (hint_wg && blockIdx.x == 0) { if (wave == 0) end_hint_body(a); return; }
+  const int g = int(blockIdx.x) - hint_wg;
   if (g < n_item_wg) {
     // items g and g + n_item_wg: a gyroscope cell and an accelerometer cell where the problem has both (the items come sorted
     // by sensor). The accelerometer's rows are staged ~4 us after the gyroscope's and [J r]ᵀ[J r] is 10 tiles x 16 MFMAs for

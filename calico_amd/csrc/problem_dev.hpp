@@ -120,7 +120,7 @@ struct EvalArgs {
   // the host enqueues the next iteration only on "go" (progress word 2), so that a solve that ends leaves no iteration of
   // early-exit kernels behind on the stream. nullptr: no hint.
   int* hint_progress;
-  int hint_seq, hint_pad;
+  int hint_seq, hint_first;       // hint_first: the hint's workgroup is block 0 of eval_cells_kernel (else the last one)
   double hint_ftol, hint_ptol;
   // Cell workgroups (plans with `fuse_expand`; eval_cells_kernel): the Jacobian launch runs workgroups of TWO waves -- the
   // (at most two) frames of one camera cell, which then expand the cell's block together out of LDS: no compact record
