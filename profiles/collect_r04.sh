@@ -45,6 +45,10 @@ for c in 1 2 4; do for v in panel mfma; do CALICO_ELIM=$v timeout 300 python $RE
 for sw in CALICO_FUSE_EXPAND CALICO_PREDICT_END CALICO_ARENA CALICO_GATHER_XCD; do for r in 1 2 3; do for v in 0 1; do env $sw=$v timeout 300 python $REPO/bench.py --no-cpu-baseline --repeats 60 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$sw=$v', round(d['value'],1), 'it/s', d['ms_per_step'], 'ms/iteration')"; done; done; done > $OUT/r04_second_half_ab.txt
 for c in 1 2 4; do for v in 0 1; do CALICO_FUSE_EXPAND=$v timeout 300 python $REPO/bench.py --config $c --no-cpu-baseline --repeats 30 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('configs[$c] CALICO_FUSE_EXPAND=$v', round(d['value'],1), 'it/s')"; done; done >> $OUT/r04_second_half_ab.txt
 if [ -x $REPO/profiles/microbench/bin/any_order ]; then timeout 90 $REPO/profiles/microbench/bin/any_order > $OUT/r04_any_order_launch_microbench.txt 2>&1; fi
+if [ -x $REPO/profiles/microbench/bin/first_touch ]; then timeout 90 $REPO/profiles/microbench/bin/first_touch > $OUT/r04_first_touch_microbench.txt 2>&1; fi
+if [ -x $REPO/profiles/microbench/bin/icache_cold ]; then timeout 90 $REPO/profiles/microbench/bin/icache_cold > $OUT/r04_instruction_fetch_microbench.txt 2>&1; fi
+# 6c. the heads of the tree levels / the reduced solve (third part of the round): the in-tree build against HEAD~n is not
+#     kept as a switch (the changes are structural); profiles/r04_heads_ab.txt holds the same-box runs of the variants
 # 7. the 32x32 block elimination alone on a CU (microbenchmark; built by profiles/microbench/run_block_factor.sh)
 if [ -x $REPO/profiles/microbench/bin/block_factor ]; then timeout 60 $REPO/profiles/microbench/bin/block_factor > $OUT/r04_block_elimination_microbench.txt 2>&1; fi
 ls -la $OUT
