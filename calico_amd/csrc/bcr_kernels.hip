@@ -1683,7 +1683,8 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
     }
     // (the block count as a compile-time constant: thread tid's entries tid + 512 u then sit at folded row f0 + (16 / NB) u
     //  and a fixed position -- no division, and most of the index arithmetic folds)
-    auto load_fold = [&](auto nb_tag) {
+    auto load_fold = [&](auto nb_tag, auto two_tag) {
+      constexpr bool TWO = decltype(two_tag)::value;       // a second K-slice to add
       constexpr int NB = decltype(nb_tag)::value, MP = 32 * NB, NFOLD = MP / 2 * MP, NU = (NFOLD + kDenseThreads - 1) / kDenseThreads;
       double v[NU];
       int rc[NU];
@@ -1695,7 +1696,7 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
         const int r = low ? f : MP - 1 - f, c = low ? p : p - f - 1;
         rc[u] = r << 8 | c;
         const int rl = min(r, m - 1), cl = min(c, rl), off = rl * M1 + cl;
-        v[u] = (0.0 + Sp[off] * 1.0) + Sp[off + slice1] * w1;
+        v[u] = TWO ? (0.0 + Sp[off] * 1.0) + Sp[off + slice1] * w1 : Sp[off];
       }
       if (terminated) return;
 #pragma unroll
@@ -1704,10 +1705,17 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
         if (tid + kDenseThreads * u < NFOLD) A[r * DNL + c] = (r < m) ? v[u] : (r == c ? 1.0 : 0.0);
       }
     };
-    if (nb == 4) load_fold(std::integral_constant<int, 4>());
-    else if (nb == 3) load_fold(std::integral_constant<int, 3>());
-    else if (nb == 2) load_fold(std::integral_constant<int, 2>());
-    else load_fold(std::integral_constant<int, 1>());
+    if (nsl > 1) {
+      if (nb == 4) load_fold(std::integral_constant<int, 4>(), std::true_type());
+      else if (nb == 3) load_fold(std::integral_constant<int, 3>(), std::true_type());
+      else if (nb == 2) load_fold(std::integral_constant<int, 2>(), std::true_type());
+      else load_fold(std::integral_constant<int, 1>(), std::true_type());
+    } else {
+      if (nb == 4) load_fold(std::integral_constant<int, 4>(), std::false_type());
+      else if (nb == 3) load_fold(std::integral_constant<int, 3>(), std::false_type());
+      else if (nb == 2) load_fold(std::integral_constant<int, 2>(), std::false_type());
+      else load_fold(std::integral_constant<int, 1>(), std::false_type());
+    }
     if (terminated) return;
     if (diag_thread) A[rd * DNL + rd] = rd < m ? vdiag : 1.0;
     if (tid < 128) {

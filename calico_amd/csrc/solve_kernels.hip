@@ -2011,8 +2011,14 @@ int reduced_schur_slices(const SolveArgs& a) {
   const char* e = std::getenv("CALICO_DENSE");
   const bool panel = e && std::string(e) == "panel";
   if (a.m + 1 <= 128 && !panel) {
+    // (CALICO_SCHUR_SLICES=1 / 2: A/B switch, read per solve)
+    if (const char* se = std::getenv("CALICO_SCHUR_SLICES")) return std::max(1, std::min(kSchurSlices, std::atoi(se)));
     if (a.n_cp >= 1280) return 8;
     if (a.n_cp >= 640) return 4;
+    // Short trajectories: ONE slice. The tiles' workgroups ride beside the last level's chains and have time to spare
+    // (< 1k eliminated rows each), while every slice is 16 more load instructions per thread at the head of the reduced
+    // solve, the launch's critical path (configs[3]: 30.6 -> 29.9 us, level 1 unchanged).
+    if (a.n_cp < 160) return 1;
   }
   return kSchurSlices;
 }

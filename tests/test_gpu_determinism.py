@@ -81,7 +81,7 @@ def test_solver_variants_agree(monkeypatch):
                         ("CALICO_GATHER_FIXED", "0"), ("CALICO_ELIM", "panel"),       # round 4: the block factorisation of rounds 1-3 instead of block_elim.hpp
                         ("CALICO_PREDICT_END", "0"), ("CALICO_INLINE_NODES", "0"),
                         ("CALICO_FUSE_EXPAND", "0"),        # the cell expansion in a launch of its own, IMU cells as row cells
-                        ("CALICO_GATHER_XCD", "0")]:        # the gather's workgroups in output order instead of dealt to the XCDs by stretches of time
+                        ("CALICO_GATHER_XCD", "0"), ("CALICO_SCHUR_SLICES", "2"), ("CALICO_HINT_FIRST", "0")]:        # the gather's workgroups in output order instead of dealt to the XCDs by stretches of time
         monkeypatch.setenv(name, value)
         results[(name, value)] = _solve_repeatedly(api, scene, repeats=1, max_iter=50)[0]
         monkeypatch.delenv(name)
