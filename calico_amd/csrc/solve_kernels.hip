@@ -2010,9 +2010,9 @@ int reduced_schur_slices(const SolveArgs& a) {
   // More slices there; the in-LDS 32-column-block solver adds up to eight on load (the 16-column panel solver two).
   const char* e = std::getenv("CALICO_DENSE");
   const bool panel = e && std::string(e) == "panel";
+  // (CALICO_SCHUR_SLICES=1 / 2: A/B switch, read per solve)
+  if (const char* se = std::getenv("CALICO_SCHUR_SLICES")) return std::max(1, std::min(kSchurSlices, std::atoi(se)));
   if (a.m + 1 <= 128 && !panel) {
-    // (CALICO_SCHUR_SLICES=1 / 2: A/B switch, read per solve)
-    if (const char* se = std::getenv("CALICO_SCHUR_SLICES")) return std::max(1, std::min(kSchurSlices, std::atoi(se)));
     if (a.n_cp >= 1280) return 8;
     if (a.n_cp >= 640) return 4;
     // Short trajectories: ONE slice. The tiles' workgroups ride beside the last level's chains and have time to spare
@@ -2020,6 +2020,10 @@ int reduced_schur_slices(const SolveArgs& a) {
     // solve, the launch's critical path (configs[3]: 30.6 -> 29.9 us, level 1 unchanged).
     if (a.n_cp < 160) return 1;
   }
+  // (the blocked factorisation of a larger system adds its slices up in its first step, the longest of its launches:
+  //  configs[4], 222 control points: 3425 -> 3548 it/s with one slice; at 440 control points the tiles' workgroups would
+  //  end the last level's launch -- there the in-LDS path loses 2.9 % with one)
+  if (a.n_cp < 320) return 1;
   return kSchurSlices;
 }
 // Dense solve of the (m+1)x(m+1) augmented reduced system in a.Spart (ks K-slices) -> a.y[n_s ...]
