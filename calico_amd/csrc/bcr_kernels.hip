@@ -1635,7 +1635,11 @@ constexpr int DNL = 129;     // row stride of the dense matrix in LDS
 // below (Z = A_ij L⁻ᵀ comes out of the factorisation, in place) and the right-hand side as a single-row tile (z = g L⁻ᵀ) --,
 // waves 4..7 beside them the trailing tiles of the block before that the current block does not touch; between two
 // blocks one phase: right-hand side of the rows below, and the trailing update of the NEXT block's two column tiles.
+// COH (the body rides in reduced_fused_kernel behind the blocked steps of the same launch): what those steps wrote -- the
+// system that is left, the factor's panels, the forward-substituted right-hand side -- is read with L1-bypassing loads.
+template <bool COH = false>
 DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const Handoff& ho, int t0 = 0, int outer_back = 0, int elim = 0) {
+  auto ldc = [](const double* p) { return COH ? load_sc1(p) : *p; };
   const long long t_entry = CAL_DEV_TIMING(a.debug != 0) ? __builtin_readcyclecounter() : 0;
   LmState* st = a.st;
   const int terminated = st->terminated;
@@ -1662,7 +1666,7 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
     if (tid < 128) {
       const int c = min(tid, m - 1);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) rhs_acc += Sp[size_t(min(k, nsl - 1)) * mm + size_t(m) * M1 + c] * (k < nsl ? 1.0 : 0.0);
+      for (int k = 0; k < 8; ++k) rhs_acc += ldc(Sp + size_t(min(k, nsl - 1)) * mm + size_t(m) * M1 + c) * (k < nsl ? 1.0 : 0.0);
     }
     // The lower triangle FOLDED into a rectangle of mp/2 rows of mp entries, dealt flat over the workgroup (sixteen entries per
     // thread at mp = 128): folded row f is row f with its diagonal (f + 1 entries) followed by the strict lower part of row
@@ -1679,7 +1683,7 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
     double vdiag = 0.0;
     {
       const int rl = min(rd, m - 1), off = rl * M1 + rl;
-      vdiag = (0.0 + Sp[off] * 1.0) + Sp[off + slice1] * w1;
+      vdiag = (0.0 + ldc(Sp + off) * 1.0) + ldc(Sp + off + slice1) * w1;
     }
     // (the block count as a compile-time constant: thread tid's entries tid + 512 u then sit at folded row f0 + (16 / NB) u
     //  and a fixed position -- no division, and most of the index arithmetic folds)
@@ -1696,7 +1700,7 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
         const int r = low ? f : MP - 1 - f, c = low ? p : p - f - 1;
         rc[u] = r << 8 | c;
         const int rl = min(r, m - 1), cl = min(c, rl), off = rl * M1 + cl;
-        v[u] = TWO ? (0.0 + Sp[off] * 1.0) + Sp[off + slice1] * w1 : Sp[off];
+        v[u] = TWO ? (0.0 + ldc(Sp + off) * 1.0) + ldc(Sp + off + slice1) * w1 : ldc(Sp + off);
       }
       if (terminated) return;
 #pragma unroll
@@ -2006,7 +2010,7 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
       for (int i0 = c0 + BP + g; i0 < mt; i0 += 64) {
         double lv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) lv[u] = Lg[size_t(min(i0 + 16 * u, mt - 1)) * M1 + c0 + c];
+        for (int u = 0; u < 4; ++u) lv[u] = ldc(Lg + size_t(min(i0 + 16 * u, mt - 1)) * M1 + c0 + c);
 #pragma unroll
         for (int u = 0; u < 4; ++u) part += i0 + 16 * u < mt ? lv[u] * ybig[i0 + 16 * u] : 0.0;
       }
@@ -2014,10 +2018,10 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int e = tid + kDenseThreads * u, r = e >> 5, c2 = e & 31;
-        const double v = Lg[size_t(c0 + r) * M1 + c0 + c2];
+        const double v = ldc(Lg + size_t(c0 + r) * M1 + c0 + c2);
         Mt[r * 33 + c2] = c2 > r ? v : (c2 == r ? 1.0 / v : 0.0);
       }
-      const double zq = tid < BP ? Lg[size_t(mt) * M1 + c0 + tid] : 0.0;
+      const double zq = tid < BP ? ldc(Lg + size_t(mt) * M1 + c0 + tid) : 0.0;
       lds_barrier();
       if (tid < BP) {
         double pd = 0.0;
@@ -2092,10 +2096,16 @@ void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s, int t0,
 // ---------------------------------------------------------------------------
 constexpr int kStepThreads = 512;
 constexpr int PTL = 65;       // row stride of the transposed panel blocks [32][64]
-__global__ __launch_bounds__(kStepThreads) void reduced_block_step_mfma_kernel(SolveArgs a, int j, int nsl) {
+// FUSED (reduced_fused_kernel: all steps and the in-LDS solve in one launch, step j + 1 behind a fan-in of step j's
+// workgroups): the trailing matrix and the factor's panels leave with write-through stores and are read with L1-bypassing
+// loads; `bid` is the workgroup's number within its step. Returns without a word on a terminated solve -- the caller arrives
+// at the fan-in either way.
+template <bool FUSED>
+DEVI void reduced_block_step_body(const SolveArgs& a, int j, int nsl, int bid, double* lds) {
+  auto ldA = [](const double* p) { return FUSED ? load_sc1(p) : *p; };
+  auto stA = [](double* p, double v) { if (FUSED) store_sc1(p, v); else *p = v; };
   LmState* st = a.st;
   if (st->terminated) return;
-  extern __shared__ double lds[];
   double* const Daug = lds;                        // [64][DLD]: rows 0..31 A_jj -> L_jj, rows 32..63 identity -> L⁻ᵀ
   double* const PT = Daug + 64 * DLD;              // [2][32][PTL]: panel rows of block rows I and K, transposed
   double* const ZT = PT + 2 * BP * PTL;            // [2][32][PTL]: Zᵀ = L⁻¹ Pᵀ
@@ -2106,7 +2116,7 @@ __global__ __launch_bounds__(kStepThreads) void reduced_block_step_mfma_kernel(S
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, lk = lane >> 4;
   const int c0 = BP * j, t0 = c0 + BP;
-  int I = 0, rem = blockIdx.x;
+  int I = 0, rem = bid;
   while (rem > I) { rem -= I + 1; ++I; }
   const int K = rem;
   const int rI = t0 + 64 * I, rK = t0 + 64 * K;
@@ -2120,8 +2130,8 @@ __global__ __launch_bounds__(kStepThreads) void reduced_block_step_mfma_kernel(S
   for (int u = 0; u < 2; ++u) {      // pivot block: the lower triangle is stored, the upper one mirrored
     const int e = tid + kStepThreads * u, r = e >> 5, c = e & 31;
     const size_t o = size_t(c0 + max(r, c)) * m1 + c0 + min(r, c);
-    double v = A[o];
-    for (int k = 1; k < nsl; ++k) v += A[size_t(k) * msq + o];
+    double v = ldA(A + o);
+    for (int k = 1; k < nsl; ++k) v += ldA(A + size_t(k) * msq + o);
     dv[u] = v;
   }
 #pragma unroll
@@ -2132,8 +2142,8 @@ __global__ __launch_bounds__(kStepThreads) void reduced_block_step_mfma_kernel(S
       const int e = tid + kStepThreads * u, r = e >> 5, c = e & 31;
       const int row = rb + r;
       const size_t o = size_t(min(row, m1 - 1)) * m1 + c0 + c;
-      double v = A[o];
-      for (int k = 1; k < nsl; ++k) v += A[size_t(k) * msq + o];
+      double v = ldA(A + o);
+      for (int k = 1; k < nsl; ++k) v += ldA(A + size_t(k) * msq + o);
       pv[h][u] = row < m1 ? v : 0.0;
     }
   }
@@ -2147,8 +2157,8 @@ __global__ __launch_bounds__(kStepThreads) void reduced_block_step_mfma_kernel(S
     for (int r = 0; r < 4; ++r) {
       const int ur = rI + 16 * ti + lk + 4 * r, uc = rK + 16 * tj + l16;
       const size_t o = size_t(min(ur, m1 - 1)) * m1 + min(uc, m1 - 1);
-      double v = A[o];
-      for (int k = 1; k < nsl; ++k) v += A[size_t(k) * msq + o];
+      double v = ldA(A + o);
+      for (int k = 1; k < nsl; ++k) v += ldA(A + size_t(k) * msq + o);
       tacc[q][r] = v;
     }
   }
@@ -2190,18 +2200,18 @@ __global__ __launch_bounds__(kStepThreads) void reduced_block_step_mfma_kernel(S
   }
   lds_barrier();
   // ---- file the panel: L_jj (workgroup 0), the rows below (first tile column) ----
-  if (blockIdx.x == 0) {      // (L⁻ᵀ in the strict upper triangle beside L: the backward sweep multiplies by it, its diagonal is 1 / L_rr)
+  if (bid == 0) {      // (L⁻ᵀ in the strict upper triangle beside L: the backward sweep multiplies by it, its diagonal is 1 / L_rr)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int e = tid + kStepThreads * u, r = e >> 5, c = e & 31;
-      L[size_t(c0 + r) * m1 + c0 + c] = c <= r ? Daug[r * DLD + c] : Daug[(BP + r) * DLD + c];
+      stA(L + size_t(c0 + r) * m1 + c0 + c, c <= r ? Daug[r * DLD + c] : Daug[(BP + r) * DLD + c]);
     }
   }
   if (K == 0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = tid + kStepThreads * u, r = e >> 5, c = e & 31;
-      if (rI + r < m1) L[size_t(rI + r) * m1 + c0 + c] = ZT[c * PTL + r];
+      if (rI + r < m1) stA(L + size_t(rI + r) * m1 + c0 + c, ZT[c * PTL + r]);
     }
   }
   // ---- tile update: A_IK -= Z_I Z_Kᵀ ----
@@ -2212,14 +2222,57 @@ __global__ __launch_bounds__(kStepThreads) void reduced_block_step_mfma_kernel(S
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ur = rI + 16 * ti + lk + 4 * r, uc = rK + 16 * tj + l16;
-      if (ur < m1 && uc <= ur) A[size_t(ur) * m1 + uc] = tacc[q][r];
+      if (ur < m1 && uc <= ur) stA(A + size_t(ur) * m1 + uc, tacc[q][r]);
     }
   }
+}
+__global__ __launch_bounds__(kStepThreads) void reduced_block_step_mfma_kernel(SolveArgs a, int j, int nsl) {
+  extern __shared__ double lds[];
+  reduced_block_step_body<false>(a, j, nsl, int(blockIdx.x), lds);
+}
+// Workgroups of step j of the blocked factorisation (T(T+1)/2 tiles of 64x64 below the panel, at least one)
+__host__ __device__ inline int reduced_step_workgroups(int m1, int j) {
+  const int rows = m1 - BP * (j + 1), T = rows > 0 ? (rows + 63) / 64 : 0;
+  return T > 0 ? T * (T + 1) / 2 : 1;
+}
+// The whole blocked factorisation of a reduced system of more than 128 columns in ONE launch: the workgroups of step j + 1
+// wait for those of step j at a fan-in word (words[j]; every workgroup arrives, terminated solve or not), the last
+// workgroup is the in-LDS solver of what the steps leave (dense_block_solve_body with the blocked backward sweep behind
+// it) and waits for the last step. All of them are resident at once (launch_reduced_fused checks the count), so nobody
+// waits for a workgroup that has no CU. The solver's workgroup clears the words behind its wait: every other waiter has
+// passed its own by then (it has arrived at a later word), and the next launch finds zeros.
+static_assert(kStepThreads == kDenseThreads, "one launch, one workgroup size");
+__global__ __launch_bounds__(kStepThreads) void reduced_fused_kernel(SolveArgs a, int nsteps, int nsl, int* words, int elim) {
+  extern __shared__ double lds[];
+  const int m1 = a.m + 1;
+  int bid = blockIdx.x, j = 0;
+  for (; j < nsteps; ++j) { const int nw = reduced_step_workgroups(m1, j); if (bid < nw) break; bid -= nw; }
+  if (j < nsteps) {
+    if (j > 0) fanin_wait(words + j - 1, reduced_step_workgroups(m1, j - 1));
+    reduced_block_step_body<true>(a, j, j == 0 ? nsl : 1, bid, lds);
+    fanin_arrive(words + j);
+    return;
+  }
+  fanin_wait(words + nsteps - 1, reduced_step_workgroups(m1, nsteps - 1));
+  if (int(threadIdx.x) < nsteps) __hip_atomic_store(words + threadIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  dense_block_solve_body<true>(a, 1, lds, Handoff{nullptr, 0}, BP * nsteps, 1, elim);
 }
 size_t reduced_block_step_lds_bytes() { return size_t(64 * DLD + 4 * BP * PTL + 80 + 128 + kStepThreads) * sizeof(double); }
 hipError_t configure_reduced_block_step() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&reduced_block_step_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                              int(reduced_block_step_lds_bytes()));
+}
+size_t reduced_fused_lds_bytes() { return std::max(reduced_block_step_lds_bytes(), dense_block_solve_lds_bytes()); }
+hipError_t configure_reduced_fused() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&reduced_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(reduced_fused_lds_bytes()));
+}
+// false: too many workgroups to count on all of them being resident together (one per CU with the solver's LDS footprint)
+bool launch_reduced_fused(const SolveArgs& a, int nsteps, int nsl, int* words, hipStream_t s) {
+  int n_wg = 1;
+  for (int j = 0; j < nsteps; ++j) n_wg += reduced_step_workgroups(a.m + 1, j);
+  if (nsteps < 1 || nsteps > 8 || n_wg > 128) return false;
+  hipLaunchKernelGGL(reduced_fused_kernel, dim3(n_wg), dim3(kStepThreads), reduced_fused_lds_bytes(), s, a, nsteps, nsl, words, block_elim_enabled() ? 1 : 0);
+  return true;
 }
 void launch_reduced_block_step(const SolveArgs& a, int j, int nsl, int n_wg, hipStream_t s) {
   hipLaunchKernelGGL(reduced_block_step_mfma_kernel, dim3(n_wg), dim3(kStepThreads), reduced_block_step_lds_bytes(), s, a, j, nsl);

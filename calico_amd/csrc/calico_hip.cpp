@@ -84,6 +84,7 @@ size_t bcr_back_lds_bytes(int q_max, int m1p);
 hipError_t configure_bcr_kernels(int q_max, int m1p);
 hipError_t configure_dense_block_solve();
 hipError_t configure_reduced_block_step();
+hipError_t configure_reduced_fused();
 size_t dense_block_solve_lds_bytes();
 void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, int level, int keep0, int n_keep, const LmOptionsDev& o,
                       const double* x, const BlockDev* blocks, int n_blocks, int with_post_eval, IterLog* log, int log_cap, int jacobi,
@@ -93,7 +94,7 @@ void launch_bcr_schur(const SolveArgs& a, const BcrArgs& b, int ks, const LmOpti
 void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, bool top, bool extras, bool border_rows, int q_max,
                      const double* x, double* x_cand, const BlockDev* blocks, int n_blocks, const BcrTopSeps& ts, hipStream_t s);
 
-void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipStream_t s);
+void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipStream_t s, int* fan_words);
 bool dense_back_fusable(const SolveArgs& a, int ks, int q_max, bool border_rows);
 size_t dense_back_lds_bytes(int q_max, int m1p);
 hipError_t configure_dense_back_bytes(size_t lds);
@@ -1578,6 +1579,7 @@ int configure_kernels(calico_problem* p) {
   HIP_TRY(p, configure_solve_kernels(nw[1], nw[2], nw[3]));
   HIP_TRY(p, configure_dense_block_solve());
   HIP_TRY(p, configure_reduced_block_step());
+  HIP_TRY(p, configure_reduced_fused());
   if (nw[4]) HIP_TRY(p, configure_bcr_kernels(int(nw[5]), int(nw[6])));
   if (nw[7]) HIP_TRY(p, configure_dense_back_bytes(nw[7]));
   cur = nw;
@@ -1809,7 +1811,7 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
     p->handoff_seq = p->handoff_seq % 0x3fffffff + 1;
     launch_dense_back(sa, b, ks, lf.node0, lf.n_nodes, lf.q_max, p->d_x.p, p->d_xc.p, p->d_blocks.p, n_blocks, ts, p->d_handoff.p, p->handoff_seq, s);
   } else {
-    launch_reduced_solve(sa, p->dense_in_lds, ks, s);
+    launch_reduced_solve(sa, p->dense_in_lds, ks, s, p->d_handoff.p + 8);      // (words 8..15: the fan-ins of a blocked factorisation in one launch)
   }
   p->timer.end(s);
   for (int l = L - 1; l >= 0; --l) {

@@ -2029,7 +2029,8 @@ int reduced_schur_slices(const SolveArgs& a) {
 // Dense solve of the (m+1)x(m+1) augmented reduced system in a.Spart (ks K-slices) -> a.y[n_s ...]
 void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s, int t0 = 0, int outer_back = 0);     // bcr_kernels.hip
 void launch_reduced_block_step(const SolveArgs& a, int j, int nsl, int n_wg, hipStream_t s);     // bcr_kernels.hip
-void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipStream_t s) {
+bool launch_reduced_fused(const SolveArgs& a, int nsteps, int nsl, int* words, hipStream_t s);     // bcr_kernels.hip
+void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipStream_t s, int* fan_words) {
   const int m1 = a.m + 1;
   const bool blocked = reduced_is_blocked(a);
   // CALICO_DENSE=panel keeps the 16-column panel kernel for the in-LDS case (A/B switch)
@@ -2046,12 +2047,18 @@ void launch_reduced_solve(const SolveArgs& a, bool reduced_in_lds, int ks, hipSt
     // CALICO_BLOCK_STEP=valu: round 2's step kernel (in-wave column Cholesky on 64 rows, VALU tile update) and backward
     // sweep in a launch of its own -- A/B switch
     const bool step_mfma = [] { const char* e = std::getenv("CALICO_BLOCK_STEP"); return !(e && std::string(e) == "valu"); }();
+    const bool fused_back = step_mfma && use_block && mt1 >= 2 && a.m <= 1024;     // (the dense solver goes on with the panels' backward sweep)
+    // CALICO_REDUCED_FUSED=1: all of it in ONE launch (reduced_fused_kernel: the steps behind fan-ins of one another, the
+    // in-LDS solver last). Off by default: a step has nothing to do before the step in front of it is through, so a fan-in
+    // only replaces the boundary -- by L1-bypassing loads and write-through stores of everything that crosses it: configs[4]
+    // 3545 -> 3520 it/s (read per solve).
+    const bool one_launch = fused_back && fan_words && [] { const char* e = std::getenv("CALICO_REDUCED_FUSED"); return e && std::atoi(e) != 0; }();
+    if (one_launch && launch_reduced_fused(a, steps, ks, fan_words, s)) return;
     for (int j = 0; j < steps; ++j) {
       const int rows = m1 - kRB * (j + 1), T = rows > 0 ? (rows + 63) / 64 : 0;
       if (step_mfma) launch_reduced_block_step(a, j, j == 0 ? ks : 1, T > 0 ? T * (T + 1) / 2 : 1, s);
       else hipLaunchKernelGGL(reduced_block_step_kernel, dim3(T > 0 ? T * (T + 1) / 2 : 1), dim3(256), 0, s, a, j, j == 0 ? ks : 1);
     }
-    const bool fused_back = step_mfma && use_block && mt1 >= 2 && a.m <= 1024;     // (the dense solver goes on with the panels' backward sweep)
     if (use_block && mt1 >= 2) launch_dense_block_solve(a, 1, s, t0, fused_back ? 1 : 0);     // (the 32-column-block solver of the small systems)
     else {
       const size_t lds = (size_t(mt1) * ((16 * ((mt1 + 15) / 16)) | 1) + mt1 + 32 + 128 + 256) * sizeof(double);
@@ -2092,7 +2099,7 @@ void launch_solve(const SolveArgs& a, const LmOptionsDev& o, const double* x, do
   const int nt = (m1 + 15) / 16;
   const int ks = reduced_schur_slices(a);
   hipLaunchKernelGGL(schur_kernel, dim3(nt * (nt + 1) / 2 * ks), dim3(256), 0, s, a, ks);
-  launch_reduced_solve(a, reduced_in_lds, ks, s);
+  launch_reduced_solve(a, reduced_in_lds, ks, s, nullptr);
   hipLaunchKernelGGL(border_matvec_kernel, dim3((a.n_s() + 3) / 4), dim3(256), 0, s, a);
   {
     const size_t bl = band_backsolve_lds_bytes(a);

@@ -206,7 +206,13 @@ def test_large_reduced_system_kernels_agree(monkeypatch):
                            pixel_noise=0.1, gyro_noise=1e-3, accel_noise=1e-2, robust=True, segment_duration=4.0 / 23.9,
                            max_cam_obs=20000, n_imus=2)
     runs = {}
-    for step, dense in (("", ""), ("valu", ""), ("", "panel")):
+    for step, dense, fused in (("", "", ""), ("valu", "", ""), ("", "panel", ""), ("", "", "1")):
+        # (fused = "1": all steps and the in-LDS solver in ONE launch behind in-launch fan-ins, reduced_fused_kernel --
+        #  measured 0.7 % slower than a launch per step at configs[4], hence off by default)
+        if fused:
+            monkeypatch.setenv("CALICO_REDUCED_FUSED", fused)
+        else:
+            monkeypatch.delenv("CALICO_REDUCED_FUSED", raising=False)
         if step:
             monkeypatch.setenv("CALICO_BLOCK_STEP", step)
         else:
@@ -215,8 +221,9 @@ def test_large_reduced_system_kernels_agree(monkeypatch):
             monkeypatch.setenv("CALICO_DENSE", dense)
         else:
             monkeypatch.delenv("CALICO_DENSE", raising=False)
-        runs[(step, dense)] = _solve_repeatedly(api, scene, repeats=2, max_iter=20)
-    ref = runs[("", "")]
+        runs[(step, dense, fused)] = _solve_repeatedly(api, scene, repeats=2, max_iter=20)
+    monkeypatch.delenv("CALICO_REDUCED_FUSED", raising=False)
+    ref = runs[("", "", "")]
     assert ref[0][0] > 3
     assert ref[0][2] == ref[1][2] and np.array_equal(ref[0][3], ref[1][3]), "the default path is not reproducible"
     for key, rr in runs.items():
