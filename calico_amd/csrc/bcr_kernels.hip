@@ -1665,8 +1665,14 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
     double rhs_acc = 0.0;
     if (tid < 128) {
       const int c = min(tid, m - 1);
+      // (one request per slice there is: these two waves carry the longest share of the load phase's instructions)
+      const double* const rp = Sp + size_t(m) * M1 + c;
+      rhs_acc = 0.0 + ldc(rp);
+      if (nsl > 1) rhs_acc += ldc(rp + mm);
+      if (nsl > 2) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) rhs_acc += ldc(Sp + size_t(min(k, nsl - 1)) * mm + size_t(m) * M1 + c) * (k < nsl ? 1.0 : 0.0);
+        for (int k = 2; k < 8; ++k) rhs_acc += ldc(rp + size_t(min(k, nsl - 1)) * mm) * (k < nsl ? 1.0 : 0.0);
+      }
     }
     // The lower triangle FOLDED into a rectangle of mp/2 rows of mp entries, dealt flat over the workgroup (sixteen entries per
     // thread at mp = 128): folded row f is row f with its diagonal (f + 1 entries) followed by the strict lower part of row
