@@ -124,7 +124,7 @@ ABI_SYMBOLS = [
     "comm_get_unique_id", "comm_init_rccl", "comm_info", "problem_finalize", "plan_cache_stats", "plan_cache_clear",
 ]
 # Test hooks (calico_amd/csrc/calico_hip_testing.h): exported, not part of the drop-in surface.
-TEST_SYMBOLS = ["debug_lm_control_replay"]
+TEST_SYMBOLS = ["debug_lm_control_replay", "debug_plan_info"]
 
 
 class CApi:
@@ -182,6 +182,7 @@ class CApi:
             g("plan_cache_clear", C.c_int32, [])
             g("debug_lm_control_replay", C.c_int32,
               [C.c_int32, C.c_int32, D, I, C.POINTER(SolverOptions), D, I, D])
+            g("debug_plan_info", C.c_int32, [P, I, C.c_int32])
 
     def _get(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)
@@ -391,6 +392,13 @@ class Problem:
 
     def finalize(self):
         self._check(self.api.problem_finalize(self.h))
+
+    def plan_info(self):
+        """Test hook (calico_hip_testing.h): which evaluation route / solver the plan of this handle takes."""
+        out = np.zeros(8, np.int32)
+        self._check(self.api.debug_plan_info(self.h, out.ctypes.data_as(C.POINTER(C.c_int32)), 8))
+        keys = ("fuse_expand", "frames", "items", "cells", "max_frames_per_cell", "max_items_per_cell", "tree_solver", "m")
+        return dict(zip(keys, (int(v) for v in out)))
 
     def comm_init_rccl(self, unique_id, rank, world_size):
         """Native exchange: the handle creates its own RCCL communicator from the 128-byte id (see comm_unique_id)."""

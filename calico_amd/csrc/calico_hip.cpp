@@ -186,16 +186,19 @@ struct HSensor {
 // Device memory of plans and workspaces comes out of a few large slabs instead of one hipMalloc per buffer: a handle
 // has some forty buffers, most of them a few KB, and a buffer of its own sits on pages of its own -- every kernel's
 // first touch of each (state, descriptors, index lists, ...) then costs an address translation of its own behind the
-// kernel boundary. One slab is one allocation of >= 64 MB: contiguous, mapped with the largest fragments the driver
+// kernel boundary. One slab is one allocation of 64 MB: contiguous, mapped with the largest fragments the driver
 // has. First fit over a free list ordered by address, neighbours merged on release; a request no slab can serve opens
-// a new slab (a multiple of 64 MB), and if that fails the request goes to hipMalloc as before. The slabs are never
-// returned (like the stream and pinned pools: no HIP calls during static destruction). CALICO_ARENA=0: hipMalloc per
-// buffer (rounds 1-4).
+// a new slab, and if that fails the request goes to hipMalloc as before. A request larger than a slab is an allocation
+// of its own (hipMalloc / hipFree: it has large fragments anyway and must not pin memory for good).
+// Slabs go back to the driver: trim() frees every slab that is one free extent -- calico_plan_cache_clear() frees all of
+// them, calico_problem_destroy() all but one per device (the next handle's) -- so a process that once solved a large
+// problem, or that shares the GPU with PyTorch / RCCL, does not keep that memory. (No HIP calls during static
+// destruction: what is still held at exit is the driver's to reclaim.) CALICO_ARENA=0: hipMalloc per buffer (rounds 1-4).
 class DeviceArena {
  public:
   static DeviceArena& get() { static DeviceArena* a = new DeviceArena; return *a; }
   hipError_t alloc(void** out, size_t bytes) {
-    if (!enabled_) return hipMalloc(out, bytes);
+    if (!enabled_ || bytes > kSlab) return hipMalloc(out, bytes);
     bytes = (bytes + kAlign - 1) / kAlign * kAlign;
     std::lock_guard<std::mutex> g(mu_);
     int dev = 0; (void)hipGetDevice(&dev);
@@ -213,47 +216,85 @@ class DeviceArena {
         }
       }
       if (pass == 1) break;
-      const size_t want = (bytes + kSlab - 1) / kSlab * kSlab;
       void* base = nullptr;
-      if (hipMalloc(&base, want) != hipSuccess) { (void)hipGetLastError(); break; }
-      Slab sl; sl.base = static_cast<char*>(base); sl.size = want; sl.device = dev; sl.free.emplace(0, want);
+      if (hipMalloc(&base, kSlab) != hipSuccess) { (void)hipGetLastError(); break; }
+      Slab sl; sl.base = static_cast<char*>(base); sl.size = kSlab; sl.device = dev; sl.free.emplace(0, kSlab);
       slabs_.push_back(std::move(sl));
     }
     return hipMalloc(out, bytes);      // (not in used_: release() hands it to hipFree)
   }
   void release(void* p) {
     if (!p) return;
-    // hipFree waits for the device; a block that goes back to the free list must do the same (a solve returns while the
-    // early-exit kernels of the iterations enqueued ahead are still on its stream)
-    if (enabled_) (void)hipDeviceSynchronize();
+    int owner = -1;
     {
       std::lock_guard<std::mutex> g(mu_);
-      auto u = used_.find(p);
-      if (u != used_.end()) {
-        const size_t bytes = u->second;
-        used_.erase(u);
-        for (Slab& sl : slabs_) {
-          char* c = static_cast<char*>(p);
-          if (c < sl.base || c >= sl.base + sl.size) continue;
-          size_t off = size_t(c - sl.base), len = bytes;
-          auto next = sl.free.lower_bound(off);
-          if (next != sl.free.end() && next->first == off + len) { len += next->second; next = sl.free.erase(next); }
-          if (next != sl.free.begin()) {
-            auto prev = std::prev(next);
-            if (prev->first + prev->second == off) { off = prev->first; len += prev->second; sl.free.erase(prev); }
-          }
-          sl.free.emplace(off, len);
-          return;
-        }
-        return;
+      if (used_.count(p))
+        for (const Slab& sl : slabs_)
+          if (static_cast<char*>(p) >= sl.base && static_cast<char*>(p) < sl.base + sl.size) { owner = sl.device; break; }
+    }
+    if (owner < 0) { (void)hipFree(p); return; }
+    // hipFree waits for the device; a block that goes back to the free list must do the same (a solve returns while the
+    // early-exit kernels of the iterations enqueued ahead are still on its stream) -- for the device that OWNS the slab,
+    // and once per batch of releases (Batch below), not once per buffer
+    if (batch_device() != owner) sync_device(owner);
+    std::lock_guard<std::mutex> g(mu_);
+    auto u = used_.find(p);
+    if (u == used_.end()) return;
+    const size_t bytes = u->second;
+    used_.erase(u);
+    for (Slab& sl : slabs_) {
+      char* c = static_cast<char*>(p);
+      if (c < sl.base || c >= sl.base + sl.size) continue;
+      size_t off = size_t(c - sl.base), len = bytes;
+      auto next = sl.free.lower_bound(off);
+      if (next != sl.free.end() && next->first == off + len) { len += next->second; next = sl.free.erase(next); }
+      if (next != sl.free.begin()) {
+        auto prev = std::prev(next);
+        if (prev->first + prev->second == off) { off = prev->first; len += prev->second; sl.free.erase(prev); }
+      }
+      sl.free.emplace(off, len);
+      return;
+    }
+  }
+  // Everything a handle or a plan gives back at once (some forty buffers): ONE wait for the owning device, up front.
+  struct Batch {
+    explicit Batch(int device) : prev_(batch_device()) { if (DeviceArena::get().enabled_) { sync_device(device); batch_device() = device; } }
+    ~Batch() { batch_device() = prev_; }
+    Batch(const Batch&) = delete;
+    Batch& operator=(const Batch&) = delete;
+   private:
+    int prev_;
+  };
+  // Frees the slabs nothing lives in; `keep_per_device` of them stay per device for the next handle. Returns the bytes freed.
+  size_t trim(int keep_per_device) {
+    std::vector<Slab> drop;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      std::map<int, int> kept;
+      for (size_t i = 0; i < slabs_.size();) {
+        Slab& sl = slabs_[i];
+        const bool idle = sl.free.size() == 1 && sl.free.begin()->first == 0 && sl.free.begin()->second == sl.size;
+        if (idle && kept[sl.device]++ >= keep_per_device) { drop.push_back(std::move(sl)); slabs_.erase(slabs_.begin() + long(i)); }
+        else ++i;
       }
     }
-    (void)hipFree(p);
+    size_t bytes = 0;
+    for (Slab& sl : drop) { (void)hipFree(sl.base); bytes += sl.size; }     // (hipFree waits for the device itself)
+    return bytes;
   }
+  size_t slab_bytes() { std::lock_guard<std::mutex> g(mu_); size_t b = 0; for (const Slab& sl : slabs_) b += sl.size; return b; }
  private:
   static constexpr size_t kAlign = 4096, kSlab = size_t(64) << 20;
   struct Slab { char* base = nullptr; size_t size = 0; int device = 0; std::map<size_t, size_t> free; };
   DeviceArena() { const char* e = std::getenv("CALICO_ARENA"); enabled_ = !e || std::atoi(e) != 0; }
+  static int& batch_device() { static thread_local int d = -1; return d; }
+  static void sync_device(int device) {
+    int cur = device;
+    (void)hipGetDevice(&cur);
+    if (cur != device) (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    if (cur != device) (void)hipSetDevice(cur);
+  }
   std::mutex mu_;
   std::vector<Slab> slabs_;
   std::unordered_map<void*, size_t> used_;
@@ -905,7 +946,7 @@ int build_plan(calico_problem* p) {
         }
       }
       need = (need + 1) & ~size_t(1);
-      if (2 * need * sizeof(double) + 2048 > kMaxLds) fuse = false;
+      if (cells_launch_lds_bytes(need) > kCellsMaxLds) fuse = false;     // (the same bound the kernel's attribute is set to)
       p->pair_wave_lds_doubles = int(need);
     }
     {
@@ -1244,9 +1285,11 @@ int build_plan(calico_problem* p) {
   HIP_TRY(p, p->d_cp_active.upload(cp_active, s));
   DevBuf<int> d_cnt;                    // (scratch of the device's list build; freed behind the synchronisation below)
   DevBuf<long long> d_scan;
-  const int zero_slot = int(comp_base + comp_off + row_store);      // a word of the partials nobody writes: allocated and cleared with them
+  // a word of the partials nobody writes (allocated and cleared with them): what padded list entries point to. The lists
+  // hold 32-bit positions, so the whole partials buffer must be addressable by one -- checked for every kind of list
+  if (comp_base + comp_off + row_store + 2 >= size_t(0x7fffffff)) return p->set_error(CALICO_UNIMPLEMENTED, "problem too large for 32-bit gather indices");
+  const int zero_slot = int(comp_base + comp_off + row_store);
   if (gs_ok) {
-    if (size_t(zero_slot) + 2 >= size_t(0x7fffffff)) return p->set_error(CALICO_UNIMPLEMENTED, "problem too large for 32-bit gather indices");
     HIP_TRY(p, p->d_gs_tab.upload(gs_tab, s));
     gsd.tab = p->d_gs_tab.p;
     const int per_out = int(layouts.size()) * k;      // (<= 96)
@@ -1277,7 +1320,10 @@ int build_plan(calico_problem* p) {
   HIP_TRY(p, p->d_ptr_fat.upload(ptr_fat, s));
   // the thin outputs' lists at a fixed stride per lane class: the gather then needs no pointer load in front of its index
   // loads (CALICO_GATHER_FIXED=0: the CSR form; read per plan and part of its key)
-  p->gather_fixed = [] { const char* e = std::getenv("CALICO_GATHER_FIXED"); return !e || std::atoi(e) != 0; }() && p->n_thin > 0;
+  // Only for the device-built lists: their lengths are bounded by the structure (layouts x k <= thin_per_lane x 8 per output),
+  // which is what the fixed stride relies on; host-built lists (plans the table cannot describe) keep the CSR form -- padding
+  // each of their short lists to 48 / 96 slots would multiply the index memory, and nothing bounds their length.
+  p->gather_fixed = [] { const char* e = std::getenv("CALICO_GATHER_FIXED"); return !e || std::atoi(e) != 0; }() && p->n_thin > 0 && gs_ok;
   if (p->gather_fixed) {
     HIP_TRY(p, p->d_idx_fixed.alloc(gather_fixed_entries(p->n_thin, p->n_thin8, p->n_thin4, p->thin_per_lane) + 8));
     launch_gather_pack_fixed(p->d_ptr_thin.p, p->d_idx_thin.p, p->n_thin, p->n_thin8, p->n_thin4, p->thin_per_lane, zero_slot, p->d_idx_fixed.p, s);
@@ -1642,14 +1688,22 @@ int finalize(calico_problem* p) {
         static_cast<PlanDev&>(*p).alias_from(e->dev);
         p->plan = e;
         PlanCache& c = plan_cache();
-        std::lock_guard<std::mutex> lock(c.mu);
-        e->last_use = ++c.tick;
-        if (c.entries.size() >= PlanCache::kMaxEntries) {
-          size_t old = 0;
-          for (size_t i = 1; i < c.entries.size(); ++i) if (c.entries[i]->last_use < c.entries[old]->last_use) old = i;
-          c.entries.erase(c.entries.begin() + long(old));      // (handles that still use it keep it alive)
+        std::shared_ptr<PlanEntry> evicted;
+        {
+          std::lock_guard<std::mutex> lock(c.mu);
+          e->last_use = ++c.tick;
+          if (c.entries.size() >= PlanCache::kMaxEntries) {
+            size_t old = 0;
+            for (size_t i = 1; i < c.entries.size(); ++i) if (c.entries[i]->last_use < c.entries[old]->last_use) old = i;
+            evicted = std::move(c.entries[old]);
+            c.entries.erase(c.entries.begin() + long(old));      // (handles that still use it keep it alive)
+          }
+          c.entries.push_back(e);
         }
-        c.entries.push_back(e);
+        if (evicted && evicted.use_count() == 1) {       // its buffers go back now: one wait for ITS device, outside the cache's lock
+          DeviceArena::Batch batch(evicted->key.device);
+          evicted.reset();
+        }
       }
     }
     section(hit ? "plan adopted" : "plan built");
@@ -1735,6 +1789,9 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, c
     launch_eval_frames(ea, p->stream);
     launch_eval(ea, true, p->stream);
   }
+  // a launch the runtime refuses (too much LDS for the kernel's attribute, a bad grid) would leave last iteration's blocks
+  // in place and the solve would go wrong silently on stale partials: ask (a thread-local read, no synchronisation)
+  HIP_TRY(p, hipGetLastError());
   p->timer.end(p->stream);
   p->timer.begin(1, p->stream);
   // the host knows which buffer is filled: multi-rank runs either read the state back every iteration or (batched)
@@ -1946,7 +2003,11 @@ void calico_problem_destroy(calico_problem* p) {
     std::vector<hipStream_t>& v = sp.idle[p->device];
     if (v.size() < StreamPool::kMaxIdle) v.push_back(p->stream); else (void)hipStreamDestroy(p->stream);
   }
-  delete p;
+  {
+    DeviceArena::Batch batch(p->device);     // what the handle owns goes back to the arena behind ONE wait for its device
+    delete p;
+  }
+  DeviceArena::get().trim(1);                // slabs nothing lives in go back to the driver (one stays for the next handle)
 }
 
 int32_t calico_plan_cache_stats(int64_t* hits, int64_t* misses, int64_t* entries) {
@@ -1964,8 +2025,16 @@ int32_t calico_plan_cache_clear(void) {
   {
     std::lock_guard<std::mutex> lock(c.mu);
     drop.swap(c.entries);      // (entries that live handles still refer to are freed with the last of them)
-    for (const std::shared_ptr<PlanEntry>& e : drop) e->pool.clear();
   }
+  for (std::shared_ptr<PlanEntry>& e : drop) {
+    DeviceArena::Batch batch(e->key.device);
+    {
+      std::lock_guard<std::mutex> lock(c.mu);      // (a live handle of this plan may be taking a workspace from the pool)
+      e->pool.clear();
+    }
+    e.reset();
+  }
+  DeviceArena::get().trim(0);   // every slab no live handle has a buffer in goes back to the driver
   return CALICO_OK;
 }
 
@@ -2475,6 +2544,23 @@ int32_t calico_debug_lm_control_replay(int32_t device, int32_t n, const double* 
       hipMemcpy(accepted_out, d_acc.p, size_t(n) * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
       hipMemcpy(cost_column_out, d_cost.p, size_t(n) * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
     return CALICO_INTERNAL;
+  return CALICO_OK;
+}
+
+int32_t calico_debug_plan_info(calico_problem* p, int32_t* out, int32_t n) {
+  if (!p || !out || n < 0 || n > 8) return CALICO_INVALID_ARGUMENT;
+  int rc = finalize(p);
+  if (rc != CALICO_OK) return rc;
+  int max_frames = 0, max_items = 0, run = 0, prev_layout = -1, prev_seg = -1;
+  for (const CellDev& c : p->h_cells) if (c.prim_off >= 0) max_frames = std::max(max_frames, c.frame_count);   // (camera cells; < 0: IMU cells)
+  for (const ItemDev& it : p->h_jac_items) {
+    run = (it.layout == prev_layout && it.seg == prev_seg) ? run + 1 : 1;
+    prev_layout = it.layout; prev_seg = it.seg;
+    max_items = std::max(max_items, run);
+  }
+  const int v[8] = {p->fuse_expand ? 1 : 0, p->n_fitems, p->n_jac_items, int(p->h_cells.size()), max_frames, max_items,
+                    p->use_bcr ? 1 : 0, p->m};
+  for (int i = 0; i < n; ++i) out[i] = v[i];
   return CALICO_OK;
 }
 

@@ -22,6 +22,14 @@ int32_t calico_debug_lm_control_replay(int32_t device, int32_t n, const double* 
                                        const calico_solver_options* options, double* radius_out, int32_t* accepted_out,
                                        double* cost_column_out);
 
+/* What calico_problem_finalize decided for the handle's structure (finalizes the handle if it has not been yet), so
+ * that a test can assert WHICH evaluation route it is comparing with the oracle. out[0..n) (n <= 8) receives:
+ *   [0] fuse_expand (1: eval_cells_kernel -- cell workgroups; 0: eval_jacobian_kernel + expand_cells_kernel + row cells),
+ *   [1] camera frames on the frame path, [2] work items of the generic / IMU path, [3] cells,
+ *   [4] most frames in one camera cell, [5] most work items in one (layout, segment) of the item path,
+ *   [6] 1: tree solver, 0: sequential banded solver, [7] m (tangent size of the calibration blocks). */
+int32_t calico_debug_plan_info(calico_problem* problem, int32_t* out, int32_t n);
+
 #ifdef __cplusplus
 }
 #endif

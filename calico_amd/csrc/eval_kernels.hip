@@ -1196,8 +1196,8 @@ DEV void eval_cells_body(const EvalArgs& a, double* lds) {
     // (the late wave does not wait for the early one: it raises a word in LDS when its rows are staged -- the word is cleared
     //  in front of a barrier both waves pass at once -- and goes on with its share; the early wave looks at the word when its own
     //  block is done)
-    volatile int* const staged = reinterpret_cast<volatile int*>(lds + 2 * size_t(a.wave_lds_doubles));
-    if (tid == 0) *staged = 0;
+    int* const staged = reinterpret_cast<int*>(lds + 2 * size_t(a.wave_lds_doubles));
+    if (tid == 0) __hip_atomic_store(staged, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
     ItemStage st;
     eval_items_body<true, 6>(a, mine, lds_w, &st);
@@ -1205,7 +1205,11 @@ DEV void eval_cells_body(const EvalArgs& a, double* lds) {
     if (!late_m) {
       stage_b_dispatch<0>(lds_w, a.row_pad, st.nrows, st.n1, st.out);
       if (dbg) tq2 = __builtin_readcyclecounter();
-      while (*staged == 0) __builtin_amdgcn_s_sleep(1);
+      // (LDS executes a wave's accesses in order and the late wave drains its stores in front of the flag's: once the flag
+      //  is seen the rows are there. The compiler must not move the rows' reads in front of the loop: atomic load + barrier
+      //  for the compiler, like elim_follow's channel reads in block_elim.hpp)
+      while (__hip_atomic_load(staged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
       if (dbg) tq3 = __builtin_readcyclecounter();
       const ItemDev* op = a.items + other;
       const int n1o = op->L.ncols + 1, nro = (op->S.kind == 0 ? 2 : 3) * op->obs_count;
@@ -1213,7 +1217,8 @@ DEV void eval_cells_body(const EvalArgs& a, double* lds) {
     } else {
       if (dbg) tq2 = __builtin_readcyclecounter();
       wave_lds_sync();                       // (the rows are in LDS)
-      if ((tid & 63) == 0) *staged = 1;
+      asm volatile("" ::: "memory");
+      if ((tid & 63) == 0) __hip_atomic_store(staged, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (dbg) tq3 = __builtin_readcyclecounter();
       stage_b_dispatch<1>(lds_w, a.row_pad, st.nrows, st.n1, st.out);
     }
@@ -1534,7 +1539,7 @@ void launch_eval_jacobian(const EvalArgs& a, hipStream_t stream) {
   if (a.pair_mode) {
     const int hint = a.hint_progress && a.st ? 1 : 0;
     hipLaunchKernelGGL(eval_cells_kernel, dim3(((a.n_items + 1) >> 1) + (a.n_fitems >> 1) + hint), dim3(128),
-                       (2 * size_t(a.wave_lds_doubles) + 2) * sizeof(double), stream, a);
+                       cells_launch_lds_bytes(size_t(a.wave_lds_doubles)), stream, a);
     return;
   }
   size_t lds = size_t(a.lds_cols) * a.row_pad * sizeof(double);
@@ -1561,7 +1566,7 @@ hipError_t configure_eval_kernels(size_t max_lds_bytes) {
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&expand_cells_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_cells_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_cells_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(kCellsMaxLds));
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_jacobian_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           int(std::max<size_t>(std::max(max_lds_bytes, frame_lds_bytes()), 80 * 1024)));

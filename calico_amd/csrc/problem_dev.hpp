@@ -28,6 +28,10 @@ namespace cal {
 
 constexpr int kRowsPerItem = 128;   // LDS rows staged per work item (64 camera obs × 2)
 constexpr int kRowPad = 129;        // largest row stride (doubles) of a staged Jacobian column
+// eval_cells_kernel: the dynamic LDS its launch may ask for. ONE constant for the plan's decision (cell workgroups or
+// not), the kernel's attribute and the launch: cells_launch_lds_bytes() is what a launch asks for.
+constexpr size_t kCellsMaxLds = 158 * 1024;
+constexpr size_t cells_launch_lds_bytes(size_t wave_lds_doubles) { return (2 * wave_lds_doubles + 2) * sizeof(double); }
 
 struct SensorDev {
   int kind, model, K, loss;

@@ -225,7 +225,9 @@ int32_t calico_problem_finalize(calico_problem* p);
  * (batch_optimizer.cpp:57-70), and a rebuilt problem of known structure then only uploads its values. A structure that
  * differs in any of those inputs is planned afresh. CALICO_PLAN_CACHE=0 in the environment switches the cache off.
  * calico_plan_cache_stats: look-ups served from the cache / planned afresh since the process started, plans held.
- * calico_plan_cache_clear: drops the cached plans and workspaces (device memory of plans no live handle uses is freed). */
+ * calico_plan_cache_clear: drops the cached plans and workspaces; the device memory of plans no live handle uses, and
+ * every allocation slab of the library nothing lives in any more, goes back to the driver (hipFree). Destroying a handle
+ * does the same for all idle slabs but one per device. */
 int32_t calico_plan_cache_stats(int64_t* hits_out, int64_t* misses_out, int64_t* entries_out);
 int32_t calico_plan_cache_clear(void);
 

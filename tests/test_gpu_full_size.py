@@ -47,11 +47,7 @@ def test_normal_equations_and_first_iterations_match_oracle(config, hip, oracle)
     for a, b in zip(ig, ir):
         assert a.step_is_successful == b.step_is_successful, table
         assert abs(a.cost - b.cost) <= 1e-7 * abs(b.cost), table       # the third LM step amplifies rounding differences
-    eg, ctg = syn.read_back(gpu, scene)
-    er, ctr = syn.read_back(ref, scene)
-    for a, b in zip(eg, er):
-        assert np.abs(a["intrinsics"] - b["intrinsics"]).max() <= 1e-6 * np.abs(b["intrinsics"]).max()
-    assert np.abs(ctg - ctr).max() <= 1e-6 * max(1.0, np.abs(ctr).max())
+    _assert_every_estimate_close(gpu, ref, scene)        # intrinsics, q, t, latency of every sensor and the control points
 
 
 def _assert_every_estimate_close(gpu, ref, scene, rtol=1e-6):
@@ -126,11 +122,7 @@ def test_long_trajectories_match_oracle(shape, hip, oracle):
         assert a.step_is_successful == b.step_is_successful
         assert abs(a.cost - b.cost) <= 1e-7 * abs(b.cost)
         assert abs(a.trust_region_radius - b.trust_region_radius) <= 1e-6 * b.trust_region_radius
-    eg, ctg = syn.read_back(gpu, scene)
-    er, ctr = syn.read_back(ref, scene)
-    for a, b in zip(eg, er):
-        assert np.abs(a["intrinsics"] - b["intrinsics"]).max() <= 1e-6 * np.abs(b["intrinsics"]).max()
-    assert np.abs(ctg - ctr).max() <= 1e-6 * max(1.0, np.abs(ctr).max())
+    _assert_every_estimate_close(gpu, ref, scene)        # intrinsics, q, t, latency of every sensor and the control points
 
 
 def test_full_solve_converges_and_repeats_bit_identically(config, hip):

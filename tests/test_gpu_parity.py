@@ -208,3 +208,103 @@ def test_project_matches_measurements_and_gives_zero_residuals(hip):
     cost, _, _ = built2.problem.evaluate()
     # (the residual + Jacobian kernel contracts its multiply-adds differently from the residual-only one: rounding level)
     assert cost < 1e-18
+
+
+# ---- the evaluation route for shapes outside the cell workgroups (camera.cpp:115-153 / accelerometer.cpp:35-56 add whatever
+#      was measured: a 30 Hz camera on 10 Hz knots puts three frames into a spline segment, a 400 Hz IMU forty samples) ----
+_ROUTE_SCENES = {
+    # name: (cam_rate, imu_rate, what the plan must look like)
+    "three_frames_per_cell": (30.0, 50.0, dict(max_frames_per_cell=3)),
+    "several_items_per_imu_cell": (10.0, 400.0, dict(max_items_per_cell=2)),
+    "both": (30.0, 400.0, dict(max_frames_per_cell=3, max_items_per_cell=2)),
+}
+
+
+def _route_scene(name, robust=True, seed=13, camera_model=1, imu_model=3):
+    cam_rate, imu_rate, _ = _ROUTE_SCENES[name]
+    # knots at 10 Hz (make_scene's default) over 3 s: 0.1 s segments
+    return syn.make_scene(2, camera_model, True, imu_model, cam_rate=cam_rate, imu_rate=imu_rate, duration=3.0,
+                          segment_duration=3.0 / 23.9, pixel_noise=0.1, gyro_noise=1e-3, accel_noise=1e-2, robust=robust,
+                          seed=seed)
+
+
+def _assert_route(gpu, name):
+    info = gpu.problem.plan_info()
+    assert info["fuse_expand"] == 0, info             # eval_jacobian_kernel + expand_cells_kernel + row cells
+    assert info["frames"] > 0 and info["items"] > 0, info
+    for key, least in _ROUTE_SCENES[name][2].items():
+        assert info[key] >= least, (key, info)
+    return info
+
+
+def test_default_shapes_take_the_cell_workgroups(hip):
+    """The counterpart of the route tests below: the shapes every other parity test uses are evaluated by
+    eval_cells_kernel (so together the two routes are both compared with the oracle)."""
+    gpu = syn.build_problem(hip, small_scene(camera_model=1, n_cameras=2, imu=True, robust=True))
+    info = gpu.problem.plan_info()
+    assert info["fuse_expand"] == 1 and info["max_frames_per_cell"] <= 2 and info["tree_solver"] == 1, info
+
+
+@pytest.mark.parametrize("robust", [False, True])
+@pytest.mark.parametrize("name", sorted(_ROUTE_SCENES))
+def test_unfused_route_jtj_parity(name, robust, hip, oracle):
+    """[cost, Jtr, JtJ] of the frame records + expansion launch + IMU row cells against the oracle, 1e-9."""
+    scene = _route_scene(name, robust=robust)
+    gpu, ref = both(scene, hip, oracle)
+    _assert_route(gpu, name)
+    assert_eval_close(gpu, ref)
+    for i, s in enumerate(scene.sensors):
+        rg, vg = gpu.problem.residuals(gpu.sensor_ids[i], s.n, s.dim)
+        rr, vr = ref.problem.residuals(ref.sensor_ids[i], s.n, s.dim)
+        assert np.array_equal(vg, vr)
+        assert np.abs(rg - rr).max() <= 1e-9 * max(1.0, np.abs(rr).max())
+
+
+@pytest.mark.parametrize("camera_model,imu_model", [(3, 2), (5, 1)])
+def test_unfused_route_other_models(camera_model, imu_model, hip, oracle):
+    scene = _route_scene("both", camera_model=camera_model, imu_model=imu_model, seed=17)
+    gpu, ref = both(scene, hip, oracle)
+    _assert_route(gpu, "both")
+    assert_eval_close(gpu, ref)
+
+
+@pytest.mark.parametrize("name", sorted(_ROUTE_SCENES))
+def test_unfused_route_converged_solve_matches_oracle(name, hip, oracle):
+    """Both sides to convergence with the default options: termination, iteration count, accept / reject sequence, cost per
+    iteration, every estimate (1e-6) and the tau = 3 inlier masks (bit-exact)."""
+    scene = _route_scene(name, seed=19)
+    gpu, ref, sg, sr = solve_both(scene, hip, oracle, max_iter=50)
+    _assert_route(gpu, name)
+    assert sg.termination_type == sr.termination_type == _capi.CONVERGENCE
+    assert sg.num_iterations == sr.num_iterations
+    ig, ir = gpu.problem.iterations(), ref.problem.iterations()
+    assert [i.step_is_successful for i in ig] == [i.step_is_successful for i in ir]
+    for a, b in zip(ig, ir):
+        assert abs(a.cost - b.cost) <= 1e-6 * abs(b.cost)
+    assert abs(sg.final_cost - sr.final_cost) <= 1e-8 * sr.final_cost
+    assert_estimates_close(gpu, ref, scene)
+    for i, s in enumerate(scene.sensors):
+        if s.kind == _capi.SENSOR_CAMERA:
+            assert np.array_equal(gpu.problem.inlier_mask(gpu.sensor_ids[i], s.n, 3.0),
+                                  ref.problem.inlier_mask(ref.sensor_ids[i], s.n, 3.0))
+
+
+def test_unfused_route_at_configs3_size(hip, oracle):
+    """configs[3]'s rig with a 30 Hz camera and a 400 Hz IMU (the rates of a real rig; bench.py's shape is 20 / 200 Hz):
+    ~150k blocks through the frame records, the expansion launch and four-item IMU row cells -- one evaluation to 1e-9 and
+    three LM iterations against the oracle."""
+    scene = syn.make_scene(4, 1, True, 3, cam_rate=30.0, imu_rate=400.0, duration=8.7, chart="april", seed=0xCA11C0 + 3,
+                           pixel_noise=0.1, gyro_noise=1.7e-4 * np.sqrt(200.0), accel_noise=2e-3 * np.sqrt(200.0), robust=True,
+                           segment_duration=8.7 / 23.9)
+    gpu, ref = both(scene, hip, oracle)
+    info = gpu.problem.plan_info()
+    assert info["fuse_expand"] == 0 and info["max_frames_per_cell"] >= 3 and info["max_items_per_cell"] >= 2, info
+    assert sum(s.n for s in scene.sensors) > 140000
+    assert_eval_close(gpu, ref)
+    gpu, ref, sg, sr = solve_both(scene, hip, oracle, max_iter=3, num_threads=64)
+    ig, ir = gpu.problem.iterations(), ref.problem.iterations()
+    assert len(ig) == len(ir)
+    for a, b in zip(ig, ir):
+        assert a.step_is_successful == b.step_is_successful
+        assert abs(a.cost - b.cost) <= 1e-8 * abs(b.cost)
+    assert_estimates_close(gpu, ref, scene)

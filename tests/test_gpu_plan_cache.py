@@ -140,3 +140,45 @@ def test_setup_cost_of_a_known_structure(hip):
         b.problem.close()
     print("configs[3] add_* / finalize ms: first %s, then %s" % (t[0], t[1:]))
     assert min(x[1] for x in t[1:]) < 0.5 * t[0][1]
+
+
+def test_device_memory_goes_back_to_the_driver(hip):
+    """The library's allocation slabs (64 MB each; a buffer larger than a slab is an allocation of its own) are not kept for
+    good: destroying the handles leaves at most one idle slab per device, calico_plan_cache_clear() none -- a long-lived
+    process that shares the GPU with PyTorch / RCCL, or that once solved a large problem, gets its memory back."""
+    import torch
+    MB = 1 << 20
+
+    def cycle(scene):
+        b = syn.build_problem(hip, scene)
+        _solve(b, hip, n=3)
+        b.problem.close()
+
+    small = _scene(seed=23)
+    # configs[3]'s rig over 3 s: ~36k blocks, partials + workspaces beyond one slab
+    large = syn.make_scene(4, 1, True, 3, cam_rate=20.0, imu_rate=200.0, duration=3.0, chart="april", seed=29, pixel_noise=0.1,
+                           gyro_noise=1e-3, accel_noise=1e-2, robust=True, segment_duration=3.0 / 23.9)
+    cycle(small)                      # code objects, streams, pinned pools: what a process keeps whatever it does
+    cycle(large)
+    hip.plan_cache_clear()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    held = syn.build_problem(hip, large)
+    _solve(held, hip, n=3)
+    in_use = free0 - torch.cuda.mem_get_info(0)[0]
+    assert in_use >= 16 * MB          # (the test would prove nothing otherwise)
+    held.problem.close()
+    del held
+    cycle(small)
+    hip.plan_cache_clear()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 <= 4 * MB, (free0, free1, in_use)
+    # ... and with the cache left alone, handles come and go without the footprint growing
+    cycle(large)
+    base = torch.cuda.mem_get_info(0)[0]
+    for _ in range(3):
+        cycle(large)
+        cycle(small)
+    assert base - torch.cuda.mem_get_info(0)[0] <= 4 * MB
+    hip.plan_cache_clear()
