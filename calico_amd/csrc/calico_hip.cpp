@@ -138,8 +138,17 @@ RcclApi& rccl() {
       names.push_back("/opt/rocm/lib/librccl.so.1"); names.push_back("/opt/rocm/lib/librccl.so");
     }
     std::string why;
+    // An RCCL the process already holds (PyTorch brings its own librccl.so) is the one to use: two copies in one process
+    // end in a double free at exit. And a copy this library loads stays private to it (RTLD_LOCAL: the entry points are
+    // taken with dlsym) -- loaded globally before PyTorch, its symbols would interpose on the ones PyTorch's own copy
+    // expects to bind.
     for (const std::string& n : names) {
-      a.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
+      a.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_NOLOAD);
+      if (a.lib) break;
+    }
+    for (const std::string& n : names) {
+      if (a.lib) break;
+      a.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
       if (a.lib) break;
       const char* e = dlerror();         // (dlerror() clears its state: one call per failure)
       if (e) why = e;

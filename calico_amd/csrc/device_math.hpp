@@ -156,6 +156,31 @@ DEV void dsincos(D1 a, D1* s, D1* c) {
   s->v = sv; s->d = a.d * cv;
   c->v = cv; c->d = -a.d * sv;
 }
+// A value picked by the lane's place in a triple (jl = 0, 1, 2) WITHOUT control flow. Written as `jl == 0 ? a : (jl == 1 ?
+// b : c)` the compiler threads the many choices on the same jl of an IMU block into exec-masked regions: some sixty
+// branches (s_and_saveexec / s_cbranch) around register moves, a third of the block's instructions, every taken branch an
+// instruction-fetch bubble on the longest single-wave chain of the evaluation. Here the choice is bit arithmetic on masks
+// the optimiser cannot see through (an empty asm makes them opaque, or it would turn the and / or back into selects):
+// two v_bfi_b32 per 32-bit half.
+struct Lane3 { unsigned m0, m1; };      // all ones where jl == 0 / jl == 1
+DEV Lane3 lane3(int jl) {
+  Lane3 l; l.m0 = jl == 0 ? ~0u : 0u; l.m1 = jl == 1 ? ~0u : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(l.m0), "+v"(l.m1));
+#endif
+  return l;
+}
+DEV double pick3(const Lane3& l, double a, double b, double c) {
+  unsigned long long ua, ub, uc;
+  __builtin_memcpy(&ua, &a, 8); __builtin_memcpy(&ub, &b, 8); __builtin_memcpy(&uc, &c, 8);
+  const unsigned alo = unsigned(ua), ahi = unsigned(ua >> 32), blo = unsigned(ub), bhi = unsigned(ub >> 32), clo = unsigned(uc), chi = unsigned(uc >> 32);
+  const unsigned tlo = (blo & l.m1) | (clo & ~l.m1), thi = (bhi & l.m1) | (chi & ~l.m1);
+  const unsigned rlo = (alo & l.m0) | (tlo & ~l.m0), rhi = (ahi & l.m0) | (thi & ~l.m0);
+  const unsigned long long ur = (static_cast<unsigned long long>(rhi) << 32) | rlo;
+  double r;
+  __builtin_memcpy(&r, &ur, 8);
+  return r;
+}
 DEV double val(double a) { return a; }
 DEV double val(D3 a) { return a.v; }
 DEV double val(D1 a) { return a.v; }
@@ -478,6 +503,12 @@ DEV void imu_project(int model, const double* __restrict__ k, V3 w, double f[3],
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) Mw[i][j] = (i == j) ? s : 0.0;
+      // (the callers pick their component of every 3-wide group of columns without control flow: the groups that hold
+      //  a column of this model -- [0, 6) -- must be defined throughout)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) dK[i][j] = 0.0;
       dK[0][0] = w.x; dK[1][0] = w.y; dK[2][0] = w.z;
       if (model == 2) {
 #pragma unroll

@@ -209,10 +209,10 @@ DEV bool camera_dispatch(const ItemCtx& c, double px, double py, double stamp, c
 // The Jacobian rows of an IMU block are formed by THREE lanes (`jl` = 0, 1, 2 = lane of the observation's triple): all
 // of them evaluate the residual, lane jl differentiates along φ_jl and files the columns of every 3-wide group that
 // belong to component jl -- the single-lane chain these blocks were is the longest of the Jacobian launch.
-// Element [q][jl] of a 3×3 matrix every lane of the triple holds
-DEV double col_of(const M3& A, int q, int jl) { return jl == 0 ? A.m[q][0] : (jl == 1 ? A.m[q][1] : A.m[q][2]); }
-DEV double col_of(const double A[3][3], int q, int jl) { return jl == 0 ? A[q][0] : (jl == 1 ? A[q][1] : A[q][2]); }
-DEV double pick(const double v[6], int off, int jl) { return jl == 0 ? v[off] : (jl == 1 ? v[off + 1] : v[off + 2]); }
+// Element [q][jl] of a 3×3 matrix every lane of the triple holds (pick3: no control flow on jl, see device_math.hpp)
+DEV double col_of(const M3& A, int q, const Lane3& l) { return pick3(l, A.m[q][0], A.m[q][1], A.m[q][2]); }
+DEV double col_of(const double A[3][3], int q, const Lane3& l) { return pick3(l, A[q][0], A[q][1], A[q][2]); }
+DEV double pick(const double v[6], int off, const Lane3& l) { return pick3(l, v[off], v[off + 1], v[off + 2]); }
 // sum over the triple, in lane order (the latency column: Σ over the three pose components), valid in lane 0 of the triple
 DEV double triple_sum(double t, int jl) {
   const int base = int(threadIdx.x & 63) - jl;
@@ -221,9 +221,9 @@ DEV double triple_sum(double t, int jl) {
 }
 
 // omega = J(phi)·phid and column jl of W = d omega / d phi (dual number along φ_jl).
-DEV void omega_and_dphi_col(V3 phi, V3 phid, int jl, V3* omega, double Wcol[3], Rodrigues<double>* Rv) {
+DEV void omega_and_dphi_col(V3 phi, V3 phid, const Lane3& l3, V3* omega, double Wcol[3], Rodrigues<double>* Rv) {
   D1 px = mk1(phi.x), py = mk1(phi.y), pz = mk1(phi.z);
-  px.d = jl == 0 ? 1.0 : 0.0; py.d = jl == 1 ? 1.0 : 0.0; pz.d = jl == 2 ? 1.0 : 0.0;
+  px.d = pick3(l3, 1.0, 0.0, 0.0); py.d = pick3(l3, 0.0, 1.0, 0.0); pz.d = pick3(l3, 0.0, 0.0, 1.0);
   const Rodrigues<D1> R = rodrigues<D1>(px, py, pz, false);
   *Rv = rod_value(R);
   D1 ox, oy, oz;
@@ -250,9 +250,10 @@ DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], cons
   V3 omega;
   double Wcol[3] = {0.0, 0.0, 0.0};
   M3 Jl;
+  const Lane3 l3 = lane3(jl);
   if constexpr (JAC) {
     Rodrigues<double> Rv;
-    omega_and_dphi_col(phi, phid, jl, &omega, Wcol, &Rv);
+    omega_and_dphi_col(phi, phid, l3, &omega, Wcol, &Rv);
     Jl = rod_J_matrix(Rv);
   } else {
     const Rodrigues<double> R = rodrigues<double>(phi.x, phi.y, phi.z, false);
@@ -281,7 +282,7 @@ DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], cons
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       A0c[i] = -(B[i][0] * Wcol[0] + B[i][1] * Wcol[1] + B[i][2] * Wcol[2]);
-      A1c[i] = -(B[i][0] * col_of(Jl, 0, jl) + B[i][1] * col_of(Jl, 1, jl) + B[i][2] * col_of(Jl, 2, jl));
+      A1c[i] = -(B[i][0] * col_of(Jl, 0, l3) + B[i][1] * col_of(Jl, 1, l3) + B[i][2] * col_of(Jl, 2, l3));
     }
 #pragma unroll
     for (int i = 0; i < kMaxOrder; ++i) {
@@ -294,19 +295,27 @@ DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], cons
       }
     }
     if (L.c_intr >= 0) {
+      // lane jl files the columns j = jl, jl + 3, ... (its component of every 3-wide group): the group's three candidates are
+      // picked without control flow, only the bound on K predicates the stores
       const int K = imu_num_params(S.model);
 #pragma unroll
-      for (int j = 0; j < kMaxIntr; ++j) {
-        if (j >= K || j % 3 != jl) continue;
+      for (int g3 = 0; g3 < kMaxIntr; g3 += 3) {
+        if (g3 >= K) continue;      // (wave-uniform)
+        const int j = g3 + jl;
+        double v[3];
 #pragma unroll
-        for (int rr = 0; rr < 3; ++rr) sink.put(L.c_intr + j, rr, fac * dK[rr][j]);
+        for (int rr = 0; rr < 3; ++rr) v[rr] = fac * pick3(l3, dK[rr][g3], dK[rr][g3 + 1], dK[rr][g3 + 2]);
+        if (j < K) {
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr) sink.put(L.c_intr + j, rr, v[rr]);
+        }
       }
     }
     if (L.c_q >= 0) {  // d og / d delta = -2 R_rgᵀ [omega]×
       const M3 So = skew(omega);
       double RtSc[3];   // column jl of R_rgᵀ [omega]×
 #pragma unroll
-      for (int i = 0; i < 3; ++i) RtSc[i] = R_rg.m[0][i] * col_of(So, 0, jl) + R_rg.m[1][i] * col_of(So, 1, jl) + R_rg.m[2][i] * col_of(So, 2, jl);
+      for (int i = 0; i < 3; ++i) RtSc[i] = R_rg.m[0][i] * col_of(So, 0, l3) + R_rg.m[1][i] * col_of(So, 1, l3) + R_rg.m[2][i] * col_of(So, 2, l3);
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr)
         sink.put(L.c_q + jl, rr, -2.0 * fac * (Mw[rr][0] * RtSc[0] + Mw[rr][1] * RtSc[1] + Mw[rr][2] * RtSc[2]));
@@ -318,7 +327,7 @@ DEV bool gyro_block(const ItemCtx& c, V3 meas, double stamp, double res[3], cons
     if (L.c_lat >= 0) {
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr) {
-        const double s = triple_sum(A0c[rr] * pick(P[1], 0, jl) + A1c[rr] * pick(P[ND - 1], 0, jl), jl);
+        const double s = triple_sum(A0c[rr] * pick(P[1], 0, l3) + A1c[rr] * pick(P[ND - 1], 0, l3), jl);
         if (jl == 0) sink.put(L.c_lat, rr, -s);
       }
     }
@@ -353,9 +362,11 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
   double Hphid_row[3] = {0.0, 0.0, 0.0};                              // row jl of H(phi)·phid
   Rodrigues<double> Rd;   // the coefficients at phi as plain doubles (Jacobian path)
   Rd.zero = true;
+  const Lane3 l3 = lane3(jl);
+  const double e0 = pick3(l3, 1.0, 0.0, 0.0), e1 = pick3(l3, 0.0, 1.0, 0.0), e2 = pick3(l3, 0.0, 0.0, 1.0);     // unit vector of this lane's direction
   if constexpr (JAC) {
     D1 px = mk1(phi.x), py = mk1(phi.y), pz = mk1(phi.z);
-    px.d = jl == 0 ? 1.0 : 0.0; py.d = jl == 1 ? 1.0 : 0.0; pz.d = jl == 2 ? 1.0 : 0.0;
+    px.d = e0; py.d = e1; pz.d = e2;
     const Rodrigues<D1> R = rodrigues<D1>(px, py, pz, true);
     Rd = rod_value(R);
     D1 o[3], jdd[3], Hv[3][3];
@@ -370,7 +381,7 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       dw_col[j] = o[j].d; da_col[j] = al[j].d;
-      Hphid_row[j] = jl == 0 ? Hv[0][j].v : (jl == 1 ? Hv[1][j].v : Hv[2][j].v);
+      Hphid_row[j] = pick3(l3, Hv[0][j].v, Hv[1][j].v, Hv[2][j].v);
     }
   } else {
     const Rodrigues<double> R = rodrigues<double>(phi.x, phi.y, phi.z, true);
@@ -416,7 +427,7 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
     // sum needs the slice of this lane's direction, the second is row jl of H·phid (already there)
     const M3 Jl = rod_J_matrix(Rd);
     double Hs[3][3];
-    rod_H_apply<double>(Rd, jl == 0 ? 1.0 : 0.0, jl == 1 ? 1.0 : 0.0, jl == 2 ? 1.0 : 0.0, Hs);
+    rod_H_apply<double>(Rd, e0, e1, e2, Hs);
     double dad_col[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) dad_col[j] = (Hs[0][j] * phid.x + Hs[1][j] * phid.y + Hs[2][j] * phid.z) + Hphid_row[j];
@@ -428,7 +439,7 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
       double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int q2 = 0; q2 < 3; ++q2) {
-        const double jq = col_of(Jl, q2, jl);
+        const double jq = col_of(Jl, q2, l3);
         s0 += -Sr.m[i][q2] * jq + dbdw[i][q2] * dw_col[q2] + St.m[i][q2] * da_col[q2];
         s1 += dbdw[i][q2] * jq + St.m[i][q2] * dad_col[q2];
         s2 += St.m[i][q2] * jq;
@@ -443,7 +454,7 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
 #pragma unroll
       for (int q2 = 0; q2 < 3; ++q2) {
         s0 += Bm[i][q2] * dbc[q2]; s1 += Bm[i][q2] * dbdc[q2];
-        s2 += Bm[i][q2] * dbddc[q2]; s3 += Bm[i][q2] * col_of(R_rw, q2, jl);
+        s2 += Bm[i][q2] * dbddc[q2]; s3 += Bm[i][q2] * col_of(R_rw, q2, l3);
       }
       A0c[i] = -s0; A1c[i] = -s1; A2rc[i] = -s2; A2tc[i] = s3;
     }
@@ -458,19 +469,27 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
       }
     }
     if (L.c_intr >= 0) {
+      // lane jl files the columns j = jl, jl + 3, ... (its component of every 3-wide group): the group's three candidates are
+      // picked without control flow, only the bound on K predicates the stores
       const int K = imu_num_params(S.model);
 #pragma unroll
-      for (int j = 0; j < kMaxIntr; ++j) {
-        if (j >= K || j % 3 != jl) continue;
+      for (int g3 = 0; g3 < kMaxIntr; g3 += 3) {
+        if (g3 >= K) continue;      // (wave-uniform)
+        const int j = g3 + jl;
+        double v[3];
 #pragma unroll
-        for (int rr = 0; rr < 3; ++rr) sink.put(L.c_intr + j, rr, fac * dK[rr][j]);
+        for (int rr = 0; rr < 3; ++rr) v[rr] = fac * pick3(l3, dK[rr][g3], dK[rr][g3 + 1], dK[rr][g3 + 2]);
+        if (j < K) {
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr) sink.put(L.c_intr + j, rr, v[rr]);
+        }
       }
     }
     if (L.c_q >= 0) {  // d f / d delta = 2 R_raᵀ [b]×
       const M3 Sb = skew(b);
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr)
-        sink.put(L.c_q + jl, rr, 2.0 * (Bm[rr][0] * col_of(Sb, 0, jl) + Bm[rr][1] * col_of(Sb, 1, jl) + Bm[rr][2] * col_of(Sb, 2, jl)));
+        sink.put(L.c_q + jl, rr, 2.0 * (Bm[rr][0] * col_of(Sb, 0, l3) + Bm[rr][1] * col_of(Sb, 1, l3) + Bm[rr][2] * col_of(Sb, 2, l3)));
     }
     if (L.c_t >= 0) {  // db/dt = [omega]×[omega]× - [alpha]×
       const M3 So = skew(omega), Sa = skew(alpha);
@@ -479,15 +498,15 @@ DEV bool accel_block(const ItemCtx& c, V3 meas, double stamp, double res[3], con
       for (int rr = 0; rr < 3; ++rr) {
         double s = 0.0;
 #pragma unroll
-        for (int q2 = 0; q2 < 3; ++q2) s += Bm[rr][q2] * (col_of(So2, q2, jl) - col_of(Sa, q2, jl));
+        for (int q2 = 0; q2 < 3; ++q2) s += Bm[rr][q2] * (col_of(So2, q2, l3) - col_of(Sa, q2, l3));
         sink.put(L.c_t + jl, rr, s);
       }
     }
     if (L.c_lat >= 0) {
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr) {
-        const double t = A0c[rr] * pick(P[1], 0, jl) + A1c[rr] * pick(P[2], 0, jl) + A2rc[rr] * pick(P[ND - 1], 0, jl) +
-                         A2tc[rr] * pick(P[ND - 1], 3, jl);
+        const double t = A0c[rr] * pick(P[1], 0, l3) + A1c[rr] * pick(P[2], 0, l3) + A2rc[rr] * pick(P[ND - 1], 0, l3) +
+                         A2tc[rr] * pick(P[ND - 1], 3, l3);
         const double s = triple_sum(t, jl);
         if (jl == 0) sink.put(L.c_lat, rr, -s);
       }

@@ -23,4 +23,12 @@ def oracle():
 @pytest.fixture(scope="session")
 def hip():
     import helpers
+    # PyTorch's HIP runtime (and its own librccl) first, as in bench.py: the library then shares them whatever the order
+    # of the tests in the session (some tests create torch streams, others an RCCL communicator)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except ImportError:
+        pass
     return helpers.hip_api()

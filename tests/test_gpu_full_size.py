@@ -190,7 +190,7 @@ def test_config4_three_pass_outlier_tagging(hip, oracle):
         sg, sr = g.problem.solve(_options(hip, 50)), r.problem.solve(_options(oracle, 50))
         assert sg.num_residual_blocks == sr.num_residual_blocks
         assert sg.termination_type == sr.termination_type == _capi.CONVERGENCE
-        assert abs(sg.final_cost - sr.final_cost) <= 1e-6 * sr.final_cost
+        assert abs(sg.final_cost - sr.final_cost) <= 1e-8 * sr.final_cost
         est, ctrl = syn.read_back(r, ref_scene)
         nxt = copy.deepcopy(ref_scene)
         n_pass = 0

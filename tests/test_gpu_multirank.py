@@ -167,6 +167,113 @@ def test_two_ranks_on_one_gpu_equal_single_rank(batched, hip):
     assert np.array_equal(results[0][5], results[1][5])
 
 
+def test_two_handles_one_device_stream_ordered_exchange_at_configs3_size(hip, monkeypatch):
+    """The buffer choreography of the native multi-rank path -- zero-filled exchange target, the rank's gather into it, the
+    exchange on the handle's stream, commit_kernel for an accepted candidate, iterations enqueued ahead of the device in
+    batches -- with the semantics of a world of TWO at the size of BASELINE configs[3], on one GPU: rank 0 and rank 1 are two
+    handles of this process on streams of their own, each driven by its own thread, and the exchange is a stream-ordered
+    stand-in for ncclAllReduce (nothing in it waits on the host for the device: copy to a staging buffer, event, wait for
+    the peer's event, sum in rank order -- so that, unlike the two-process test above whose callback blocks on a device-to-
+    host copy, the library's asynchronous loop really runs ahead of the kernels). Both ranks must walk the single-rank
+    solve's iterations and agree with each other bit for bit. (RCCL itself refuses two ranks on one device.)"""
+    import threading
+    import torch
+    from calico_amd import synthetic as syn
+    monkeypatch.setenv("CALICO_MULTIRANK_ASYNC", "1")
+    scene = syn.config_scene(3)
+    world = 2
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    staged = [dict() for _ in range(world)]       # rank -> call number -> (staging tensor, event): kept alive to the end
+    calls = [0] * world
+    meet = threading.Barrier(world, timeout=120)
+    lock = threading.Lock()
+    errors = []
+
+    def make_allreduce(rank):
+        def allreduce(ctx, buf, n, strm):
+            try:
+                k = calls[rank]
+                calls[rank] += 1
+                assert strm == streams[rank].cuda_stream
+                with torch.cuda.stream(streams[rank]):
+                    mine = torch.as_tensor(_DevArray(buf, n), device="cuda")
+                    stage = mine.clone()
+                    ev = torch.cuda.Event()
+                    ev.record(streams[rank])
+                    with lock:
+                        staged[rank][k] = (stage, ev)
+                    meet.wait()                      # both ranks have ENQUEUED call k (a rank that issued fewer calls: timeout)
+                    with lock:
+                        parts = [staged[r][k] for r in range(world)]
+                    streams[rank].wait_event(parts[1 - rank][1])
+                    torch.add(parts[0][0], parts[1][0], out=mine)     # rank order: the same bits on both ranks
+                return 0
+            except Exception as e:      # (an exception must not unwind through the C frames)
+                errors.append(repr(e))
+                return 13
+        return allreduce
+
+    results = [None] * world
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            built = syn.build_problem(hip, scene)
+            P = built.problem
+            P.set_stream(streams[rank].cuda_stream)
+            P.set_shard(rank, world)
+            P.set_allreduce(make_allreduce(rank))
+            o = hip.default_options()
+            o.minimizer_progress_to_stdout = 0
+            o.max_num_iterations = 50
+            o.sync_every = 4
+            s = P.solve(o)
+            est, ctrl = syn.read_back(built, scene)
+            results[rank] = (s, [(i.iteration, i.step_is_successful, i.cost) for i in P.iterations()], est, ctrl, P.comm_info())
+            streams[rank].synchronize()
+            P.close()
+        except Exception as e:
+            errors.append("rank %d: %r" % (rank, e))
+            meet.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert all(r is not None for r in results)
+    single = syn.build_problem(hip, scene)
+    o = hip.default_options()
+    o.minimizer_progress_to_stdout = 0
+    o.max_num_iterations = 50
+    s0 = single.problem.solve(o)
+    its0 = [(i.iteration, i.step_is_successful, i.cost) for i in single.problem.iterations()]
+    est0, ctrl0 = syn.read_back(single, scene)
+    assert calls[0] == calls[1] and calls[0] >= s0.num_iterations
+    blocks = 0
+    for rank, (s, its, est, ctrl, info) in enumerate(results):
+        assert info[0] == rank and info[1] == world and info[3] == scene.num_blocks
+        blocks += info[2]
+        assert s.termination_type == s0.termination_type == _capi_convergence() and s.num_iterations == s0.num_iterations
+        assert [(a, b) for a, b, _ in its] == [(a, b) for a, b, _ in its0]
+        for (_, _, c1), (_, _, c0) in zip(its, its0):
+            assert abs(c1 - c0) <= 1e-9 * abs(c0)
+        assert abs(s.final_cost - s0.final_cost) <= 1e-9 * s0.final_cost
+        assert np.abs(ctrl - ctrl0).max() <= 1e-8 * np.abs(ctrl0).max()
+        for a, b in zip(est, est0):
+            for key in ("intrinsics", "q", "t"):
+                assert np.abs(a[key] - b[key]).max() <= 1e-8 * max(1e-3, np.abs(b[key]).max()), key
+    assert blocks == scene.num_blocks
+    assert np.array_equal(results[0][3], results[1][3])              # replicated solve of one deterministic sum
+    assert results[0][1] == results[1][1]
+
+
+def _capi_convergence():
+    from calico_amd import _capi
+    return _capi.CONVERGENCE
+
+
 def _rccl_worker(rank, world, id_bytes, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
