@@ -299,7 +299,13 @@ struct BcrPre { double d[NU], bt[NU], at[NU], f[NF]; };
 #define BCR_FIRST_BLOCK_ALL_WAVES 1
 #endif
 
-template <bool FROM_R, bool ELIM>
+// LA (look-ahead, round 5; ELIM only): between two blocks of a chain only what the NEXT block's chief waits for stays in
+// front of the step's second barrier -- the operands of every Schur product read into registers and the three tiles of
+// next.D -= Z^BᵀZ^B --; the chief then starts on the next block at once. The followers of the A and F tiles form the update
+// of their own input tiles (next.A -= Z^BᵀZ^A, next.F -= Z^BᵀZ^F) straight in the registers the elimination keeps them in
+// (elim_follow with use_pre: same layout), the loader waves file Z and carry the left separator's sums, and the next block's
+// requests go out right behind the barrier. Same products in the same order as without it: bit-identical.
+template <bool FROM_R, bool ELIM, bool LA = false>
 __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, BcrArgs b, int node0, int n_nodes, int nfs, int level,
                                                                    int keep0, int n_keep, LmOptionsDev o, int with_post,
                                                                    const double* __restrict__ x, const BlockDev* __restrict__ blocks,
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   const double* const R_buf0 = a.R;
   const double* const R_buf1 = a.R + a.r_stride;
   const FromR fr = {a, o, radius, (FROM_R && with_post == 2) ? (jacobi_scaling ? 1 : 2) : 0};
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform for the compiler too: the roles of the waves are alternatives -- scalar branches, registers per path -- not masked regions that run one after the other)
   // Workgroup -> (node, role), XCD-aware: workgroup p runs on XCD p % 8, each XCD has its own L2, and all roles of a node
   // read the same spine blocks -- so node c takes the workgroups p = (c % 8) + 8·slot: one L2 serves its roles. The
   // first 8·slots workgroups are (node, role) pairs (those of nodes that do not exist return), the others are the
@@ -488,8 +494,8 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   extern __shared__ double lds[];
   double* const Daug = lds;                        // [2][64·DLD]
   double* const Xb = Daug + 2 * 64 * DLD;          // [2][32·XLD]
-  double* const Zb = Xb + 2 * BP * XLD;            // [32·XLD]
-  double* const dinv = Zb + BP * XLD;              // [80]
+  double* const Zb_base = Xb + 2 * BP * XLD;       // [32·XLD], LA: [2][32·XLD]
+  double* const dinv = Zb_base + (LA ? 2 : 1) * BP * XLD;    // [80]
   double* const bcast = dinv + 80;                 // [128]
   double* const dump = bcast + 128 + tid;          // [512]
   const ElimChannel ech = elim_channel(bcast + 128 + kLevelThreads);      // [kElimBufDoubles] (ELIM)
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       if (e < BB) {
         const int r = e >> 5, c = e & 31;
         Dp[r * DLD + c] = pr.d[u];
-        Dp[(BP + r) * DLD + c] = r == c ? 1.0 : 0.0;
+        if (!ELIM) Dp[(BP + r) * DLD + c] = r == c ? 1.0 : 0.0;      // (the block elimination forms the identity rows in registers; its L⁻ᵀ in these rows is still being filed when the next commit comes)
         Xp[c * XLD + CB + r] = pr.bt[u];     // B[row of this block][next's dim] = G[next's dim][row]
         Xp[r * XLD + CA + c] = pr.at[u];     // A[row of this block][left separator's dim] = G_left as stored
       }
@@ -701,21 +707,38 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   if (CAL_DEV_TIMING(a.debug >= 4)) t_first = __builtin_readcyclecounter() - t_kernel;
   // (the barriers of the step loop order LDS traffic only: __syncthreads() would also drain the global loads of the
   //  next block, which are meant to stay in flight while this one is factored)
+  // LA: the left separator's sums live in loader waves 5 and 6 (wave 4 shares its SIMD with the chief, wave 7 with the
+  // follower the next block's diagonal waits for): role 0: wave 5 tiles (0,0) and (1,0) [acc_a, acc_a2], wave 6 tile (1,1);
+  // border roles: row tile 0 on wave 5, 1 on wave 6
+  const bool la_acc_owner = LA && (wave == 5 || wave == 6), la_acc_owner2 = LA && role == 0 && wave == 5;
+  const int la_acc_p = role == 0 ? CA + (wave == 6 ? 16 : 0) : CA + 16 * (wave - 5);
+  const int la_acc_q = role == 0 ? CA + (wave == 6 ? 16 : 0) : CF;
+  f64x4 acc_a2 = {0.0, 0.0, 0.0, 0.0};
+  Pre pr;
+  f64x4 pre0[2], pre1[2];       // LA: a follower's own input tiles of the next block, updated (wave 2: the two A tiles; wave 1 of a border role: the F tile)
+  if (LA && q > 1 && loader) fetch(1, pr, std::false_type(), lmap);
+  const int lane_outer = lane;
   for (int i = 0; i < q; ++i) {
+    // (the lane number made opaque once per step: every LDS / global address of a step is lane arithmetic, and kept across
+    //  the loop as loop invariants -- some hundred of them over all roles -- they were what the registers ran out on; a few
+    //  integer instructions per step form them again)
+    int lane_step = lane_outer;
+    if (LA) asm volatile("" : "+v"(lane_step));
+    const int lane = lane_step, l16 = lane & 15, lk = lane >> 4, tid = 64 * wave + lane;
     const int p = i & 1;
+    double* const Zb = Zb_base + (LA ? p * BP * XLD : 0);      // LA: Z of step i is still read while the followers of step i + 1 write theirs
     double* Dp = Daug + p * 64 * DLD;
     double* Xp = Xb + p * BP * XLD;
     double* Dn = Daug + (p ^ 1) * 64 * DLD;
     double* Xn = Xb + (p ^ 1) * BP * XLD;
     const bool last = i + 1 == q;
     const int blk = blk0 + i;
-    Pre pr;
     const long long t_step = CAL_DEV_TIMING(a.debug != 0) ? __builtin_readcyclecounter() : 0;
     if (CAL_DEV_TIMING(a.debug >= 4)) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) if (k == i) t_top[k] = t_step - t_kernel;
     }
-    if (!last && loader) fetch(i + 1, pr, std::false_type(), lmap);            // in flight while the block is factored
+    if (!LA && !last && loader) fetch(i + 1, pr, std::false_type(), lmap);     // in flight while the block is factored (LA: requested behind the step before)
     if (CAL_DEV_TIMING(a.debug == 2 && bid < 1 && lane == 0 && wave >= 4)) printf("level %d step %d wave %d: requests issued at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
     if (ELIM) {
       // ---- D = L Lᵀ, Z = L⁻¹X and (role 0) L⁻ᵀ in one pass: wave 0 the spine, waves 1..3 two row tiles each ----
@@ -726,15 +749,19 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           elim_follow<2>(t, ech, lane);
         } else {
           const ElimTile t[1] = {{Xp + CF, 1, XLD, Zb + CF, 1, XLD, 0, nullptr}};
-          elim_follow<1>(t, ech, lane);
+          elim_follow<1>(t, ech, lane, LA && i > 0, pre0, pre1);
         }
       } else if (wave == 2 || wave == 3) {
         const int c0 = wave == 2 ? CA : CB;
         const ElimTile t[2] = {{Xp + c0, 1, XLD, Zb + c0, 1, XLD, 0, nullptr}, {Xp + c0 + 16, 1, XLD, Zb + c0 + 16, 1, XLD, 0, nullptr}};
-        elim_follow<2>(t, ech, lane);
+        elim_follow<2>(t, ech, lane, LA && wave == 2 && i > 0, pre0, pre1);
       }
+      if (CAL_DEV_TIMING(a.debug >= 4 && LA && i == 1 && lane == 0)) bcast[8 + wave] = double(__builtin_readcyclecounter() - t_kernel);
       if (CAL_DEV_TIMING(a.debug == 2 && bid < 1 && lane == 0 && wave < 4)) printf("level %d step %d wave %d: elimination done at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
-      if (!last && loader) commit(p ^ 1, pr, lmap);
+      if (!last && loader) {
+        commit(p ^ 1, pr, lmap);
+      }
+      if (CAL_DEV_TIMING(a.debug >= 4 && LA && i == 1 && lane == 0 && wave >= 4)) bcast[8 + wave] = double(__builtin_readcyclecounter() - t_kernel);
       if (CAL_DEV_TIMING(a.debug == 2 && bid < 1 && lane == 0 && wave >= 4)) printf("level %d step %d wave %d: committed at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
       LTICK(3)
     } else {
@@ -775,6 +802,94 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       for (int k = 0; k < 4; ++k) if (k == i) t_bara[k] = __builtin_readcyclecounter() - t_kernel;
     }
     if (ELIM && !last) elim_reset(ech, tid, kLevelThreads);      // (the followers are through; the barrier at the end of the step orders it)
+    if (LA && !last) {
+      // ---- look-ahead: in front of the barrier only next.D -= Z^BᵀZ^B (and the next block's requests); behind it the other
+      //      Schur products, read from THIS step's Z buffer (the followers of the next block write the other one) ----
+      // operand of the 16x16x4 product for sixteen columns of Z: lane (l16, lk) holds Z[lk + 4u][col0 + l16]
+      auto ops = [&](int col0, double (&v)[8]) {
+        const double* pp = Zb + lk * XLD + col0 + l16;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pp[4 * u * XLD];
+      };
+      if (wave == 0 || wave == 2 || wave == 3) {      // next.D -= Z^BᵀZ^B: tiles (0,0), (1,0), (1,1) -- the upper right one is read by nobody
+        const int it = (wave & 3) >> 1, jt = wave & 1;
+        const int row0 = 16 * it + lk, col0 = 16 * jt + l16;
+        const bool dbgw = CAL_DEV_TIMING(a.debug >= 4 && i == 1 && lane == 0 && wave == 0);
+        if (dbgw) bcast[16] = double(__builtin_readcyclecounter() - t_kernel);
+        double zp[8], zq[8];
+        ops(CB + 16 * it, zp);
+        if (it != jt) ops(CB + 16 * jt, zq);
+        f64x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Dn[(row0 + 4 * r) * DLD + col0];
+        if (dbgw) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); bcast[17] = double(__builtin_readcyclecounter() - t_kernel); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-zp[u], it != jt ? zq[u] : zp[u], acc, 0, 0, 0);
+        if (dbgw) { asm volatile("" :: "v"(acc[0])); bcast[18] = double(__builtin_readcyclecounter() - t_kernel); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Dn[(row0 + 4 * r) * DLD + col0] = acc[r];
+      }
+      LTICK(5)
+      if (CAL_DEV_TIMING(a.debug >= 4 && i == 1 && lane == 0)) bcast[wave] = double(__builtin_readcyclecounter() - t_kernel);
+      lds_barrier();
+      LTICK(6)
+      // the next block but one: requested first thing behind the barrier, in flight while the next block is factored (in
+      // front of the barrier its address arithmetic -- 6k clocks at level 0 -- held the chief up)
+      if (i + 2 < q && loader) fetch(i + 2, pr, std::false_type(), lmap);
+      const bool wF = role > 0 && wave == 1;
+      if (wave == 2) {        // next.A -= Z^BᵀZ^A, in the (negated) form the elimination holds its tiles in
+        double zb0[8], zb1[8], za[8];
+        ops(CB, zb0); ops(CB + 16, zb1);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          ops(CA + 16 * jt, za);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pre0[jt][r] = -Xn[(lk + 4 * r) * XLD + CA + 16 * jt + l16];
+            pre1[jt][r] = -Xn[(16 + lk + 4 * r) * XLD + CA + 16 * jt + l16];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            pre0[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(zb0[u], za[u], pre0[jt], 0, 0, 0);
+            pre1[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(zb1[u], za[u], pre1[jt], 0, 0, 0);
+          }
+        }
+      }
+      if (wF) {               // next.F -= Z^BᵀZ^F
+        double zb0[8], zb1[8], zf[8];
+        ops(CB, zb0); ops(CB + 16, zb1); ops(CF, zf);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pre0[0][r] = -Xn[(lk + 4 * r) * XLD + CF + l16];
+          pre1[0][r] = -Xn[(16 + lk + 4 * r) * XLD + CF + l16];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          pre0[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(zb0[u], zf[u], pre0[0], 0, 0, 0);
+          pre1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(zb1[u], zf[u], pre1[0], 0, 0, 0);
+        }
+      }
+      // what the back-substitution needs: filed by the loader waves
+      if (wave >= 4) {
+        const int lt2 = tid - 256;
+        if (role == 0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = lt2 + 256 * u, r = e >> 5, c = e & 31;
+            b.M[size_t(blk) * BB + e] = Dp[(BP + r) * DLD + c];
+            b.ZA[size_t(blk) * BB + e] = Zb[r * XLD + CA + c];
+            b.ZB[size_t(blk) * BB + e] = Zb[r * XLD + CB + c];
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) { const int e = lt2 + 256 * u; put(b.Y + size_t(blk) * fblk + size_t(e >> 4) * m1p + f0 + (e & 15), Zb[(e >> 4) * XLD + CF + (e & 15)]); }
+        }
+      }
+      // what the left separator collects over the chain (see la_acc_tile: on loader waves that do not share a SIMD with the chief)
+      if (left >= 0 && la_acc_owner) acc_a = atb_tile<true>(Zb, XLD, la_acc_p, Zb, XLD, la_acc_q, 0, BP, acc_a, lane);
+      if (left >= 0 && la_acc_owner2) acc_a2 = atb_tile<true>(Zb, XLD, CA + 16, Zb, XLD, CA, 0, BP, acc_a2, lane);
+      continue;
+    }
     // ---- file what the back-substitution needs ----
     if (role == 0) {
 #pragma unroll
@@ -848,7 +963,10 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     }
     // ---- what the left separator collects over the chain ----
     if (left >= 0) {
-      if (role == 0) {
+      if (LA) {       // (the owners of the sums are loader waves: see la_acc_owner)
+        if (la_acc_owner) acc_a = atb_tile<true>(Zb, XLD, la_acc_p, Zb, XLD, la_acc_q, 0, BP, acc_a, lane);
+        if (la_acc_owner2) acc_a2 = atb_tile<true>(Zb, XLD, CA + 16, Zb, XLD, CA, 0, BP, acc_a2, lane);
+      } else if (role == 0) {
         if (wave < 4 && !sym_skip) acc_a = atb_tile<true>(Zb, XLD, CA + 16 * it, Zb, XLD, CA + 16 * jt, 0, BP, acc_a, lane);
       } else if (wave == 2 || wave == 3) {
         acc_a = atb_tile<true>(Zb, XLD, CA + 16 * (wave - 2), Zb, XLD, CF, 0, BP, acc_a, lane);
@@ -864,18 +982,24 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
 #undef LTICK
   if (left >= 0) {
     if (role == 0) {
-      if (wave < 4 && !(ELIM && wave == 1)) {
-        const int it = wave >> 1, jt = wave & 1;
+      if (LA ? la_acc_owner : (wave < 4 && !(ELIM && wave == 1))) {
+        const int it = LA ? (wave == 6 ? 1 : 0) : wave >> 1, jt = LA ? (wave == 6 ? 1 : 0) : wave & 1;
         double* dst = pendD_w + (size_t(left) * 2 + 1) * BB;
 #pragma unroll
         for (int r = 0; r < 4; ++r) put(dst + (16 * it + lk + 4 * r) * BP + 16 * jt + l16, acc_a[r]);
+        if (la_acc_owner2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) put(dst + (16 + lk + 4 * r) * BP + l16, acc_a2[r]);
+        }
       }
-    } else if (wave == 2 || wave == 3) {
+    } else if (LA ? la_acc_owner : (wave == 2 || wave == 3)) {
+      const int h = LA ? wave - 5 : wave - 2;
       double* dst = pendF_w + (size_t(left) * 2 + 1) * fblk + f0 + l16;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) put(dst + size_t(16 * (wave - 2) + lk + 4 * r) * m1p, acc_a[r]);
+      for (int r = 0; r < 4; ++r) put(dst + size_t(16 * h + lk + 4 * r) * m1p, acc_a[r]);
     }
   }
+  if (CAL_DEV_TIMING(a.debug >= 4 && LA && tid == 0 && bid < 4 && q > 1)) printf("bcr_level %d wg %d: arrival at the second barrier of step 1 by wave: %.0f %.0f %.0f %.0f %.0f %.0f %.0f %.0f | end of the elimination (commit for 4..7) of step 1 by wave: %.0f %.0f %.0f %.0f %.0f %.0f %.0f %.0f | wave 0, step 1: behind the first barrier %.0f, operands there %.0f, products done %.0f\n", level, bid, bcast[0], bcast[1], bcast[2], bcast[3], bcast[4], bcast[5], bcast[6], bcast[7], bcast[8], bcast[9], bcast[10], bcast[11], bcast[12], bcast[13], bcast[14], bcast[15], bcast[16], bcast[17], bcast[18]);
   if (CAL_DEV_TIMING(a.debug >= 4 && tid == 0 && (bid < 9 || bid % 7 == 0))) printf("bcr_level %d: chain workgroup %d (role %d) lived %lld clocks: set-up done at %lld, first block in LDS at %lld, chain done at %lld | steps begin %lld %lld %lld %lld | wave 0 through with its part %lld %lld %lld %lld | Z there %lld %lld %lld %lld\n", level, bid, role, (long long)(__builtin_readcyclecounter() - t_kernel), t_setup, t_first, t_loop, t_top[0], t_top[1], t_top[2], t_top[3], t_elim[0], t_elim[1], t_elim[2], t_elim[3], t_bara[0], t_bara[1], t_bara[2], t_bara[3]);
   if (role == 0 && wave == 0 && lane == 0 && !(pmin > 0.0)) st->chol_failed = 1;
   if (pub) fanin_arrive(fan_word);
@@ -2345,13 +2469,19 @@ void launch_dense_back(const SolveArgs& a, const BcrArgs& b, int ks, int node0, 
 // ---- launch helpers ---------------------------------------------------------
 // CALICO_ELIM=panel: the block factorisation of rounds 1-3 (two in-wave panels + tile update + Z phase); read per solve (A/B switch)
 bool block_elim_enabled() { const char* e = std::getenv("CALICO_ELIM"); return !(e && std::string(e) == "panel"); }
-size_t bcr_level_lds_bytes() { return size_t(2 * 64 * DLD + 3 * BP * XLD + 80 + 128 + kLevelThreads + kElimBufDoubles) * sizeof(double); }
+// CALICO_LOOKAHEAD=1: the tree levels' steps with look-ahead (bcr_level_kernel<.., LA>); read per solve (A/B switch). OFF by
+// default: bit-identical, but measured 1.2 us SLOWER per level-0 launch at configs[3] (26.2 against 25.0 us, same box,
+// profiles/r05_lookahead_ab.txt) -- the chief does start ~2.5k clocks earlier per step, but a step is then bounded by the
+// loader waves' commit of the next block (they lose the Schur phase as load time) and by the two barriers' own latency.
+static bool level_lookahead_enabled() { const char* e = std::getenv("CALICO_LOOKAHEAD"); return e && std::atoi(e) != 0; }
+size_t bcr_level_lds_bytes() { return size_t(2 * 64 * DLD + 4 * BP * XLD + 80 + 128 + kLevelThreads + kElimBufDoubles) * sizeof(double); }      // (4: X twice, Z twice with the look-ahead)
 size_t bcr_back_lds_bytes(int q_max, int m1p) {
   return (size_t(2) * q_max * BP * DLD + kBcrMaxChain * BP + 3 * BP + m1p + size_t(q_max) * BP + 4 * BP) * sizeof(double);
 }
 hipError_t configure_bcr_kernels(int q_max, int m1p) {
   hipError_t e = hipSuccess;
   for (const void* f : {reinterpret_cast<const void*>(&bcr_level_kernel<true, true>), reinterpret_cast<const void*>(&bcr_level_kernel<false, true>),
+                        reinterpret_cast<const void*>(&bcr_level_kernel<true, true, true>), reinterpret_cast<const void*>(&bcr_level_kernel<false, true, true>),
                         reinterpret_cast<const void*>(&bcr_level_kernel<true, false>), reinterpret_cast<const void*>(&bcr_level_kernel<false, false>)}) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(bcr_level_lds_bytes()));
     if (e != hipSuccess) return e;
@@ -2376,9 +2506,9 @@ void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nod
   const int nfs = (a.mc + 1 + kBcrFS - 1) / kBcrFS;
   const int n_apply = n_keep > 0 ? std::min(64, std::max(1, n_keep * 4)) : 0;
   const int main_span = 8 * ((n_nodes + 7) / 8) * (1 + nfs);      // (node, role) workgroups laid out by XCD: see the kernel
-  const bool elim = block_elim_enabled();
+  const bool elim = block_elim_enabled(), la = level_lookahead_enabled();
   if (level == 0) {
-    hipLaunchKernelGGL((elim ? bcr_level_kernel<true, true> : bcr_level_kernel<true, false>), dim3(main_span + n_apply + (with_post_eval ? 1 : 0)), dim3(kLevelThreads),
+    hipLaunchKernelGGL((elim ? (la ? bcr_level_kernel<true, true, true> : bcr_level_kernel<true, true>) : bcr_level_kernel<true, false>), dim3(main_span + n_apply + (with_post_eval ? 1 : 0)), dim3(kLevelThreads),
                        bcr_level_lds_bytes(), s, a, b, node0, n_nodes, nfs, level, keep0, n_keep, o, with_post_eval, x, blocks, n_blocks,
                        log, log_cap, jacobi, 0, 0, 1, fan_word, 0, inl);
   } else {
@@ -2388,7 +2518,7 @@ void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nod
     const int n_schur_wg = schur_ks > 0 ? nt * (nt + 1) / 2 * schur_ks : 0;
     const int n_root_wg = schur_ks > 0 ? std::max(1, (br * (a.mc + 1 + br) + kLevelThreads - 1) / kLevelThreads) : 0;
     const int n_prod = n_nodes * (1 + nfs) + n_apply;        // the workgroups of this level that really exist
-    hipLaunchKernelGGL((elim ? bcr_level_kernel<false, true> : bcr_level_kernel<false, false>), dim3(main_span + n_apply + n_schur_wg + n_root_wg), dim3(kLevelThreads), bcr_level_lds_bytes(), s, a, b,
+    hipLaunchKernelGGL((elim ? (la ? bcr_level_kernel<false, true, true> : bcr_level_kernel<false, true>) : bcr_level_kernel<false, false>), dim3(main_span + n_apply + n_schur_wg + n_root_wg), dim3(kLevelThreads), bcr_level_lds_bytes(), s, a, b,
                        node0, n_nodes, nfs, level, keep0, n_keep, o, 0, x, blocks, n_blocks, log, log_cap, jacobi, n_schur_wg, n_root_wg,
                        std::max(1, schur_ks), schur_ks > 0 ? fan_word : nullptr, n_prod, inl);
   }

@@ -181,13 +181,20 @@ struct ElimTile {
 };
 
 // A follower with NT row tiles (compile-time unrolled; the descriptors are wave-uniform).
+// use_pre: the tiles come in registers -- pre0[q] / pre1[q] = the NEGATED entries of tile q against the block's columns 0..15 /
+// 16..31 in the accumulator layout (register r of lane (l16, lk): row l16 of the tile, column lk + 4r) -- instead of being
+// loaded from t[q].in: the tree levels' followers form the Schur update of their own input tiles in exactly that layout
+// (bcr_level_kernel, look-ahead), so the updated tiles never go through LDS.
+// (`use_pre` is a run-time, wave-uniform flag and not a template parameter: a second instantiation of the eight steps
+//  doubled the loop-invariant output addresses the compiler keeps across the caller's loop -- into scratch.)
 template <int NT>
-DEVI void elim_follow(const ElimTile (&t)[NT], const ElimChannel ch, int lane) {
+DEVI void elim_follow(const ElimTile (&t)[NT], const ElimChannel ch, int lane, bool use_pre = false, const f64x4* pre0 = nullptr, const f64x4* pre1 = nullptr) {
   const int l16 = lane & 15, lk = lane >> 4;
   const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
   f64x4 x0[NT], x1[NT];
 #pragma unroll
   for (int q = 0; q < NT; ++q) {
+    if (use_pre) { x0[q] = pre0[q]; x1[q] = pre1[q]; continue; }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int c = lk + 4 * r;
