@@ -266,19 +266,27 @@ def roofline_object(scene, world, args, ms_per_step, iter_bytes, dense_ms, dense
                                   "the kernel does not move those bytes",
         "counters": eval_c,
     }
+    # The dominant kernel of THIS run: the longer of the two launches timed live with HIP events (the reduced system's launch
+    # and the evaluation launch; the tree levels are shorter than either at every configuration measured) -- the committed
+    # profile only says which kernels are candidates (dominant_kernel_from_profiles ranks by average launch per iteration).
+    eval_dominates = (not phase_n[8]) or jac_ms > dense_ms
+    live = evaluation if eval_dominates else dominant
+    live_c = eval_c if eval_dominates else dense_c
+    dominant["is_dominant_in_this_run"] = not eval_dominates
+    evaluation["is_dominant_in_this_run"] = eval_dominates
     return {
         "bound": "hbm", "limited_by": "latency (dependent FP64 chains of single waves and five kernel boundaries per iteration; DESIGN.md 4)",
         "achieved": iter_bytes / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": iter_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "algorithmic_bytes_per_iteration": iter_bytes,
         # `traffic`: HBM bytes per launch of the dominant kernel (PMC, per the guide's corrections); null when there is no committed pass for this run's shape
-        "traffic": dense_c.get("hbm_bytes_per_launch"), "traffic_source": not_this_run,
-        "kernel": dominant["kernel"], "kernel_avg_launch_ms": dominant["avg_launch_ms"], "event_bracket_ms": bracket_ms,
+        "traffic": live_c.get("hbm_bytes_per_launch"), "traffic_source": not_this_run,
+        "kernel": live["kernel"], "kernel_avg_launch_ms": live["avg_launch_ms"], "event_bracket_ms": bracket_ms,
         "linear_solve_share_of_step": lin_ms / ms_per_step if wu_n[2] else None,
         "linear_solve_ms": lin_ms if wu_n[2] else None,
         "dominant_kernel": dominant,
         "evaluation_kernel": evaluation,
-        "mfma_utilisation": {"kernel": "dense_back_kernel", "mfma_util": dense_c.get("mfma_util"), "fp64_frac": dense_c.get("fp64_frac_of_78.6_tflops"),
+        "mfma_utilisation": {"kernel": "eval_cells_kernel" if eval_dominates else "dense_back_kernel", "mfma_util": live_c.get("mfma_util"), "fp64_frac": live_c.get("fp64_frac_of_78.6_tflops"),
                              "source": not_this_run,
                              "definition": "SQ_VALU_MFMA_BUSY_CYCLES (sum over SIMDs) / (kernel duration x 2.4 GHz x 1024 SIMDs); fp64_frac: FP64 flops / duration / 78.6 TFLOP/s"},
         "fp64_by_kernel": ({"source": not_this_run, "kernels": fp64_js.get("kernels")} if fp64_js else None),
@@ -507,8 +515,8 @@ def main():
     timed_solves(max(1, args.warmup))
     wu_ms, wu_n = read_phases()
     # timed region: only the Jacobian kernel (phase 0) and the reduced-system launch (phase 6: the longest kernel of an
-    # iteration) carry events, and only every 16th of their launches -- an event
-    # pair costs ~6 us of stream time on either side of the kernel. The K-step sample is a few milliseconds long, so it is
+    # iteration) carry events, and only every 64th of their launches (one launch of each per sample; round 4: every 16th,
+    # two per sample and 1.5 % of the sample's time) -- an event pair costs ~6 us of stream time on either side of the kernel. The K-step sample is a few milliseconds long, so it is
     # repeated and the MEDIAN sample is the one reported (box-to-box and run-to-run spread is several per cent).
     # By default the samples add up to >= 8 s of contiguous GPU work (9 s are aimed at: the first, estimating sample runs slower) (a 20-iteration sample is ~3 ms: the driver's 5-second utilisation
     # sampler would otherwise never see the device busy); --repeats N fixes the count.
@@ -527,7 +535,7 @@ def main():
             repeats = int(t.item())
     samples = []
     for _ in range(repeats):
-        P.set_phase_timing(0x41 | (16 << 8))             # (restarts the accumulated phase times)
+        P.set_phase_timing(0x41 | (64 << 8))             # (restarts the accumulated phase times; every 64th launch: the first of each sample)
         barrier()
         t0 = time.perf_counter()
         rec = timed_solves(args.steps)

@@ -596,13 +596,16 @@ __device__ __attribute__((noinline)) void stage_b_mfma(LdsRows lds, int pad, int
     }
   }
 }
-// PART 0: all tiles; 1: the first 60 % of the upper triangle's tiles in row-major order (the late wave's share: it starts on
+// PART 0: all tiles; 1: the first three quarters of the upper triangle's tiles in row-major order (the late wave's share: it starts on
 // them the moment its rows are staged); 2: the rest (the early wave's, behind its own block).
 // (Every call costs ~4k clocks on top of its MFMAs, so a share is one call: splitting the early wave's own tiles around the
 //  hand-over as well measured slower.)
 template <int NT, int PART>
 DEV void stage_b_part(LdsRows lds, int pad, int nrows, int n1, double* out) {
-  constexpr int T = NT * (NT + 1) / 2, n_main = (3 * T + 2) / 5;
+  // (round 5: three quarters, it was 60 % -- with the IMU blocks' lane-dependent choices free of branches the late wave's
+  //  rows are staged at 24.8k clocks instead of 39.6k, the early wave is through with its own block at 35k: at 60 % the early
+  //  wave ended at 44.6k, the late one at 36.5k)
+  constexpr int T = NT * (NT + 1) / 2, n_main = (3 * T + 2) / 4;
   if constexpr (PART == 0) stage_b_mfma<NT>(lds, pad, nrows, n1, out);
   else if constexpr (PART == 1) { if constexpr (n_main > 0) stage_b_mfma<NT, 0, n_main>(lds, pad, nrows, n1, out); }
   else { if constexpr (n_main < T) stage_b_mfma<NT, n_main, T>(lds, pad, nrows, n1, out); }
@@ -1104,7 +1107,11 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds, FrameP
   // ---- compact record: M_ext (PE×PE) then coef (n1). The expansion TᵀMT -- out(i, j) = coef_i coef_j M_ext(prim_i, prim_j)
   //      -- is done once per CELL by expand_cells_kernel over all its frames. Only prim rows / columns < P1e and the
   //      latency row / column PT are read there; the others are written as they lie. ----
-  if (fp) { fp->Me = Me; fp->coef = coef; fp->PE = PE; fp->n1 = n1; return; }      // (the cell's workgroup expands out of LDS: no record)
+  if (fp) {      // (the cell's workgroup expands out of LDS: no record)
+    if (dbg) printf("eval_frames cycles (frame of %d blocks, %d small / %d prim cols, cell workgroup): frame-constants %lld  barrier %lld  blocks %lld  M-mfma %lld  M-to-lds [sums %lld  Ms+B %lld  N %lld  M %lld  latency %lld]\n",
+                    it.obs_count, Ps, P1e, tph[0], tph[1], tph[2], tph[3], tph[6], tph[7], tph[8], tph[9], tph[4]);
+    fp->Me = Me; fp->coef = coef; fp->PE = PE; fp->n1 = n1; return;
+  }
   double* out = a.partials + it.partial_off;
   const int nme = PE * PE;
   for (int i = lane; i < nme; i += 64) out[i] = Me[i];

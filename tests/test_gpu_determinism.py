@@ -335,3 +335,38 @@ def test_cell_workgroups_equal_the_expansion_launch(monkeypatch):
             assert first[0] == ref[0] and first[1] == ref[1]
             np.testing.assert_allclose(first[2], ref[2], rtol=1e-9)
             np.testing.assert_allclose(first[3], ref[3], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_chain_look_ahead_is_bit_identical(monkeypatch):
+    """Round 5: the tree levels' chain steps with look-ahead (bcr_level_kernel<.., LA>, CALICO_LOOKAHEAD=1: the chief starts on
+    the next block of a chain behind the diagonal's Schur update alone, the followers form the update of their own input
+    tiles in registers, Z is double-buffered, the loader waves carry the left separator's sums) reorder WHO computes a
+    product and WHEN, never the products or the order of a sum: every iteration, cost and estimate must equal the default
+    path's bit for bit -- chains of 4 (configs[3]'s shape), of 8 (long trajectory, several levels) and of 2 / 3 (leaf
+    override), border roles and role 0 alike; three repeats each (a hazard between a step's LDS buffers would show as a
+    run-to-run difference)."""
+    api = helpers.hip_api()
+    common = dict(chart="april", pixel_noise=0.1, gyro_noise=1e-3, accel_noise=1e-2, robust=True, max_cam_obs=6000)
+    scenes = [
+        (syn.make_scene(4, 1, True, 3, cam_rate=10.0, imu_rate=100.0, duration=8.7, seed=41, segment_duration=8.7 / 23.9, **common), None),
+        (syn.make_scene(2, 1, True, 2, seed=4), None),        # 185 control points: several tree levels
+        (syn.make_scene(2, 3, True, 2, cam_rate=10.0, imu_rate=100.0, duration=6.0, seed=42, segment_duration=6.0 / 23.9, **common), "2"),
+        (syn.make_scene(2, 3, True, 2, cam_rate=10.0, imu_rate=100.0, duration=6.0, seed=42, segment_duration=6.0 / 23.9, **common), "3"),
+    ]
+    for sc, leaf in scenes:
+        if leaf:
+            monkeypatch.setenv("CALICO_BCR_LEAF", leaf)
+        runs = {}
+        for la in ("0", "1"):
+            monkeypatch.setenv("CALICO_LOOKAHEAD", la)
+            runs[la] = _solve_repeatedly(api, sc, repeats=3, max_iter=20)
+        monkeypatch.delenv("CALICO_LOOKAHEAD")
+        if leaf:
+            monkeypatch.delenv("CALICO_BCR_LEAF")
+        ref = runs["0"][0]
+        assert ref[0] > 3
+        for la in ("0", "1"):
+            for r in runs[la]:
+                assert r[0] == ref[0] and r[1] == ref[1] and r[2] == ref[2], (la, leaf)
+                assert np.array_equal(r[3], ref[3]), (la, leaf)
