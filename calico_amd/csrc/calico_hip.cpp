@@ -920,7 +920,7 @@ int build_plan(calico_problem* p) {
             CellDev c;
             c.layout = kq.layout; c.seg = kq.seg; c.frame_begin = int(p->h_fitems.size()); c.frame_count = 0;
             c.partial_off = int64_t(poff); c.prim_off = 0;
-            poff += size_t(layouts[size_t(kq.layout)].ncols + 1) * (layouts[size_t(kq.layout)].ncols + 1);
+            poff += size_t(tri_size(layouts[size_t(kq.layout)].ncols + 1));      // (the block's upper triangle, packed: problem_dev.hpp)
             p->h_cells.push_back(c);
           }
           p->h_cells.back().frame_count += 1;
@@ -1009,7 +1009,7 @@ int build_plan(calico_problem* p) {
         p->h_cells.push_back(c);
         it.rows_off = -2;            // (< 0: the item forms its own block; -2: that block is listed as a cell's)
         it.partial_off = int64_t(poff);
-        poff += size_t(n1) * n1;
+        poff += size_t(tri_size(n1));
       } else if (row_cells_ok && hs.kind != CALICO_SENSOR_CAMERA && n1 <= 112) {
         it.partial_off = 0; it.rows_off = 0;   // row store offset assigned below, once the staging dimensions are known
         if (p->h_cells.empty() || p->h_cells.back().prim_off >= 0 || p->h_cells.back().layout != it.layout ||
@@ -1017,7 +1017,7 @@ int build_plan(calico_problem* p) {
           CellDev c;
           c.layout = it.layout; c.seg = it.seg; c.frame_begin = int(p->h_jac_items.size()); c.frame_count = 0;
           c.partial_off = int64_t(poff); c.src_off = 0; c.n1 = n1; c.PE = hs.dim() * imu_chunk_items; c.prim_off = -1; c.pad0 = 0;
-          poff += size_t(n1) * n1;
+          poff += size_t(tri_size(n1));
           p->h_cells.push_back(c);
         }
         p->h_cells.back().frame_count += 1;
@@ -1025,7 +1025,7 @@ int build_plan(calico_problem* p) {
       } else {
         it.rows_off = -1;
         it.partial_off = int64_t(poff);
-        poff += size_t(n1) * n1;
+        poff += size_t(tri_size(n1));
       }
       p->h_jac_items.push_back(it);
     }
@@ -1202,10 +1202,10 @@ int build_plan(calico_problem* p) {
     auto tan_of = [&](int c) { return c < 6 * k ? 6 * (it_seg + c / 6) + c % 6 : gmap[size_t(c - 6 * k)]; };
     for (int i = gs_ok ? 6 * k : 0; i < nc; ++i) {      // (structured gather: the spline rows have no lists)
       const int ti = tan_of(i);
-      pairs.push_back({int(sa.off_g()) + ti, int(it_poff) + i * n1 + nc});
+      pairs.push_back({int(sa.off_g()) + ti, int(it_poff) + tri_off(i, nc, n1)});
       for (int j = i; j < nc; ++j) {
         const int tj = tan_of(j);
-        const int src = int(it_poff) + i * n1 + j;
+        const int src = int(it_poff) + tri_off(i, j, n1);
         if (ti < NS && tj < NS) {
           const int a = ti / 6, b = tj / 6;  // a <= b
           pairs.push_back({int(sa.off_B()) + (a * k + (b - a)) * 36 + (ti % 6) * 6 + (tj % 6), src});

@@ -592,7 +592,7 @@ __device__ __attribute__((noinline)) void stage_b_mfma(LdsRows lds, int pad, int
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gi = 16 * I + lk + 4 * r, gj = 16 * J + lc16;
-      if (gi <= gj && gj < n1) block_store(out + size_t(gi) * n1 + gj, acc[t][r]);
+      if (gi <= gj && gj < n1) block_store(out + tri_off(gi, gj, n1), acc[t][r]);
     }
   }
 }
@@ -891,6 +891,15 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds, FrameP
   int* bsrc = reinterpret_cast<int*>(bco + ((3 * P1e + 1) & ~1));   // [P1e][3]   ... and small prim columns
   double* Me = lds + SA;                             // [PE][PE]
   double* coef = Me + ((PE * PE + 1) & ~1);          // [n1] column c of the item = coef[c] · prim column prim[c]
+  // observation of this lane in the first batch (clamped: loads stay unconditional), requested FIRST: the model point is a
+  // dependent load (offset -> point), two round trips that run beside the frame's constants (round 5: requested behind
+  // them, the first batch waited 2.9k clocks for its observations)
+  auto obs_index = [&](int b0) { return it.obs_begin + min(b0 + lane, it.obs_count - 1); };
+  int o_nx = obs_index(0);
+  const double* xm_p = a.x + a.point_off[o_nx];
+  double px_nx = a.m0[o_nx], py_nx = a.m1[o_nx];
+  uint8_t act_nx = a.active ? a.active[o_nx] : uint8_t(1);     // outlier tag (nullptr: nothing is tagged), fetched ahead like the rest
+  double xm_nx[3] = {xm_p[0], xm_p[1], xm_p[2]};
   // ---- per-frame quantities (every lane computes the same values) ----
   const int ki = it.seg + K - 1;
   const double* Mb = a.basis + size_t(it.seg) * K * K;
@@ -914,13 +923,6 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds, FrameP
   const M3 R_rw = rotmat(angle_axis_to_quat(phi));
   const M3 Jl = rod_J_matrix(rodrigues<double>(phi.x, phi.y, phi.z, false));
   const double* intr = a.x + S.intr_off;
-  // observation of this lane in the first batch (clamped: loads stay unconditional), fetched ahead of use
-  auto obs_index = [&](int b0) { return it.obs_begin + min(b0 + lane, it.obs_count - 1); };
-  int o_nx = obs_index(0);
-  double px_nx = a.m0[o_nx], py_nx = a.m1[o_nx];
-  const double* xm_p = a.x + a.point_off[o_nx];
-  double xm_nx[3] = {xm_p[0], xm_p[1], xm_p[2]};
-  uint8_t act_nx = a.active ? a.active[o_nx] : uint8_t(1);     // outlier tag (nullptr: nothing is tagged), fetched ahead like the rest
   // expansion coefficients: item column lc = coef[lc] · prim column (spline columns carry their weight w_i)
   for (int lc = lane; lc < n1; lc += 64) {
     double cf = 1.0;
@@ -1278,7 +1280,7 @@ DEV void eval_cells_body(const EvalArgs& a, double* lds) {
       const int pi = fp.e[q] & 255, pj = (fp.e[q] >> 8) & 255, pm_off = fp.e[q] >> 16;
       double acc = 0.0;
       acc += fp.coef[pi] * fp.coef[pj] * fp.Me[pm_off];
-      block_store(out + size_t(pi) * n1 + pj, acc);
+      block_store(out + tri_off(pi, pj, n1), acc);
     }
 #pragma unroll
     for (int q = 0; q < kPairQ; ++q) {
@@ -1286,7 +1288,7 @@ DEV void eval_cells_body(const EvalArgs& a, double* lds) {
       const int pi = e2[q] & 255, pj = (e2[q] >> 8) & 255, pm_off = e2[q] >> 16;
       double acc = 0.0;
       acc += fp.coef[pi] * fp.coef[pj] * fp.Me[pm_off];
-      block_store(out + size_t(pi) * n1 + pj, acc);
+      block_store(out + tri_off(pi, pj, n1), acc);
     }
     return;
   }
@@ -1304,7 +1306,7 @@ DEV void eval_cells_body(const EvalArgs& a, double* lds) {
     double acc = 0.0;
     acc += cf0[pi] * cf0[pj] * me0[pm_off];
     acc += cf0[shift + pi] * cf0[shift + pj] * me0[shift + pm_off];
-    block_store(out + size_t(pi) * n1 + pj, acc);
+    block_store(out + tri_off(pi, pj, n1), acc);
   }
 }
 
@@ -1397,7 +1399,7 @@ DEV void row_cell_body(const EvalArgs& a, const CellDev& cell, double* lds) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gi = 16 * tI[q] + lk + 4 * r, gj = 16 * tJ[q] + lc16;
-      if (gi <= gj && gj < n1) out[size_t(gi) * n1 + gj] = acc[q][r];
+      if (gi <= gj && gj < n1) out[tri_off(gi, gj, n1)] = acc[q][r];
     }
   }
 }
@@ -1463,7 +1465,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
   double* out = a.partials + cell.partial_off;
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
-    if (tid + 256 * q < n_pairs) out[size_t(pi[q]) * n1 + pj[q]] = acc[q];
+    if (tid + 256 * q < n_pairs) out[tri_off(pi[q], pj[q], n1)] = acc[q];
   CTICK(3)
   if (dbg) printf("expand_cells cycles (cell of %d frames, n1 %d): setup+tables %lld  record copy %lld  accumulate %lld  store %lld\n",
                   cell.frame_count, n1, tph[0], tph[1], tph[2], tph[3]);

@@ -223,6 +223,12 @@ struct ControlTail {
 #else
 #define CAL_HD
 #endif
+// A cell's / work item's partial block [J r]^T[J r] is its UPPER TRIANGLE, packed row-major (round 5; a full n1 x n1 square
+// with only the upper triangle written before): entry (i, j), i <= j, at tri_off(i, j, n1); tri_size(n1) entries per block.
+// The gather touched every other 128-byte line of the squares half-used -- at configs[4] the blocks of an XCD's stretch of
+// the trajectory (59 MB over all XCDs as squares) no longer fitted its L2.
+CAL_HD inline int tri_off(int i, int j, int n1) { return i * n1 - ((i * (i - 1)) >> 1) + (j - i); }
+CAL_HD inline int tri_size(int n1) { return (n1 * (n1 + 1)) >> 1; }
 
 // Arguments of the linear-solve kernels. The reduce buffer R is laid out as
 // [cost | invalid | g(NT) | band blocks B(n_cp,k,6,6) | border E(6n_cp,m) | corner C(m,m)].

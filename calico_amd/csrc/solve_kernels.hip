@@ -106,7 +106,7 @@ DEVI int struct_sources(const GatherStruct& gs, const StructOut& q, F f) {
       if (q.tc >= 0) j = jc;
       else if (q.rhs) j = n1 - 1;
       else { j = 6 * (q.b - sg) + q.c; if (q.a == q.b && i > j) { const int t = i; i = j; j = t; } }
-      f(po + i * n1 + j);
+      f(po + tri_off(i, j, n1));      // (i <= j in every case: a spline row against a later spline column, a calibration column or the right-hand side)
       ++n;
     }
   }
