@@ -286,17 +286,36 @@ DEVI void schur_root_rows(const SolveArgs& a, const BcrArgs& b, int ks, int w0, 
 // panel | Z = MᵀX (CALICO_ELIM=panel keeps those).
 // A thread's share of a block's entries on the way from memory to LDS (bcr_level_kernel's fetch / commit): NL threads
 // take NU entries of D / B / A and NF of the F slice each, thread lt the entries lt, lt + NL, ...
+// Level 0 (round 5): the entries are dealt so that the lanes of a load run ALONG the six contiguous doubles of the band's
+// storage (R holds H(row, column) at [(column's control point, distance)][column component][row component]: the six row
+// components of one column are contiguous) -- D: only the upper triangle r <= c, row-major (528 entries, mirrored into LDS:
+// the block is symmetric; the lower half read row-major walked R with a stride of six doubles), B / A: entry e is (column
+// e >> 5, row e & 31). A 64-lane request touches ~11 lines instead of up to 64; the loaders' request -> commit time is what
+// ends every step of a chain and the head of the launch.
+constexpr int kBcrTri = BP * (BP + 1) / 2;       // 528
 template <int NL_, int NU_, int NF_>
 struct BcrLoadMap {
   static constexpr int NL = NL_, NU = NU_, NF = NF_;
+  static constexpr int NUD = (kBcrTri + NL_ - 1) / NL_;      // level 0: entries of D's upper triangle per thread
   int lt;
   int iD[NU_], iB[NU_];        // level 0: positions in R of the entries for superblock 0
+  int rcD[NU_];                // level 0: (r << 8 | c), r <= c, of the thread's D entries
   bool okD[NU_], okB[NU_];
 };
 template <int NU, int NF>
 struct BcrPre { double d[NU], bt[NU], at[NU], f[NF]; };
+// level 0: what a block's requests return, before selection and damping (fetch_request / fetch_finish)
+template <int NUD, int NU, int NF>
+struct BcrRaw { double vraw[NUD], svv[NUD], q2v[NUD], vraw1[NUD], graw[NU], garaw[NU], graw1[NU], garaw1[NU], fraw[NF], fraw1[NF]; unsigned flags; };
 #ifndef BCR_FIRST_BLOCK_ALL_WAVES
 #define BCR_FIRST_BLOCK_ALL_WAVES 1
+#endif
+// BCR_EARLY_REQUESTS=1 (compile time; round 5, measured and left OFF): the loaders issue the requests of block i + 2 in front of
+// step i's Schur phase and only finish (selection, damping, commit) at the top of step i + 1. Bit-identical; level 0 25.0 ->
+// 26.9 us (27.8 with the 18 registers it spills): the requests' address arithmetic (3-4k clocks on SIMDs shared with the chief
+// and the followers) then sits between the step's two barriers and holds the chief up by more than the earlier commit gains.
+#ifndef BCR_EARLY_REQUESTS
+#define BCR_EARLY_REQUESTS 0
 #endif
 
 // LA (look-ahead, round 5; ELIM only): between two blocks of a chain only what the NEXT block's chief waits for stays in
@@ -518,13 +537,23 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     typedef typename std::remove_reference<decltype(m)>::type M;
     if (FROM_R) {
 #pragma unroll
-      for (int u = 0; u < M::NU; ++u) {
-        const int e = min(max(m.lt, 0) + M::NL * u, BB - 1);
-        const int r = e >> 5, c = e & 31;
-        const int hi = max(r, c), lo = min(r, c);
-        const int dD = hi / 6 - lo / 6;
+      for (int u = 0; u < M::NUD; ++u) {      // D: entry eD of the row-major upper triangle -> (r, c), r <= c
+        const int eD = min(max(m.lt, 0) + M::NL * u, kBcrTri - 1);
+        // row r starts at r (2 BP + 1 - r) / 2: the float estimate is exact to +-1, fixed up
+        int r = int((float(2 * BP + 1) - sqrtf(float((2 * BP + 1) * (2 * BP + 1)) - 8.0f * float(eD))) * 0.5f);
+        r = max(0, min(BP - 1, r));
+        if (((r + 1) * (2 * BP - r)) / 2 <= eD) ++r;
+        if ((r * (2 * BP + 1 - r)) / 2 > eD) --r;
+        const int c = r + eD - (r * (2 * BP + 1 - r)) / 2;
+        m.rcD[u] = r << 8 | c;
+        const int dD = c / 6 - r / 6;
         m.okD[u] = r < RB && c < RB && dD < a.k;
-        m.iD[u] = m.okD[u] ? ((lo / 6) * a.k + dD) * 36 + (lo % 6) * 6 + hi % 6 : 0;
+        m.iD[u] = m.okD[u] ? ((r / 6) * a.k + dD) * 36 + (r % 6) * 6 + c % 6 : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < M::NU; ++u) {       // B / A: entry e -> (column e >> 5, row e & 31): lanes along the rows
+        const int e = min(max(m.lt, 0) + M::NL * u, BB - 1);
+        const int c = e >> 5, r = e & 31;
         const int dB = kBcrCps + r / 6 - c / 6;       // row r of the next superblock against column c of this one
         m.okB[u] = r < RB && c < RB && dB < a.k;
         m.iB[u] = m.okB[u] ? ((c / 6) * a.k + dB) * 36 + (c % 6) * 6 + r % 6 : 0;
@@ -535,101 +564,136 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   lmap.lt = lt;
   constexpr bool kAllFetchFirst = ELIM && BCR_FIRST_BLOCK_ALL_WAVES;
   if (!kAllFetchFirst) fill_map(lmap);       // (otherwise behind the first block's requests: the loaders' map is for the later blocks)
+  // Level 0: a block's fetch in two halves -- `fetch_request` is the address arithmetic and the loads (nothing in it waits),
+  // `fetch_finish` the selection, the damping of the diagonal and what goes to `pr` -- so that the loaders can put a block's
+  // requests in FRONT of a step's Schur phase and only finish behind it (round 5; see the step loop).
+  auto fetch_request = [&](int i, auto& rw, auto both_tag, const auto& m) {
+    typedef typename std::remove_reference<decltype(m)>::type M;
+    constexpr int NL = M::NL, NU = M::NU, NF = M::NF, NUD = M::NUD;
+    const int lt = m.lt;
+    constexpr bool BOTH = decltype(both_tag)::value;      // (first block of the launch: see R_buf0 / R_buf1)
+    const int blk = blk0 + i;
+    const bool has_next = (i + 1 < q) || right >= 0;
+    const bool has_a = (i == 0) && left >= 0;
+    // neighbours in the tree are neighbours in time at level 0 (next = blk + 1, left separator = blk - 1)
+    const int nreal = a.n_s() - RB * blk, nreal_n = nreal - RB;     // real rows of this superblock / of the next one
+    const double* const Rsel = BOTH ? R_buf0 : a.R;
+    const double* RBnd = Rsel + a.off_B() + size_t(blk) * strideB;
+    const double* RBndA = Rsel + a.off_B() + size_t(max(blk - 1, 0)) * strideB;
+    const size_t alt = BOTH ? a.r_stride : 0;      // the same entry of the other buffer
+    unsigned fl = 0;
+#pragma unroll
+    for (int u = 0; u < NUD; ++u) {        // D, upper triangle
+      const int r = m.rcD[u] >> 8, c = m.rcD[u] & 255;
+      bool act_r = true, act_c = true;
+      if (!b.all_active) {
+        const int n_cp = a.n_cp;
+        act_r = a.cp_active[min(kBcrCps * blk + r / 6, n_cp - 1)] != 0;
+        act_c = a.cp_active[min(kBcrCps * blk + c / 6, n_cp - 1)] != 0;
+      }
+      const bool vD = m.okD[u] && r < nreal && c < nreal && act_r && act_c;
+      fl |= vD ? 1u << u : 0u;
+      rw.vraw[u] = RBnd[vD ? m.iD[u] : 0];
+      if (BOTH) rw.vraw1[u] = RBnd[alt + (vD ? m.iD[u] : 0)];
+      const int ts = (r == c && r < RB && r < nreal) ? RB * blk + r : 0;
+      rw.svv[u] = a.scale[ts]; rw.q2v[u] = a.scale[a.NT() + ts];        // (harmless during a solve's first linear solve, which does not use them)
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {         // B (next superblock's rows against this one's columns), A (this one's rows against the left separator's columns)
+      const int e = min(max(lt, 0) + NL * u, BB - 1);
+      const int c = e >> 5, r = e & 31;
+      bool act_r = true, act_c = true, act_rn = true, act_cl = true;
+      if (!b.all_active) {
+        const int n_cp = a.n_cp;
+        act_r = a.cp_active[min(kBcrCps * blk + r / 6, n_cp - 1)] != 0;
+        act_c = a.cp_active[min(kBcrCps * blk + c / 6, n_cp - 1)] != 0;
+        act_rn = a.cp_active[min(kBcrCps * (blk + 1) + r / 6, n_cp - 1)] != 0;
+        act_cl = a.cp_active[min(max(kBcrCps * (blk - 1) + c / 6, 0), n_cp - 1)] != 0;
+      }
+      const bool vB = m.okB[u] && has_next && r < nreal_n && act_rn && act_c;
+      fl |= vB ? 1u << (8 + u) : 0u;
+      rw.graw[u] = RBnd[vB ? m.iB[u] : 0];
+      if (BOTH) rw.graw1[u] = RBnd[alt + (vB ? m.iB[u] : 0)];
+      const bool vA = m.okB[u] && has_a && r < nreal && act_r && act_cl;
+      fl |= vA ? 1u << (16 + u) : 0u;
+      rw.garaw[u] = 0.0;
+      if (has_a) rw.garaw[u] = RBndA[vA ? m.iB[u] : 0];      // (only the first block of a chain touches the left separator)
+      rw.garaw1[u] = 0.0;
+      if (BOTH && has_a) rw.garaw1[u] = RBndA[alt + (vA ? m.iB[u] : 0)];
+    }
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int e = min(max(lt, 0) + NL * u, BP * kBcrFS - 1);
+      const int r = e >> 4, col = role > 0 ? f0 + (e & 15) : 0;
+      const int t = RB * blk + r;
+      bool act_r = true;
+      if (!b.all_active) act_r = a.cp_active[min(kBcrCps * blk + r / 6, a.n_cp - 1)] != 0;
+      const bool vF = role > 0 && r < RB && r < nreal && col <= a.mc && act_r;
+      fl |= vF ? 1u << (24 + u) : 0u;
+      const size_t idx = vF ? (col < a.mc ? a.off_E() + size_t(t) * a.mc + col : a.off_g() + t) : a.off_g();
+      rw.fraw[u] = Rsel[idx];
+      if (BOTH) rw.fraw1[u] = Rsel[alt + idx];
+    }
+    rw.flags = fl;
+  };
+  // (every load of the block is requested before the first store: the damping of a diagonal entry is filed -- a.dadd -- as it
+  //  is formed, and as far as the compiler knows that store may alias a.R)
+  auto fetch_finish = [&](int i, auto& rw, auto& pr, auto both_tag, const auto& m) {
+    typedef typename std::remove_reference<decltype(m)>::type M;
+    constexpr int NU = M::NU, NF = M::NF, NUD = M::NUD;
+    constexpr bool BOTH = decltype(both_tag)::value;
+    const int blk = blk0 + i;
+    const int nreal = a.n_s() - RB * blk;
+    const unsigned fl = rw.flags;
+    if (BOTH) {
+      const bool second = r_cur_v != 0;
+#pragma unroll
+      for (int u = 0; u < NUD; ++u) rw.vraw[u] = second ? rw.vraw1[u] : rw.vraw[u];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { rw.graw[u] = second ? rw.graw1[u] : rw.graw[u]; rw.garaw[u] = second ? rw.garaw1[u] : rw.garaw[u]; }
+#pragma unroll
+      for (int u = 0; u < NF; ++u) rw.fraw[u] = second ? rw.fraw1[u] : rw.fraw[u];
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) { pr.bt[u] = (fl >> (8 + u)) & 1 ? rw.graw[u] : 0.0; pr.at[u] = (fl >> (16 + u)) & 1 ? rw.garaw[u] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < NUD; ++u) {
+      const int r = m.rcD[u] >> 8, c = m.rcD[u] & 255;
+      const bool vD = (fl >> u) & 1;
+      double v = vD ? rw.vraw[u] : 0.0;
+      {
+        // LM damping of a diagonal entry (FromR::damping), for every entry and selected afterwards (no branch around
+        // loads). 1 / (radius s^2) as a product of 1 / radius (once per thread) and the filed 1 / s^2; only a solve's
+        // first linear solve, which forms the scale itself, divides.
+        const bool dg = r == c;
+        const int t = RB * blk + r;
+        const bool real_row = r < RB && r < nreal;
+        double d;
+        const double inv_radius = 1.0 / radius;       // (once per thread: the same value in every entry)
+        if (fr.first_scale == 0) d = fmin(fmax(v * rw.svv[u] * rw.svv[u], o.min_lm_diagonal), o.max_lm_diagonal) * (inv_radius * rw.q2v[u]);
+        else d = fr.damping(v, (dg && real_row) ? t : 0);
+        if (dg) {
+          if (vD) { v += d; if (role == 0) a.dadd[t] = d; }
+          else { v = 1.0; if (role == 0 && real_row) a.dadd[t] = 0.0; }
+        }
+      }
+      pr.d[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < NF; ++u) pr.f[u] = (fl >> (24 + u)) & 1 ? rw.fraw[u] : 0.0;
+  };
   auto fetch = [&](int i, auto& pr, auto both_tag, const auto& m) {
     typedef typename std::remove_reference<decltype(m)>::type M;
     constexpr int NL = M::NL, NU = M::NU, NF = M::NF;
     const int lt = m.lt;
-    constexpr bool BOTH = decltype(both_tag)::value;      // (FROM_R, first block of the launch: see R_buf0 / R_buf1)
     const int blk = blk0 + i, mask = pend_mask;
     const bool has_next = (i + 1 < q) || right >= 0;
     const bool has_a = (i == 0) && left >= 0;
     const size_t lc = size_t(left > 0 ? left : 0);
     if (FROM_R) {
-      // neighbours in the tree are neighbours in time at level 0 (next = blk + 1, left separator = blk - 1)
-      const int nreal = a.n_s() - RB * blk, nreal_n = nreal - RB;     // real rows of this superblock / of the next one
-      const double* const Rsel = BOTH ? R_buf0 : a.R;
-      const double* RBnd = Rsel + a.off_B() + size_t(blk) * strideB;
-      const double* RBndA = Rsel + a.off_B() + size_t(max(blk - 1, 0)) * strideB;
-      const size_t alt = BOTH ? a.r_stride : 0;      // the same entry of the other buffer
-      // Two passes: every load of the block is REQUESTED before the first store. The damping of a diagonal entry is filed
-      // (a.dadd) as it is formed, and as far as the compiler knows that store may alias a.R -- with the store inside the
-      // loop over the entries every entry's loads waited for the entry before it: NU dependent round trips per block
-      // instead of one (the head of the launch and every step's loads were that much longer).
-      double vraw[NU], graw[NU], garaw[NU], svv[NU], q2v[NU], fraw[NF];
-      double vraw1[NU], graw1[NU], garaw1[NU], fraw1[NF];
-      bool vDs[NU], vBs[NU], vAs[NU], vFs[NF];
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        const int e = min(max(lt, 0) + NL * u, BB - 1);
-        const int r = e >> 5, c = e & 31;
-        bool act_r = true, act_c = true, act_rn = true, act_cl = true;
-        if (!b.all_active) {
-          const int n_cp = a.n_cp;
-          act_r = a.cp_active[min(kBcrCps * blk + r / 6, n_cp - 1)] != 0;
-          act_c = a.cp_active[min(kBcrCps * blk + c / 6, n_cp - 1)] != 0;
-          act_rn = a.cp_active[min(kBcrCps * (blk + 1) + r / 6, n_cp - 1)] != 0;
-          act_cl = a.cp_active[min(max(kBcrCps * (blk - 1) + c / 6, 0), n_cp - 1)] != 0;
-        }
-        vDs[u] = m.okD[u] && r < nreal && c < nreal && act_r && act_c;
-        vraw[u] = RBnd[vDs[u] ? m.iD[u] : 0];
-        if (BOTH) vraw1[u] = RBnd[alt + (vDs[u] ? m.iD[u] : 0)];
-        const int ts = (r == c && r < RB && r < nreal) ? RB * blk + r : 0;
-        svv[u] = a.scale[ts]; q2v[u] = a.scale[a.NT() + ts];        // (harmless during a solve's first linear solve, which does not use them)
-        vBs[u] = m.okB[u] && has_next && r < nreal_n && act_rn && act_c;
-        graw[u] = RBnd[vBs[u] ? m.iB[u] : 0];
-        if (BOTH) graw1[u] = RBnd[alt + (vBs[u] ? m.iB[u] : 0)];
-        vAs[u] = m.okB[u] && has_a && r < nreal && act_r && act_cl;
-        garaw[u] = 0.0;
-        if (has_a) garaw[u] = RBndA[vAs[u] ? m.iB[u] : 0];      // (only the first block of a chain touches the left separator)
-        garaw1[u] = 0.0;
-        if (BOTH && has_a) garaw1[u] = RBndA[alt + (vAs[u] ? m.iB[u] : 0)];
-      }
-#pragma unroll
-      for (int u = 0; u < NF; ++u) {
-        const int e = min(max(lt, 0) + NL * u, BP * kBcrFS - 1);
-        const int r = e >> 4, col = role > 0 ? f0 + (e & 15) : 0;
-        const int t = RB * blk + r;
-        bool act_r = true;
-        if (!b.all_active) act_r = a.cp_active[min(kBcrCps * blk + r / 6, a.n_cp - 1)] != 0;
-        vFs[u] = role > 0 && r < RB && r < nreal && col <= a.mc && act_r;
-        const size_t idx = vFs[u] ? (col < a.mc ? a.off_E() + size_t(t) * a.mc + col : a.off_g() + t) : a.off_g();
-        fraw[u] = Rsel[idx];
-        if (BOTH) fraw1[u] = Rsel[alt + idx];
-      }
-      if (BOTH) {
-        const bool second = r_cur_v != 0;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) { vraw[u] = second ? vraw1[u] : vraw[u]; graw[u] = second ? graw1[u] : graw[u]; garaw[u] = second ? garaw1[u] : garaw[u]; }
-#pragma unroll
-        for (int u = 0; u < NF; ++u) fraw[u] = second ? fraw1[u] : fraw[u];
-      }
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        const int e = min(max(lt, 0) + NL * u, BB - 1);
-        const int r = e >> 5, c = e & 31;
-        double v = vDs[u] ? vraw[u] : 0.0;
-        {
-          // LM damping of a diagonal entry (FromR::damping), for every entry and selected afterwards (no branch around
-          // loads). 1 / (radius s^2) as a product of 1 / radius (once per thread) and the filed 1 / s^2; only a solve's
-          // first linear solve, which forms the scale itself, divides.
-          const bool dg = r == c;
-          const int t = RB * blk + r;
-          const bool real_row = r < RB && r < nreal;
-          double d;
-          const double inv_radius = 1.0 / radius;       // (once per thread: the same value in every entry)
-          if (fr.first_scale == 0) d = fmin(fmax(v * svv[u] * svv[u], o.min_lm_diagonal), o.max_lm_diagonal) * (inv_radius * q2v[u]);
-          else d = fr.damping(v, (dg && real_row) ? t : 0);
-          if (dg) {
-            if (vDs[u]) { v += d; if (role == 0) a.dadd[t] = d; }
-            else { v = 1.0; if (role == 0 && real_row) a.dadd[t] = 0.0; }
-          }
-        }
-        pr.d[u] = v;
-        pr.bt[u] = vBs[u] ? graw[u] : 0.0;
-        pr.at[u] = vAs[u] ? garaw[u] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < NF; ++u) pr.f[u] = vFs[u] ? fraw[u] : 0.0;
+      BcrRaw<M::NUD, NU, NF> rw;
+      fetch_request(i, rw, both_tag, m);
+      fetch_finish(i, rw, pr, both_tag, m);
       return;
     }
 #pragma unroll
@@ -663,6 +727,26 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     const int lt = m.lt;
     double* Dp = Daug + p * 64 * DLD;
     double* Xp = Xb + p * BP * XLD;
+    if (FROM_R) {
+#pragma unroll
+      for (int u = 0; u < M::NUD; ++u) {      // D: the upper triangle as fetched, mirrored (the block is symmetric)
+        if (lt + NL * u < kBcrTri) {
+          const int r = m.rcD[u] >> 8, c = m.rcD[u] & 255;
+          Dp[r * DLD + c] = pr.d[u];
+          if (r != c) Dp[c * DLD + r] = pr.d[u];
+          if (!ELIM) { Dp[(BP + r) * DLD + c] = r == c ? 1.0 : 0.0; if (r != c) Dp[(BP + c) * DLD + r] = 0.0; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int e = lt + NL * u;
+        if (e < BB) {
+          const int c = e >> 5, r = e & 31;     // (level 0 deals B / A by columns: see BcrLoadMap)
+          Xp[c * XLD + CB + r] = pr.bt[u];     // B[row of this block][next's dim] = G[next's dim][row]
+          Xp[r * XLD + CA + c] = pr.at[u];     // A[row of this block][left separator's dim] = G_left as stored
+        }
+      }
+    } else {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int e = lt + NL * u;
@@ -673,6 +757,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         Xp[c * XLD + CB + r] = pr.bt[u];     // B[row of this block][next's dim] = G[next's dim][row]
         Xp[r * XLD + CA + c] = pr.at[u];     // A[row of this block][left separator's dim] = G_left as stored
       }
+    }
     }
 #pragma unroll
     for (int u = 0; u < NF; ++u) {
@@ -714,6 +799,8 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   const int la_acc_p = role == 0 ? CA + (wave == 6 ? 16 : 0) : CA + 16 * (wave - 5);
   const int la_acc_q = role == 0 ? CA + (wave == 6 ? 16 : 0) : CF;
   f64x4 acc_a2 = {0.0, 0.0, 0.0, 0.0};
+  constexpr bool kEarly = FROM_R && ELIM && !LA && BCR_EARLY_REQUESTS;
+  BcrRaw<BcrLoadMap<NL, NU, NF>::NUD, NU, NF> rw_early;
   Pre pr;
   f64x4 pre0[2], pre1[2];       // LA: a follower's own input tiles of the next block, updated (wave 2: the two A tiles; wave 1 of a border role: the F tile)
   if (LA && q > 1 && loader) fetch(1, pr, std::false_type(), lmap);
@@ -738,7 +825,16 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
 #pragma unroll
       for (int k = 0; k < 4; ++k) if (k == i) t_top[k] = t_step - t_kernel;
     }
-    if (!LA && !last && loader) fetch(i + 1, pr, std::false_type(), lmap);     // in flight while the block is factored (LA: requested behind the step before)
+    if (CAL_DEV_TIMING(a.debug >= 4 && !LA && i == 1 && lane == 0 && wave >= 4)) bcast[16 + wave] = double(__builtin_readcyclecounter() - t_kernel);
+    if (!LA && !last && loader) {
+      // in flight while the block is factored (LA: requested behind the step before). EARLY (level 0, block elimination): the
+      // requests of block i + 1 went out in front of the LAST step's Schur phase -- only the selection, the damping and the
+      // commit are left, at once: the loaders' request -> commit time (address arithmetic 3-4k clocks on SIMDs they share with
+      // the chief and the followers, then the round trip) was the tail of every step, 1.5-2k clocks behind the followers.
+      if (kEarly && i > 0) fetch_finish(i + 1, rw_early, pr, std::false_type(), lmap);
+      else fetch(i + 1, pr, std::false_type(), lmap);
+    }
+    if (CAL_DEV_TIMING(a.debug >= 4 && !LA && i == 1 && lane == 0 && wave >= 4)) bcast[24 + wave] = double(__builtin_readcyclecounter() - t_kernel);
     if (CAL_DEV_TIMING(a.debug == 2 && bid < 1 && lane == 0 && wave >= 4)) printf("level %d step %d wave %d: requests issued at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
     if (ELIM) {
       // ---- D = L Lᵀ, Z = L⁻¹X and (role 0) L⁻ᵀ in one pass: wave 0 the spine, waves 1..3 two row tiles each ----
@@ -756,12 +852,12 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         const ElimTile t[2] = {{Xp + c0, 1, XLD, Zb + c0, 1, XLD, 0, nullptr}, {Xp + c0 + 16, 1, XLD, Zb + c0 + 16, 1, XLD, 0, nullptr}};
         elim_follow<2>(t, ech, lane, LA && wave == 2 && i > 0, pre0, pre1);
       }
-      if (CAL_DEV_TIMING(a.debug >= 4 && LA && i == 1 && lane == 0)) bcast[8 + wave] = double(__builtin_readcyclecounter() - t_kernel);
+      if (CAL_DEV_TIMING(a.debug >= 4 && i == 1 && lane == 0)) bcast[8 + wave] = double(__builtin_readcyclecounter() - t_kernel);
       if (CAL_DEV_TIMING(a.debug == 2 && bid < 1 && lane == 0 && wave < 4)) printf("level %d step %d wave %d: elimination done at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
       if (!last && loader) {
         commit(p ^ 1, pr, lmap);
       }
-      if (CAL_DEV_TIMING(a.debug >= 4 && LA && i == 1 && lane == 0 && wave >= 4)) bcast[8 + wave] = double(__builtin_readcyclecounter() - t_kernel);
+      if (CAL_DEV_TIMING(a.debug >= 4 && i == 1 && lane == 0 && wave >= 4)) bcast[8 + wave] = double(__builtin_readcyclecounter() - t_kernel);
       if (CAL_DEV_TIMING(a.debug == 2 && bid < 1 && lane == 0 && wave >= 4)) printf("level %d step %d wave %d: committed at %lld clocks of the step\n", level, i, wave, (long long)(__builtin_readcyclecounter() - t_step));
       LTICK(3)
     } else {
@@ -802,6 +898,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       for (int k = 0; k < 4; ++k) if (k == i) t_bara[k] = __builtin_readcyclecounter() - t_kernel;
     }
     if (ELIM && !last) elim_reset(ech, tid, kLevelThreads);      // (the followers are through; the barrier at the end of the step orders it)
+    if (kEarly && i + 2 < q && loader) fetch_request(i + 2, rw_early, std::false_type(), lmap);      // (nothing in it waits: see the top of the loop)
     if (LA && !last) {
       // ---- look-ahead: in front of the barrier only next.D -= Z^BᵀZ^B (and the next block's requests); behind it the other
       //      Schur products, read from THIS step's Z buffer (the followers of the next block write the other one) ----
@@ -999,6 +1096,8 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       for (int r = 0; r < 4; ++r) put(dst + size_t(16 * h + lk + 4 * r) * m1p, acc_a[r]);
     }
   }
+  if (CAL_DEV_TIMING(a.debug >= 4 && !LA && tid == 0 && bid < 4 && q > 1)) printf("bcr_level %d wg %d, step 1: loaders (waves 4..7) begin their requests at %.0f %.0f %.0f %.0f, have issued them at %.0f %.0f %.0f %.0f, have committed at %.0f %.0f %.0f %.0f | chief / followers through at %.0f %.0f %.0f %.0f\n", level, bid,
+      bcast[20], bcast[21], bcast[22], bcast[23], bcast[28], bcast[29], bcast[30], bcast[31], bcast[12], bcast[13], bcast[14], bcast[15], bcast[8], bcast[9], bcast[10], bcast[11]);
   if (CAL_DEV_TIMING(a.debug >= 4 && LA && tid == 0 && bid < 4 && q > 1)) printf("bcr_level %d wg %d: arrival at the second barrier of step 1 by wave: %.0f %.0f %.0f %.0f %.0f %.0f %.0f %.0f | end of the elimination (commit for 4..7) of step 1 by wave: %.0f %.0f %.0f %.0f %.0f %.0f %.0f %.0f | wave 0, step 1: behind the first barrier %.0f, operands there %.0f, products done %.0f\n", level, bid, bcast[0], bcast[1], bcast[2], bcast[3], bcast[4], bcast[5], bcast[6], bcast[7], bcast[8], bcast[9], bcast[10], bcast[11], bcast[12], bcast[13], bcast[14], bcast[15], bcast[16], bcast[17], bcast[18]);
   if (CAL_DEV_TIMING(a.debug >= 4 && tid == 0 && (bid < 9 || bid % 7 == 0))) printf("bcr_level %d: chain workgroup %d (role %d) lived %lld clocks: set-up done at %lld, first block in LDS at %lld, chain done at %lld | steps begin %lld %lld %lld %lld | wave 0 through with its part %lld %lld %lld %lld | Z there %lld %lld %lld %lld\n", level, bid, role, (long long)(__builtin_readcyclecounter() - t_kernel), t_setup, t_first, t_loop, t_top[0], t_top[1], t_top[2], t_top[3], t_elim[0], t_elim[1], t_elim[2], t_elim[3], t_bara[0], t_bara[1], t_bara[2], t_bara[3]);
   if (role == 0 && wave == 0 && lane == 0 && !(pmin > 0.0)) st->chol_failed = 1;
