@@ -94,8 +94,9 @@ def test_converged_solve_matches_oracle_on_every_estimate(index, hip, oracle):
 def test_long_trajectories_match_oracle(shape, hip, oracle):
     """Long trajectories against the oracle (they were only benchmarked before): configs[3] at 50 Hz knots -- 440 control
     points, a 6-level elimination tree -- and the shape of the run the reference's notebook holds -- one camera + IMU,
-    1453 control points (8763 unknowns), an 8-level tree. One evaluation of [cost, Jtr, JtJ] to 1e-9 and the first three
-    LM iterations (accept / reject, cost per iteration, estimates). The oracle factors the dense normal equations (its
+    1453 control points (8763 unknowns), an 8-level tree. One evaluation of [cost, Jtr, JtJ] to 1e-9, then the solve -- fifteen LM
+    iterations at 440 control points (round 5; three before), the first three at 1453 -- compared iteration by iteration (accept / reject,
+    cost, radius) and on EVERY estimate (intrinsics, q, t, latency, control points). The oracle factors the dense normal equations (its
     blocked, threaded Cholesky takes over beyond 1500 unknowns: tests/test_oracle_known_answers.py pins it to the plain one)."""
     scene = syn.config_scene(shape)
     assert len(scene.ctrl) == {5: 440, 6: 1453}[shape]
@@ -113,11 +114,17 @@ def test_long_trajectories_match_oracle(shape, hip, oracle):
         worst = max(worst, float(blk.max()))
     assert worst <= 1e-9
     del Hg, Hr
-    n_it = 3
+    # 440 control points: fifteen iterations -- the radius has grown to 1e11 by then; this shape (50 Hz knots under 20 Hz
+    # cameras) is weakly constrained, and from iteration ~19 on, at radii beyond 1e13, whether the all but undamped normal
+    # equations still factor is decided by rounding: device and oracle then take different accept / reject paths (measured:
+    # costs equal to 1e-9 through iteration 18, the oracle's factorisation fails first at iteration 24). 1453 control
+    # points: 8763 dense unknowns per oracle iteration -- three of them
+    n_it = 15 if shape == 5 else 3
     sg_, sr_ = gpu.problem.solve(_options(hip, n_it)), ref.problem.solve(_options(oracle, n_it))
+    assert sg_.termination_type == sr_.termination_type
     assert sg_.num_effective_parameters_reduced == sr_.num_effective_parameters_reduced
     ig, ir = gpu.problem.iterations(), ref.problem.iterations()
-    assert len(ig) == len(ir) == n_it + 1
+    assert len(ig) == len(ir) and (len(ig) == n_it + 1 or sg_.termination_type == _capi.CONVERGENCE)
     for a, b in zip(ig, ir):
         assert a.step_is_successful == b.step_is_successful
         assert abs(a.cost - b.cost) <= 1e-7 * abs(b.cost)
