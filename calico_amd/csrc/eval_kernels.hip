@@ -847,7 +847,7 @@ DEV bool frame_camera_block(const SensorDev& S, const double* intr, const M3& R_
 // then M_ext [PE][PE]; then the expansion coefficients [n1].
 DEV int frame_area_a(int Ps, int PTs, int P1e) {
   const int after = PTs * PTs + ((Ps * P1e + 1) & ~1) + ((3 * P1e + 1) & ~1) + ((3 * P1e + 1) / 2 + 1);
-  return (max(Ps * kFramePad, after) + 1) & ~1;
+  return (max((Ps + 1) * kFramePad, after) + 1) & ~1;      // (+ 1: the zero column, see eval_frames_body)
 }
 
 // value of `v` in lane `l` (l a compile-time constant after unrolling), wave-uniform
@@ -939,9 +939,16 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds, FrameP
   const int lc16 = lane & 15, lk = lane >> 4;
   const bool two = PTs > 16;
   f64x4 acc00 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
-  const bool col0_ok = lc16 < Ps, col1_ok = 16 + lc16 < Ps;
-  const double* op0 = Jp + min(lc16, Ps - 1) * kFramePad + lk;        // columns past Ps - 1 are masked below
-  const double* op1 = Jp + min(16 + lc16, Ps - 1) * kFramePad + lk;
+  // Round 5: NO arithmetic between the products. On this part a wave's v_mfma_f64 and its VALU instructions do not overlap
+  // at all -- not only the FP64 ones: two v_cndmask in front of every product make it 103 clocks instead of 64
+  // (profiles/microbench/mfma_f64_rate.hip) --, and the operands used to be masked one by one (columns past the layout's, rows
+  // past the batch's): 72 products of a 144-block frame took 9.5-10k clocks. Now the lanes of columns that do not exist read
+  // a column of zeros (staged column Ps, cleared once per frame) and the rows a short batch does not fill are cleared by the
+  // lanes that have no block, so a group is eight loads and eight products.
+  double* const zcol = Jp + Ps * kFramePad;
+  for (int i = lane; i < kFramePad; i += 64) zcol[i] = 0.0;
+  const double* op0 = (lc16 < Ps ? Jp + lc16 * kFramePad : zcol) + lk;
+  const double* op1 = (16 + lc16 < Ps ? Jp + (16 + lc16) * kFramePad : zcol) + lk;
   double cost = 0.0, n_bad = 0.0;
   FTICK(0)
   for (int b0 = 0; b0 < it.obs_count; b0 += 64) {
@@ -958,7 +965,7 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds, FrameP
       xm_nx[0] = xm_p[0]; xm_nx[1] = xm_p[1]; xm_nx[2] = xm_p[2];
       if (a.active) act_nx = a.active[o_nx];
     }
-    if (lane < nb && !on) {
+    if (!on && (lane < nb || nb < 64)) {      // a tagged block, or (short batch) a lane without a block: its two rows are zeros
       for (int c = 0; c < Ps; ++c) { Jp[c * kFramePad + 2 * lane] = 0.0; Jp[c * kFramePad + 2 * lane + 1] = 0.0; }
     }
     if (on) {
@@ -983,33 +990,38 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds, FrameP
     FTICK(2)
     const int nrows = 2 * nb;
     // operands are fetched eight steps (32 rows) at a time so the LDS latency is paid once per group
+    if (!two) {
+      // one tile (<= 16 small prim columns: the usual case)
+      // (requesting the next group's operands in front of this group's products was slower: the register moves it takes are
+      //  VALU instructions again -- 8.0k clocks against 7.0k)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (32 * g < nrows) {
-        if (!two) {
+      for (int g = 0; g < 4; ++g) {
+        if (32 * g < nrows) {
           double v0[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) v0[u] = op0[32 * g + 4 * u];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const double x0 = (col0_ok && 32 * g + 4 * u + lk < nrows) ? v0[u] : 0.0;
-            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc00, 0, 0, 0);
-          }
+          for (int u = 0; u < 8; ++u) acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0[u], v0[u], acc00, 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (32 * g < nrows) {
+        if (false) {
         } else {
           double v0[8], v1[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) { v0[u] = op0[32 * g + 4 * u]; v1[u] = op1[32 * g + 4 * u]; }
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const bool rok = 32 * g + 4 * u + lk < nrows;
-            const double x0 = rok ? v0[u] : 0.0;                   // columns 0..15 always exist when PTs = 32
-            const double x1 = (col1_ok && rok) ? v1[u] : 0.0;
-            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc00, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, acc11, 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0[u], v0[u], acc00, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[u], v0[u], acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[u], v1[u], acc11, 0, 0, 0);
           }
         }
       }
+    }
     }
     FTICK(3)
   }
@@ -1549,7 +1561,7 @@ void launch_mark_outliers(const double* res, const uint8_t* valid, uint8_t* acti
 size_t frame_lds_doubles(int Ps, int P1e, int n1) {
   const int PTs = (Ps + 15) & ~15, PE = P1e + 1;
   const int after = PTs * PTs + ((Ps * P1e + 1) & ~1) + ((3 * P1e + 1) & ~1) + ((3 * P1e + 1) / 2 + 1);
-  const int SA = (std::max(Ps * kFramePad, after) + 1) & ~1;
+  const int SA = (std::max((Ps + 1) * kFramePad, after) + 1) & ~1;
   return size_t(SA) + size_t((PE * PE + 1) & ~1) + size_t(n1) + 16;
 }
 size_t frame_lds_bytes() { return frame_lds_doubles(25, 31, kMaxLocalCols) * sizeof(double); }
