@@ -951,7 +951,7 @@ int build_plan(calico_problem* p) {
           const int Ps = 7 + (L.c_intr >= 0 ? hs.K : 0) + 3 * (L.c_bq >= 0);
           need = std::max(need, frame_lds_doubles(Ps, P1, L.ncols + 1));
         } else {
-          need = std::max(need, size_t((L.ncols + 1 + 3) & ~3) * size_t((3 * imu_chunk_items + 1) | 1));
+          need = std::max(need, size_t((L.ncols + 1 + 15) & ~15) * size_t((((3 * imu_chunk_items + 3) & ~3) + 1) | 1));      // (as lds_cols x row_pad below)
         }
       }
       need = (need + 1) & ~size_t(1);
@@ -1122,8 +1122,10 @@ int build_plan(calico_problem* p) {
       jr = std::max(jr, p->sensors[size_t(L.sensor)].dim() * it.obs_count);
     }
     (void)max_cols;
-    p->lds_cols = (jc + 3) & ~3;
-    p->row_pad = (jr + 1) | 1;
+    // whole groups of sixteen columns and of four rows: stage B reads them without masks (eval_kernels.hip, stage_b_mfma;
+    // the padding is cleared by the work item)
+    p->lds_cols = (jc + 15) & ~15;
+    p->row_pad = (((jr + 3) & ~3) + 1) | 1;
   }
   if (size_t(p->lds_cols) * p->row_pad * sizeof(double) > kMaxLds)
     return p->set_error(CALICO_UNIMPLEMENTED, "too many Jacobian columns per residual block for the LDS staging area");

@@ -554,45 +554,86 @@ __device__ __attribute__((noinline)) void stage_b_mfma(LdsRows lds, int pad, int
   f64x4 acc[NP];
 #pragma unroll
   for (int t = 0; t < NP; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
-  // Loads are unconditional on clamped (row, column) -- always a valid staged value -- and masked by a 0/1 factor:
-  // a conditional load splits the loop body into blocks.
+  // Round 5: NO arithmetic between the products (a wave's VALU instructions and its FP64 MFMAs do not overlap:
+  // profiles/microbench/mfma_f64_rate.hip). The staging area holds whole groups of sixteen columns and whole groups of four
+  // rows -- the columns past n1 and the rows past nrows are ZEROS (eval_items_body clears them) --, so an operand is a plain
+  // load: no clamped index, no 0/1 factor (eight v_mul_f64 and the index arithmetic per k-step before: ~89 clocks per product
+  // against 64). Two k-steps per trip on two sets of operand registers: the next k-step's operands are requested in front of
+  // this one's products without a register move, and the pointers advance once per trip.
   LdsRows cp[NT];
-  double cm[NT];
 #pragma unroll
-  for (int t = G0; t < NT; ++t) {
-    const int c = 16 * t + lc16;
-    cm[t] = c < n1 ? 1.0 : 0.0;
-    cp[t] = lds + (c < n1 ? c : n1 - 1) * pad;
-  }
-  // (the next k-step's operands are requested before this one's MFMAs are issued: an LDS round trip per k-step in front of
-  //  64 x tiles of matrix pipe otherwise)
-  double nx[NT];
-  {
-    const int rc = min(lk, nrows - 1);
+  for (int t = G0; t < NT; ++t) cp[t] = lds + (16 * t + lc16) * pad + lk;
+  // (the trip count in a scalar register -- a function that is not inlined gets its arguments in vector registers, and with a
+  //  trip count the compiler takes for lane-dependent the loop is exec-masked blocks between which it cannot count the
+  //  outstanding LDS requests: it waited for ALL of them, the ones just issued included, in front of every group of products)
+  const int ksteps = __builtin_amdgcn_readfirstlane((nrows + 3) >> 2);
+  double oa[NT], ob[NT];
 #pragma unroll
-    for (int t = G0; t < NT; ++t) nx[t] = cp[t][rc];
-  }
-  for (int r0 = 0; r0 < nrows; r0 += 4) {
-    const double rm = r0 + lk < nrows ? 1.0 : 0.0;
-    double op[NT];
+  for (int t = G0; t < NT; ++t) oa[t] = cp[t][0];
+  int k = 0;
+  for (; k + 2 < ksteps; k += 2) {        // k-steps k and k + 1; k + 2's operands requested
 #pragma unroll
-    for (int t = G0; t < NT; ++t) op[t] = nx[t] * (cm[t] * rm);
-    const int rn = min(r0 + 4 + lk, nrows - 1);
-#pragma unroll
-    for (int t = G0; t < NT; ++t) nx[t] = cp[t][rn];
+    for (int t = G0; t < NT; ++t) ob[t] = cp[t][4];
     __builtin_amdgcn_sched_barrier(0);      // (left to itself the scheduler sinks these requests into the next trip, right in front of their use)
 #pragma unroll
     for (int t = 0; t < NP; ++t)
-      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[tiles.row[T0 + t]], op[tiles.col[T0 + t]], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[tiles.row[T0 + t]], oa[tiles.col[T0 + t]], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = G0; t < NT; ++t) oa[t] = cp[t][8];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NP; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ob[tiles.row[T0 + t]], ob[tiles.col[T0 + t]], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = G0; t < NT; ++t) cp[t] += 8;
   }
-  // C/D layout: col = lane & 15, row = (lane >> 4) + 4·reg
+  if (k + 1 < ksteps) {                   // two k-steps left
+#pragma unroll
+    for (int t = G0; t < NT; ++t) ob[t] = cp[t][4];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NP; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[tiles.row[T0 + t]], oa[tiles.col[T0 + t]], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NP; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ob[tiles.row[T0 + t]], ob[tiles.col[T0 + t]], acc[t], 0, 0, 0);
+  } else if (k < ksteps) {                // one
+#pragma unroll
+    for (int t = 0; t < NP; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[tiles.row[T0 + t]], oa[tiles.col[T0 + t]], acc[t], 0, 0, 0);
+  }
+  // C/D layout: col = lane & 15, row = (lane >> 4) + 4·reg. Forty stores per ten tiles: the block is named as GLOBAL memory
+  // with 32-bit offsets from one base (through the generic pointer every store was a flat_store behind a 64-bit multiply-add:
+  // 470 instructions, ~6k clocks per call with the stores' completion -- as much as two thirds of the products), the packed
+  // row's start is formed once per (tile row, register) and shared by the tiles of the row, and a tile above the diagonal
+  // needs no row / column comparison.
+  typedef double __attribute__((address_space(1))) * GlobalBlock;
+  GlobalBlock og = (GlobalBlock)out;
+  // start of packed row gi = lk + 4 s (s = 4 I + r), less gi: tri_off(gi, gj, n1) = rs[s] + gj. By recurrence -- rs(gi + 4) =
+  // rs(gi) + 4 n1 - 4 gi - 10 --: two additions per row instead of two multiplications
+  unsigned rs[4 * NT];
+  {
+    int gi = lk;
+    int v = gi * n1 - ((gi * (gi - 1)) >> 1) - gi;
+#pragma unroll
+    for (int q = 0; q < 4 * NT; ++q) { rs[q] = unsigned(v); v += 4 * n1 - 4 * gi - 10; gi += 4; }
+  }
 #pragma unroll
   for (int t = 0; t < NP; ++t) {
     const int I = tiles.row[T0 + t], J = tiles.col[T0 + t];
+    const int gj = 16 * J + lc16;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int gi = 16 * I + lk + 4 * r, gj = 16 * J + lc16;
-      if (gi <= gj && gj < n1) block_store(out + tri_off(gi, gj, n1), acc[t][r]);
+      const int gi = 16 * I + lk + 4 * r;
+      const bool keep = (I < J || gi <= gj) && gj < n1;
+      if (keep) {
+        const unsigned off = rs[4 * I + r] + unsigned(gj);      // (unsigned: one base in scalar registers + a 32-bit offset per store)
+#ifdef CALICO_BLOCK_STORE_PLAIN
+        og[off] = acc[t][r];
+#else
+        __hip_atomic_store(og + off, acc[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+      }
     }
   }
 }
@@ -707,10 +748,18 @@ DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds, Item
 #pragma unroll
       for (int r = 0; r < 3; ++r) if (r < dim) sink.put(ncols, r, res[r]);
     }
+    const int n1 = ncols + 1;
+    if (it.rows_off < 0) {
+      // stage B reads whole groups of sixteen columns and of four rows without masks: the columns [n1, 16 ceil(n1 / 16)) and
+      // the rows [nrows, 4 ceil(nrows / 4)) of the staging area are zeros (the host sizes the area for them: lds_cols, row_pad)
+      const int nrows4 = (nrows + 3) & ~3, ncols16 = (n1 + 15) & ~15;
+      const int extra_r = nrows4 - nrows;
+      for (int e = lane; e < extra_r * n1; e += 64) lds[(e / extra_r) * row_pad + nrows + e % extra_r] = 0.0;
+      for (int e = lane; e < (ncols16 - n1) * nrows4; e += 64) lds[(n1 + e / nrows4) * row_pad + e % nrows4] = 0.0;
+    }
     wave_lds_sync();
     // Stage B: P = [J r]ᵀ [J r] on the matrix cores, upper 16×16 tiles (same scheme as the frame kernel: operand
     // element (col = 16t + (lane & 15), row = r0 + (lane >> 4)) serves as A of tile row t and as B of tile column t).
-    const int n1 = ncols + 1;
     if (it.rows_off >= 0) {
       // the rows go to the cell kernel, which forms [J r]ᵀ[J r] for all work items of the cell at once with four
       // waves: on the long single-lane chain of an IMU block this wave would spend another quarter of its time here

@@ -11,7 +11,29 @@ __global__ void mfma_rate(double* out, unsigned long long* ticks, int chain) {
   for (int i = 0; i < kAcc; ++i) acc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
   const double a = double(threadIdx.x & 15) * 1e-3, b = double(threadIdx.x >> 4) * 1e-3;
   const unsigned long long t0 = __builtin_readcyclecounter();
-  if (chain == 2) {   // ONE accumulator, and the operand of every product selected by two VALU instructions (v_cndmask) in front of it: the frames' loop
+  if (chain == 4 || chain == 5) {   // stage B's shape: ten accumulators, four operand registers in the pairs of the upper triangle; 5: the four operands loaded from LDS per k-step
+    __shared__ double sh[4 * 68];
+    for (int i = threadIdx.x; i < 4 * 68; i += blockDim.x) sh[i] = 1e-3 * double(i % 13);
+    __syncthreads();
+    f64x4 c8 = f64x4{0, 0, 0, 0}, c9 = c8;
+    double o0 = a, o1 = b, o2 = a + b, o3 = a - b;
+    const double* sp = sh + (threadIdx.x & 3);
+    for (int it = 0; it < kIter * kAcc / 10; ++it) {
+      if (chain == 5) { o0 = sp[(it & 15) * 4]; o1 = sp[68 + (it & 15) * 4]; o2 = sp[136 + (it & 15) * 4]; o3 = sp[204 + (it & 15) * 4]; }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(o0, o0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(o0, o1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(o0, o2, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(o0, o3, acc[3], 0, 0, 0);
+      acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(o1, o1, acc[4], 0, 0, 0);
+      acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(o1, o2, acc[5], 0, 0, 0);
+      acc[6] = __builtin_amdgcn_mfma_f64_16x16x4f64(o1, o3, acc[6], 0, 0, 0);
+      acc[7] = __builtin_amdgcn_mfma_f64_16x16x4f64(o2, o2, acc[7], 0, 0, 0);
+      c8 = __builtin_amdgcn_mfma_f64_16x16x4f64(o2, o3, c8, 0, 0, 0);
+      c9 = __builtin_amdgcn_mfma_f64_16x16x4f64(o3, o3, c9, 0, 0, 0);
+    }
+    acc[0] += c8 + c9;
+  } else if (chain == 2) {   // ONE accumulator, and the operand of every product selected by two VALU instructions (v_cndmask) in front of it: the frames' loop
     int rows = int(ticks[0] & 127) + 64;     // (not known at compile time)
     for (int it = 0; it < kIter * kAcc; ++it) {
       const double x = ((threadIdx.x >> 4) + (it & 31) * 4 < rows) ? a : 0.0;
@@ -52,6 +74,8 @@ int main() {
   const Cfg cfgs[] = {{1, 1, 0, "one wave alone on a CU, 8 accumulators"}, {1, 1, 1, "one wave alone, ONE accumulator (dependent chain)"},
                       {1, 1, 2, "one wave alone, one accumulator, operand selected (2 x v_cndmask) in front of EVERY product"},
                       {1, 1, 3, "one wave alone, one accumulator, eight operands selected, then eight products"},
+                      {1, 1, 4, "one wave alone, stage B's shape: ten accumulators, operands in registers (A != B)"},
+                      {1, 1, 5, "one wave alone, stage B's shape, the four operands loaded from LDS per k-step"},
                       {1, 4, 0, "four waves (one per SIMD) of one CU"}, {1, 8, 0, "eight waves (two per SIMD) of one CU"},
                       {256, 1, 0, "one wave on each of 256 CUs"}, {256, 4, 0, "four waves on each of 256 CUs (the chip's FP64 matrix peak)"},
                       {1024, 4, 0, "1024 workgroups of four waves"}};
