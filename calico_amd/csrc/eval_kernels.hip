@@ -546,7 +546,10 @@ template <int NT> struct StageBTiles {      // tile t of the row-major upper tri
 };
 typedef const double __attribute__((address_space(3))) * LdsRows;
 template <int NT, int T0 = 0, int T1 = NT * (NT + 1) / 2>
-__device__ __attribute__((noinline)) void stage_b_mfma(LdsRows lds, int pad, int nrows, int n1, double* out) {
+// (inlined since round 5: a function that is not inlined waits for its stores to complete before it returns -- ~1.3k clocks per
+//  call for the tiles' write-through stores, three calls per IMU pair; inlined, the stores of a wave's last call complete behind
+//  the wave. With the staged rows named as LDS and the trip count scalar the inlined body no longer needs its own register budget.)
+DEV void stage_b_mfma(LdsRows lds, int pad, int nrows, int n1, double* out) {
   const int lane = threadIdx.x & 63, lc16 = lane & 15, lk = lane >> 4;
   constexpr int NP = T1 - T0;
   constexpr StageBTiles<NT> tiles{};
