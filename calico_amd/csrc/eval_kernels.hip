@@ -1017,7 +1017,9 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds, FrameP
       xm_nx[0] = xm_p[0]; xm_nx[1] = xm_p[1]; xm_nx[2] = xm_p[2];
       if (a.active) act_nx = a.active[o_nx];
     }
-    if (!on && (lane < nb || nb < 64)) {      // a tagged block, or (short batch) a lane without a block: its two rows are zeros
+    // a tagged block, or (short batch) a lane without a block whose two rows lie in a group of 32 rows the products read: zeros
+    // (a batch of 16 blocks -- the third of a 144-block frame -- fills its one group: nothing to clear)
+    if (!on && lane < ((nb + 15) & ~15)) {
       for (int c = 0; c < Ps; ++c) { Jp[c * kFramePad + 2 * lane] = 0.0; Jp[c * kFramePad + 2 * lane + 1] = 0.0; }
     }
     if (on) {
