@@ -59,6 +59,36 @@ def algorithmic_bytes_per_iteration(scene):
     return total
 
 
+def host_cpu_info():
+    """Model string, physical cores and sockets of the host from /proc/cpuinfo, and the CPUs this process may run on."""
+    model, pairs, sockets = None, set(), set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                phys = v
+                sockets.add(v)
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None and core is not None:
+                pairs.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            pairs.add((phys, core))
+    except OSError:
+        pass
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = os.cpu_count() or 1
+    return {"model": model or "unknown", "physical_cores": len(pairs) or None, "sockets": len(sockets) or None,
+            "cpus_allowed": allowed}
+
+
 def cpu_baseline(scene, min_seconds=10.0):
     """The CPU oracle (restatement of the reference's Ceres path: dual-number autodiff in 4-wide passes, dense normal
     equations, dense Cholesky, std::thread pool honouring num_threads) on the host cores of this box, as SURVEY.md 8(d) /
@@ -72,6 +102,7 @@ def cpu_baseline(scene, min_seconds=10.0):
     api = helpers.oracle_api()
     cores = os.cpu_count() or 1
     all_threads = max(1, min(cores, 64))
+    host = host_cpu_info()
 
     def run(threads, iters, budget_s, max_solves):
         o = api.default_options()
@@ -102,7 +133,12 @@ def cpu_baseline(scene, min_seconds=10.0):
             sweep.append(run(th, iters, 0.0, 1)[0])
     full, last = run(all_threads, 50, min_seconds, 20)
     sweep.append(full)
+    # "cores" = the threads the all-cores leg actually ran on (the oracle's pool is capped at 64); what the box has is
+    # stated next to it: logical CPUs, physical cores, sockets and the model string (north_star: "core count stated")
     return {"value": full["iterations_per_s"], "unit": "LM iterations/s", "cores": all_threads, "kind": "port",
+            "num_threads": all_threads, "host_logical_cpus": cores, "host_physical_cores": host["physical_cores"],
+            "host_sockets": host["sockets"], "host_cpu_model": host["model"],
+            "host_cpus_allowed": host["cpus_allowed"],
             "iterations_to_convergence": int(last.num_iterations), "termination": last.message.decode(),
             "by_num_threads": sweep,
             "sample": "%d LM iterations in %d solves to convergence (+ initial evaluations) of the same %d-block problem on %d threads, "

@@ -297,6 +297,9 @@ template <int NL_, int NU_, int NF_>
 struct BcrLoadMap {
   static constexpr int NL = NL_, NU = NU_, NF = NF_;
   static constexpr int NUD = (kBcrTri + NL_ - 1) / NL_;      // level 0: entries of D's upper triangle per thread
+  // iD / rcD / okD are declared [NU] and walked up to NUD; fetch_request packs the entries' validity bits of D, B, A and F
+  // into one byte each of a 32-bit word
+  static_assert(NUD <= NU_ && NU_ <= 8 && NF_ <= 8, "BcrLoadMap: per-thread entry counts must fit the arrays and the flag bytes");
   int lt;
   int iD[NU_], iB[NU_];        // level 0: positions in R of the entries for superblock 0
   int rcD[NU_];                // level 0: (r << 8 | c), r <= c, of the thread's D entries

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>     // types only: the library itself is loaded on first use (RcclApi below)
 #include <dlfcn.h>
+#include <link.h>
 
 #include <algorithm>
 #include <chrono>
@@ -22,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <array>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -200,7 +202,7 @@ struct HSensor {
 // a new slab, and if that fails the request goes to hipMalloc as before. A request larger than a slab is an allocation
 // of its own (hipMalloc / hipFree: it has large fragments anyway and must not pin memory for good).
 // Slabs go back to the driver: trim() frees every slab that is one free extent -- calico_plan_cache_clear() frees all of
-// them, calico_problem_destroy() all but one per device (the next handle's) -- so a process that once solved a large
+// them, calico_problem_destroy() all but CALICO_ARENA_KEEP_SLABS idle ones per device (default 4) -- so a process that once solved a large
 // problem, or that shares the GPU with PyTorch / RCCL, does not keep that memory. (No HIP calls during static
 // destruction: what is still held at exit is the driver's to reclaim.) CALICO_ARENA=0: hipMalloc per buffer (rounds 1-4).
 class DeviceArena {
@@ -1794,15 +1796,21 @@ int enqueue_jacobian_eval(calico_problem* p, const LmState* st, int need_flag, c
   }
   ea.items = p->d_jac_items.p; ea.n_items = p->n_jac_items; ea.cost_index_base = p->n_fitems;
   if (p->fuse_expand) { ea.pair_mode = 1; ea.wave_lds_doubles = p->pair_wave_lds_doubles; }      // (the plan has frames and order 6 then)
+  // a launch the runtime refuses (too much LDS for the kernel's attribute, a bad grid) would leave last iteration's blocks
+  // in place and the solve would go wrong silently on stale partials: ask behind EVERY launch (a thread-local read, no
+  // synchronisation). The thread's error word is cleared first -- a benign error some other code on this thread left behind
+  // (a PyTorch probe, a hipMalloc fallback) is not this solve's --, and asked per launch: hipGetLastError() reports the last
+  // call only on some runtimes, so a refused first launch must not hide behind a second one that went through.
+  (void)hipGetLastError();
   if (p->order == 6 && p->n_fitems > 0) {
     launch_eval_jacobian(ea, p->stream);                  // camera frames (item-cost slots [0, n_fitems)) + everything else
+    HIP_TRY(p, hipGetLastError());
   } else {
     launch_eval_frames(ea, p->stream);
+    HIP_TRY(p, hipGetLastError());
     launch_eval(ea, true, p->stream);
+    HIP_TRY(p, hipGetLastError());
   }
-  // a launch the runtime refuses (too much LDS for the kernel's attribute, a bad grid) would leave last iteration's blocks
-  // in place and the solve would go wrong silently on stale partials: ask (a thread-local read, no synchronisation)
-  HIP_TRY(p, hipGetLastError());
   p->timer.end(p->stream);
   p->timer.begin(1, p->stream);
   // the host knows which buffer is filled: multi-rank runs either read the state back every iteration or (batched)
@@ -2018,7 +2026,11 @@ void calico_problem_destroy(calico_problem* p) {
     DeviceArena::Batch batch(p->device);     // what the handle owns goes back to the arena behind ONE wait for its device
     delete p;
   }
-  DeviceArena::get().trim(1);                // slabs nothing lives in go back to the driver (one stays for the next handle)
+  // Idle slabs beyond a few go back to the driver -- lazily: hipFree waits for the whole device (other handles' streams,
+  // PyTorch's), and a create / solve / destroy loop over a problem of several slabs would hipMalloc them again every cycle.
+  // CALICO_ARENA_KEEP_SLABS (default 4 = 256 MB per device) idle slabs stay; calico_plan_cache_clear() frees them all.
+  static const int keep_slabs = [] { const char* e = std::getenv("CALICO_ARENA_KEEP_SLABS"); return e ? std::max(0, std::atoi(e)) : 4; }();
+  DeviceArena::get().trim(keep_slabs);
 }
 
 int32_t calico_plan_cache_stats(int64_t* hits, int64_t* misses, int64_t* entries) {
@@ -2803,10 +2815,33 @@ int32_t calico_comm_get_unique_id(uint8_t* id_out) {
   return CALICO_OK;
 }
 
+// How many distinct librccl images the process holds. More than one means this library loaded its private copy BEFORE the
+// application brought its own (PyTorch imported after the first communicator call): both copies work, but two RCCLs in one
+// process have ended in a double free at exit. The load order that avoids it -- the application's RCCL first -- is documented
+// in include/calico_hip.h; here the situation is detected and said out loud, once.
+static int rccl_images_loaded() {
+  std::vector<std::string> seen;
+  dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* data) {
+    auto* v = static_cast<std::vector<std::string>*>(data);
+    const std::string n = info->dlpi_name ? info->dlpi_name : "";
+    const size_t slash = n.rfind('/');
+    if (n.compare(slash == std::string::npos ? 0 : slash + 1, 7, "librccl") == 0 && std::find(v->begin(), v->end(), n) == v->end()) v->push_back(n);
+    return 0;
+  }, &seen);
+  return int(seen.size());
+}
+
 int32_t calico_comm_init_rccl(calico_problem* p, const uint8_t* id, int32_t rank, int32_t world_size) {
   if (!p || !id) return CALICO_INVALID_ARGUMENT;
   if (world_size < 1 || rank < 0 || rank >= world_size) return p->set_error(CALICO_INVALID_ARGUMENT, "bad rank / world size");
   if (!rccl().ok()) return p->set_error(CALICO_INTERNAL, rccl().error);
+  if (rccl_images_loaded() > 1) {
+    static std::atomic<bool> said{false};
+    if (!said.exchange(true))
+      std::fprintf(stderr, "[calico] warning: two librccl images are loaded in this process (this library loaded its own before the "
+                           "application's -- e.g. torch was imported after the first calico_comm_* call). Load the application's RCCL "
+                           "first, or point CALICO_RCCL_LIB at the same file.\n");
+  }
   HIP_TRY(p, hipSetDevice(p->device));
   if (p->comm) { if (p->stream) (void)hipStreamSynchronize(p->stream); (void)rccl().CommDestroy(p->comm); p->comm = nullptr; }
   ncclUniqueId uid;

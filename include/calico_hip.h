@@ -318,6 +318,11 @@ int32_t calico_evaluate(calico_problem* p, double* cost, double* gradient,
  * calico_comm_get_unique_id and hands it to every rank by whatever means the application has (MPI, a file, a
  * torch.distributed broadcast); every rank then calls calico_comm_init_rccl, which also selects its shard (like
  * calico_problem_set_shard). One process per GPU; the communicator lives until the handle is destroyed.
+ * LOAD ORDER: librccl is dlopen()ed by the first calico_comm_* call -- an RCCL the process already holds is adopted
+ * (RTLD_NOLOAD by soname), otherwise a private copy is loaded (RTLD_LOCAL; CALICO_RCCL_LIB names a particular file).
+ * An application that brings its own RCCL (PyTorch does) must therefore load it BEFORE the first calico_comm_* call:
+ * two RCCL images in one process have ended in a double free at exit. calico_comm_init_rccl warns on stderr when it
+ * finds two.
  * Replaces nothing in the reference (it is single-process); SURVEY.md 8(b),(e). */
 #define CALICO_COMM_ID_BYTES 128
 int32_t calico_comm_get_unique_id(uint8_t* id_out /* CALICO_COMM_ID_BYTES */);
