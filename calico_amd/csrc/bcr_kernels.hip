@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <type_traits>
 
@@ -327,7 +328,66 @@ struct BcrRaw { double vraw[NUD], svv[NUD], q2v[NUD], vraw1[NUD], graw[NU], gara
 // of their own input tiles (next.A -= Z^BᵀZ^A, next.F -= Z^BᵀZ^F) straight in the registers the elimination keeps them in
 // (elim_follow with use_pre: same layout), the loader waves file Z and carry the left separator's sums, and the next block's
 // requests go out right behind the barrier. Same products in the same order as without it: bit-identical.
-template <bool FROM_R, bool ELIM, bool LA = false>
+// Rolling chief (bcr_level_kernel<.., ROLL>): where a lane's tile entries sit in the band's storage, by spline order k = 1..6 --
+// the band is uniform in time, so the positions are those of superblock 0 (superblock I adds I·strideB) and depend on nothing
+// but k and the lane. Per lane 48 words: [0..11] byte offsets of the spine's entries (tiles (0,0), (0,1), (1,1), register 0..3 each:
+// elim_load_spine), [12..27] of the rows of Bᵀ (tile qt, column half h, register r at 12 + (2 qt + h) 4 + r: elim_load_rows), [28] which
+// of them exist (spine: bits 0..11, Bᵀ: bits 16..31), [29] the same for Aᵀ, [32..47] byte offsets of the rows of Aᵀ (the first block
+// of a chain against the separator on its left, counted from THAT superblock's storage). Computed on the host at configure time:
+// in the kernel it was ~450 instructions of index arithmetic per wave in front of the first request -- cold code at the head of a launch.
+constexpr int kRollTabWords = 48;
+__device__ unsigned g_roll_tab[6][64][kRollTabWords];
+static void fill_roll_table(unsigned (*tab)[64][kRollTabWords]) {
+  constexpr int RB = 6 * kBcrCps;
+  for (int k = 1; k <= 6; ++k) {
+    auto pos = [&](int hi, int lo, bool& ok) {      // H(hi, lo), lo <= hi, counted from the start of lo's superblock
+      const int d = hi / 6 - lo / 6;
+      ok = d < k;
+      return unsigned(8 * (((lo / 6) * k + (ok ? d : 0)) * 36 + (lo % 6) * 6 + hi % 6));
+    };
+    for (int lane = 0; lane < 64; ++lane) {
+      unsigned* t = tab[k - 1][lane];
+      for (int i = 0; i < kRollTabWords; ++i) t[i] = 0;
+      const int l16 = lane & 15, lk = lane >> 4;
+      unsigned okS = 0, okB = 0, okA = 0;
+      for (int r = 0; r < 4; ++r) {
+        const int c = lk + 4 * r, hi = std::max(l16, c), lo = std::min(l16, c);
+        bool ok;
+        t[r] = pos(hi, lo, ok); if (ok) okS |= 1u << r;
+        t[4 + r] = pos(16 + l16, c, ok); if (ok && 16 + l16 < RB) okS |= 1u << (4 + r);
+        t[8 + r] = pos(16 + hi, 16 + lo, ok); if (ok && 16 + hi < RB) okS |= 1u << (8 + r);
+      }
+      for (int qt = 0; qt < 2; ++qt)
+        for (int h = 0; h < 2; ++h)
+          for (int r = 0; r < 4; ++r) {
+            const int e = (qt * 2 + h) * 4 + r;
+            bool ok;
+            {      // Bᵀ: the next block's row rn against this block's column c
+              const int c = 16 * h + lk + 4 * r, rn = 16 * qt + l16;
+              t[12 + e] = pos(RB + rn, c, ok);
+              if (ok && rn < RB && c < RB) okB |= 1u << e;
+            }
+            {      // Aᵀ: this block's row rb against the left separator's column cs
+              const int rb = 16 * h + lk + 4 * r, cs = 16 * qt + l16;
+              t[32 + e] = pos(RB + rb, cs, ok);
+              if (ok && rb < RB && cs < RB) okA |= 1u << e;
+            }
+          }
+      t[28] = okS | okB << 16;
+      t[29] = okA;
+    }
+  }
+}
+static hipError_t upload_roll_table() {
+  static unsigned host_tab[6][64][kRollTabWords];
+  static std::once_flag once;
+  std::call_once(once, [] { fill_roll_table(host_tab); });
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_roll_tab), host_tab, sizeof(host_tab));
+}
+
+// ROLL (round 6; level 0 with the block elimination): the chain without a workgroup barrier between its blocks -- see the
+// "rolling chief" section in front of the step loop.
+template <bool FROM_R, bool ELIM, bool LA = false, bool ROLL = false>
 __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, BcrArgs b, int node0, int n_nodes, int nfs, int level,
                                                                    int keep0, int n_keep, LmOptionsDev o, int with_post,
                                                                    const double* __restrict__ x, const BlockDev* __restrict__ blocks,
@@ -521,7 +581,8 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   double* const bcast = dinv + 80;                 // [128]
   double* const dump = bcast + 128 + tid;          // [512]
   const ElimChannel ech = elim_channel(bcast + 128 + kLevelThreads);      // [kElimBufDoubles] (ELIM)
-  if (ELIM) elim_reset(ech, tid, kLevelThreads);   // (the barrier behind the first block's commit orders it)
+  static_assert(!ROLL || (FROM_R && ELIM && !LA), "the rolling chief is level 0's, on the block elimination");
+  if (ELIM && !ROLL) elim_reset(ech, tid, kLevelThreads);   // (the barrier behind the first block's commit orders it)
   const int l16 = lane & 15, lk = lane >> 4;
   // ---- global -> registers -> LDS of one chain block. Loaders are waves 1-3 and 5-7 (384 threads: three entries each
   // of D / B / A, two of the F slice); wave 0 goes straight to the factorisation, it is the critical path of every step. ----
@@ -776,6 +837,511 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   double pmin = 1.0;
   // U_aa (role 0: waves 0..3, tile (wave >> 1, wave & 1)) or U_aF (border roles: waves 2, 3, row tile wave - 2)
   f64x4 acc_a = {0.0, 0.0, 0.0, 0.0};
+  if constexpr (ROLL) {
+    // ================================================================================================================
+    // The rolling chief (round 6). A chain step used to be: elimination (chief 6.8k clocks, followers 0.7k behind) | barrier |
+    // filing + the Schur updates of the next block out of LDS (3.4k) | barrier -- 12k clocks, of which the dependent chain
+    // is the chief's 6.8k --, behind a head of 12-15k clocks (state -> loads -> staging in LDS -> barrier -> first pivot). Here
+    // nothing of the chain waits at a barrier:
+    //   * waves 0 and 1 take turns as the chief. While one of them factors block k, the other follows it with the rows of
+    //     Bᵀ = T(k+1, k)ᵀ (-> Z^B) and accumulates D_{k+1} -= Z^BᵀZ^B, step by step, in the chief's own register layout
+    //     (elim_follow_d): when the chief publishes its last pivot, the follower is one step of products away from holding the
+    //     next block's diagonal and goes on as ITS chief (elim_chief_reg); the old chief turns follower of the new one;
+    //   * tiles come from the reduce buffer R(x) in the layout their wave holds them in: a lane's entries sit at offsets that
+    //     depend on the lane alone (the band is uniform in time; g_roll_tab), so a tile is one load per register, the damping
+    //     applied on the way. The first chief and the first follower load their own (both reduce buffers: which one holds
+    //     R(x) is a word of the state, still on its way) and start one round trip after the kernel does; the later blocks'
+    //     inputs are staged as tile IMAGES in LDS by wave 7, a block ahead -- 28 conflict-free reads for the follower;
+    //   * wave 2 follows with the rows of Aᵀ (-> Z^A); its input for block k+1 is the fill -Z^B_kᵀZ^A_k, formed in the registers
+    //     the elimination keeps it in as soon as block k's Z^B is complete. Wave 3: the identity rows (role 0: L⁻ᵀ) or the rows of
+    //     the role's F slice (-> Z^F), its input F_{k+1} - Z^B_kᵀZ^F_k formed the same way. They start a block behind its chief
+    //     and catch up (a follower's step is ~400 clocks, the chief's ~850);
+    //   * waves 4..7, once block k's followers are through, file what the back-substitution reads, add up what the left
+    //     separator collects, and clear the block's channel.
+    // Order is kept by single-writer counters in LDS (a wave's LDS instructions execute in order: data first, then the
+    // counter; a reader polls the counter, then reads). Z, L⁻ᵀ, the channel and the tile images are double-buffered by parity.
+    // Same products in the same order as the barrier form: bit-identical results (profiles/dev/bitwise.py).
+    // Needs every control point observed (b.all_active: the host launches the barrier form otherwise).
+    // ================================================================================================================
+    constexpr int kImg = 28 * 64;                         // a follower's inputs: spine (12 registers) + rows of Bᵀ (16), by lane
+    double* const Zr = lds;                               // [2][32·XLD] Z = [Z^A | Z^B | Z^F] by block parity
+    double* const Mr = Zr + 2 * BP * XLD;                 // [2][32·DLD] L⁻ᵀ (role 0)
+    double* const chb = Mr + 2 * BP * DLD;                // [2][kElimBufDoubles] channels
+    double* const img = chb + 2 * kElimBufDoubles;        // [2][kImg] tile images
+    int* const ctr = reinterpret_cast<int*>(img + 2 * kImg);                // [16] counters
+    long long* const tstamp = reinterpret_cast<long long*>(ctr + 16);       // [8 waves][4 blocks][2] (dev timing)
+    static_assert(2 * BP * XLD + 2 * BP * DLD + 2 * kElimBufDoubles + 2 * kImg + 8 + 64 + 16 <= 2 * 64 * DLD + 4 * BP * XLD + 80 + 128 + kLevelThreads + kElimBufDoubles,
+                  "the rolling chief's LDS layout must fit the level kernels' allocation");
+    enum { C_DONE_D0 = 0, C_DONE_D1 = 1, C_DONE_A = 2, C_DONE_F = 3, C_TAKEN_A = 4, C_TAKEN_F = 5, C_TAKEN_D0 = 6, C_TAKEN_D1 = 7, C_FILED = 8, C_STAGED = 12 };
+    auto ctr_set = [&](int idx, int v) {
+      asm volatile("" ::: "memory");
+      if (lane == 0) __hip_atomic_store(ctr + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");
+    };
+    // cond(c): c(i) = counter i (wave-uniform); polls until it holds
+    auto ctr_wait = [&](auto cond) {
+      for (;;) {
+        const int cv = __hip_atomic_load(ctr + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (cond([&](int i) { return __builtin_amdgcn_readlane(cv, i); })) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      asm volatile("" ::: "memory");
+    };
+    auto all4_ge = [&](auto& c, int base, int v) { return c(base) >= v && c(base + 1) >= v && c(base + 2) >= v && c(base + 3) >= v; };
+    auto done_d = [&](auto& c, int j) { return c((j & 1) ? C_DONE_D0 : C_DONE_D1) >= j + 1; };      // block j's Z^B complete (its follower: wave 1 for even j)
+    const bool tdbg = CAL_DEV_TIMING(a.debug >= 4);
+    auto stamp = [&](int k, int which) { if (tdbg && lane == 0 && k < 4) tstamp[(wave * 4 + k) * 2 + which] = __builtin_readcyclecounter() - t_kernel; };
+    long long* const hs = tstamp + 64;      // [2 waves][8] head anatomy of the two chiefs (dev timing)
+    auto hstamp = [&](int i) { if (tdbg && lane == 0 && wave < 2) hs[wave * 8 + i] = __builtin_readcyclecounter() - t_kernel; };
+    hstamp(0);
+    // The launch's ONLY barrier, at its top: channels and counters are clear behind it (all waves arrive within a few hundred
+    // clocks of the kernel's start; nobody has waited for anything yet). The lanes' offset tables are requested in front of it.
+    const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    const bool has_left = left >= 0;
+    const int n_s = a.n_s(), kk = a.k;
+    const bool tile_wave = wave < 2 || wave == 7;         // the waves that load spines and rows of Bᵀ from R(x)
+    uint4 tv[8];
+    unsigned tmask = 0;
+    {
+      const unsigned* const tl = &g_roll_tab[min(max(kk, 1), 6) - 1][lane][0];
+      if (wave == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tv[i] = reinterpret_cast<const uint4*>(tl)[8 + i];
+#pragma unroll
+        for (int i = 4; i < 8; ++i) tv[i] = tv[0];
+        tmask = tl[29];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tv[i] = reinterpret_cast<const uint4*>(tl)[tile_wave ? i : 0];
+      }
+    }
+    for (int e = tid; e < 2 * kElimBufDoubles; e += kLevelThreads) reinterpret_cast<unsigned long long*>(chb)[e] = kElimSentinel;
+    if (tid < 16) ctr[tid] = 0;
+    if (tdbg && tid < 64) tstamp[tid] = 0;
+    hstamp(1);
+    lds_barrier();
+    hstamp(2);
+    const size_t alt = a.r_stride;                        // the same entry of the other reduce buffer
+    const double* const bandR = R_buf0 + a.off_B();       // (+ alt: buffer 1) superblock I's storage starts at I·strideB
+    // base + zext(byte offset): the scalar-base + 32-bit-vector-offset form of a global load -- one instruction per request
+    auto ldo = [](const double* base, unsigned byte_off) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off); };
+    // operand of the 16x16x4 products for sixteen columns of a Z buffer: lane (l16, lk) holds Z[lk + 4u][col0 + l16]
+    auto zops = [&](const double* Zb, int col0, double (&v)[8]) {
+      const double* pp = Zb + lk * XLD + col0 + l16;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pp[4 * u * XLD];
+    };
+    if (tile_wave) {
+      // this lane's entries of a spine (tiles (0,0), (0,1), (1,1): elim_load_spine) and of the rows of Bᵀ (two row tiles of
+      // sixteen dimensions of the next block against this block's 32 columns: elim_load_rows) in the band's storage
+      unsigned oS[12], oB[16];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { oS[4 * i] = tv[i].x; oS[4 * i + 1] = tv[i].y; oS[4 * i + 2] = tv[i].z; oS[4 * i + 3] = tv[i].w; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { oB[4 * i] = tv[3 + i].x; oB[4 * i + 1] = tv[3 + i].y; oB[4 * i + 2] = tv[3 + i].z; oB[4 * i + 3] = tv[3 + i].w; }
+      const unsigned okS = tv[7].x & 0xffffu, okB = tv[7].x >> 16;
+      const bool diag_lane = l16 >= lk && ((l16 - lk) & 3) == 0;      // register (l16 - lk) / 4 of tiles (0,0) and (1,1) is a diagonal entry
+      struct Inputs { double sp[12], sc[4], bt[16]; };
+      // requests: spine of superblock I, the Jacobi scales of its diagonal entries, rows of Bᵀ of superblock J
+      auto req_scale = [&](int I, double (&sc)[4]) {
+        const int nreal = n_s - RB * I;
+        const unsigned t0 = (diag_lane && l16 < nreal) ? RB * I + l16 : 0, t1 = (diag_lane && 16 + l16 < RB && 16 + l16 < nreal) ? RB * I + 16 + l16 : 0;
+        sc[0] = ldo(a.scale, 8u * t0); sc[1] = ldo(a.scale + a.NT(), 8u * t0); sc[2] = ldo(a.scale, 8u * t1); sc[3] = ldo(a.scale + a.NT(), 8u * t1);
+      };
+      auto req_spine = [&](int I, double (&sp)[12], const double* base) {
+        const double* p = base + size_t(I) * strideB;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) sp[e] = ldo(p, oS[e]);
+      };
+      auto req_b = [&](int J, double (&bt)[16], const double* base) {
+        const double* p = base + size_t(J) * strideB;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bt[e] = ldo(p, oB[e]);
+      };
+      // what arrived -> tiles. Spine: structure, the trajectory's end, LM damping of the diagonal (FromR::diag_block); role 0 files dadd.
+      const double inv_radius = 1.0 / radius;
+      auto take_spine = [&](int I, const double (&sp)[12], const double (&sc)[4], f64x4& t00, f64x4& t01, f64x4& t11) {
+        const int nreal = n_s - RB * I;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = lk + 4 * r, hi = max(l16, c);
+          const bool v00 = ((okS >> r) & 1) && hi < nreal, v01 = ((okS >> (4 + r)) & 1) && 16 + l16 < nreal, v11 = ((okS >> (8 + r)) & 1) && 16 + hi < nreal;
+          double e00 = v00 ? sp[r] : 0.0, e11 = v11 ? sp[8 + r] : 0.0;
+          const double e01 = v01 ? sp[4 + r] : 0.0;
+          if (l16 == c) {
+            // diagonal entries (rows l16 and 16 + l16): damped where the row is real, 1 on padding rows
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int row = 16 * h + l16, t = RB * I + row;
+              const bool vd = h == 0 ? v00 : v11, real_row = row < RB && row < nreal;
+              double& e = h == 0 ? e00 : e11;
+              double d;
+              if (fr.first_scale == 0) d = fmin(fmax(e * sc[2 * h] * sc[2 * h], o.min_lm_diagonal), o.max_lm_diagonal) * (inv_radius * sc[2 * h + 1]);
+              else d = fr.damping(e, real_row ? t : 0);
+              if (vd) { e += d; if (role == 0) a.dadd[t] = d; }
+              else { e = 1.0; if (role == 0 && real_row) a.dadd[t] = 0.0; }
+            }
+          }
+          t00[r] = -e00; t01[r] = -e01; t11[r] = -e11;
+        }
+      };
+      auto take_b = [&](int k, const double (&bt)[16], f64x4 (&x0)[2], f64x4 (&x1)[2]) {
+        const bool has_next = (k + 1 < q) || right >= 0;
+        const int nreal_n = n_s - RB * (blk0 + k + 1);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          const bool row_ok = has_next && 16 * qt + l16 < nreal_n;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            x0[qt][r] = -((((okB >> ((qt * 2 + 0) * 4 + r)) & 1) && row_ok) ? bt[(qt * 2 + 0) * 4 + r] : 0.0);
+            x1[qt][r] = -((((okB >> ((qt * 2 + 1) * 4 + r)) & 1) && row_ok) ? bt[(qt * 2 + 1) * 4 + r] : 0.0);
+          }
+        }
+      };
+      if (wave < 2) {
+        // ---- the two chiefs ----
+        const int par = wave;
+        f64x4 t00 = zero4, t01 = zero4, t11 = zero4;
+        f64x4 x0[2], x1[2], n00 = zero4, n01 = zero4, n11 = zero4;      // wave 1: what it follows block 0 with
+        // ---- head: the first chief's spine / the first follower's rows of Bᵀ and the second block's spine, from both buffers ----
+        {
+          Inputs in, alt_in;
+          if (par == 0) {
+            req_spine(blk0, in.sp, bandR); req_spine(blk0, alt_in.sp, bandR + alt); req_scale(blk0, in.sc);
+          } else {
+            req_b(blk0, in.bt, bandR); req_b(blk0, alt_in.bt, bandR + alt);
+            if (q > 1) { req_spine(blk0 + 1, in.sp, bandR); req_spine(blk0 + 1, alt_in.sp, bandR + alt); req_scale(blk0 + 1, in.sc); }
+          }
+          hstamp(3);
+          if (uniform(terminated_v)) return;
+          hstamp(4);
+          const bool second = uniform(r_cur_v) != 0;
+#pragma unroll
+          for (int e = 0; e < 12; ++e) in.sp[e] = second ? alt_in.sp[e] : in.sp[e];
+          if (tdbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); hstamp(5); }
+          if (par == 0) take_spine(blk0, in.sp, in.sc, t00, t01, t11);
+          else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) in.bt[e] = second ? alt_in.bt[e] : in.bt[e];
+            take_b(0, in.bt, x0, x1);
+            if (q > 1) take_spine(blk0 + 1, in.sp, in.sc, n00, n01, n11);
+          }
+          hstamp(6);
+        }
+        for (int k = 0; k < q; ++k) {
+          const ElimChannel chk = elim_channel(chb + (k & 1) * kElimBufDoubles);
+          if ((k & 1) == par) {
+            if (k >= 2) ctr_wait([&](auto c) { return all4_ge(c, C_FILED, k - 1); });
+            stamp(k, 0);
+            elim_chief_reg<0>(t00, t01, t11, nullptr, 0, chk, lane);
+            stamp(k, 1);
+          } else {
+            if (k > 0) {
+              // the tile images wave 7 staged for this block: spine of block k + 1 (zeros behind the chain's last block), rows of Bᵀ
+              ctr_wait([&](auto c) { return c(C_STAGED) >= k + 1 && (k < 2 || (all4_ge(c, C_FILED, k - 1) && c(C_TAKEN_A) >= k && (role == 0 || c(C_TAKEN_F) >= k))); });
+              const double* im = img + (k & 1) * kImg + lane;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                n00[r] = im[(0 + r) * 64]; n01[r] = im[(4 + r) * 64]; n11[r] = im[(8 + r) * 64];
+                x0[0][r] = im[(12 + r) * 64]; x1[0][r] = im[(16 + r) * 64]; x0[1][r] = im[(20 + r) * 64]; x1[1][r] = im[(24 + r) * 64];
+              }
+              ctr_set(par == 0 ? C_TAKEN_D0 : C_TAKEN_D1, k + 1);
+            }
+            stamp(k, 0);
+            double* const Zk = Zr + (k & 1) * BP * XLD;
+            elim_follow_d(x0, x1, Zk + CB, Zk + CB + 16, 1, XLD, chk, lane, n00, n01, n11);
+            ctr_set(par == 0 ? C_DONE_D0 : C_DONE_D1, k + 1);
+            stamp(k, 1);
+            if (k + 1 < q) { t00 = n00; t01 = n01; t11 = n11; }
+            else if (right >= 0 && role == 0) {
+              // pending D of the right separator, from its left (side 0): -Z^BᵀZ^B; the tiles hold +Z^BᵀZ^B. Tiles (0,0), (1,0), (1,1)
+              // (nobody reads the upper right one); the diagonal tiles are symmetric: written along the rows.
+              double* dst = pendD_w + (size_t(right) * 2 + 0) * BB;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int c = lk + 4 * r;
+                dst[c * BP + l16] = -n00[r];
+                dst[(16 + l16) * BP + c] = -n01[r];
+                dst[(16 + c) * BP + 16 + l16] = -n11[r];
+              }
+            }
+          }
+        }
+      } else {
+        // ---- wave 7: stages the followers' inputs of blocks 1.. as tile images, a block ahead; files with waves 4..6 ----
+        if (uniform(terminated_v)) return;
+        a.R = uniform(r_cur_v) ? R_buf1 : R_buf0;
+        const double* const bandC = a.R + a.off_B();      // R(x)'s band
+        const int lt2 = tid - 256;
+        for (int k = 0; k < q; ++k) {
+          const int j = k + 1;
+          if (j < q) {
+            stamp(k, 0);
+            Inputs in;
+            req_b(blk0 + j, in.bt, bandC);
+            if (j + 1 < q) { req_spine(blk0 + j + 1, in.sp, bandC); req_scale(blk0 + j + 1, in.sc); }
+            f64x4 x0[2], x1[2], n00 = zero4, n01 = zero4, n11 = zero4;
+            take_b(j, in.bt, x0, x1);
+            if (j + 1 < q) take_spine(blk0 + j + 1, in.sp, in.sc, n00, n01, n11);
+            // (the image of block j - 2 has been taken: its follower is this block's)
+            if (j >= 3) ctr_wait([&](auto c) { return c((j & 1) ? C_TAKEN_D0 : C_TAKEN_D1) >= j - 1; });
+            double* im = img + (j & 1) * kImg + lane;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              im[(0 + r) * 64] = n00[r]; im[(4 + r) * 64] = n01[r]; im[(8 + r) * 64] = n11[r];
+              im[(12 + r) * 64] = x0[0][r]; im[(16 + r) * 64] = x1[0][r]; im[(20 + r) * 64] = x0[1][r]; im[(24 + r) * 64] = x1[1][r];
+            }
+            ctr_set(C_STAGED, j + 1);
+            stamp(k, 1);
+          }
+          ctr_wait([&](auto c) { return done_d(c, k) && c(C_DONE_A) >= k + 1 && c(C_DONE_F) >= k + 1; });
+          const int blk = blk0 + k;
+          const double* const Zk = Zr + (k & 1) * BP * XLD;
+          if (role == 0) {
+            const double* const Mk = Mr + (k & 1) * BP * DLD;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int e = lt2 + 256 * u, r = e >> 5, c = e & 31;
+              b.M[size_t(blk) * BB + e] = Mk[r * DLD + c];
+              b.ZA[size_t(blk) * BB + e] = Zk[r * XLD + CA + c];
+              b.ZB[size_t(blk) * BB + e] = Zk[r * XLD + CB + c];
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int e = lt2 + 256 * u; b.Y[size_t(blk) * fblk + size_t(e >> 4) * m1p + f0 + (e & 15)] = Zk[(e >> 4) * XLD + CF + (e & 15)]; }
+          }
+          {
+            unsigned long long* cp = reinterpret_cast<unsigned long long*>(chb + (k & 1) * kElimBufDoubles);
+            for (int e = lt2; e < kElimBufDoubles; e += 256) cp[e] = kElimSentinel;
+          }
+          ctr_set(C_FILED + 3, k + 1);
+        }
+      }
+    } else if (wave == 2) {
+      // ---- the rows of Aᵀ: Z^A. First block: T(block, left separator) from R(x); from the second on the fill -Z^BᵀZ^A ----
+      f64x4 pre0[2] = {zero4, zero4}, pre1[2] = {zero4, zero4};
+      {
+        // entry (this block's row rb, the left separator's column cs): tile qt holds cs = 16 qt + l16, register r rb = 16 h + lk + 4 r
+        // (g_roll_tab words 32..47, counted from the left separator's superblock)
+        double av[16], av1[16];
+        unsigned oA[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { oA[4 * i] = tv[i].x; oA[4 * i + 1] = tv[i].y; oA[4 * i + 2] = tv[i].z; oA[4 * i + 3] = tv[i].w; }
+        const double* p = bandR + size_t(max(blk0 - 1, 0)) * strideB;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          av[e] = 0.0; av1[e] = 0.0;
+          if (has_left) { av[e] = ldo(p, oA[e]); av1[e] = ldo(p + alt, oA[e]); }
+        }
+        if (uniform(terminated_v)) return;
+        const bool second = uniform(r_cur_v) != 0;
+        const int nreal = n_s - RB * blk0;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e0 = (qt * 2 + 0) * 4 + r, e1 = (qt * 2 + 1) * 4 + r;
+            const bool v0 = ((tmask >> e0) & 1) && has_left && lk + 4 * r < nreal, v1 = ((tmask >> e1) & 1) && has_left && 16 + lk + 4 * r < nreal;
+            pre0[qt][r] = -(v0 ? (second ? av1[e0] : av[e0]) : 0.0);
+            pre1[qt][r] = -(v1 ? (second ? av1[e1] : av[e1]) : 0.0);
+          }
+        }
+      }
+      auto fill_pre = [&](const double* Zp) {      // pre = -(0 - Z^BᵀZ^A), in the elimination's (negated) tile layout
+        double zb0[8], zb1[8], za[8];
+        zops(Zp, CB, zb0); zops(Zp, CB + 16, zb1);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          zops(Zp, CA + 16 * jt, za);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pre0[jt][r] = -0.0; pre1[jt][r] = -0.0; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            pre0[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(zb0[u], za[u], pre0[jt], 0, 0, 0);
+            pre1[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(zb1[u], za[u], pre1[jt], 0, 0, 0);
+          }
+        }
+      };
+      for (int k = 0; k < q; ++k) {
+        const ElimChannel chk = elim_channel(chb + (k & 1) * kElimBufDoubles);
+        double* const Zk = Zr + (k & 1) * BP * XLD;
+        if (k > 0) {
+          ctr_wait([&](auto c) { return done_d(c, k - 1); });
+          stamp(k, 0);
+          if (has_left) fill_pre(Zr + ((k - 1) & 1) * BP * XLD);
+        } else stamp(k, 0);
+        ctr_set(C_TAKEN_A, k + 1);
+        if (k >= 2) ctr_wait([&](auto c) { return all4_ge(c, C_FILED, k - 1); });
+        const ElimTile t[2] = {{Zk, 0, 0, Zk + CA, 1, XLD, 0, nullptr}, {Zk, 0, 0, Zk + CA + 16, 1, XLD, 0, nullptr}};
+        elim_follow<2>(t, chk, lane, true, pre0, pre1);
+        ctr_set(C_DONE_A, k + 1);
+        stamp(k, 1);
+      }
+      if (right >= 0 && has_left && role == 0) {
+        // fill T(right, left) = -Z^BᵀZ^A of the chain's last block: the left separator's coupling to its next survivor
+        ctr_wait([&](auto c) { return done_d(c, q - 1); });
+        fill_pre(Zr + ((q - 1) & 1) * BP * XLD);
+        double* dst = Gw + size_t(left) * BB;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            dst[(lk + 4 * r) * BP + 16 * jt + l16] = -pre0[jt][r];
+            dst[(16 + lk + 4 * r) * BP + 16 * jt + l16] = -pre1[jt][r];
+          }
+        }
+      }
+    } else if (wave == 3) {
+      if (role == 0) {
+        // ---- the identity rows: L⁻ᵀ ----
+        if (uniform(terminated_v)) return;
+        for (int k = 0; k < q; ++k) {
+          const ElimChannel chk = elim_channel(chb + (k & 1) * kElimBufDoubles);
+          double* const Mk = Mr + (k & 1) * BP * DLD;
+          if (k >= 2) ctr_wait([&](auto c) { return all4_ge(c, C_FILED, k - 1); });
+          stamp(k, 0);
+          const ElimTile t[2] = {{Mk, 0, 0, Mk, DLD, 1, 1, nullptr}, {Mk, 0, 0, Mk + 16 * DLD, DLD, 1, 2, nullptr}};
+          elim_follow<2>(t, chk, lane);
+          ctr_set(C_DONE_F, k + 1);
+          stamp(k, 1);
+        }
+      } else {
+        // ---- the rows of the role's F slice: Z^F; input F_k - Z^BᵀZ^F of the block before; F_{k+1} is requested a block ahead ----
+        f64x4 pre0[1], pre1[1];
+        const int col = f0 + l16;
+        auto req_f = [&](int k, double (&fv)[8], const double* Rb) {
+          const int nreal = n_s - RB * (blk0 + k);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int r = 16 * (e >> 2) + lk + 4 * (e & 3), t = RB * (blk0 + k) + r;
+            const bool vF = r < RB && r < nreal && col <= a.mc;
+            fv[e] = Rb[vF ? (col < a.mc ? a.off_E() + size_t(t) * a.mc + col : a.off_g() + t) : a.off_g()];
+          }
+        };
+        auto f_valid = [&](int k, int e) {
+          const int r = 16 * (e >> 2) + lk + 4 * (e & 3);
+          return r < RB && r < n_s - RB * (blk0 + k) && col <= a.mc;
+        };
+        double fv[8];
+        {
+          double fv1[8];
+          req_f(0, fv, R_buf0); req_f(0, fv1, R_buf1);
+          if (uniform(terminated_v)) return;
+          const bool second = uniform(r_cur_v) != 0;
+          a.R = second ? R_buf1 : R_buf0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fv[e] = second ? fv1[e] : fv[e];
+        }
+        for (int k = 0; k < q; ++k) {
+          const ElimChannel chk = elim_channel(chb + (k & 1) * kElimBufDoubles);
+          double* const Zk = Zr + (k & 1) * BP * XLD;
+          if (k > 0) ctr_wait([&](auto c) { return done_d(c, k - 1); });
+          stamp(k, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pre0[0][r] = -(f_valid(k, r) ? fv[r] : 0.0); pre1[0][r] = -(f_valid(k, 4 + r) ? fv[4 + r] : 0.0); }
+          if (k + 1 < q) req_f(k + 1, fv, a.R);
+          if (k > 0) {
+            const double* Zp = Zr + ((k - 1) & 1) * BP * XLD;
+            double zb0[8], zb1[8], zf[8];
+            zops(Zp, CB, zb0); zops(Zp, CB + 16, zb1); zops(Zp, CF, zf);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              pre0[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(zb0[u], zf[u], pre0[0], 0, 0, 0);
+              pre1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(zb1[u], zf[u], pre1[0], 0, 0, 0);
+            }
+          }
+          ctr_set(C_TAKEN_F, k + 1);
+          if (k >= 2) ctr_wait([&](auto c) { return all4_ge(c, C_FILED, k - 1); });
+          const ElimTile t[1] = {{Zk, 0, 0, Zk + CF, 1, XLD, 0, nullptr}};
+          elim_follow<1>(t, chk, lane, true, pre0, pre1);
+          ctr_set(C_DONE_F, k + 1);
+          stamp(k, 1);
+        }
+        if (right >= 0) {
+          // pending F of the right separator: -Z^BᵀZ^F of the chain's last block
+          ctr_wait([&](auto c) { return done_d(c, q - 1); });
+          const double* Zp = Zr + ((q - 1) & 1) * BP * XLD;
+          double zb0[8], zb1[8], zf[8];
+          zops(Zp, CB, zb0); zops(Zp, CB + 16, zb1); zops(Zp, CF, zf);
+          f64x4 s0 = zero4, s1 = zero4;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-zb0[u], zf[u], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-zb1[u], zf[u], s1, 0, 0, 0);
+          }
+          double* dst = pendF_w + (size_t(right) * 2 + 0) * fblk + f0 + l16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { dst[size_t(lk + 4 * r) * m1p] = s0[r]; dst[size_t(16 + lk + 4 * r) * m1p] = s1[r]; }
+        }
+      }
+    } else {
+      // ---- waves 4..6: filing, the left separator's sums, the channel ----
+      if (uniform(terminated_v)) return;
+      const int w4 = wave - 4, lt2 = tid - 256;
+      const bool acc_owner = wave == 5 || wave == 6, acc_owner2 = role == 0 && wave == 5;
+      const int acc_p = role == 0 ? CA + (wave == 6 ? 16 : 0) : CA + 16 * (wave - 5);
+      const int acc_q = role == 0 ? CA + (wave == 6 ? 16 : 0) : CF;
+      f64x4 acc2 = zero4;
+      for (int k = 0; k < q; ++k) {
+        ctr_wait([&](auto c) { return done_d(c, k) && c(C_DONE_A) >= k + 1 && c(C_DONE_F) >= k + 1; });
+        stamp(k, 0);
+        const int blk = blk0 + k;
+        const double* const Zk = Zr + (k & 1) * BP * XLD;
+        if (role == 0) {
+          const double* const Mk = Mr + (k & 1) * BP * DLD;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = lt2 + 256 * u, r = e >> 5, c = e & 31;
+            b.M[size_t(blk) * BB + e] = Mk[r * DLD + c];
+            b.ZA[size_t(blk) * BB + e] = Zk[r * XLD + CA + c];
+            b.ZB[size_t(blk) * BB + e] = Zk[r * XLD + CB + c];
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) { const int e = lt2 + 256 * u; b.Y[size_t(blk) * fblk + size_t(e >> 4) * m1p + f0 + (e & 15)] = Zk[(e >> 4) * XLD + CF + (e & 15)]; }
+        }
+        if (has_left && acc_owner) acc_a = atb_tile<true>(Zk, XLD, acc_p, Zk, XLD, acc_q, 0, BP, acc_a, lane);
+        if (has_left && acc_owner2) acc2 = atb_tile<true>(Zk, XLD, CA + 16, Zk, XLD, CA, 0, BP, acc2, lane);
+        // (the followers of block k are through with its channel; block k+2's chief and followers wait for this wave's word)
+        {
+          unsigned long long* cp = reinterpret_cast<unsigned long long*>(chb + (k & 1) * kElimBufDoubles);
+          for (int e = lt2; e < kElimBufDoubles; e += 256) cp[e] = kElimSentinel;
+        }
+        ctr_set(C_FILED + w4, k + 1);
+        stamp(k, 1);
+      }
+      if (has_left) {
+        if (role == 0) {
+          if (acc_owner) {
+            const int it = wave == 6 ? 1 : 0, jt = it;
+            double* dst = pendD_w + (size_t(left) * 2 + 1) * BB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(16 * it + lk + 4 * r) * BP + 16 * jt + l16] = acc_a[r];
+            if (acc_owner2) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) dst[(16 + lk + 4 * r) * BP + l16] = acc2[r];
+            }
+          }
+        } else if (acc_owner) {
+          const int h = wave - 5;
+          double* dst = pendF_w + (size_t(left) * 2 + 1) * fblk + f0 + l16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[size_t(16 * h + lk + 4 * r) * m1p] = acc_a[r];
+        }
+      }
+    }
+    if (tdbg) {
+      __syncthreads();
+      if (tid == 0 && (bid < 2 || bid == 7 || bid == 8)) {
+        printf("bcr_level 0 (rolling) wg %d role %d q %d lived %lld clocks: set-up %lld | head of wave 0: entry %lld, at the barrier %lld, behind it %lld, requests out %lld, state there %lld, data there %lld, tiles %lld | wave 1: %lld %lld %lld %lld %lld %lld %lld\n", bid, role, q, (long long)(__builtin_readcyclecounter() - t_kernel), t_setup,
+               hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[8], hs[9], hs[10], hs[11], hs[12], hs[13], hs[14]);
+        for (int w = 0; w < 8; ++w)
+          printf("  wg %d wave %d, begin-end by block: %lld-%lld %lld-%lld %lld-%lld %lld-%lld\n", bid, w, tstamp[(w * 4 + 0) * 2], tstamp[(w * 4 + 0) * 2 + 1],
+                 tstamp[(w * 4 + 1) * 2], tstamp[(w * 4 + 1) * 2 + 1], tstamp[(w * 4 + 2) * 2], tstamp[(w * 4 + 2) * 2 + 1], tstamp[(w * 4 + 3) * 2], tstamp[(w * 4 + 3) * 2 + 1]);
+      }
+    }
+    return;
+  }
   {
     // ELIM: nobody has anything else to do before the first block is in LDS -- all eight waves fetch it, two entries of
     // D / B / A and one of the F slice each (half the instructions per thread of the loaders' share of a later block)
@@ -2576,15 +3142,20 @@ bool block_elim_enabled() { const char* e = std::getenv("CALICO_ELIM"); return !
 // profiles/r05_lookahead_ab.txt) -- the chief does start ~2.5k clocks earlier per step, but a step is then bounded by the
 // loader waves' commit of the next block (they lose the Schur phase as load time) and by the two barriers' own latency.
 static bool level_lookahead_enabled() { const char* e = std::getenv("CALICO_LOOKAHEAD"); return e && std::atoi(e) != 0; }
+// CALICO_ROLL=1: level 0's chains with the rolling chief (bcr_level_kernel<true, true, false, true>: no workgroup barrier between
+// the blocks of a chain); read per solve (A/B switch)
+static bool level_roll_enabled() { const char* e = std::getenv("CALICO_ROLL"); return e && std::atoi(e) != 0; }
 size_t bcr_level_lds_bytes() { return size_t(2 * 64 * DLD + 4 * BP * XLD + 80 + 128 + kLevelThreads + kElimBufDoubles) * sizeof(double); }      // (4: X twice, Z twice with the look-ahead)
 size_t bcr_back_lds_bytes(int q_max, int m1p) {
   return (size_t(2) * q_max * BP * DLD + kBcrMaxChain * BP + 3 * BP + m1p + size_t(q_max) * BP + 4 * BP) * sizeof(double);
 }
 hipError_t configure_bcr_kernels(int q_max, int m1p) {
-  hipError_t e = hipSuccess;
+  hipError_t e = upload_roll_table();      // (per device: a __device__ symbol lives on each of them)
+  if (e != hipSuccess) return e;
   for (const void* f : {reinterpret_cast<const void*>(&bcr_level_kernel<true, true>), reinterpret_cast<const void*>(&bcr_level_kernel<false, true>),
                         reinterpret_cast<const void*>(&bcr_level_kernel<true, true, true>), reinterpret_cast<const void*>(&bcr_level_kernel<false, true, true>),
-                        reinterpret_cast<const void*>(&bcr_level_kernel<true, false>), reinterpret_cast<const void*>(&bcr_level_kernel<false, false>)}) {
+                        reinterpret_cast<const void*>(&bcr_level_kernel<true, false>), reinterpret_cast<const void*>(&bcr_level_kernel<false, false>),
+                        reinterpret_cast<const void*>(&bcr_level_kernel<true, true, false, true>)}) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(bcr_level_lds_bytes()));
     if (e != hipSuccess) return e;
   }
@@ -2610,7 +3181,8 @@ void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nod
   const int main_span = 8 * ((n_nodes + 7) / 8) * (1 + nfs);      // (node, role) workgroups laid out by XCD: see the kernel
   const bool elim = block_elim_enabled(), la = level_lookahead_enabled();
   if (level == 0) {
-    hipLaunchKernelGGL((elim ? (la ? bcr_level_kernel<true, true, true> : bcr_level_kernel<true, true>) : bcr_level_kernel<true, false>), dim3(main_span + n_apply + (with_post_eval ? 1 : 0)), dim3(kLevelThreads),
+    const bool roll = elim && !la && level_roll_enabled();
+    hipLaunchKernelGGL((roll ? bcr_level_kernel<true, true, false, true> : elim ? (la ? bcr_level_kernel<true, true, true> : bcr_level_kernel<true, true>) : bcr_level_kernel<true, false>), dim3(main_span + n_apply + (with_post_eval ? 1 : 0)), dim3(kLevelThreads),
                        bcr_level_lds_bytes(), s, a, b, node0, n_nodes, nfs, level, keep0, n_keep, o, with_post_eval, x, blocks, n_blocks,
                        log, log_cap, jacobi, 0, 0, 1, fan_word, 0, inl);
   } else {

@@ -104,11 +104,9 @@ struct PivotChain {
 // The chief. In: rows 0..31 of A (LDS, row stride LD): the block, lower triangle (the upper one is not read).
 // Out (WRITE_L = 1): rows 0..31: L, lower triangle (above the diagonal undefined); WRITE_L = 2: the lower triangle only --
 // in place in a matrix whose strict upper triangle belongs to somebody else (the dense solve keeps L⁻ᵀ there).
-template <int WRITE_L, bool TS = false>
-DEVI void elim_chief(double* A, int LD, const ElimChannel ch, int lane, long long* ts = nullptr) {
+// The spine of a 32x32 block as the chief holds it: tiles (0,0), (0,1), (1,1), negated, from the lower triangle of A (LDS, row stride LD).
+DEVI void elim_load_spine(const double* A, int LD, int lane, f64x4& t00, f64x4& t01, f64x4& t11) {
   const int l16 = lane & 15, lk = lane >> 4;
-  const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
-  f64x4 t00, t01, t11;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int c = lk + 4 * r;
@@ -117,6 +115,22 @@ DEVI void elim_chief(double* A, int LD, const ElimChannel ch, int lane, long lon
     t01[r] = -A[(16 + l16) * LD + c];
     t11[r] = -A[(16 + hi) * LD + 16 + lo];
   }
+}
+// The chief on a spine it already holds in registers (round 6, the tree levels' rolling chief: the wave that followed the block
+// before with the rows of Bᵀ formed this block's diagonal -- D_next -= Z^BᵀZ^B, step by step, elim_follow_d -- in exactly this
+// layout). WRITE_L as elim_chief; A is only touched when WRITE_L != 0.
+template <int WRITE_L, bool TS = false>
+DEVI void elim_chief_reg(f64x4 t00, f64x4 t01, f64x4 t11, double* A, int LD, const ElimChannel ch, int lane, long long* ts = nullptr);
+template <int WRITE_L, bool TS = false>
+DEVI void elim_chief(double* A, int LD, const ElimChannel ch, int lane, long long* ts = nullptr) {
+  f64x4 t00, t01, t11;
+  elim_load_spine(A, LD, lane, t00, t01, t11);
+  elim_chief_reg<WRITE_L, TS>(t00, t01, t11, A, LD, ch, lane, ts);
+}
+template <int WRITE_L, bool TS>
+DEVI void elim_chief_reg(f64x4 t00, f64x4 t01, f64x4 t11, double* A, int LD, const ElimChannel ch, int lane, long long* ts) {
+  const int l16 = lane & 15, lk = lane >> 4;
+  const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
   PivotChain pc;
   pc.l16 = l16;
   pc.e0 = lk == 0 ? -1.0 : 0.0; pc.e1 = lk == 1 ? -1.0 : 0.0; pc.e2 = lk == 2 ? -1.0 : 0.0; pc.e3 = lk == 3 ? -1.0 : 0.0;
@@ -245,6 +259,71 @@ DEVI void elim_follow(const ElimTile (&t)[NT], const ElimChannel ch, int lane, b
       if (need_l0) x0[q] = CAL_MFMA(l0, lp[q], x0[q]);
       if (need_l1 && !(J == 1 && u == 3)) x1[q] = CAL_MFMA(l1, lp[q], x1[q]);
     }
+    v[0] = nv[0]; v[1] = nv[1]; v[2] = nv[2];
+  }
+}
+
+
+// The rows of a follower's tile, negated, in the accumulator layout (what elim_follow loads itself): x0 / x1 = the tile against the
+// block's columns 0..15 / 16..31. Apart from elim_follow_d so that the caller can tell the world "taken" between the loads and the steps.
+DEVI void elim_load_rows(const double* in, int in_row, int in_col, int lane, f64x4& x0, f64x4& x1) {
+  const int l16 = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = lk + 4 * r;
+    x0[r] = -in[l16 * in_row + c * in_col];
+    x1[r] = -in[l16 * in_row + (16 + c) * in_col];
+  }
+}
+// The follower that becomes the next block's chief (round 6): its two row tiles are the rows of Bᵀ = T(next, this)ᵀ -- sixteen
+// dimensions of the NEXT block each, against this block's 32 columns --, so its panel products are the step's four rows of Z^B, and
+//     D_next -= Z^BᵀZ^B = Σ_steps lp lpᵀ
+// accumulates, step by step, in the three spine tiles `n00`, `n01`, `n11` (negated, the chief's layout: elim_load_spine) straight
+// from the panel products' result registers: the same 16x16x4 products in the same order as the tile products PᵀQ that used to
+// form the update out of LDS behind a barrier (k = 4s .. 4s+3 per product, s ascending), so the sums are bit-identical. When the
+// last step's products are through, the wave holds the next block's damped, updated diagonal and goes on as its chief
+// (elim_chief_reg) -- nothing of it passes through LDS and nobody waits at a barrier.
+// x0 / x1 [2]: the two row tiles (elim_load_rows); out[q]: where tile q's result entry (i, c) goes, out[q][i * out_row + c * out_col].
+DEVI void elim_follow_d(f64x4 (&x0)[2], f64x4 (&x1)[2], double* out0, double* out1, int out_row, int out_col, const ElimChannel ch, int lane,
+                        f64x4& n00, f64x4& n01, f64x4& n11) {
+  const int l16 = lane & 15, lk = lane >> 4;
+  const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+  const unsigned long long* const sub = reinterpret_cast<const unsigned long long*>(ch.buf) + lane;
+  unsigned long long v[3] = {0, 0, 0}, nv[3] = {0, 0, 0};
+  auto request = [&](int s, unsigned long long (&d)[3]) {
+    const bool need_l0 = s < 3, need_l1 = s < 7;
+    if (need_l1) d[2] = __hip_atomic_load(sub + s * kElimStep + 2 * kElimSlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    d[0] = __hip_atomic_load(sub + s * kElimStep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (need_l0) d[1] = __hip_atomic_load(sub + s * kElimStep + kElimSlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+  };
+  request(0, v);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int J = s >> 2, u = s & 3;
+    const bool need_l0 = s < 3, need_l1 = s < 7;
+    while (__builtin_amdgcn_ballot_w64((need_l1 ? v[2] : v[0]) == kElimSentinel) != 0) { __builtin_amdgcn_s_sleep(1); request(s, v); }
+    const double w = __longlong_as_double((long long)v[0]);
+    const double l0 = need_l0 ? __longlong_as_double((long long)v[1]) : 0.0;
+    const double l1 = need_l1 ? __longlong_as_double((long long)v[2]) : 0.0;
+    if (s < 7) request(s + 1, nv);
+    const f64x4 pa = CAL_MFMA(w, (J == 0 ? x0[0][u] : x1[0][u]), zero4);
+    const f64x4 pb = CAL_MFMA(w, (J == 0 ? x0[1][u] : x1[1][u]), zero4);
+    const double la = pa[0], lb = pb[0];
+    // what the NEXT step's panel products wait for first, then the next block's diagonal (its tile (0,0) first: the pivot chain of
+    // the block this wave is about to be the chief of starts there)
+    if (need_l0) { x0[0] = CAL_MFMA(l0, la, x0[0]); x0[1] = CAL_MFMA(l0, lb, x0[1]); }
+    if (need_l1 && !(J == 1 && u == 3)) { x1[0] = CAL_MFMA(l1, la, x1[0]); x1[1] = CAL_MFMA(l1, lb, x1[1]); }
+    n00 = CAL_MFMA(la, la, n00);
+    n01 = CAL_MFMA(la, lb, n01);
+    n11 = CAL_MFMA(lb, lb, n11);
+    {
+      const int col = 4 * s + lk;
+      out0[l16 * out_row + col * out_col] = la;
+      out1[l16 * out_row + col * out_col] = lb;
+    }
+    CAL_KEEP(pa); CAL_KEEP(pb);
     v[0] = nv[0]; v[1] = nv[1]; v[2] = nv[2];
   }
 }
