@@ -401,6 +401,17 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   const int terminated_v = stv->terminated;
   const double radius = stv->radius;          // (stays in a VGPR: only arithmetic uses it)
   const int r_cur_v = FROM_R ? stv->rcur : 0;
+  // ROLL: the lanes' offset table (g_roll_tab) is asked for with the state, at the kernel's first instructions -- its round trip
+  // (~4k clocks behind a kernel boundary) then runs beside the state's and the set-up below instead of behind them. Every wave
+  // asks for the same words, used or not: straight-line requests, nothing waits for them before they are used.
+  uint4 tv[8], tva[4];
+  if constexpr (ROLL) {
+    const uint4* const tl = reinterpret_cast<const uint4*>(&g_roll_tab[min(max(a.k, 1), 6) - 1][threadIdx.x & 63][0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tv[i] = tl[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tva[i] = tl[8 + i];
+  }
   // `pub` (the last level's launch when the Schur complement rides in it): this level's workgroups are the PRODUCERS of
   // an in-launch fan-in -- what the riders read (Y rows, the root's pending slots, separators updated in place) leaves
   // with write-through stores, and every producing workgroup arrives at `fan_word` once, terminated or not; the riders
@@ -859,18 +870,19 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     //   * waves 4..7, once block k's followers are through, file what the back-substitution reads, add up what the left
     //     separator collects, and clear the block's channel.
     // Order is kept by single-writer counters in LDS (a wave's LDS instructions execute in order: data first, then the
-    // counter; a reader polls the counter, then reads). Z, L⁻ᵀ, the channel and the tile images are double-buffered by parity.
+    // counter; a reader polls the counter, then reads). Z, L⁻ᵀ and the tile images are double-buffered by parity, the channel three deep.
     // Same products in the same order as the barrier form: bit-identical results (profiles/dev/bitwise.py).
     // Needs every control point observed (b.all_active: the host launches the barrier form otherwise).
     // ================================================================================================================
     constexpr int kImg = 28 * 64;                         // a follower's inputs: spine (12 registers) + rows of Bᵀ (16), by lane
     double* const Zr = lds;                               // [2][32·XLD] Z = [Z^A | Z^B | Z^F] by block parity
     double* const Mr = Zr + 2 * BP * XLD;                 // [2][32·DLD] L⁻ᵀ (role 0)
-    double* const chb = Mr + 2 * BP * DLD;                // [2][kElimBufDoubles] channels
-    double* const img = chb + 2 * kElimBufDoubles;        // [2][kImg] tile images
+    double* const chb = Mr + 2 * BP * DLD;                // [3][kElimBufDoubles] channels, block k's: k % 3 (a chief never waits for its channel:
+                                                          // the one it writes was cleared behind block k - 3, and the wave saw that as block k - 1's follower)
+    double* const img = chb + 3 * kElimBufDoubles;        // [2][kImg] tile images
     int* const ctr = reinterpret_cast<int*>(img + 2 * kImg);                // [16] counters
     long long* const tstamp = reinterpret_cast<long long*>(ctr + 16);       // [8 waves][4 blocks][2] (dev timing)
-    static_assert(2 * BP * XLD + 2 * BP * DLD + 2 * kElimBufDoubles + 2 * kImg + 8 + 64 + 16 <= 2 * 64 * DLD + 4 * BP * XLD + 80 + 128 + kLevelThreads + kElimBufDoubles,
+    static_assert(2 * BP * XLD + 2 * BP * DLD + 3 * kElimBufDoubles + 2 * kImg + 8 + 64 + 16 <= 2 * 64 * DLD + 4 * BP * XLD + 80 + 128 + kLevelThreads + kElimBufDoubles,
                   "the rolling chief's LDS layout must fit the level kernels' allocation");
     enum { C_DONE_D0 = 0, C_DONE_D1 = 1, C_DONE_A = 2, C_DONE_F = 3, C_TAKEN_A = 4, C_TAKEN_F = 5, C_TAKEN_D0 = 6, C_TAKEN_D1 = 7, C_FILED = 8, C_STAGED = 12 };
     auto ctr_set = [&](int idx, int v) {
@@ -900,27 +912,14 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     const bool has_left = left >= 0;
     const int n_s = a.n_s(), kk = a.k;
     const bool tile_wave = wave < 2 || wave == 7;         // the waves that load spines and rows of Bᵀ from R(x)
-    uint4 tv[8];
-    unsigned tmask = 0;
-    {
-      const unsigned* const tl = &g_roll_tab[min(max(kk, 1), 6) - 1][lane][0];
-      if (wave == 2) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tv[i] = reinterpret_cast<const uint4*>(tl)[8 + i];
-#pragma unroll
-        for (int i = 4; i < 8; ++i) tv[i] = tv[0];
-        tmask = tl[29];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) tv[i] = reinterpret_cast<const uint4*>(tl)[tile_wave ? i : 0];
-      }
-    }
-    for (int e = tid; e < 2 * kElimBufDoubles; e += kLevelThreads) reinterpret_cast<unsigned long long*>(chb)[e] = kElimSentinel;
+    const unsigned tmask = tv[7].y;
+    for (int e = tid; e < 3 * kElimBufDoubles; e += kLevelThreads) reinterpret_cast<unsigned long long*>(chb)[e] = kElimSentinel;
     if (tid < 16) ctr[tid] = 0;
     if (tdbg && tid < 64) tstamp[tid] = 0;
     hstamp(1);
     lds_barrier();
     hstamp(2);
+    if (CAL_DEV_TIMING(a.debug == 5)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); hstamp(7); }      // (when have the state and the table arrived?)
     const size_t alt = a.r_stride;                        // the same entry of the other reduce buffer
     const double* const bandR = R_buf0 + a.off_B();       // (+ alt: buffer 1) superblock I's storage starts at I·strideB
     // base + zext(byte offset): the scalar-base + 32-bit-vector-offset form of a global load -- one instruction per request
@@ -962,27 +961,33 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       const double inv_radius = 1.0 / radius;
       auto take_spine = [&](int I, const double (&sp)[12], const double (&sc)[4], f64x4& t00, f64x4& t01, f64x4& t11) {
         const int nreal = n_s - RB * I;
+        double e00[4], e01[4], e11[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int c = lk + 4 * r, hi = max(l16, c);
           const bool v00 = ((okS >> r) & 1) && hi < nreal, v01 = ((okS >> (4 + r)) & 1) && 16 + l16 < nreal, v11 = ((okS >> (8 + r)) & 1) && 16 + hi < nreal;
-          double e00 = v00 ? sp[r] : 0.0, e11 = v11 ? sp[8 + r] : 0.0;
-          const double e01 = v01 ? sp[4 + r] : 0.0;
-          if (l16 == c) {
-            // diagonal entries (rows l16 and 16 + l16): damped where the row is real, 1 on padding rows
+          e00[r] = v00 ? sp[r] : 0.0; e01[r] = v01 ? sp[4 + r] : 0.0; e11[r] = v11 ? sp[8 + r] : 0.0;
+        }
+        // the lane's diagonal entries (rows l16 and 16 + l16: register (l16 - lk) / 4 of tiles (0,0) and (1,1) in the lanes that
+        // have one), ONCE per lane and without a branch on the register: damped where the row is real, 1 on padding rows
+        const int dr = (l16 - lk) >> 2;
+        double dg[2];
+        dg[0] = dr == 1 ? e00[1] : (dr == 2 ? e00[2] : (dr == 3 ? e00[3] : e00[0]));
+        dg[1] = dr == 1 ? e11[1] : (dr == 2 ? e11[2] : (dr == 3 ? e11[3] : e11[0]));
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const int row = 16 * h + l16, t = RB * I + row;
-              const bool vd = h == 0 ? v00 : v11, real_row = row < RB && row < nreal;
-              double& e = h == 0 ? e00 : e11;
-              double d;
-              if (fr.first_scale == 0) d = fmin(fmax(e * sc[2 * h] * sc[2 * h], o.min_lm_diagonal), o.max_lm_diagonal) * (inv_radius * sc[2 * h + 1]);
-              else d = fr.damping(e, real_row ? t : 0);
-              if (vd) { e += d; if (role == 0) a.dadd[t] = d; }
-              else { e = 1.0; if (role == 0 && real_row) a.dadd[t] = 0.0; }
-            }
-          }
-          t00[r] = -e00; t01[r] = -e01; t11[r] = -e11;
+        for (int h = 0; h < 2; ++h) {
+          const int row = 16 * h + l16, t = RB * I + row;
+          const bool real_row = row < RB && row < nreal;
+          double d;
+          if (fr.first_scale == 0) d = fmin(fmax(dg[h] * sc[2 * h] * sc[2 * h], o.min_lm_diagonal), o.max_lm_diagonal) * (inv_radius * sc[2 * h + 1]);
+          else d = fr.damping(dg[h], real_row ? t : 0);
+          if (diag_lane && real_row && role == 0) a.dadd[t] = d;
+          dg[h] = real_row ? dg[h] + d : 1.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool is_d = diag_lane && dr == r;
+          t00[r] = -(is_d ? dg[0] : e00[r]); t01[r] = -e01[r]; t11[r] = -(is_d ? dg[1] : e11[r]);
         }
       };
       auto take_b = [&](int k, const double (&bt)[16], f64x4 (&x0)[2], f64x4 (&x1)[2]) {
@@ -1029,9 +1034,8 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           hstamp(6);
         }
         for (int k = 0; k < q; ++k) {
-          const ElimChannel chk = elim_channel(chb + (k & 1) * kElimBufDoubles);
+          const ElimChannel chk = elim_channel(chb + (k % 3) * kElimBufDoubles);
           if ((k & 1) == par) {
-            if (k >= 2) ctr_wait([&](auto c) { return all4_ge(c, C_FILED, k - 1); });
             stamp(k, 0);
             elim_chief_reg<0>(t00, t01, t11, nullptr, 0, chk, lane);
             stamp(k, 1);
@@ -1111,7 +1115,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
             for (int u = 0; u < 2; ++u) { const int e = lt2 + 256 * u; b.Y[size_t(blk) * fblk + size_t(e >> 4) * m1p + f0 + (e & 15)] = Zk[(e >> 4) * XLD + CF + (e & 15)]; }
           }
           {
-            unsigned long long* cp = reinterpret_cast<unsigned long long*>(chb + (k & 1) * kElimBufDoubles);
+            unsigned long long* cp = reinterpret_cast<unsigned long long*>(chb + (k % 3) * kElimBufDoubles);
             for (int e = lt2; e < kElimBufDoubles; e += 256) cp[e] = kElimSentinel;
           }
           ctr_set(C_FILED + 3, k + 1);
@@ -1126,7 +1130,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         double av[16], av1[16];
         unsigned oA[16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { oA[4 * i] = tv[i].x; oA[4 * i + 1] = tv[i].y; oA[4 * i + 2] = tv[i].z; oA[4 * i + 3] = tv[i].w; }
+        for (int i = 0; i < 4; ++i) { oA[4 * i] = tva[i].x; oA[4 * i + 1] = tva[i].y; oA[4 * i + 2] = tva[i].z; oA[4 * i + 3] = tva[i].w; }
         const double* p = bandR + size_t(max(blk0 - 1, 0)) * strideB;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -1163,7 +1167,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         }
       };
       for (int k = 0; k < q; ++k) {
-        const ElimChannel chk = elim_channel(chb + (k & 1) * kElimBufDoubles);
+        const ElimChannel chk = elim_channel(chb + (k % 3) * kElimBufDoubles);
         double* const Zk = Zr + (k & 1) * BP * XLD;
         if (k > 0) {
           ctr_wait([&](auto c) { return done_d(c, k - 1); });
@@ -1196,7 +1200,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         // ---- the identity rows: L⁻ᵀ ----
         if (uniform(terminated_v)) return;
         for (int k = 0; k < q; ++k) {
-          const ElimChannel chk = elim_channel(chb + (k & 1) * kElimBufDoubles);
+          const ElimChannel chk = elim_channel(chb + (k % 3) * kElimBufDoubles);
           double* const Mk = Mr + (k & 1) * BP * DLD;
           if (k >= 2) ctr_wait([&](auto c) { return all4_ge(c, C_FILED, k - 1); });
           stamp(k, 0);
@@ -1233,7 +1237,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           for (int e = 0; e < 8; ++e) fv[e] = second ? fv1[e] : fv[e];
         }
         for (int k = 0; k < q; ++k) {
-          const ElimChannel chk = elim_channel(chb + (k & 1) * kElimBufDoubles);
+          const ElimChannel chk = elim_channel(chb + (k % 3) * kElimBufDoubles);
           double* const Zk = Zr + (k & 1) * BP * XLD;
           if (k > 0) ctr_wait([&](auto c) { return done_d(c, k - 1); });
           stamp(k, 0);
@@ -1304,7 +1308,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         if (has_left && acc_owner2) acc2 = atb_tile<true>(Zk, XLD, CA + 16, Zk, XLD, CA, 0, BP, acc2, lane);
         // (the followers of block k are through with its channel; block k+2's chief and followers wait for this wave's word)
         {
-          unsigned long long* cp = reinterpret_cast<unsigned long long*>(chb + (k & 1) * kElimBufDoubles);
+          unsigned long long* cp = reinterpret_cast<unsigned long long*>(chb + (k % 3) * kElimBufDoubles);
           for (int e = lt2; e < kElimBufDoubles; e += 256) cp[e] = kElimSentinel;
         }
         ctr_set(C_FILED + w4, k + 1);
@@ -1333,8 +1337,8 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     if (tdbg) {
       __syncthreads();
       if (tid == 0 && (bid < 2 || bid == 7 || bid == 8)) {
-        printf("bcr_level 0 (rolling) wg %d role %d q %d lived %lld clocks: set-up %lld | head of wave 0: entry %lld, at the barrier %lld, behind it %lld, requests out %lld, state there %lld, data there %lld, tiles %lld | wave 1: %lld %lld %lld %lld %lld %lld %lld\n", bid, role, q, (long long)(__builtin_readcyclecounter() - t_kernel), t_setup,
-               hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[8], hs[9], hs[10], hs[11], hs[12], hs[13], hs[14]);
+        printf("bcr_level 0 (rolling) wg %d role %d q %d lived %lld clocks: set-up %lld | head of wave 0: entry %lld, at the barrier %lld, behind it %lld, requests out %lld, state there %lld, data there %lld, tiles %lld (all loads there %lld) | wave 1: %lld %lld %lld %lld %lld %lld %lld\n", bid, role, q, (long long)(__builtin_readcyclecounter() - t_kernel), t_setup,
+               hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[7], hs[8], hs[9], hs[10], hs[11], hs[12], hs[13], hs[14]);
         for (int w = 0; w < 8; ++w)
           printf("  wg %d wave %d, begin-end by block: %lld-%lld %lld-%lld %lld-%lld %lld-%lld\n", bid, w, tstamp[(w * 4 + 0) * 2], tstamp[(w * 4 + 0) * 2 + 1],
                  tstamp[(w * 4 + 1) * 2], tstamp[(w * 4 + 1) * 2 + 1], tstamp[(w * 4 + 2) * 2], tstamp[(w * 4 + 2) * 2 + 1], tstamp[(w * 4 + 3) * 2], tstamp[(w * 4 + 3) * 2 + 1]);
@@ -3142,9 +3146,9 @@ bool block_elim_enabled() { const char* e = std::getenv("CALICO_ELIM"); return !
 // profiles/r05_lookahead_ab.txt) -- the chief does start ~2.5k clocks earlier per step, but a step is then bounded by the
 // loader waves' commit of the next block (they lose the Schur phase as load time) and by the two barriers' own latency.
 static bool level_lookahead_enabled() { const char* e = std::getenv("CALICO_LOOKAHEAD"); return e && std::atoi(e) != 0; }
-// CALICO_ROLL=1: level 0's chains with the rolling chief (bcr_level_kernel<true, true, false, true>: no workgroup barrier between
-// the blocks of a chain); read per solve (A/B switch)
-static bool level_roll_enabled() { const char* e = std::getenv("CALICO_ROLL"); return e && std::atoi(e) != 0; }
+// Level 0's chains with the rolling chief (bcr_level_kernel<true, true, false, true>: no workgroup barrier between the blocks of
+// a chain), the default wherever every control point is observed; CALICO_ROLL=0: the barrier form (A/B switch, read per solve)
+static bool level_roll_enabled() { const char* e = std::getenv("CALICO_ROLL"); return !e || std::atoi(e) != 0; }
 size_t bcr_level_lds_bytes() { return size_t(2 * 64 * DLD + 4 * BP * XLD + 80 + 128 + kLevelThreads + kElimBufDoubles) * sizeof(double); }      // (4: X twice, Z twice with the look-ahead)
 size_t bcr_back_lds_bytes(int q_max, int m1p) {
   return (size_t(2) * q_max * BP * DLD + kBcrMaxChain * BP + 3 * BP + m1p + size_t(q_max) * BP + 4 * BP) * sizeof(double);
@@ -3181,7 +3185,7 @@ void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nod
   const int main_span = 8 * ((n_nodes + 7) / 8) * (1 + nfs);      // (node, role) workgroups laid out by XCD: see the kernel
   const bool elim = block_elim_enabled(), la = level_lookahead_enabled();
   if (level == 0) {
-    const bool roll = elim && !la && level_roll_enabled();
+    const bool roll = elim && !la && b.all_active && a.k >= 1 && a.k <= 6 && level_roll_enabled();
     hipLaunchKernelGGL((roll ? bcr_level_kernel<true, true, false, true> : elim ? (la ? bcr_level_kernel<true, true, true> : bcr_level_kernel<true, true>) : bcr_level_kernel<true, false>), dim3(main_span + n_apply + (with_post_eval ? 1 : 0)), dim3(kLevelThreads),
                        bcr_level_lds_bytes(), s, a, b, node0, n_nodes, nfs, level, keep0, n_keep, o, with_post_eval, x, blocks, n_blocks,
                        log, log_cap, jacobi, 0, 0, 1, fan_word, 0, inl);
