@@ -185,6 +185,19 @@ DEVI void schur_tile(const SolveArgs& a, const BcrArgs& b, const FromR& fr, int 
   const double* pa = b.Y + ca;
   const double* pb = b.Y + cb;
   const int f0 = LATE ? late0 : -1, f1 = LATE ? late1 : -1;
+  // The entry of the damped corner this thread will store (threads 0..255: entry tid of the tile), requested FIRST: C(r, c) and
+  // the diagonal's Jacobi scale are two dependent round trips (~2k clocks each) that depend on nothing this launch computes -- taken
+  // behind the rows' sums (and, riding in the last level's launch, behind the fan-in) they were the tail of the launch.
+  double s0_pre = 0.0;
+  if (tid < 256) {
+    const int r = tr * 16 + (tid >> 4), c = tc * 16 + (tid & 15);
+    if (r < m1y && c <= r && slice == 0) {
+      if (r < mc) {
+        s0_pre = a.R[a.off_C() + size_t(r) * mc + c];
+        if (r == c) { const double d = fr.damping(s0_pre, a.n_s() + r); a.dadd[a.n_s() + r] = d; s0_pre += d; }
+      } else if (c < mc) s0_pre = a.R[a.off_g() + a.n_s() + c];
+    }
+  }
   f64x4 acc = {0.0, 0.0, 0.0, 0.0};
   for (int k0 = w_begin; k0 < w_end; k0 += 32) {
     double va[8], vb[8];
@@ -226,14 +239,7 @@ DEVI void schur_tile(const SolveArgs& a, const BcrArgs& b, const FromR& fr, int 
     if (r < m1y && c <= r) {
       const int fi = r < mc ? r : m, fc = c < mc ? c : m;   // final index: the right-hand side sits behind the root rows
       // corner of the damped system: C(r, c) (+ damping on the diagonal), right-hand side g_c in row m; (m, m) is unused
-      double s0 = 0.0;
-      if (slice == 0) {
-        if (r < mc) {
-          s0 = a.R[a.off_C() + size_t(r) * mc + c];
-          if (r == c) { const double d = fr.damping(s0, a.n_s() + r); a.dadd[a.n_s() + r] = d; s0 += d; }
-        } else if (c < mc) s0 = a.R[a.off_g() + a.n_s() + c];
-      }
-      a.Spart[size_t(slice) * msq + size_t(fi) * m1 + fc] = s0 - sum;
+      a.Spart[size_t(slice) * msq + size_t(fi) * m1 + fc] = s0_pre - sum;
     }
   }
 }
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   // (~4k clocks behind a kernel boundary) then runs beside the state's and the set-up below instead of behind them. Every wave
   // asks for the same words, used or not: straight-line requests, nothing waits for them before they are used.
   uint4 tv[8], tva[4];
-  if constexpr (ROLL) {
+  if constexpr (ROLL && FROM_R) {
     const uint4* const tl = reinterpret_cast<const uint4*>(&g_roll_tab[min(max(a.k, 1), 6) - 1][threadIdx.x & 63][0]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) tv[i] = tl[i];
@@ -428,9 +434,12 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       // (the last level has one or two nodes of one superblock each)
       const int lb0 = inl.n > 0 ? inl.nd[0].blk0 : b.nodes[node0].blk0, lb1 = n_nodes > 1 ? (inl.n > 0 ? inl.nd[1].blk0 : b.nodes[node0 + 1].blk0) : -1;
       schur_tile<kLevelThreads / 64, true>(a, b, frs, w / schur_ks, w % schur_ks, schur_ks, lds_s, fan_word, n_prod, lb0, lb1);
+      if (CAL_DEV_TIMING((a.debug == 4 || a.debug == 6) && threadIdx.x == 0 && w < 2)) printf("bcr_level %d: Schur tile rider %d lived %lld clocks\n", level, w, (long long)(__builtin_readcyclecounter() - t_kernel));
     } else {
       fanin_wait(fan_word, n_prod);
+      const long long t_fan = CAL_DEV_TIMING(a.debug == 4 || a.debug == 6) ? __builtin_readcyclecounter() - t_kernel : 0;
       schur_root_rows<true>(a, b, schur_ks, w - n_schur_wg, n_root_wg, kLevelThreads);
+      if (CAL_DEV_TIMING((a.debug == 4 || a.debug == 6) && threadIdx.x == 0 && w == n_schur_wg)) printf("bcr_level %d: root-row rider: fan-in complete at %lld clocks, lived %lld\n", level, t_fan, (long long)(__builtin_readcyclecounter() - t_kernel));
     }
     return;
   }
@@ -592,7 +601,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
   double* const bcast = dinv + 80;                 // [128]
   double* const dump = bcast + 128 + tid;          // [512]
   const ElimChannel ech = elim_channel(bcast + 128 + kLevelThreads);      // [kElimBufDoubles] (ELIM)
-  static_assert(!ROLL || (FROM_R && ELIM && !LA), "the rolling chief is level 0's, on the block elimination");
+  static_assert(!ROLL || (ELIM && !LA), "the rolling chief works on the block elimination");
   if (ELIM && !ROLL) elim_reset(ech, tid, kLevelThreads);   // (the barrier behind the first block's commit orders it)
   const int l16 = lane & 15, lk = lane >> 4;
   // ---- global -> registers -> LDS of one chain block. Loaders are waves 1-3 and 5-7 (384 threads: three entries each
@@ -873,6 +882,9 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     // counter; a reader polls the counter, then reads). Z, L⁻ᵀ and the tile images are double-buffered by parity, the channel three deep.
     // Same products in the same order as the barrier form: bit-identical results (profiles/dev/bitwise.py).
     // Needs every control point observed (b.all_active: the host launches the barrier form otherwise).
+    // The levels above level 0 (FROM_R = false; single-block chains: the host sends longer ones to the barrier form): the same waves
+    // in the same roles, each taking its tiles straight from D / G / F and the pending slots -- no staging, no barrier but the
+    // first --, and the chain's results leave as the barrier form's do (write-through where the Schur complement's riders read them).
     // ================================================================================================================
     constexpr int kImg = 28 * 64;                         // a follower's inputs: spine (12 registers) + rows of Bᵀ (16), by lane
     double* const Zr = lds;                               // [2][32·XLD] Z = [Z^A | Z^B | Z^F] by block parity
@@ -911,8 +923,9 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
     const bool has_left = left >= 0;
     const int n_s = a.n_s(), kk = a.k;
-    const bool tile_wave = wave < 2 || wave == 7;         // the waves that load spines and rows of Bᵀ from R(x)
-    const unsigned tmask = tv[7].y;
+    const bool tile_wave = wave < 2 || (FROM_R && wave == 7);         // the waves that load spines and rows of Bᵀ
+    const unsigned tmask = FROM_R ? tv[7].y : 0u;
+    auto leave_terminated = [&]() { if (pub) fanin_arrive(fan_word); };      // (every wave of the workgroup takes this exit or none does)
     for (int e = tid; e < 3 * kElimBufDoubles; e += kLevelThreads) reinterpret_cast<unsigned long long*>(chb)[e] = kElimSentinel;
     if (tid < 16) ctr[tid] = 0;
     if (tdbg && tid < 64) tstamp[tid] = 0;
@@ -931,6 +944,60 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       for (int u = 0; u < 8; ++u) v[u] = pp[4 * u * XLD];
     };
     if (tile_wave) {
+      if constexpr (!FROM_R) {
+        // ---- an upper level's two chief-side waves: wave 0 factors the (single) block, wave 1 follows with the rows of Bᵀ and
+        //      leaves -Z^BᵀZ^B in the right separator's pending slot (elim_follow_d against a zero diagonal) ----
+        const int blk = blk0, mask = pend_mask;
+        const ElimChannel chk = elim_channel(chb);
+        auto summed = [&](const double* base, const double* p0, const double* p1, int o) {
+          const double v0 = base[o], v1 = p0[o], v2 = p1[o];
+          return (v0 + ((mask & 1) ? v1 : 0.0)) + ((mask & 2) ? v2 : 0.0);
+        };
+        if (wave == 0) {
+          const double* const Db = b.D + size_t(blk) * BB;
+          const double* const P0 = pendD_r + (size_t(blk) * 2 + 0) * BB;
+          const double* const P1 = pendD_r + (size_t(blk) * 2 + 1) * BB;
+          f64x4 t00, t01, t11;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = lk + 4 * r, hi = max(l16, c), lo = min(l16, c);
+            t00[r] = -summed(Db, P0, P1, hi * BP + lo);
+            t01[r] = -summed(Db, P0, P1, (16 + l16) * BP + c);
+            t11[r] = -summed(Db, P0, P1, (16 + hi) * BP + 16 + lo);
+          }
+          if (uniform(terminated_v)) { leave_terminated(); return; }
+          stamp(0, 0);
+          elim_chief_reg<0>(t00, t01, t11, nullptr, 0, chk, lane);
+          stamp(0, 1);
+        } else {
+          const bool has_next = right >= 0;
+          const double* const Gb = Gr + size_t(blk) * BB;      // G[next's dim][this block's dim]
+          f64x4 x0[2], x1[2], n00 = zero4, n01 = zero4, n11 = zero4;
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const double g0 = Gb[(16 * qt + l16) * BP + lk + 4 * r], g1 = Gb[(16 * qt + l16) * BP + 16 + lk + 4 * r];
+              x0[qt][r] = -(has_next ? g0 : 0.0); x1[qt][r] = -(has_next ? g1 : 0.0);
+            }
+          }
+          if (uniform(terminated_v)) { leave_terminated(); return; }
+          stamp(0, 0);
+          elim_follow_d(x0, x1, Zr + CB, Zr + CB + 16, 1, XLD, chk, lane, n00, n01, n11);
+          ctr_set(C_DONE_D1, 1);
+          stamp(0, 1);
+          if (right >= 0 && role == 0) {
+            double* dst = pendD_w + (size_t(right) * 2 + 0) * BB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int c = lk + 4 * r;
+              put(dst + c * BP + l16, -n00[r]);
+              put(dst + (16 + l16) * BP + c, -n01[r]);
+              put(dst + (16 + c) * BP + 16 + l16, -n11[r]);
+            }
+          }
+        }
+      } else {
       // this lane's entries of a spine (tiles (0,0), (0,1), (1,1): elim_load_spine) and of the rows of Bᵀ (two row tiles of
       // sixteen dimensions of the next block against this block's 32 columns: elim_load_rows) in the band's storage
       unsigned oS[12], oB[16];
@@ -1018,7 +1085,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
             if (q > 1) { req_spine(blk0 + 1, in.sp, bandR); req_spine(blk0 + 1, alt_in.sp, bandR + alt); req_scale(blk0 + 1, in.sc); }
           }
           hstamp(3);
-          if (uniform(terminated_v)) return;
+          if (uniform(terminated_v)) { leave_terminated(); return; }
           hstamp(4);
           const bool second = uniform(r_cur_v) != 0;
 #pragma unroll
@@ -1073,7 +1140,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         }
       } else {
         // ---- wave 7: stages the followers' inputs of blocks 1.. as tile images, a block ahead; files with waves 4..6 ----
-        if (uniform(terminated_v)) return;
+        if (uniform(terminated_v)) { leave_terminated(); return; }
         a.R = uniform(r_cur_v) ? R_buf1 : R_buf0;
         const double* const bandC = a.R + a.off_B();      // R(x)'s band
         const int lt2 = tid - 256;
@@ -1121,10 +1188,11 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           ctr_set(C_FILED + 3, k + 1);
         }
       }
+      }
     } else if (wave == 2) {
       // ---- the rows of Aᵀ: Z^A. First block: T(block, left separator) from R(x); from the second on the fill -Z^BᵀZ^A ----
       f64x4 pre0[2] = {zero4, zero4}, pre1[2] = {zero4, zero4};
-      {
+      if constexpr (FROM_R) {
         // entry (this block's row rb, the left separator's column cs): tile qt holds cs = 16 qt + l16, register r rb = 16 h + lk + 4 r
         // (g_roll_tab words 32..47, counted from the left separator's superblock)
         double av[16], av1[16];
@@ -1137,7 +1205,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           av[e] = 0.0; av1[e] = 0.0;
           if (has_left) { av[e] = ldo(p, oA[e]); av1[e] = ldo(p + alt, oA[e]); }
         }
-        if (uniform(terminated_v)) return;
+        if (uniform(terminated_v)) { leave_terminated(); return; }
         const bool second = uniform(r_cur_v) != 0;
         const int nreal = n_s - RB * blk0;
 #pragma unroll
@@ -1150,6 +1218,18 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
             pre1[qt][r] = -(v1 ? (second ? av1[e1] : av[e1]) : 0.0);
           }
         }
+      } else {
+        // G[left separator][this block's dim][the separator's dim]
+        const double* const Ga = Gr + size_t(left > 0 ? left : 0) * BB;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double g0 = Ga[(lk + 4 * r) * BP + 16 * qt + l16], g1 = Ga[(16 + lk + 4 * r) * BP + 16 * qt + l16];
+            pre0[qt][r] = -(has_left ? g0 : 0.0); pre1[qt][r] = -(has_left ? g1 : 0.0);
+          }
+        }
+        if (uniform(terminated_v)) { leave_terminated(); return; }
       }
       auto fill_pre = [&](const double* Zp) {      // pre = -(0 - Z^BᵀZ^A), in the elimination's (negated) tile layout
         double zb0[8], zb1[8], za[8];
@@ -1198,7 +1278,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     } else if (wave == 3) {
       if (role == 0) {
         // ---- the identity rows: L⁻ᵀ ----
-        if (uniform(terminated_v)) return;
+        if (uniform(terminated_v)) { leave_terminated(); return; }
         for (int k = 0; k < q; ++k) {
           const ElimChannel chk = elim_channel(chb + (k % 3) * kElimBufDoubles);
           double* const Mk = Mr + (k & 1) * BP * DLD;
@@ -1223,18 +1303,33 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           }
         };
         auto f_valid = [&](int k, int e) {
+          if (!FROM_R) return true;      // (D / F of a separator hold the padding's values themselves)
           const int r = 16 * (e >> 2) + lk + 4 * (e & 3);
           return r < RB && r < n_s - RB * (blk0 + k) && col <= a.mc;
         };
         double fv[8];
         {
-          double fv1[8];
-          req_f(0, fv, R_buf0); req_f(0, fv1, R_buf1);
-          if (uniform(terminated_v)) return;
-          const bool second = uniform(r_cur_v) != 0;
-          a.R = second ? R_buf1 : R_buf0;
+          if constexpr (FROM_R) {
+            double fv1[8];
+            req_f(0, fv, R_buf0); req_f(0, fv1, R_buf1);
+            if (uniform(terminated_v)) { leave_terminated(); return; }
+            const bool second = uniform(r_cur_v) != 0;
+            a.R = second ? R_buf1 : R_buf0;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) fv[e] = second ? fv1[e] : fv[e];
+            for (int e = 0; e < 8; ++e) fv[e] = second ? fv1[e] : fv[e];
+          } else {
+            // F + what the chains on either side left for this separator (the sum the barrier form's loaders take)
+            const double* const Fb = b.F + size_t(blk0) * fblk;
+            const double* const P0 = pendF_r + (size_t(blk0) * 2 + 0) * fblk;
+            const double* const P1 = pendF_r + (size_t(blk0) * 2 + 1) * fblk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const size_t o2 = size_t(16 * (e >> 2) + lk + 4 * (e & 3)) * m1p + col;
+              const double v0 = Fb[o2], v1 = P0[o2], v2 = P1[o2];
+              fv[e] = (v0 + ((pend_mask & 1) ? v1 : 0.0)) + ((pend_mask & 2) ? v2 : 0.0);
+            }
+            if (uniform(terminated_v)) { leave_terminated(); return; }
+          }
         }
         for (int k = 0; k < q; ++k) {
           const ElimChannel chk = elim_channel(chb + (k % 3) * kElimBufDoubles);
@@ -1243,7 +1338,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           stamp(k, 0);
 #pragma unroll
           for (int r = 0; r < 4; ++r) { pre0[0][r] = -(f_valid(k, r) ? fv[r] : 0.0); pre1[0][r] = -(f_valid(k, 4 + r) ? fv[4 + r] : 0.0); }
-          if (k + 1 < q) req_f(k + 1, fv, a.R);
+          if (FROM_R && k + 1 < q) req_f(k + 1, fv, a.R);
           if (k > 0) {
             const double* Zp = Zr + ((k - 1) & 1) * BP * XLD;
             double zb0[8], zb1[8], zf[8];
@@ -1275,12 +1370,12 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           }
           double* dst = pendF_w + (size_t(right) * 2 + 0) * fblk + f0 + l16;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { dst[size_t(lk + 4 * r) * m1p] = s0[r]; dst[size_t(16 + lk + 4 * r) * m1p] = s1[r]; }
+          for (int r = 0; r < 4; ++r) { put(dst + size_t(lk + 4 * r) * m1p, s0[r]); put(dst + size_t(16 + lk + 4 * r) * m1p, s1[r]); }
         }
       }
     } else {
       // ---- waves 4..6: filing, the left separator's sums, the channel ----
-      if (uniform(terminated_v)) return;
+      if (uniform(terminated_v)) { leave_terminated(); return; }
       const int w4 = wave - 4, lt2 = tid - 256;
       const bool acc_owner = wave == 5 || wave == 6, acc_owner2 = role == 0 && wave == 5;
       const int acc_p = role == 0 ? CA + (wave == 6 ? 16 : 0) : CA + 16 * (wave - 5);
@@ -1292,17 +1387,21 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         const int blk = blk0 + k;
         const double* const Zk = Zr + (k & 1) * BP * XLD;
         if (role == 0) {
-          const double* const Mk = Mr + (k & 1) * BP * DLD;
+          // (an upper level with riders behind it: what only the back-substitution reads is filed BEHIND the fan-in -- the
+          //  arrival drains every store of the wave, and these 24 KB are nobody's business in this launch)
+          if (!pub) {
+            const double* const Mk = Mr + (k & 1) * BP * DLD;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int e = lt2 + 256 * u, r = e >> 5, c = e & 31;
-            b.M[size_t(blk) * BB + e] = Mk[r * DLD + c];
-            b.ZA[size_t(blk) * BB + e] = Zk[r * XLD + CA + c];
-            b.ZB[size_t(blk) * BB + e] = Zk[r * XLD + CB + c];
+            for (int u = 0; u < 4; ++u) {
+              const int e = lt2 + 256 * u, r = e >> 5, c = e & 31;
+              b.M[size_t(blk) * BB + e] = Mk[r * DLD + c];
+              b.ZA[size_t(blk) * BB + e] = Zk[r * XLD + CA + c];
+              b.ZB[size_t(blk) * BB + e] = Zk[r * XLD + CB + c];
+            }
           }
         } else {
 #pragma unroll
-          for (int u = 0; u < 2; ++u) { const int e = lt2 + 256 * u; b.Y[size_t(blk) * fblk + size_t(e >> 4) * m1p + f0 + (e & 15)] = Zk[(e >> 4) * XLD + CF + (e & 15)]; }
+          for (int u = 0; u < 2; ++u) { const int e = lt2 + 256 * u; put(b.Y + size_t(blk) * fblk + size_t(e >> 4) * m1p + f0 + (e & 15), Zk[(e >> 4) * XLD + CF + (e & 15)]); }
         }
         if (has_left && acc_owner) acc_a = atb_tile<true>(Zk, XLD, acc_p, Zk, XLD, acc_q, 0, BP, acc_a, lane);
         if (has_left && acc_owner2) acc2 = atb_tile<true>(Zk, XLD, CA + 16, Zk, XLD, CA, 0, BP, acc2, lane);
@@ -1320,28 +1419,41 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
             const int it = wave == 6 ? 1 : 0, jt = it;
             double* dst = pendD_w + (size_t(left) * 2 + 1) * BB;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(16 * it + lk + 4 * r) * BP + 16 * jt + l16] = acc_a[r];
+            for (int r = 0; r < 4; ++r) put(dst + (16 * it + lk + 4 * r) * BP + 16 * jt + l16, acc_a[r]);
             if (acc_owner2) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) dst[(16 + lk + 4 * r) * BP + l16] = acc2[r];
+              for (int r = 0; r < 4; ++r) put(dst + (16 + lk + 4 * r) * BP + l16, acc2[r]);
             }
           }
         } else if (acc_owner) {
           const int h = wave - 5;
           double* dst = pendF_w + (size_t(left) * 2 + 1) * fblk + f0 + l16;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dst[size_t(16 * h + lk + 4 * r) * m1p] = acc_a[r];
+          for (int r = 0; r < 4; ++r) put(dst + size_t(16 * h + lk + 4 * r) * m1p, acc_a[r]);
         }
       }
     }
     if (tdbg) {
       __syncthreads();
       if (tid == 0 && (bid < 2 || bid == 7 || bid == 8)) {
-        printf("bcr_level 0 (rolling) wg %d role %d q %d lived %lld clocks: set-up %lld | head of wave 0: entry %lld, at the barrier %lld, behind it %lld, requests out %lld, state there %lld, data there %lld, tiles %lld (all loads there %lld) | wave 1: %lld %lld %lld %lld %lld %lld %lld\n", bid, role, q, (long long)(__builtin_readcyclecounter() - t_kernel), t_setup,
+        printf("bcr_level %d (rolling) wg %d role %d q %d lived %lld clocks: set-up %lld | head of wave 0: entry %lld, at the barrier %lld, behind it %lld, requests out %lld, state there %lld, data there %lld, tiles %lld (all loads there %lld) | wave 1: %lld %lld %lld %lld %lld %lld %lld\n", level, bid, role, q, (long long)(__builtin_readcyclecounter() - t_kernel), t_setup,
                hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[7], hs[8], hs[9], hs[10], hs[11], hs[12], hs[13], hs[14]);
         for (int w = 0; w < 8; ++w)
           printf("  wg %d wave %d, begin-end by block: %lld-%lld %lld-%lld %lld-%lld %lld-%lld\n", bid, w, tstamp[(w * 4 + 0) * 2], tstamp[(w * 4 + 0) * 2 + 1],
                  tstamp[(w * 4 + 1) * 2], tstamp[(w * 4 + 1) * 2 + 1], tstamp[(w * 4 + 2) * 2], tstamp[(w * 4 + 2) * 2 + 1], tstamp[(w * 4 + 3) * 2], tstamp[(w * 4 + 3) * 2 + 1]);
+      }
+    }
+    if (pub) {
+      fanin_arrive(fan_word);
+      if (role == 0 && wave >= 4) {      // (single-block chains: q == 1)
+        const int lt2 = tid - 256;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = lt2 + 256 * u, r = e >> 5, c = e & 31;
+          b.M[size_t(blk0) * BB + e] = Mr[r * DLD + c];
+          b.ZA[size_t(blk0) * BB + e] = Zr[r * XLD + CA + c];
+          b.ZB[size_t(blk0) * BB + e] = Zr[r * XLD + CB + c];
+        }
       }
     }
     return;
@@ -3149,6 +3261,10 @@ static bool level_lookahead_enabled() { const char* e = std::getenv("CALICO_LOOK
 // Level 0's chains with the rolling chief (bcr_level_kernel<true, true, false, true>: no workgroup barrier between the blocks of
 // a chain), the default wherever every control point is observed; CALICO_ROLL=0: the barrier form (A/B switch, read per solve)
 static bool level_roll_enabled() { const char* e = std::getenv("CALICO_ROLL"); return !e || std::atoi(e) != 0; }
+// the same form on the levels above level 0 (single-block chains): CALICO_ROLL_UPPER=1
+// (NOT the default: the chains of an upper level end 2-3k clocks earlier with it, the launch does not -- it ends with the Schur
+//  complement's riders behind the fan-in --, and the iteration rate is 0.7-1.5 % lower at every shape measured.)
+static bool level_roll_upper_enabled() { const char* e = std::getenv("CALICO_ROLL_UPPER"); return e && std::atoi(e) != 0; }
 size_t bcr_level_lds_bytes() { return size_t(2 * 64 * DLD + 4 * BP * XLD + 80 + 128 + kLevelThreads + kElimBufDoubles) * sizeof(double); }      // (4: X twice, Z twice with the look-ahead)
 size_t bcr_back_lds_bytes(int q_max, int m1p) {
   return (size_t(2) * q_max * BP * DLD + kBcrMaxChain * BP + 3 * BP + m1p + size_t(q_max) * BP + 4 * BP) * sizeof(double);
@@ -3159,7 +3275,7 @@ hipError_t configure_bcr_kernels(int q_max, int m1p) {
   for (const void* f : {reinterpret_cast<const void*>(&bcr_level_kernel<true, true>), reinterpret_cast<const void*>(&bcr_level_kernel<false, true>),
                         reinterpret_cast<const void*>(&bcr_level_kernel<true, true, true>), reinterpret_cast<const void*>(&bcr_level_kernel<false, true, true>),
                         reinterpret_cast<const void*>(&bcr_level_kernel<true, false>), reinterpret_cast<const void*>(&bcr_level_kernel<false, false>),
-                        reinterpret_cast<const void*>(&bcr_level_kernel<true, true, false, true>)}) {
+                        reinterpret_cast<const void*>(&bcr_level_kernel<true, true, false, true>), reinterpret_cast<const void*>(&bcr_level_kernel<false, true, false, true>)}) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(bcr_level_lds_bytes()));
     if (e != hipSuccess) return e;
   }
@@ -3179,7 +3295,7 @@ hipError_t configure_bcr_kernels(int q_max, int m1p) {
 // this level's workgroups and take its results over the fan-in word; level 0 (`fan_word` given) resets the word.
 void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, int level, int keep0, int n_keep, const LmOptionsDev& o,
                       const double* x, const BlockDev* blocks, int n_blocks, int with_post_eval, IterLog* log, int log_cap, int jacobi,
-                      hipStream_t s, int schur_ks, int* fan_word, const BcrInlineNodes& inl) {
+                      hipStream_t s, int schur_ks, int* fan_word, const BcrInlineNodes& inl, int q_max) {
   const int nfs = (a.mc + 1 + kBcrFS - 1) / kBcrFS;
   const int n_apply = n_keep > 0 ? std::min(64, std::max(1, n_keep * 4)) : 0;
   const int main_span = 8 * ((n_nodes + 7) / 8) * (1 + nfs);      // (node, role) workgroups laid out by XCD: see the kernel
@@ -3196,7 +3312,8 @@ void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nod
     const int n_schur_wg = schur_ks > 0 ? nt * (nt + 1) / 2 * schur_ks : 0;
     const int n_root_wg = schur_ks > 0 ? std::max(1, (br * (a.mc + 1 + br) + kLevelThreads - 1) / kLevelThreads) : 0;
     const int n_prod = n_nodes * (1 + nfs) + n_apply;        // the workgroups of this level that really exist
-    hipLaunchKernelGGL((elim ? (la ? bcr_level_kernel<false, true, true> : bcr_level_kernel<false, true>) : bcr_level_kernel<false, false>), dim3(main_span + n_apply + n_schur_wg + n_root_wg), dim3(kLevelThreads), bcr_level_lds_bytes(), s, a, b,
+    const bool roll = elim && !la && q_max == 1 && level_roll_enabled() && level_roll_upper_enabled();      // (single-block chains: see the kernel)
+    hipLaunchKernelGGL((roll ? bcr_level_kernel<false, true, false, true> : elim ? (la ? bcr_level_kernel<false, true, true> : bcr_level_kernel<false, true>) : bcr_level_kernel<false, false>), dim3(main_span + n_apply + n_schur_wg + n_root_wg), dim3(kLevelThreads), bcr_level_lds_bytes(), s, a, b,
                        node0, n_nodes, nfs, level, keep0, n_keep, o, 0, x, blocks, n_blocks, log, log_cap, jacobi, n_schur_wg, n_root_wg,
                        std::max(1, schur_ks), schur_ks > 0 ? fan_word : nullptr, n_prod, inl);
   }

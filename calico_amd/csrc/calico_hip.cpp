@@ -90,7 +90,7 @@ hipError_t configure_reduced_fused();
 size_t dense_block_solve_lds_bytes();
 void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, int level, int keep0, int n_keep, const LmOptionsDev& o,
                       const double* x, const BlockDev* blocks, int n_blocks, int with_post_eval, IterLog* log, int log_cap, int jacobi,
-                      hipStream_t s, int schur_ks, int* fan_word, const BcrInlineNodes& inl);
+                      hipStream_t s, int schur_ks, int* fan_word, const BcrInlineNodes& inl, int q_max);
 bool schur_rides_in_last_level(int n_levels, int n_last_nodes, int root);
 void launch_bcr_schur(const SolveArgs& a, const BcrArgs& b, int ks, const LmOptionsDev& o, hipStream_t s);
 void launch_bcr_back(const SolveArgs& a, const BcrArgs& b, int node0, int n_nodes, bool top, bool extras, bool border_rows, int q_max,
@@ -1859,7 +1859,7 @@ void enqueue_linear_solve(calico_problem* p, const SolveArgs& sa, const LmOption
       else if (lv.n_nodes <= 4) { inl.n = lv.n_nodes; for (int i = 0; i < lv.n_nodes; ++i) inl.nd[i] = p->h_bcr_nodes[size_t(lv.node0 + i)]; }
     }
     launch_bcr_level(sa, b, lv.node0, lv.n_nodes, l, lv.keep0, lv.n_keep, o, p->d_x.p, p->d_blocks.p, n_blocks, l == 0 ? with_post_eval : 0,
-                     p->d_log.p, kLogCap, jacobi, s, schur_rides && l == L - 1 ? ks : 0, schur_rides ? fan_word : nullptr, inl);
+                     p->d_log.p, kLogCap, jacobi, s, schur_rides && l == L - 1 ? ks : 0, schur_rides ? fan_word : nullptr, inl, lv.q_max);
   }
   if (!schur_rides) launch_bcr_schur(sa, b, ks, o, s);
   // The top level of the tree is one or two single superblocks next to the root: their back-substitution rides in the
