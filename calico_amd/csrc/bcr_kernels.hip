@@ -3297,8 +3297,17 @@ void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nod
                       const double* x, const BlockDev* blocks, int n_blocks, int with_post_eval, IterLog* log, int log_cap, int jacobi,
                       hipStream_t s, int schur_ks, int* fan_word, const BcrInlineNodes& inl, int q_max) {
   const int nfs = (a.mc + 1 + kBcrFS - 1) / kBcrFS;
-  const int n_apply = n_keep > 0 ? std::min(64, std::max(1, n_keep * 4)) : 0;
+  int n_apply = n_keep > 0 ? std::min(64, std::max(1, n_keep * 4)) : 0;
   const int main_span = 8 * ((n_nodes + 7) / 8) * (1 + nfs);      // (node, role) workgroups laid out by XCD: see the kernel
+  // One workgroup of this kernel fills a CU (its LDS), and the part has 256 of them: where the chains leave room, the separators'
+  // workgroups (and level 0's bookkeeping workgroup, the last of the grid) are kept inside that room -- a workgroup that is only
+  // dispatched when another has ended starts ~15k clocks late, and the bookkeeping one then ends the launch (440 control points:
+  // 224 + 64 + 1 workgroups, level 0 21.5 us with the chains done at 13 us).
+  {
+    constexpr int kCUs = 256;
+    const int room = kCUs - main_span - (level == 0 && with_post_eval ? 1 : 0);
+    if (room >= 8 && n_apply > room) n_apply = room;
+  }
   const bool elim = block_elim_enabled(), la = level_lookahead_enabled();
   if (level == 0) {
     const bool roll = elim && !la && b.all_active && a.k >= 1 && a.k <= 6 && level_roll_enabled();
