@@ -370,3 +370,47 @@ def test_chain_look_ahead_is_bit_identical(monkeypatch):
             for r in runs[la]:
                 assert r[0] == ref[0] and r[1] == ref[1] and r[2] == ref[2], (la, leaf)
                 assert np.array_equal(r[3], ref[3]), (la, leaf)
+
+
+@pytest.mark.gpu
+def test_rolling_chief_equals_the_barrier_form_bit_for_bit(monkeypatch):
+    """Round 6: level 0 of the tree solver eliminates its chains with a ROLLING CHIEF (bcr_level_kernel<.., ROLL>): waves 0 and 1
+    take turns as the chief, the follower forms the next block's diagonal D_{k+1} - Z^BᵀZ^B step by step in the chief's own
+    register layout and goes on as its chief, tiles come from R(x) through a per-lane offset table, later blocks' inputs are
+    staged as tile images a block ahead, and nothing waits at a workgroup barrier -- order is kept by single-writer counters
+    and write-once channels in LDS. The products and their order are those of the barrier form (CALICO_ROLL=0), so every
+    iterate must come out BIT FOR BIT the same -- for chains of 1, 2, 3, 4 and 8 blocks (odd / even hand-overs, the channel
+    ring of three wrapping, the image ring of two wrapping), a trajectory whose last superblock is partly padding, spline orders
+    4 and 5 (other band structure in the offset table), with and without the same form on the upper levels
+    (CALICO_ROLL_UPPER=1) -- and repeat itself run to run (a follower that read a tile image, a channel entry or a Z row too
+    early, or a buffer reused too soon, shows as a run-to-run difference or a difference to the barrier form)."""
+    api = helpers.hip_api()
+    common = dict(chart="april", pixel_noise=0.1, gyro_noise=1e-3, accel_noise=1e-2, robust=True, max_cam_obs=6000)
+    scenes = [
+        ("92 control points", syn.make_scene(4, 1, True, 3, cam_rate=10.0, imu_rate=100.0, duration=8.7, seed=41, segment_duration=8.7 / 23.9, **common), ("", "1", "2", "3", "8")),
+        ("185 control points", syn.make_scene(2, 1, True, 2, seed=4), ("", "3")),
+        ("ragged end", syn.make_scene(2, 1, True, 3, cam_rate=10.0, imu_rate=100.0, duration=7.3, seed=43, segment_duration=7.3 / 23.9, **common), ("", "2")),
+    ]
+    for order in (4, 5):
+        scenes.append(("order %d" % order, syn.make_scene(2, 1, True, 3, cam_rate=10.0, imu_rate=100.0, duration=6.0, seed=44 + order, segment_duration=6.0 / 23.9,
+                                                           order=order, **common), ("",)))
+    for name, sc, leaves in scenes:
+        for leaf in leaves:
+            if leaf:
+                monkeypatch.setenv("CALICO_BCR_LEAF", leaf)
+            else:
+                monkeypatch.delenv("CALICO_BCR_LEAF", raising=False)
+            runs = {}
+            for roll, upper in (("0", "0"), ("1", "0"), ("1", "1")):
+                monkeypatch.setenv("CALICO_ROLL", roll)
+                monkeypatch.setenv("CALICO_ROLL_UPPER", upper)
+                runs[(roll, upper)] = _solve_repeatedly(api, sc, repeats=3 if roll == "1" else 1, max_iter=12)
+            monkeypatch.delenv("CALICO_ROLL")
+            monkeypatch.delenv("CALICO_ROLL_UPPER")
+            ref = runs[("0", "0")][0]
+            assert ref[0] >= 3, (name, leaf)
+            for key, reps in runs.items():
+                for r in reps:
+                    assert r[0] == ref[0] and r[1] == ref[1] and r[2] == ref[2], (name, leaf, key)
+                    assert np.array_equal(r[3], ref[3]), (name, leaf, key)
+    monkeypatch.delenv("CALICO_BCR_LEAF", raising=False)
