@@ -35,6 +35,7 @@
 namespace cal {
 
 bool block_elim_enabled();
+static int dense_elim_mode();
 
 namespace {
 constexpr int BP = kBcrBP;              // 32
@@ -2533,6 +2534,8 @@ __global__ __launch_bounds__(kBackThreads) void bcr_back_kernel(SolveArgs a, Bcr
 // ---------------------------------------------------------------------------
 constexpr int kDenseThreads = 512;
 constexpr int DNL = 129;     // row stride of the dense matrix in LDS
+constexpr int kDenseChan = 2 * kElimCompactDoubles;      // the panel buffer's place: [64][DLD] or the rolling form's two channels
+static_assert(kDenseChan >= 64 * DLD, "the panel buffer must fit where the channels sit");
 // (Taking the top level of the tree along in this workgroup -- back_calib + back_node for its one to three nodes -- was
 //  tried and lost: two nodes one after the other cost 12 us of dependent loads here against the 7 us of a launch that
 //  runs them side by side, and the levels below then sweep their own border rows.)
@@ -2559,8 +2562,8 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
   const int mp = BP * nb;                        // padded size (identity beyond m)
   double* A = lds;                               // [128][DNL]
   double* gv = A + 128 * DNL;                    // [128] right-hand side row, forward-substituted in place (-> z)
-  double* Daug = gv + 128;                       // [64][DLD]
-  double* dinvm = Daug + 64 * DLD;               // [128] diagonal of L⁻ᵀ
+  double* Daug = gv + 128;                       // [64][DLD] (rolling form: two compact channels, kDenseChan doubles)
+  double* dinvm = Daug + kDenseChan;             // [128] diagonal of L⁻ᵀ
   double* yv = dinvm + 128;                      // [128] solution
   double* pend = yv + 128;                       // [128] Σ_{later blocks} Lᵀ y
   double* wv = pend + 128;                       // [32]
@@ -2719,7 +2722,166 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
       Daug[(BP + r) * DLD + c] = r == c ? 1.0 : 0.0;
     }
   };
-  if (elim) {
+  if (elim == 2) {
+    // ================================================================================================================
+    // Rolling owners (round 6). The barrier form below spends, per 32-column block, 8.1k clocks in the elimination (chief 6.5k,
+    // followers 1.3k behind) and 1.5k between two barriers on the right-hand side and the trailing update of the next block's
+    // columns -- 9.6k for a dependent chain of 6.5k. Here wave j OWNS block-row j (rows 32j..32j+31) for the whole solve:
+    //   * it follows the elimination of every block l < j with its rows of that block (elim_follow_owner) and keeps its own diagonal
+    //     block D_j in registers, in the chief's layout, subtracting Z(j,l) Z(j,l)ᵀ step by step: when block j-1's last pivot is
+    //     through, the wave holds D_j complete and goes on as block j's chief (elim_chief_reg) -- no barrier, no pass over LDS;
+    //   * what block l does to the rows it will follow the NEXT block with, Z(j,l) Z(l+1,l)ᵀ, accumulates beside it in registers
+    //     (the other operand: the step's columns of the next chief's rows, read from where that wave stored them, behind its
+    //     progress word), so the owner's input for block l+1 is ready a few hundred clocks after block l is;
+    //   * wave 4 follows every block with the identity rows (L⁻ᵀ) and the right-hand side, and forms the right-hand side of the
+    //     next block's rows itself; wave 5 clears the channels behind the followers and carries the right-hand side of the rows
+    //     further down; wave 6 the one trailing block nobody owns in time (rows of block 3 x columns of block 2, from block 0).
+    // Two compact channels by block parity; order by single-writer counters (a wave's LDS instructions execute in order).
+    // ================================================================================================================
+    constexpr bool CC = true;
+    double* const chan = Daug;                                    // [2][kElimCompactDoubles]
+    int* const ctr = reinterpret_cast<int*>(bcast);               // [32]
+    long long* const ts = reinterpret_cast<long long*>(dump - tid);      // [64] (dev timing)
+    enum { K_PROG = 1, K_DONE = 2 /* + owner */, K_W4 = 6, K_RESET = 7, K_GV = 9, K_ID0 = 10, K_BG32 = 12 /* + tile: 12..15 */ };
+    for (int e = tid; e < kDenseChan; e += kDenseThreads) reinterpret_cast<unsigned long long*>(chan)[e] = kElimSentinel;
+    if (tid < 32) ctr[tid] = tid == K_RESET ? 2 : 0;
+    if (tid < 64) ts[tid] = 0;
+    lds_barrier();
+    const long long t_roll = CAL_DEV_TIMING(a.debug == 1) ? __builtin_readcyclecounter() : 0;
+    auto stamp = [&](int i) { if (CAL_DEV_TIMING(a.debug == 1 && lane == 0)) ts[i] = __builtin_readcyclecounter() - t_roll; };
+    auto ctr_set = [&](int idx, int v) {
+      asm volatile("" ::: "memory");
+      if (lane == 0) __hip_atomic_store(ctr + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");
+    };
+    auto ctr_wait = [&](auto cond) {
+      for (;;) {
+        const int cv = __hip_atomic_load(ctr + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (cond([&](int i) { return __builtin_amdgcn_readlane(cv, i); })) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      asm volatile("" ::: "memory");
+    };
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    if (uw < 4) {
+      const int j = uw;
+      if (j < nb) {
+        f64x4 d00, d01, d11;
+        elim_load_spine(A + (BP * j) * DNL + BP * j, DNL, lane, d00, d01, d11);
+        f64x4 x0[2] = {zero4, zero4}, x1[2] = {zero4, zero4}, nx0[2] = {zero4, zero4}, nx1[2] = {zero4, zero4};
+        if (j > 0) {
+          elim_load_rows(A + (BP * j) * DNL, DNL, 1, lane, x0[0], x1[0]);
+          elim_load_rows(A + (BP * j + 16) * DNL, DNL, 1, lane, x0[1], x1[1]);
+        }
+        for (int l = 0; l <= j; ++l) {
+          const int c0 = BP * l;
+          const ElimChannel chl = elim_channel(chan + (l & 1) * kElimCompactDoubles);
+          if (l >= 2) ctr_wait([&](auto c) { return c(K_RESET) >= l + 1; });
+          if (l == j) {
+            stamp(2 * l);
+            elim_chief_reg<2, false, CC>(d00, d01, d11, A + c0 * DNL + c0, DNL, chl, lane);
+            stamp(2 * l + 1);
+            if (l == 0) {
+              // block 0's identity rows (L⁻ᵀ: only the backward sweep reads it), by the one wave that has nothing left to do -- its
+              // own channel is still there. Beside the first chief on its SIMD they made its steps 40 % longer.
+              double* const blk = A;
+              const ElimTile t[2] = {{gv, 0, 0, blk, DNL, 1, 1, dinvm}, {gv, 0, 0, blk + 16 * DNL, DNL, 1, 2, dinvm + 16}};
+              elim_follow<2, CC>(t, chl, lane);
+              ctr_set(K_ID0, 1);
+            }
+          } else {
+            const bool cross = j > l + 1, dwave = j == l + 1;
+            double* const out0 = A + (BP * j) * DNL + c0;
+            const double* const c0p = A + (BP * (l + 1)) * DNL + c0;
+            stamp(8 + 8 * j + 2 * l);
+            elim_follow_owner<CC>(x0, x1, out0, out0 + 16 * DNL, DNL, chl, lane, d00, d01, d11, cross, nx0, nx1, c0p, c0p + 16 * DNL, dwave, ctr + K_PROG, 8 * l);
+            ctr_set(K_DONE + j, l + 1);
+            stamp(8 + 8 * j + 2 * l + 1);
+            if (cross) {
+              // the rows it follows block l+1 with: what the matrix holds (block 0's share of rows 3 x columns 2 comes from wave 6) + this block's share
+              if (j == 3 && l == 1) ctr_wait([&](auto c) { return c(K_BG32) >= 1 && c(K_BG32 + 1) >= 1 && c(K_BG32 + 2) >= 1 && c(K_BG32 + 3) >= 1; });
+              f64x4 b0, b1;
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                elim_load_rows(A + (BP * j + 16 * q) * DNL + BP * (l + 1), DNL, 1, lane, b0, b1);
+                x0[q] = b0 + nx0[q]; x1[q] = b1 + nx1[q];
+                nx0[q] = zero4; nx1[q] = zero4;
+              }
+            }
+          }
+        }
+      }
+    } else if (uw == 4) {
+      // identity rows (L⁻ᵀ: strict upper triangle + dinvm) and the right-hand side (in place in gv) of every block
+      for (int l = 0; l < nb; ++l) {
+        const int c0 = BP * l;
+        const ElimChannel chl = elim_channel(chan + (l & 1) * kElimCompactDoubles);
+        if (l >= 1) {
+          // the right-hand side of this block's rows: minus Z(l, l-1) z_{l-1} (the rows further down: wave 5, a block earlier)
+          ctr_wait([&](auto c) { return c(K_DONE + l) >= l && c(K_GV) >= l - 1 && c(K_RESET) >= l + 1; });
+          const int r = lane & 31, h = lane >> 5;
+          const double* zr = A + (c0 + r) * DNL + (c0 - BP) + 16 * h;
+          const double* zv = gv + (c0 - BP) + 16 * h;
+          double a4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int c = 0; c < 16; ++c) a4[c & 3] += zr[c] * zv[c];
+          double sum = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+          sum += other_half(sum);
+          if (h == 0) gv[c0 + r] -= sum;
+        }
+        double* const blk = A + c0 * DNL + c0;
+        const ElimTile t[3] = {{gv, 0, 0, blk, DNL, 1, 1, dinvm + c0}, {gv, 0, 0, blk + 16 * DNL, DNL, 1, 2, dinvm + c0 + 16},
+                               {gv + c0, 0, 1, gv + c0, 0, 1, 3, nullptr}};
+        stamp(40 + 2 * l);
+        if (l == 0) { const ElimTile t0[1] = {{gv, 0, 1, gv, 0, 1, 3, nullptr}}; elim_follow<1, CC>(t0, chl, lane); }      // (identity rows: wave 0)
+        else elim_follow<3, CC>(t, chl, lane);
+        ctr_set(K_W4, l + 1);
+        stamp(40 + 2 * l + 1);
+      }
+    } else if (uw == 5) {
+      // behind every block: its channel cleared for the block after the next; the right-hand side of the rows two blocks down and further
+      for (int l = 0; l + 2 < nb; ++l) {      // (the last two blocks' channels are nobody's any more, and no rows lie two blocks below them)
+        ctr_wait([&](auto c) {
+          bool ok = c(K_W4) >= l + 1 && (l > 0 || c(K_ID0) >= 1);
+          for (int i = l + 1; i < nb; ++i) ok = ok && c(K_DONE + i) >= l + 1;
+          return ok;
+        });
+        {
+          unsigned long long* cp = reinterpret_cast<unsigned long long*>(chan + (l & 1) * kElimCompactDoubles);
+          for (int e = lane; e < kElimCompactDoubles; e += 64) cp[e] = kElimSentinel;
+        }
+        ctr_set(K_RESET, l + 3);
+        const int c0 = BP * l, row0 = c0 + 2 * BP;
+        if (row0 < mp) {
+          const int p = min(row0 + lane, mp - 1);
+          const double* zr = A + p * DNL + c0;
+          double a4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int c = 0; c < BP; ++c) a4[c & 3] += zr[c] * gv[c0 + c];
+          if (row0 + lane < mp) gv[p] -= (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        }
+        ctr_set(K_GV, l + 1);
+        if (l == 0 && nb == 4) { trail_tile(6, 4, 0); ctr_set(K_BG32, 1); }      // (its tile of the unowned block: see below)
+      }
+    }
+    if (nb == 4 && (uw == 0 || uw >= 6)) {
+      // rows of block 3 x columns of block 2 minus block 0's share (block 1's accumulates in the owner's registers): four tiles, one
+      // each for waves 5, 6, 7 and wave 0 (behind its identity rows) -- all four on wave 6 were 2k clocks of matrix pipe beside the
+      // owner of block-row 2 on its SIMD, just when it is the next chief's follower
+      const int q4 = uw == 0 ? 3 : uw - 5;
+      ctr_wait([&](auto c) { return c(K_DONE + 2) >= 1 && c(K_DONE + 3) >= 1; });
+      trail_tile(6 + (q4 >> 1), 4 + (q4 & 1), 0);
+      ctr_set(K_BG32 + q4, 1);
+    }
+    lds_barrier();
+    if (CAL_DEV_TIMING(a.debug == 1 && tid == 0)) {
+      printf("dense_block_solve (rolling owners): chiefs begin-end %lld-%lld %lld-%lld %lld-%lld %lld-%lld, all through at %lld clocks behind the loaded system\n",
+             ts[0], ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], ts[7], (long long)(__builtin_readcyclecounter() - t_roll));
+      printf("  owner 1 follows: %lld-%lld | owner 2: %lld-%lld %lld-%lld | owner 3: %lld-%lld %lld-%lld %lld-%lld | wave 4: %lld-%lld %lld-%lld %lld-%lld %lld-%lld\n",
+             ts[16], ts[17], ts[24], ts[25], ts[26], ts[27], ts[32], ts[33], ts[34], ts[35], ts[36], ts[37], ts[40], ts[41], ts[42], ts[43], ts[44], ts[45], ts[46], ts[47]);
+    }
+  } else if (elim) {
     const ElimChannel ech = elim_channel(Daug);       // (the panel buffer is not used on this path)
     elim_reset(ech, tid, kDenseThreads);
     const int nt_all = mp / 16;
@@ -2987,13 +3149,13 @@ __global__ __launch_bounds__(kDenseThreads) void dense_back_kernel(SolveArgs a, 
                                      node0 == 0 ? q_max : 0);      // (the nodes of this launch are level 0's: launch_dense_back)
   if (CAL_DEV_TIMING(a.debug == 4 && threadIdx.x == 0)) printf("dense_back: workgroup %d lived %lld clocks (terminated %d)\n", int(blockIdx.x), (long long)(__builtin_readcyclecounter() - t_db), a.st->terminated);
 }
-size_t dense_block_solve_lds_bytes() { return size_t(128 * DNL + 128 + 64 * DLD + 128 * 3 + 32 + 128 + kDenseThreads) * sizeof(double); }
+size_t dense_block_solve_lds_bytes() { return size_t(128 * DNL + 128 + kDenseChan + 128 * 3 + 32 + 128 + kDenseThreads) * sizeof(double); }
 hipError_t configure_dense_block_solve() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_block_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                              int(dense_block_solve_lds_bytes()));
 }
 void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s, int t0, int outer_back) {
-  hipLaunchKernelGGL(dense_block_solve_kernel, dim3(1), dim3(kDenseThreads), dense_block_solve_lds_bytes(), s, a, ks, t0, outer_back, block_elim_enabled() ? 1 : 0);
+  hipLaunchKernelGGL(dense_block_solve_kernel, dim3(1), dim3(kDenseThreads), dense_block_solve_lds_bytes(), s, a, ks, t0, outer_back, t0 == 0 ? dense_elim_mode() : (block_elim_enabled() ? 1 : 0));
 }
 // ---------------------------------------------------------------------------
 // Large reduced systems (m + 1 > 128): one step of the blocked right-looking factorisation, 32 columns, over several
@@ -3238,7 +3400,7 @@ void launch_dense_back(const SolveArgs& a, const BcrArgs& b, int ks, int node0, 
                        const BlockDev* blocks, int n_blocks, const BcrTopSeps& ts, int* word, int seq, hipStream_t s) {
   const size_t lds = dense_back_lds(q_max, b.m1p);
   const dim3 grid(1 + n_nodes + 1), block(kDenseThreads);       // dense solve, the nodes, the calibration / root update
-  const int elim = block_elim_enabled() ? 1 : 0;
+  const int elim = dense_elim_mode();
 #define LAUNCH_DB(QM, SD, PR) hipLaunchKernelGGL(HIP_KERNEL_NAME(dense_back_kernel<QM, SD, PR>), grid, block, lds, s, a, b, ks, node0, n_nodes, q_max, x, x_cand, blocks, n_blocks, ts, word, seq, elim)
   if (dense_back_pre(a)) {
     if (ts.n > 0) { if (q_max <= 1) LAUNCH_DB(1, 2, true); else if (q_max <= 2) LAUNCH_DB(2, 2, true); else LAUNCH_DB(4, 2, true); }
@@ -3253,6 +3415,13 @@ void launch_dense_back(const SolveArgs& a, const BcrArgs& b, int ks, int node0, 
 // ---- launch helpers ---------------------------------------------------------
 // CALICO_ELIM=panel: the block factorisation of rounds 1-3 (two in-wave panels + tile update + Z phase); read per solve (A/B switch)
 bool block_elim_enabled() { const char* e = std::getenv("CALICO_ELIM"); return !(e && std::string(e) == "panel"); }
+// The dense reduced solve with rolling owners (dense_block_solve_body, elim == 2), the default; CALICO_DENSE_ROLL=0: the barrier
+// form (A/B switch, read per solve)
+static int dense_elim_mode() {
+  if (!block_elim_enabled()) return 0;
+  const char* e = std::getenv("CALICO_DENSE_ROLL");
+  return (!e || std::atoi(e) != 0) ? 2 : 1;
+}
 // CALICO_LOOKAHEAD=1: the tree levels' steps with look-ahead (bcr_level_kernel<.., LA>); read per solve (A/B switch). OFF by
 // default: bit-identical, but measured 1.2 us SLOWER per level-0 launch at configs[3] (26.2 against 25.0 us, same box,
 // profiles/r05_lookahead_ab.txt) -- the chief does start ~2.5k clocks earlier per step, but a step is then bounded by the

@@ -47,7 +47,13 @@ constexpr int kElimBufDoubles = 8 * kElimStep;         // write-once per factori
 // the followers' polling reads, and the wait cost it ~100 clocks per step inside the kernels.)
 constexpr unsigned long long kElimSentinel = 0x7FF8E11AE11AE11Aull;
 
-struct ElimChannel { double* buf; };      // LDS [8][3][64]
+// Compact layout (CC, round 6: the dense reduced solve keeps two channels where it had room for one): only the vectors somebody
+// reads -- w of the eight steps, l0 of steps 0..2, l1 of steps 0..6: 18 instead of 24.
+constexpr int kElimCompactDoubles = 18 * kElimSlot;
+template <bool CC> DEVI constexpr int elim_slot_w(int s) { return (CC ? s : 3 * s) * kElimSlot; }
+template <bool CC> DEVI constexpr int elim_slot_l0(int s) { return (CC ? 8 + s : 3 * s + 1) * kElimSlot; }
+template <bool CC> DEVI constexpr int elim_slot_l1(int s) { return (CC ? 11 + s : 3 * s + 2) * kElimSlot; }
+struct ElimChannel { double* buf; };      // LDS [8][3][64] (compact: [18][64])
 DEVI ElimChannel elim_channel(double* lds /* kElimBufDoubles */) { return ElimChannel{lds}; }
 // all threads of the workgroup (any time after the followers of the last factorisation are through; a barrier follows)
 DEVI void elim_reset(const ElimChannel& ch, int tid, int nthreads) {
@@ -119,7 +125,7 @@ DEVI void elim_load_spine(const double* A, int LD, int lane, f64x4& t00, f64x4& 
 // The chief on a spine it already holds in registers (round 6, the tree levels' rolling chief: the wave that followed the block
 // before with the rows of Bᵀ formed this block's diagonal -- D_next -= Z^BᵀZ^B, step by step, elim_follow_d -- in exactly this
 // layout). WRITE_L as elim_chief; A is only touched when WRITE_L != 0.
-template <int WRITE_L, bool TS = false>
+template <int WRITE_L, bool TS = false, bool CC = false>
 DEVI void elim_chief_reg(f64x4 t00, f64x4 t01, f64x4 t11, double* A, int LD, const ElimChannel ch, int lane, long long* ts = nullptr);
 template <int WRITE_L, bool TS = false>
 DEVI void elim_chief(double* A, int LD, const ElimChannel ch, int lane, long long* ts = nullptr) {
@@ -127,7 +133,7 @@ DEVI void elim_chief(double* A, int LD, const ElimChannel ch, int lane, long lon
   elim_load_spine(A, LD, lane, t00, t01, t11);
   elim_chief_reg<WRITE_L, TS>(t00, t01, t11, A, LD, ch, lane, ts);
 }
-template <int WRITE_L, bool TS>
+template <int WRITE_L, bool TS, bool CC>
 DEVI void elim_chief_reg(f64x4 t00, f64x4 t01, f64x4 t11, double* A, int LD, const ElimChannel ch, int lane, long long* ts) {
   const int l16 = lane & 15, lk = lane >> 4;
   const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
@@ -147,14 +153,14 @@ DEVI void elim_chief_reg(f64x4 t00, f64x4 t01, f64x4 t11, double* A, int LD, con
     pc.s0(); pc.s1(); pc.s2(); pc.s3(); pc.s4(); pc.s5();
     const double w = pc.s6();
     CAL_SB();
-    elim_store(pub + u * kElimStep, w);
+    elim_store(pub + elim_slot_w<CC>(u), w);
     p0 = CAL_MFMA(w, t00[u], zero4);
     p1 = CAL_MFMA(w, t01[u], zero4);
     if (u < 3) t00 = CAL_MFMA(p0[0], p0[0], t00);
     if (u < 3) t01 = CAL_MFMA(p0[0], p1[0], t01);
     t11 = CAL_MFMA(p1[0], p1[0], t11);
-    elim_store(pub + u * kElimStep + kElimSlot, p0[0]);
-    elim_store(pub + u * kElimStep + 2 * kElimSlot, p1[0]);
+    if (!CC || u < 3) elim_store(pub + elim_slot_l0<CC>(u), p0[0]);      // (nobody reads l0 of step 3: the compact layout has no place for it)
+    elim_store(pub + elim_slot_l1<CC>(u), p1[0]);
     if (WRITE_L) {
       if (WRITE_L == 1 || l16 >= 4 * u + lk) A[l16 * LD + 4 * u + lk] = p0[0];
       A[(16 + l16) * LD + 4 * u + lk] = p1[0];
@@ -170,11 +176,11 @@ DEVI void elim_chief_reg(f64x4 t00, f64x4 t01, f64x4 t11, double* A, int LD, con
     pc.s0(); pc.s1(); pc.s2(); pc.s3(); pc.s4(); pc.s5();
     const double w = pc.s6();
     CAL_SB();
-    elim_store(pub + (4 + u) * kElimStep, w);
+    elim_store(pub + elim_slot_w<CC>(4 + u), w);
     if (u == 3 && !WRITE_L) break;                // (the last step: the followers only need w)
     p1 = CAL_MFMA(w, t11[u], zero4);
     if (u < 3) t11 = CAL_MFMA(p1[0], p1[0], t11);
-    if (u < 3) elim_store(pub + (4 + u) * kElimStep + 2 * kElimSlot, p1[0]);
+    if (u < 3) elim_store(pub + elim_slot_l1<CC>(4 + u), p1[0]);
     if (WRITE_L == 1 || (WRITE_L == 2 && l16 >= 4 * u + lk)) A[(16 + l16) * LD + 16 + 4 * u + lk] = p1[0];
     CAL_SB();
     CAL_KEEP(p1);
@@ -201,7 +207,7 @@ struct ElimTile {
 // (bcr_level_kernel, look-ahead), so the updated tiles never go through LDS.
 // (`use_pre` is a run-time, wave-uniform flag and not a template parameter: a second instantiation of the eight steps
 //  doubled the loop-invariant output addresses the compiler keeps across the caller's loop -- into scratch.)
-template <int NT>
+template <int NT, bool CC = false>
 DEVI void elim_follow(const ElimTile (&t)[NT], const ElimChannel ch, int lane, bool use_pre = false, const f64x4* pre0 = nullptr, const f64x4* pre1 = nullptr) {
   const int l16 = lane & 15, lk = lane >> 4;
   const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
@@ -225,10 +231,10 @@ DEVI void elim_follow(const ElimTile (&t)[NT], const ElimChannel ch, int lane, b
   unsigned long long v[3] = {0, 0, 0}, nv[3] = {0, 0, 0};
   auto request = [&](int s, unsigned long long (&d)[3]) {
     const bool need_l0 = s < 3, need_l1 = s < 7;
-    if (need_l1) d[2] = __hip_atomic_load(sub + s * kElimStep + 2 * kElimSlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (need_l1) d[2] = __hip_atomic_load(sub + elim_slot_l1<CC>(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::: "memory");
-    d[0] = __hip_atomic_load(sub + s * kElimStep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (need_l0) d[1] = __hip_atomic_load(sub + s * kElimStep + kElimSlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    d[0] = __hip_atomic_load(sub + elim_slot_w<CC>(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (need_l0) d[1] = __hip_atomic_load(sub + elim_slot_l0<CC>(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::: "memory");
   };
   request(0, v);
@@ -284,6 +290,7 @@ DEVI void elim_load_rows(const double* in, int in_row, int in_col, int lane, f64
 // last step's products are through, the wave holds the next block's damped, updated diagonal and goes on as its chief
 // (elim_chief_reg) -- nothing of it passes through LDS and nobody waits at a barrier.
 // x0 / x1 [2]: the two row tiles (elim_load_rows); out[q]: where tile q's result entry (i, c) goes, out[q][i * out_row + c * out_col].
+template <bool CC = false>
 DEVI void elim_follow_d(f64x4 (&x0)[2], f64x4 (&x1)[2], double* out0, double* out1, int out_row, int out_col, const ElimChannel ch, int lane,
                         f64x4& n00, f64x4& n01, f64x4& n11) {
   const int l16 = lane & 15, lk = lane >> 4;
@@ -292,10 +299,10 @@ DEVI void elim_follow_d(f64x4 (&x0)[2], f64x4 (&x1)[2], double* out0, double* ou
   unsigned long long v[3] = {0, 0, 0}, nv[3] = {0, 0, 0};
   auto request = [&](int s, unsigned long long (&d)[3]) {
     const bool need_l0 = s < 3, need_l1 = s < 7;
-    if (need_l1) d[2] = __hip_atomic_load(sub + s * kElimStep + 2 * kElimSlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (need_l1) d[2] = __hip_atomic_load(sub + elim_slot_l1<CC>(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::: "memory");
-    d[0] = __hip_atomic_load(sub + s * kElimStep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (need_l0) d[1] = __hip_atomic_load(sub + s * kElimStep + kElimSlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    d[0] = __hip_atomic_load(sub + elim_slot_w<CC>(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (need_l0) d[1] = __hip_atomic_load(sub + elim_slot_l0<CC>(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::: "memory");
   };
   request(0, v);
@@ -322,6 +329,83 @@ DEVI void elim_follow_d(f64x4 (&x0)[2], f64x4 (&x1)[2], double* out0, double* ou
       const int col = 4 * s + lk;
       out0[l16 * out_row + col * out_col] = la;
       out1[l16 * out_row + col * out_col] = lb;
+    }
+    CAL_KEEP(pa); CAL_KEEP(pb);
+    v[0] = nv[0]; v[1] = nv[1]; v[2] = nv[2];
+  }
+}
+
+// The owner of a block-row of a dense symmetric matrix following the elimination of an earlier diagonal block (round 6, the dense
+// reduced solve's rolling form). Owner j holds, in registers, its rows of the block being eliminated (x0 / x1: two row tiles against
+// the block's 32 columns) and its OWN diagonal block (n00, n01, n11: the chief's layout) and per step
+//   * forms its four columns of Z (la, lb), stores them in place (out0 / out1: row stride ld, columns contiguous),
+//   * updates the rest of its rows (x0 / x1) and its diagonal block  D_j -= Z Zᵀ  from the products' result registers,
+//   * `cross` (owners two or more blocks behind the chief): also accumulates  Δ(j, l+1) = Z(j, l) Z(l+1, l)ᵀ  -- what this block does to
+//     the rows the owner will follow the NEXT block with -- in nx0 / nx1; the other operand, the step's columns of Z of the owner
+//     of block-row l+1, is read from where that owner stored it (c0p / c1p: its two row tiles) once its progress word says so;
+//   * `dwave` (the owner of block-row l+1, the next chief): publishes its progress (prog = prog_base + step + 1) behind its stores.
+// When the chief's last pivot is through, the owner of block-row l+1 holds D_{l+1} complete and goes on as the chief.
+template <bool CC>
+DEVI void elim_follow_owner(f64x4 (&x0)[2], f64x4 (&x1)[2], double* out0, double* out1, int ld, const ElimChannel ch, int lane,
+                            f64x4& n00, f64x4& n01, f64x4& n11, bool cross, f64x4 (&nx0)[2], f64x4 (&nx1)[2],
+                            const double* c0p, const double* c1p, bool dwave, int* prog, int prog_base) {
+  const int l16 = lane & 15, lk = lane >> 4;
+  const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+  const unsigned long long* const sub = reinterpret_cast<const unsigned long long*>(ch.buf) + lane;
+  unsigned long long v[3] = {0, 0, 0}, nv[3] = {0, 0, 0};
+  auto request = [&](int s, unsigned long long (&d)[3]) {
+    const bool need_l0 = s < 3, need_l1 = s < 7;
+    if (need_l1) d[2] = __hip_atomic_load(sub + elim_slot_l1<CC>(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    d[0] = __hip_atomic_load(sub + elim_slot_w<CC>(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (need_l0) d[1] = __hip_atomic_load(sub + elim_slot_l0<CC>(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+  };
+  request(0, v);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int J = s >> 2, u = s & 3;
+    const bool need_l0 = s < 3, need_l1 = s < 7;
+    while (__builtin_amdgcn_ballot_w64((need_l1 ? v[2] : v[0]) == kElimSentinel) != 0) { __builtin_amdgcn_s_sleep(1); request(s, v); }
+    const double w = __longlong_as_double((long long)v[0]);
+    const double l0 = need_l0 ? __longlong_as_double((long long)v[1]) : 0.0;
+    const double l1 = need_l1 ? __longlong_as_double((long long)v[2]) : 0.0;
+    if (s < 7) request(s + 1, nv);
+    // (the other owner's columns of this step are asked for now and looked at behind this step's own products)
+    int pv = 0;
+    double ca = 0.0, cb = 0.0;
+    auto ask_cross = [&]() {
+      pv = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");
+      ca = c0p[l16 * ld + 4 * s + lk]; cb = c1p[l16 * ld + 4 * s + lk];
+      asm volatile("" ::: "memory");
+    };
+    if (cross) ask_cross();
+    const f64x4 pa = CAL_MFMA(w, (J == 0 ? x0[0][u] : x1[0][u]), zero4);
+    const f64x4 pb = CAL_MFMA(w, (J == 0 ? x0[1][u] : x1[1][u]), zero4);
+    const double la = pa[0], lb = pb[0];
+    if (need_l0) { x0[0] = CAL_MFMA(l0, la, x0[0]); x0[1] = CAL_MFMA(l0, lb, x0[1]); }
+    if (need_l1 && !(J == 1 && u == 3)) { x1[0] = CAL_MFMA(l1, la, x1[0]); x1[1] = CAL_MFMA(l1, lb, x1[1]); }
+    n00 = CAL_MFMA(la, la, n00);
+    n01 = CAL_MFMA(la, lb, n01);
+    n11 = CAL_MFMA(lb, lb, n11);
+    {
+      // (behind the products: a store right behind the panel products waits out their latency with nothing else issued)
+      const int col = 4 * s + lk;
+      out0[l16 * ld + col] = la;
+      out1[l16 * ld + col] = lb;
+    }
+    if (dwave) {
+      asm volatile("" ::: "memory");
+      if (lane == 0) __hip_atomic_store(prog, prog_base + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");
+    }
+    if (cross) {
+      // the step's columns of Z of the next chief's rows: there once its progress word has passed this step (its stores come first)
+      while (__builtin_amdgcn_readfirstlane(pv) < prog_base + s + 1) { __builtin_amdgcn_s_sleep(1); ask_cross(); }
+      // tile (own row tile q, columns 0..15 / 16..31 of the next block) += Z_own Z_nextᵀ
+      nx0[0] = CAL_MFMA(ca, la, nx0[0]); nx1[0] = CAL_MFMA(cb, la, nx1[0]);
+      nx0[1] = CAL_MFMA(ca, lb, nx0[1]); nx1[1] = CAL_MFMA(cb, lb, nx1[1]);
     }
     CAL_KEEP(pa); CAL_KEEP(pb);
     v[0] = nv[0]; v[1] = nv[1]; v[2] = nv[2];

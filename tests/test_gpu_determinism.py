@@ -414,3 +414,43 @@ def test_rolling_chief_equals_the_barrier_form_bit_for_bit(monkeypatch):
                     assert r[0] == ref[0] and r[1] == ref[1] and r[2] == ref[2], (name, leaf, key)
                     assert np.array_equal(r[3], ref[3]), (name, leaf, key)
     monkeypatch.delenv("CALICO_BCR_LEAF", raising=False)
+
+
+@pytest.mark.gpu
+def test_rolling_owners_of_the_dense_solve_agree_with_the_barrier_form(monkeypatch):
+    """Round 6: the dense reduced solve (<= 128 unknowns) eliminates its 32-column blocks with ROLLING OWNERS (dense_block_solve_body,
+    elim == 2): wave j owns block-row j for the whole solve, keeps its diagonal block D_j in registers (the chief's layout) and
+    subtracts Z(j,l) Z(j,l)ᵀ step by step while it follows every block l < j, accumulates what block l does to the rows it follows
+    block l+1 with beside it (the other operand read from the next chief's rows behind a progress word), and goes on as block j's
+    chief when block j-1's last pivot is through -- no barrier between the blocks, two compact channels, single-writer counters.
+    The sums are those of the barrier form (CALICO_DENSE_ROLL=0) in another order: same iterations, costs to 1e-9, estimates to
+    1e-7 -- for reduced systems of one, two, three and four blocks (1 camera: 39 unknowns; stereo + IMU; 4 cameras + IMU: 122),
+    with the dense solve in a launch of its own (CALICO_FUSE_BACK=0) and riding with the back-substitution -- and the default
+    must repeat itself bit for bit (a wave that read a row, a channel entry or a progress word too early shows run to run)."""
+    api = helpers.hip_api()
+    common = dict(chart="april", pixel_noise=0.1, gyro_noise=1e-3, accel_noise=1e-2, robust=True, max_cam_obs=6000)
+    scenes = [
+        syn.make_scene(1, 1, False, cam_rate=10.0, duration=6.0, seed=51, segment_duration=6.0 / 23.9, chart="april", pixel_noise=0.1, max_cam_obs=6000),
+        syn.make_scene(2, 3, True, 2, cam_rate=10.0, imu_rate=100.0, duration=6.0, seed=52, segment_duration=6.0 / 23.9, **common),
+        syn.make_scene(3, 1, True, 3, cam_rate=10.0, imu_rate=100.0, duration=6.0, seed=53, segment_duration=6.0 / 23.9, **common),
+        syn.make_scene(4, 1, True, 3, cam_rate=10.0, imu_rate=100.0, duration=8.7, seed=54, segment_duration=8.7 / 23.9, **common),
+    ]
+    for i, sc in enumerate(scenes):
+        runs = {}
+        for roll, fuse in (("0", "1"), ("1", "1"), ("1", "0")):
+            monkeypatch.setenv("CALICO_DENSE_ROLL", roll)
+            monkeypatch.setenv("CALICO_FUSE_BACK", fuse)
+            runs[(roll, fuse)] = _solve_repeatedly(api, sc, repeats=3 if roll == "1" else 1, max_iter=15)
+        monkeypatch.delenv("CALICO_DENSE_ROLL")
+        monkeypatch.delenv("CALICO_FUSE_BACK")
+        ref = runs[("0", "1")][0]
+        assert ref[0] >= 3, i
+        for key, reps in runs.items():
+            first = reps[0]
+            for r in reps[1:]:
+                assert r[0] == first[0] and r[1] == first[1] and r[2] == first[2] and np.array_equal(r[3], first[3]), (i, key)
+            assert first[0] == ref[0] and first[1] == ref[1], (i, key)
+            np.testing.assert_allclose(first[2], ref[2], rtol=1e-9, atol=0, err_msg=str((i, key)))
+            # (absolute part: the weakly determined small components -- rotation-vector entries of 1e-4 -- move by a few 1e-10
+            #  between two orders of the same sums after fifteen iterations)
+            np.testing.assert_allclose(first[3], ref[3], rtol=1e-7, atol=2e-9, err_msg=str((i, key)))
