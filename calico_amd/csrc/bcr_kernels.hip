@@ -3155,7 +3155,7 @@ hipError_t configure_dense_block_solve() {
                              int(dense_block_solve_lds_bytes()));
 }
 void launch_dense_block_solve(const SolveArgs& a, int ks, hipStream_t s, int t0, int outer_back) {
-  hipLaunchKernelGGL(dense_block_solve_kernel, dim3(1), dim3(kDenseThreads), dense_block_solve_lds_bytes(), s, a, ks, t0, outer_back, t0 == 0 ? dense_elim_mode() : (block_elim_enabled() ? 1 : 0));
+  hipLaunchKernelGGL(dense_block_solve_kernel, dim3(1), dim3(kDenseThreads), dense_block_solve_lds_bytes(), s, a, ks, t0, outer_back, dense_elim_mode());
 }
 // ---------------------------------------------------------------------------
 // Large reduced systems (m + 1 > 128): one step of the blocked right-looking factorisation, 32 columns, over several
@@ -3347,7 +3347,7 @@ bool launch_reduced_fused(const SolveArgs& a, int nsteps, int nsl, int* words, h
   int n_wg = 1;
   for (int j = 0; j < nsteps; ++j) n_wg += reduced_step_workgroups(a.m + 1, j);
   if (nsteps < 1 || nsteps > 8 || n_wg > 128) return false;
-  hipLaunchKernelGGL(reduced_fused_kernel, dim3(n_wg), dim3(kStepThreads), reduced_fused_lds_bytes(), s, a, nsteps, nsl, words, block_elim_enabled() ? 1 : 0);
+  hipLaunchKernelGGL(reduced_fused_kernel, dim3(n_wg), dim3(kStepThreads), reduced_fused_lds_bytes(), s, a, nsteps, nsl, words, dense_elim_mode());
   return true;
 }
 void launch_reduced_block_step(const SolveArgs& a, int j, int nsl, int n_wg, hipStream_t s) {
