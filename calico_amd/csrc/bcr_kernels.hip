@@ -2569,6 +2569,13 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
   double* wv = pend + 128;                       // [32]
   double* bcast = wv + 32;                       // [128]
   double* dump = bcast + 128 + tid;              // [512]
+  if (elim == 2) {
+    // rolling owners: their channels (two compact ones in the panel buffer's place) and counters, cleared while the system's loads
+    // are on their way -- the barrier that ends the load phase orders them
+    for (int e = tid; e < kDenseChan; e += kDenseThreads) reinterpret_cast<unsigned long long*>(Daug)[e] = kElimSentinel;
+    if (tid < 32) reinterpret_cast<int*>(bcast)[tid] = tid == 7 ? 2 : 0;      // (K_RESET = 7: both channels are clear)
+    if (tid < 64) reinterpret_cast<long long*>(dump - tid)[tid] = 0;
+  }
   // ---- load: lower triangle (K-slices summed), right-hand side = row m; identity beyond m ----
   {
     const size_t mm = size_t(M1) * M1;
@@ -2743,10 +2750,7 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
     int* const ctr = reinterpret_cast<int*>(bcast);               // [32]
     long long* const ts = reinterpret_cast<long long*>(dump - tid);      // [64] (dev timing)
     enum { K_PROG = 1, K_DONE = 2 /* + owner */, K_W4 = 6, K_RESET = 7, K_GV = 9, K_ID0 = 10, K_BG32 = 12 /* + tile: 12..15 */ };
-    for (int e = tid; e < kDenseChan; e += kDenseThreads) reinterpret_cast<unsigned long long*>(chan)[e] = kElimSentinel;
-    if (tid < 32) ctr[tid] = tid == K_RESET ? 2 : 0;
-    if (tid < 64) ts[tid] = 0;
-    lds_barrier();
+    // (channels and counters were cleared in front of the load phase's barrier: see the top of the function)
     const long long t_roll = CAL_DEV_TIMING(a.debug == 1) ? __builtin_readcyclecounter() : 0;
     auto stamp = [&](int i) { if (CAL_DEV_TIMING(a.debug == 1 && lane == 0)) ts[i] = __builtin_readcyclecounter() - t_roll; };
     auto ctr_set = [&](int idx, int v) {
@@ -3035,9 +3039,11 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
   }
   lds_barrier();
   // ---- backward: y_j = L_jj⁻ᵀ (z_j - pend_j), pend_k += L_jkᵀ y_j for the blocks before ----
+  // (two barriers per block: the thread that completes pend of a column of the NEXT block to be solved forms that block's
+  //  right-hand side z - pend at once -- a stage and a barrier of its own before)
+  if (tid < BP) wv[tid] = gv[BP * (nb - 1) + tid] - pend[BP * (nb - 1) + tid];
   for (int jb = nb - 1; jb >= 0; --jb) {
     const int c0 = BP * jb;
-    if (tid < BP) wv[tid] = gv[c0 + tid] - pend[c0 + tid];
     lds_barrier();
     if (tid < 8 * BP) {                      // eight threads per row, four columns each; fixed-shape reduction
       const int r = tid >> 3, part = tid & 7;
@@ -3059,10 +3065,14 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
 #pragma unroll
       for (int u = 0; u < 8; ++u) { const int r = 8 * part + u; acc += A[(c0 + r) * DNL + col] * yv[c0 + r]; }
       acc = row4_sum(acc);
-      if (part == 0) pend[col] += acc;
+      if (part == 0) {
+        const double pc = pend[col] + acc;
+        pend[col] = pc;
+        if (col >= c0 - BP) wv[col - (c0 - BP)] = gv[col] - pc;
+      }
     }
-    lds_barrier();
   }
+  lds_barrier();      // (y of block 0 is read by other threads below)
   DTICK(7)
   if (dbg) printf("dense_block_solve wave %d cycles: load %lld | stage %lld  panel0 (rest tiles beside it) %lld  tile %lld  panel1 (rest tiles) %lld  Z %lld  file+rhs+next diagonal %lld | backward %lld\n",
                   wave, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7]);
