@@ -1855,7 +1855,9 @@ DEVI void file_update_sums(const UpdSums& s, double* sh /* [4][waves] */, double
 #pragma unroll
   for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
   if (lane == 0) { sh[wave] = v[0]; sh[16 + wave] = v[1]; sh[32 + wave] = v[2]; sh[48 + wave] = v[3]; }
-  __syncthreads();
+  // (orders LDS only: __syncthreads() would also wait for the stores of the solutions and the candidate point right in front of
+  //  this call to be written through -- a second store drain, ~2k clocks, in front of the one that ends the kernel)
+  lds_barrier();
   if (tid < 4) {
     double t = 0.0;
     for (int w = 0; w < nw; ++w) t += sh[16 * tid + w];
@@ -2277,7 +2279,7 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev n
   const int my_cp_c = my_cp_in ? my_cp : 0;
   const int my_off = b.ctrl_off[my_cp_c];
   const bool pdbg = CAL_DEV_TIMING(a.debug == 1 && blk0 == 0 && tid == 0);
-  long long pt[6] = {0, 0, 0, 0, 0, 0}, ptk = pdbg ? __builtin_readcyclecounter() : 0;
+  long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ptk = pdbg ? __builtin_readcyclecounter() : 0;
 #define PTICK(i) if (pdbg) { const long long t_ = __builtin_readcyclecounter(); pt[i] += t_ - ptk; ptk = t_; }
   // ---- requests: operands for LDS (thread (r16, sub): two entries of a row) ----
   const int r16 = tid >> 4, sub = tid & 15;
@@ -2421,6 +2423,7 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev n
       const double v = load_sc1(a.y + n_s + min(j, mc + RB - 1));
       uj[r] = j < mc ? v : ((j < mc + RB && b.root >= 0) ? v : (j == mc + BP ? 1.0 : 0.0));
     }
+    if (pdbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PTICK(5) }
     // rows 16·ct + l16 of every block: four products in the lane, then the four lane groups (lk) added up
     double pv[QM + 1][2];
 #pragma unroll
@@ -2438,6 +2441,7 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev n
     }
   }
   __syncthreads();
+  PTICK(6)
   if (tid < (QM + 1) * BP) {
     const int i = tid >> 5, r = tid & 31;
     double y = 0.0;
@@ -2446,6 +2450,7 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev n
     ych[i * BP + r] = y;      // (block QM: the right top separator = ysr)
   }
   __syncthreads();
+  PTICK(7)
   // ---- file the solutions, update the candidate point (as back_node) ----
   if (tid < q * BP || sep_row) {
     const double yj = sep_row ? ysr[tid & 31] : ych[tid];
@@ -2466,10 +2471,11 @@ DEVI void back_node_pre(const SolveArgs& a, const BcrArgs& b, const BcrNodeDev n
       s.sn += e * e; s.cn += v * v;
     }
   }
+  PTICK(8)
   file_update_sums(s, sh, b.upd, nd_slot);
   PTICK(4)
-  if (pdbg) printf("back_node_pre (q %d) cycles: requests issued + arrived %lld  to LDS %lld  recursion %lld  wait for the solve %lld  product + outputs %lld\n",
-                   q, pt[0], pt[1], pt[2], pt[3], pt[4]);
+  if (pdbg) printf("back_node_pre (q %d) cycles: requests issued + arrived %lld  to LDS %lld  recursion %lld  wait for the solve %lld | u there %lld  products + partials in LDS %lld  sums %lld  outputs stored %lld  update sums filed %lld\n",
+                   q, pt[0], pt[1], pt[2], pt[3], pt[5], pt[6], pt[7], pt[8], pt[4]);
 #undef PTICK
 }
 
