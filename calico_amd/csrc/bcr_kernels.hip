@@ -944,6 +944,28 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = pp[4 * u * XLD];
     };
+    // One column half (sixteen dimensions of the left separator) of the fill T(right, left) = -Z^BᵀZ^A of the chain's last block -- the
+    // left separator's coupling to its next survivor: 16 products. Wave 2 takes half 0, the wave that was the last block's chief (idle
+    // by then) half 1: on wave 2 alone the 32 products were the tail of the workgroup that ends the launch.
+    auto fill_half = [&](int jt) {
+      ctr_wait([&](auto c) { return done_d(c, q - 1) && c(C_DONE_A) >= q; });
+      const double* Zp = Zr + ((q - 1) & 1) * BP * XLD;
+      double zb0[8], zb1[8], za[8];
+      zops(Zp, CB, zb0); zops(Zp, CB + 16, zb1); zops(Zp, CA + 16 * jt, za);
+      f64x4 g0 = zero4, g1 = zero4;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-zb0[u], za[u], g0, 0, 0, 0);
+        g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-zb1[u], za[u], g1, 0, 0, 0);
+      }
+      double* dst = Gw + size_t(left) * BB;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dst[(lk + 4 * r) * BP + 16 * jt + l16] = g0[r];
+        dst[(16 + lk + 4 * r) * BP + 16 * jt + l16] = g1[r];
+      }
+    };
+    const bool want_fill = right >= 0 && has_left && role == 0;
     if (tile_wave) {
       if constexpr (!FROM_R) {
         // ---- an upper level's two chief-side waves: wave 0 factors the (single) block, wave 1 follows with the rows of Bᵀ and
@@ -1139,6 +1161,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
             }
           }
         }
+        if (want_fill && par == ((q - 1) & 1)) fill_half(1);      // (the last block's chief: see fill_half)
       } else {
         // ---- wave 7: stages the followers' inputs of blocks 1.. as tile images, a block ahead; files with waves 4..6 ----
         if (uniform(terminated_v)) { leave_terminated(); return; }
@@ -1262,20 +1285,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
         ctr_set(C_DONE_A, k + 1);
         stamp(k, 1);
       }
-      if (right >= 0 && has_left && role == 0) {
-        // fill T(right, left) = -Z^BᵀZ^A of the chain's last block: the left separator's coupling to its next survivor
-        ctr_wait([&](auto c) { return done_d(c, q - 1); });
-        fill_pre(Zr + ((q - 1) & 1) * BP * XLD);
-        double* dst = Gw + size_t(left) * BB;
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            dst[(lk + 4 * r) * BP + 16 * jt + l16] = -pre0[jt][r];
-            dst[(16 + lk + 4 * r) * BP + 16 * jt + l16] = -pre1[jt][r];
-          }
-        }
-      }
+      if (want_fill) { fill_half(0); if (!FROM_R) fill_half(1); }
     } else if (wave == 3) {
       if (role == 0) {
         // ---- the identity rows: L⁻ᵀ ----
