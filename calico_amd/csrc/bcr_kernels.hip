@@ -200,19 +200,27 @@ DEVI void schur_tile(const SolveArgs& a, const BcrArgs& b, const FromR& fr, int 
     }
   }
   f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-  for (int k0 = w_begin; k0 < w_end; k0 += 32) {
-    double va[8], vb[8];
+  // (batches of 32 rows, FOUR of them requested before the first is consumed: a batch at a time the wave waited out a round trip
+  //  per batch -- three in a row at configs[3] -- with nothing else to do)
+  for (int kg = w_begin; kg < w_end; kg += 128) {
+    double va[4][8], vb[4][8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int row = k0 + 4 * u + lk;
-      const size_t ro = size_t(min(row, n - 1)) * m1p;
-      va[u] = pa[ro]; vb[u] = pb[ro];
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = kg + 32 * g + 4 * u + lk;
+        const size_t ro = size_t(min(row, n - 1)) * m1p;
+        va[g][u] = pa[ro]; vb[g][u] = pb[ro];
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int row = k0 + 4 * u + lk, sb = row >> 5;
-      const bool use = row < w_end && sb != f0 && sb != f1;      // (selects on BOTH operands: a skipped row may hold anything, NaN included -- it is being rewritten by this very launch -- and 0 x NaN is NaN)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(use ? va[u] : 0.0, use ? vb[u] : 0.0, acc, 0, 0, 0);
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = kg + 32 * g + 4 * u + lk, sb = row >> 5;
+        const bool use = row < w_end && sb != f0 && sb != f1;      // (selects on BOTH operands: a skipped row may hold anything, NaN included -- it is being rewritten by this very launch -- and 0 x NaN is NaN)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(use ? va[g][u] : 0.0, use ? vb[g][u] : 0.0, acc, 0, 0, 0);
+      }
     }
   }
   if (LATE) {
