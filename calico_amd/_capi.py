@@ -395,9 +395,10 @@ class Problem:
 
     def plan_info(self):
         """Test hook (calico_hip_testing.h): which evaluation route / solver the plan of this handle takes."""
-        out = np.zeros(8, np.int32)
-        self._check(self.api.debug_plan_info(self.h, out.ctypes.data_as(C.POINTER(C.c_int32)), 8))
-        keys = ("fuse_expand", "frames", "items", "cells", "max_frames_per_cell", "max_items_per_cell", "tree_solver", "m")
+        out = np.zeros(9, np.int32)
+        self._check(self.api.debug_plan_info(self.h, out.ctypes.data_as(C.POINTER(C.c_int32)), 9))
+        keys = ("fuse_expand", "frames", "items", "cells", "max_frames_per_cell", "max_items_per_cell", "tree_solver", "m",
+                "all_control_points_observed")
         return dict(zip(keys, (int(v) for v in out)))
 
     def comm_init_rccl(self, unique_id, rank, world_size):

@@ -890,7 +890,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     // Order is kept by single-writer counters in LDS (a wave's LDS instructions execute in order: data first, then the
     // counter; a reader polls the counter, then reads). Z, L⁻ᵀ and the tile images are double-buffered by parity, the channel three deep.
     // Same products in the same order as the barrier form: bit-identical results (profiles/dev/bitwise.py).
-    // Needs every control point observed (b.all_active: the host launches the barrier form otherwise).
+    // Unobserved control points (b.all_active == 0) are padding rows / columns, by a five-bit mask per superblock asked for with its tiles.
     // The levels above level 0 (FROM_R = false; single-block chains: the host sends longer ones to the barrier form): the same waves
     // in the same roles, each taking its tiles straight from D / G / F and the pending slots -- no staging, no barrier but the
     // first --, and the chain's results leave as the barrier form's do (write-through where the Schur complement's riders read them).
@@ -974,6 +974,14 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       }
     };
     const bool want_fill = right >= 0 && has_left && role == 0;
+    // Unobserved control points (b.all_active == 0; e.g. at the ends of a trajectory longer than its data): their rows and columns
+    // are padding -- 1 on the diagonal, 0 elsewhere, like FromR::trow. A superblock's five flags are asked for with its tiles (lane
+    // j < 5: control point 5 I + j) and become a wave-uniform mask when the tiles are taken; row r of a superblock belongs to control
+    // point r / 6 (rows 30, 31: bit 5, never set).
+    const bool all_act = b.all_active != 0;
+    auto req_act = [&](int I) { return all_act ? 1 : int(a.cp_active[min(max(kBcrCps * I + (lane & 7), 0), a.n_cp - 1)]); };
+    auto act_mask = [&](int flag) { return all_act ? 31u : (unsigned(__builtin_amdgcn_ballot_w64(flag != 0 && (lane & 7) < kBcrCps)) & 31u); };
+    auto act = [](unsigned am, int row) { return ((am >> (row / 6)) & 1u) != 0; };
     if (tile_wave) {
       if constexpr (!FROM_R) {
         // ---- an upper level's two chief-side waves: wave 0 factors the (single) block, wave 1 follows with the rows of Bᵀ and
@@ -1038,7 +1046,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       for (int i = 0; i < 4; ++i) { oB[4 * i] = tv[3 + i].x; oB[4 * i + 1] = tv[3 + i].y; oB[4 * i + 2] = tv[3 + i].z; oB[4 * i + 3] = tv[3 + i].w; }
       const unsigned okS = tv[7].x & 0xffffu, okB = tv[7].x >> 16;
       const bool diag_lane = l16 >= lk && ((l16 - lk) & 3) == 0;      // register (l16 - lk) / 4 of tiles (0,0) and (1,1) is a diagonal entry
-      struct Inputs { double sp[12], sc[4], bt[16]; };
+      struct Inputs { double sp[12], sc[4], bt[16]; int fa, fn; };      // fa / fn: the activity flags of the rows' superblock J and of J + 1 (the spine's)
       // requests: spine of superblock I, the Jacobi scales of its diagonal entries, rows of Bᵀ of superblock J
       auto req_scale = [&](int I, double (&sc)[4]) {
         const int nreal = n_s - RB * I;
@@ -1057,13 +1065,15 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       };
       // what arrived -> tiles. Spine: structure, the trajectory's end, LM damping of the diagonal (FromR::diag_block); role 0 files dadd.
       const double inv_radius = 1.0 / radius;
-      auto take_spine = [&](int I, const double (&sp)[12], const double (&sc)[4], f64x4& t00, f64x4& t01, f64x4& t11) {
+      auto take_spine = [&](int I, const double (&sp)[12], const double (&sc)[4], unsigned am, f64x4& t00, f64x4& t01, f64x4& t11) {
         const int nreal = n_s - RB * I;
         double e00[4], e01[4], e11[4];
+        const bool a0 = act(am, l16), a1 = act(am, 16 + l16);      // this lane's rows l16 and 16 + l16
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int c = lk + 4 * r, hi = max(l16, c);
-          const bool v00 = ((okS >> r) & 1) && hi < nreal, v01 = ((okS >> (4 + r)) & 1) && 16 + l16 < nreal, v11 = ((okS >> (8 + r)) & 1) && 16 + hi < nreal;
+          const bool v00 = ((okS >> r) & 1) && hi < nreal && a0 && act(am, c), v01 = ((okS >> (4 + r)) & 1) && 16 + l16 < nreal && a1 && act(am, c),
+                     v11 = ((okS >> (8 + r)) & 1) && 16 + hi < nreal && a1 && act(am, 16 + c);
           e00[r] = v00 ? sp[r] : 0.0; e01[r] = v01 ? sp[4 + r] : 0.0; e11[r] = v11 ? sp[8 + r] : 0.0;
         }
         // the lane's diagonal entries (rows l16 and 16 + l16: register (l16 - lk) / 4 of tiles (0,0) and (1,1) in the lanes that
@@ -1075,11 +1085,11 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int row = 16 * h + l16, t = RB * I + row;
-          const bool real_row = row < RB && row < nreal;
+          const bool in_traj = row < RB && row < nreal, real_row = in_traj && (h == 0 ? a0 : a1);
           double d;
           if (fr.first_scale == 0) d = fmin(fmax(dg[h] * sc[2 * h] * sc[2 * h], o.min_lm_diagonal), o.max_lm_diagonal) * (inv_radius * sc[2 * h + 1]);
           else d = fr.damping(dg[h], real_row ? t : 0);
-          if (diag_lane && real_row && role == 0) a.dadd[t] = d;
+          if (diag_lane && in_traj && role == 0) a.dadd[t] = real_row ? d : 0.0;
           dg[h] = real_row ? dg[h] + d : 1.0;
         }
 #pragma unroll
@@ -1088,16 +1098,16 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           t00[r] = -(is_d ? dg[0] : e00[r]); t01[r] = -e01[r]; t11[r] = -(is_d ? dg[1] : e11[r]);
         }
       };
-      auto take_b = [&](int k, const double (&bt)[16], f64x4 (&x0)[2], f64x4 (&x1)[2]) {
+      auto take_b = [&](int k, const double (&bt)[16], unsigned am_this, unsigned am_next, f64x4 (&x0)[2], f64x4 (&x1)[2]) {
         const bool has_next = (k + 1 < q) || right >= 0;
         const int nreal_n = n_s - RB * (blk0 + k + 1);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-          const bool row_ok = has_next && 16 * qt + l16 < nreal_n;
+          const bool row_ok = has_next && 16 * qt + l16 < nreal_n && act(am_next, 16 * qt + l16);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            x0[qt][r] = -((((okB >> ((qt * 2 + 0) * 4 + r)) & 1) && row_ok) ? bt[(qt * 2 + 0) * 4 + r] : 0.0);
-            x1[qt][r] = -((((okB >> ((qt * 2 + 1) * 4 + r)) & 1) && row_ok) ? bt[(qt * 2 + 1) * 4 + r] : 0.0);
+            x0[qt][r] = -((((okB >> ((qt * 2 + 0) * 4 + r)) & 1) && row_ok && act(am_this, lk + 4 * r)) ? bt[(qt * 2 + 0) * 4 + r] : 0.0);
+            x1[qt][r] = -((((okB >> ((qt * 2 + 1) * 4 + r)) & 1) && row_ok && act(am_this, 16 + lk + 4 * r)) ? bt[(qt * 2 + 1) * 4 + r] : 0.0);
           }
         }
       };
@@ -1111,9 +1121,11 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           Inputs in, alt_in;
           if (par == 0) {
             req_spine(blk0, in.sp, bandR); req_spine(blk0, alt_in.sp, bandR + alt); req_scale(blk0, in.sc);
+            in.fn = req_act(blk0); in.fa = in.fn;
           } else {
             req_b(blk0, in.bt, bandR); req_b(blk0, alt_in.bt, bandR + alt);
             if (q > 1) { req_spine(blk0 + 1, in.sp, bandR); req_spine(blk0 + 1, alt_in.sp, bandR + alt); req_scale(blk0 + 1, in.sc); }
+            in.fa = req_act(blk0); in.fn = req_act(blk0 + 1);
           }
           hstamp(3);
           if (uniform(terminated_v)) { leave_terminated(); return; }
@@ -1122,12 +1134,13 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
 #pragma unroll
           for (int e = 0; e < 12; ++e) in.sp[e] = second ? alt_in.sp[e] : in.sp[e];
           if (tdbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); hstamp(5); }
-          if (par == 0) take_spine(blk0, in.sp, in.sc, t00, t01, t11);
+          const unsigned ma = act_mask(in.fa), mn = act_mask(in.fn);
+          if (par == 0) take_spine(blk0, in.sp, in.sc, mn, t00, t01, t11);
           else {
 #pragma unroll
             for (int e = 0; e < 16; ++e) in.bt[e] = second ? alt_in.bt[e] : in.bt[e];
-            take_b(0, in.bt, x0, x1);
-            if (q > 1) take_spine(blk0 + 1, in.sp, in.sc, n00, n01, n11);
+            take_b(0, in.bt, ma, mn, x0, x1);
+            if (q > 1) take_spine(blk0 + 1, in.sp, in.sc, mn, n00, n01, n11);
           }
           hstamp(6);
         }
@@ -1183,9 +1196,11 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
             Inputs in;
             req_b(blk0 + j, in.bt, bandC);
             if (j + 1 < q) { req_spine(blk0 + j + 1, in.sp, bandC); req_scale(blk0 + j + 1, in.sc); }
+            in.fa = req_act(blk0 + j); in.fn = req_act(blk0 + j + 1);
             f64x4 x0[2], x1[2], n00 = zero4, n01 = zero4, n11 = zero4;
-            take_b(j, in.bt, x0, x1);
-            if (j + 1 < q) take_spine(blk0 + j + 1, in.sp, in.sc, n00, n01, n11);
+            const unsigned ma = act_mask(in.fa), mn = act_mask(in.fn);
+            take_b(j, in.bt, ma, mn, x0, x1);
+            if (j + 1 < q) take_spine(blk0 + j + 1, in.sp, in.sc, mn, n00, n01, n11);
             // (the image of block j - 2 has been taken: its follower is this block's)
             if (j >= 3) ctr_wait([&](auto c) { return c((j & 1) ? C_TAKEN_D0 : C_TAKEN_D1) >= j - 1; });
             double* im = img + (j & 1) * kImg + lane;
@@ -1237,15 +1252,19 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           av[e] = 0.0; av1[e] = 0.0;
           if (has_left) { av[e] = ldo(p, oA[e]); av1[e] = ldo(p + alt, oA[e]); }
         }
+        const int f_this = req_act(blk0), f_left = req_act(blk0 - 1);
         if (uniform(terminated_v)) { leave_terminated(); return; }
         const bool second = uniform(r_cur_v) != 0;
         const int nreal = n_s - RB * blk0;
+        const unsigned m_this = act_mask(f_this), m_left = act_mask(f_left);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int e0 = (qt * 2 + 0) * 4 + r, e1 = (qt * 2 + 1) * 4 + r;
-            const bool v0 = ((tmask >> e0) & 1) && has_left && lk + 4 * r < nreal, v1 = ((tmask >> e1) & 1) && has_left && 16 + lk + 4 * r < nreal;
+            const bool col_ok = has_left && act(m_left, 16 * qt + l16);
+            const bool v0 = ((tmask >> e0) & 1) && col_ok && lk + 4 * r < nreal && act(m_this, lk + 4 * r),
+                       v1 = ((tmask >> e1) & 1) && col_ok && 16 + lk + 4 * r < nreal && act(m_this, 16 + lk + 4 * r);
             pre0[qt][r] = -(v0 ? (second ? av1[e0] : av[e0]) : 0.0);
             pre1[qt][r] = -(v1 ? (second ? av1[e1] : av[e1]) : 0.0);
           }
@@ -1321,12 +1340,14 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
             fv[e] = Rb[vF ? (col < a.mc ? a.off_E() + size_t(t) * a.mc + col : a.off_g() + t) : a.off_g()];
           }
         };
+        unsigned m_f = 31u;      // activity of the block whose F rows are in fv
         auto f_valid = [&](int k, int e) {
           if (!FROM_R) return true;      // (D / F of a separator hold the padding's values themselves)
           const int r = 16 * (e >> 2) + lk + 4 * (e & 3);
-          return r < RB && r < n_s - RB * (blk0 + k) && col <= a.mc;
+          return r < RB && r < n_s - RB * (blk0 + k) && col <= a.mc && act(m_f, r);
         };
         double fv[8];
+        int f_flag = FROM_R ? req_act(blk0) : 1;
         {
           if constexpr (FROM_R) {
             double fv1[8];
@@ -1355,9 +1376,10 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           double* const Zk = Zr + (k & 1) * BP * XLD;
           if (k > 0) ctr_wait([&](auto c) { return done_d(c, k - 1); });
           stamp(k, 0);
+          m_f = act_mask(f_flag);
 #pragma unroll
           for (int r = 0; r < 4; ++r) { pre0[0][r] = -(f_valid(k, r) ? fv[r] : 0.0); pre1[0][r] = -(f_valid(k, 4 + r) ? fv[4 + r] : 0.0); }
-          if (FROM_R && k + 1 < q) req_f(k + 1, fv, a.R);
+          if (FROM_R && k + 1 < q) { req_f(k + 1, fv, a.R); f_flag = req_act(blk0 + k + 1); }
           if (k > 0) {
             const double* Zp = Zr + ((k - 1) & 1) * BP * XLD;
             double zb0[8], zb1[8], zf[8];
@@ -3462,7 +3484,7 @@ static int dense_elim_mode() {
 // loader waves' commit of the next block (they lose the Schur phase as load time) and by the two barriers' own latency.
 static bool level_lookahead_enabled() { const char* e = std::getenv("CALICO_LOOKAHEAD"); return e && std::atoi(e) != 0; }
 // Level 0's chains with the rolling chief (bcr_level_kernel<true, true, false, true>: no workgroup barrier between the blocks of
-// a chain), the default wherever every control point is observed; CALICO_ROLL=0: the barrier form (A/B switch, read per solve)
+// a chain), the default; CALICO_ROLL=0: the barrier form (A/B switch, read per solve)
 static bool level_roll_enabled() { const char* e = std::getenv("CALICO_ROLL"); return !e || std::atoi(e) != 0; }
 // the same form on the levels above level 0 (single-block chains): CALICO_ROLL_UPPER=1
 // (NOT the default: the chains of an upper level end 2-3k clocks earlier with it, the launch does not -- it ends with the Schur
@@ -3513,7 +3535,7 @@ void launch_bcr_level(const SolveArgs& a, const BcrArgs& b, int node0, int n_nod
   }
   const bool elim = block_elim_enabled(), la = level_lookahead_enabled();
   if (level == 0) {
-    const bool roll = elim && !la && b.all_active && a.k >= 1 && a.k <= 6 && level_roll_enabled();
+    const bool roll = elim && !la && a.k >= 1 && a.k <= 6 && level_roll_enabled();
     hipLaunchKernelGGL((roll ? bcr_level_kernel<true, true, false, true> : elim ? (la ? bcr_level_kernel<true, true, true> : bcr_level_kernel<true, true>) : bcr_level_kernel<true, false>), dim3(main_span + n_apply + (with_post_eval ? 1 : 0)), dim3(kLevelThreads),
                        bcr_level_lds_bytes(), s, a, b, node0, n_nodes, nfs, level, keep0, n_keep, o, with_post_eval, x, blocks, n_blocks,
                        log, log_cap, jacobi, 0, 0, 1, fan_word, 0, inl);

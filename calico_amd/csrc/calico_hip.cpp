@@ -2571,7 +2571,7 @@ int32_t calico_debug_lm_control_replay(int32_t device, int32_t n, const double* 
 }
 
 int32_t calico_debug_plan_info(calico_problem* p, int32_t* out, int32_t n) {
-  if (!p || !out || n < 0 || n > 8) return CALICO_INVALID_ARGUMENT;
+  if (!p || !out || n < 0 || n > 9) return CALICO_INVALID_ARGUMENT;
   int rc = finalize(p);
   if (rc != CALICO_OK) return rc;
   int max_frames = 0, max_items = 0, run = 0, prev_layout = -1, prev_seg = -1;
@@ -2581,8 +2581,8 @@ int32_t calico_debug_plan_info(calico_problem* p, int32_t* out, int32_t n) {
     prev_layout = it.layout; prev_seg = it.seg;
     max_items = std::max(max_items, run);
   }
-  const int v[8] = {p->fuse_expand ? 1 : 0, p->n_fitems, p->n_jac_items, int(p->h_cells.size()), max_frames, max_items,
-                    p->use_bcr ? 1 : 0, p->m};
+  const int v[9] = {p->fuse_expand ? 1 : 0, p->n_fitems, p->n_jac_items, int(p->h_cells.size()), max_frames, max_items,
+                    p->use_bcr ? 1 : 0, p->m, p->bcr_all_active ? 1 : 0};
   for (int i = 0; i < n; ++i) out[i] = v[i];
   return CALICO_OK;
 }

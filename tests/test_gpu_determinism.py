@@ -381,7 +381,7 @@ def test_rolling_chief_equals_the_barrier_form_bit_for_bit(monkeypatch):
     and write-once channels in LDS. The products and their order are those of the barrier form (CALICO_ROLL=0), so every
     iterate must come out BIT FOR BIT the same -- for chains of 1, 2, 3, 4 and 8 blocks (odd / even hand-overs, the channel
     ring of three wrapping, the image ring of two wrapping), a trajectory whose last superblock is partly padding, spline orders
-    4 and 5 (other band structure in the offset table), with and without the same form on the upper levels
+    4 and 5 (other band structure in the offset table), a trajectory with unobserved control points, with and without the same form on the upper levels
     (CALICO_ROLL_UPPER=1) -- and repeat itself run to run (a follower that read a tile image, a channel entry or a Z row too
     early, or a buffer reused too soon, shows as a run-to-run difference or a difference to the barrier form)."""
     api = helpers.hip_api()
@@ -391,6 +391,11 @@ def test_rolling_chief_equals_the_barrier_form_bit_for_bit(monkeypatch):
         ("185 control points", syn.make_scene(2, 1, True, 2, seed=4), ("", "3")),
         ("ragged end", syn.make_scene(2, 1, True, 3, cam_rate=10.0, imu_rate=100.0, duration=7.3, seed=43, segment_duration=7.3 / 23.9, **common), ("", "2")),
     ]
+    # data over the first 5 s of a trajectory of 8.7 s: the control points behind it are unobserved -- padding rows in the tiles (a
+    # five-bit activity mask per superblock)
+    unobserved = syn.make_scene(2, 1, True, 3, cam_rate=10.0, imu_rate=100.0, duration=5.0, seed=62, segment_duration=8.7 / 23.9, **common)
+    assert syn.build_problem(api, unobserved).problem.plan_info()["all_control_points_observed"] == 0
+    scenes.append(("unobserved control points", unobserved, ("", "2", "3")))
     for order in (4, 5):
         scenes.append(("order %d" % order, syn.make_scene(2, 1, True, 3, cam_rate=10.0, imu_rate=100.0, duration=6.0, seed=44 + order, segment_duration=6.0 / 23.9,
                                                            order=order, **common), ("",)))
