@@ -1065,7 +1065,11 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
       };
       // what arrived -> tiles. Spine: structure, the trajectory's end, LM damping of the diagonal (FromR::diag_block); role 0 files dadd.
       const double inv_radius = 1.0 / radius;
-      auto take_spine = [&](int I, const double (&sp)[12], const double (&sc)[4], unsigned am, f64x4& t00, f64x4& t01, f64x4& t11) {
+      // (ACT: with the activity tests compiled in; where every control point is observed -- a wave-uniform branch at the call -- the tests
+      //  are not there at all: a hundred instructions of cold code less in front of the first pivot)
+      auto take_spine_t = [&](auto act_tag, int I, const double (&sp)[12], const double (&sc)[4], unsigned am, f64x4& t00, f64x4& t01, f64x4& t11) {
+        constexpr bool ACT = decltype(act_tag)::value;
+        auto act = [](unsigned m_, int row) { return !ACT || ((m_ >> (row / 6)) & 1u) != 0; };
         const int nreal = n_s - RB * I;
         double e00[4], e01[4], e11[4];
         const bool a0 = act(am, l16), a1 = act(am, 16 + l16);      // this lane's rows l16 and 16 + l16
@@ -1098,7 +1102,12 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
           t00[r] = -(is_d ? dg[0] : e00[r]); t01[r] = -e01[r]; t11[r] = -(is_d ? dg[1] : e11[r]);
         }
       };
-      auto take_b = [&](int k, const double (&bt)[16], unsigned am_this, unsigned am_next, f64x4 (&x0)[2], f64x4 (&x1)[2]) {
+      auto take_spine = [&](int I, const double (&sp)[12], const double (&sc)[4], unsigned am, f64x4& t00, f64x4& t01, f64x4& t11) {
+        if (all_act) take_spine_t(std::false_type(), I, sp, sc, am, t00, t01, t11); else take_spine_t(std::true_type(), I, sp, sc, am, t00, t01, t11);
+      };
+      auto take_b_t = [&](auto act_tag, int k, const double (&bt)[16], unsigned am_this, unsigned am_next, f64x4 (&x0)[2], f64x4 (&x1)[2]) {
+        constexpr bool ACT = decltype(act_tag)::value;
+        auto act = [](unsigned m_, int row) { return !ACT || ((m_ >> (row / 6)) & 1u) != 0; };
         const bool has_next = (k + 1 < q) || right >= 0;
         const int nreal_n = n_s - RB * (blk0 + k + 1);
 #pragma unroll
@@ -1110,6 +1119,9 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
             x1[qt][r] = -((((okB >> ((qt * 2 + 1) * 4 + r)) & 1) && row_ok && act(am_this, 16 + lk + 4 * r)) ? bt[(qt * 2 + 1) * 4 + r] : 0.0);
           }
         }
+      };
+      auto take_b = [&](int k, const double (&bt)[16], unsigned am_this, unsigned am_next, f64x4 (&x0)[2], f64x4 (&x1)[2]) {
+        if (all_act) take_b_t(std::false_type(), k, bt, am_this, am_next, x0, x1); else take_b_t(std::true_type(), k, bt, am_this, am_next, x0, x1);
       };
       if (wave < 2) {
         // ---- the two chiefs ----
