@@ -393,11 +393,17 @@ static void fill_roll_table(unsigned (*tab)[64][kRollTabWords]) {
     }
   }
 }
-static hipError_t upload_roll_table() {
+static hipError_t upload_roll_table() {      // (called under configure_kernels' lock)
   static unsigned host_tab[6][64][kRollTabWords];
   static std::once_flag once;
   std::call_once(once, [] { fill_roll_table(host_tab); });
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_roll_tab), host_tab, sizeof(host_tab));
+  static bool done[64] = {};       // once per device: the symbol lives on each of them, and the copy waits for the device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+  const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_roll_tab), host_tab, sizeof(host_tab));
+  if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
+  return e;
 }
 
 // ROLL (round 6; level 0 with the block elimination): the chain without a workgroup barrier between its blocks -- see the
