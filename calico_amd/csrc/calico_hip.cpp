@@ -600,7 +600,12 @@ void build_bcr_plan(calico_problem* p) {
     for (int c = 1; c <= kBcrMaxChain; ++c) {
       const int n_sep = N > c ? N / (c + 1) : 0;
       const int L = 1 + levels_after(n_sep);
-      const double cost = 6.0 * L + 4.0 * (c + L - 1);
+      double cost = 6.0 * L + 4.0 * (c + L - 1);
+      // One workgroup of a level launch fills a CU and the part has 256: a level 0 whose (node, role) workgroups (laid out by XCD:
+      // nodes padded to a multiple of eight), eight separators' workgroups and the bookkeeping one do not fit runs its tail in a
+      // second dispatch round (1453 control points, chains of four: 256 + 64 + 1 workgroups, level 0 34.7 us; chains of five: +2.9 % it/s)
+      const int per = 1 + p->bcr_m1p / 16, nodes = n_sep + 1;
+      if (8 * ((nodes + 7) / 8) * per + 9 > 256) cost += 5.0;
       if (cost < best) { best = cost; q = c; }
     }
     if (const char* e = std::getenv("CALICO_BCR_LEAF")) q = std::max(1, std::min(kBcrMaxChain, std::atoi(e)));
@@ -753,8 +758,8 @@ int build_plan(calico_problem* p) {
       p->sep_s = 0; p->sep_n = 0;
       p->bcr_all_active = true;
       for (int i = 0; i < n_cp; ++i) p->bcr_all_active = p->bcr_all_active && cp_active[size_t(i)] != 0;
-      build_bcr_plan(p);
       p->bcr_m1p = 16 * ((m + 1 + 15) / 16);
+      build_bcr_plan(p);
     }
   }
   const int NS = 6 * n_cp;
