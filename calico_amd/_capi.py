@@ -124,7 +124,7 @@ ABI_SYMBOLS = [
     "comm_get_unique_id", "comm_init_rccl", "comm_info", "problem_finalize", "plan_cache_stats", "plan_cache_clear",
 ]
 # Test hooks (calico_amd/csrc/calico_hip_testing.h): exported, not part of the drop-in surface.
-TEST_SYMBOLS = ["debug_lm_control_replay", "debug_plan_info"]
+TEST_SYMBOLS = ["debug_lm_control_replay", "debug_plan_info", "debug_roll_table"]
 
 
 class CApi:
@@ -183,6 +183,7 @@ class CApi:
             g("debug_lm_control_replay", C.c_int32,
               [C.c_int32, C.c_int32, D, I, C.POINTER(SolverOptions), D, I, D])
             g("debug_plan_info", C.c_int32, [P, I, C.c_int32])
+            g("debug_roll_table", C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_uint32)])
 
     def _get(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)

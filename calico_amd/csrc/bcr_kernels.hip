@@ -393,6 +393,13 @@ static void fill_roll_table(unsigned (*tab)[64][kRollTabWords]) {
     }
   }
 }
+// (test hook, host only: the row of the table for spline order k and a lane -- tests/test_host_abi.py checks it against the band's layout)
+void roll_table_row(int k, int lane, unsigned* out) {
+  static unsigned tab[6][64][kRollTabWords];
+  static std::once_flag once;
+  std::call_once(once, [] { fill_roll_table(tab); });
+  for (int i = 0; i < kRollTabWords; ++i) out[i] = tab[k - 1][lane][i];
+}
 static hipError_t upload_roll_table() {      // (called under configure_kernels' lock)
   static unsigned host_tab[6][64][kRollTabWords];
   static std::once_flag once;

@@ -84,6 +84,7 @@ void launch_debug_control_replay(LmState* st, const LmOptionsDev& o, const doubl
 size_t bcr_level_lds_bytes();
 size_t bcr_back_lds_bytes(int q_max, int m1p);
 hipError_t configure_bcr_kernels(int q_max, int m1p);
+void roll_table_row(int k, int lane, unsigned* out);      // (host only: test hook)
 hipError_t configure_dense_block_solve();
 hipError_t configure_reduced_block_step();
 hipError_t configure_reduced_fused();
@@ -2572,6 +2573,12 @@ int32_t calico_debug_lm_control_replay(int32_t device, int32_t n, const double* 
       hipMemcpy(accepted_out, d_acc.p, size_t(n) * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
       hipMemcpy(cost_column_out, d_cost.p, size_t(n) * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
     return CALICO_INTERNAL;
+  return CALICO_OK;
+}
+
+int32_t calico_debug_roll_table(int32_t spline_order, int32_t lane, uint32_t* out48) {
+  if (!out48 || spline_order < 1 || spline_order > 6 || lane < 0 || lane > 63) return CALICO_INVALID_ARGUMENT;
+  cal::roll_table_row(spline_order, lane, out48);
   return CALICO_OK;
 }
 

@@ -98,3 +98,59 @@ def test_missing_rccl_is_a_clean_error():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "status 13 13" in r.stdout, r.stdout
+
+
+def test_rolling_chief_offset_table_matches_the_band_layout(hiplib):
+    """bcr_kernels.hip, g_roll_tab (host-built, no device needed): where a lane's tile entries sit in the band's storage. The reduce
+    buffer holds H(row, column) of the band at [(column's control point) * k + distance][column component][row component] (36 doubles
+    per 6x6 block; solve_dev.hpp band_entry), superblock I = control points 5 I .. 5 I + 4 starting at I * 5 * k * 36. Restated here
+    independently for every spline order 1..6 and lane: the spine's entries (tiles (0,0), (0,1), (1,1) of the 32x32 superblock in the
+    elimination's register layout: lane (l16, lk), register r <-> row l16 (+16), column lk + 4 r (+16), taken from the lower triangle),
+    the rows of B^T (next superblock's row 16 qt + l16 against this one's column 16 h + lk + 4 r) and of A^T (this superblock's row
+    16 h + lk + 4 r against the LEFT one's column 16 qt + l16, counted from the left superblock's storage), with the masks of the
+    entries that exist (inside the band: distance < k; inside the 30 real rows)."""
+    fn = hiplib.calico_debug_roll_table
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_uint32)]
+    out = (C.c_uint32 * 48)()
+    assert fn(0, 0, out) != 0 and fn(7, 0, out) != 0 and fn(6, 64, out) != 0      # argument checks
+
+    def pos(hi, lo, k):      # H(hi, lo), lo <= hi, rows counted from the start of lo's superblock; None outside the band
+        d = hi // 6 - lo // 6
+        return 8 * (((lo // 6) * k + d) * 36 + (lo % 6) * 6 + hi % 6) if d < k else None
+
+    for k in range(1, 7):
+        for lane in range(64):
+            assert fn(k, lane, out) == 0
+            t = list(out)
+            l16, lk = lane & 15, lane >> 4
+            ok_s, ok_b, ok_a = t[28] & 0xffff, t[28] >> 16, t[29]
+            for r in range(4):
+                c = lk + 4 * r
+                hi, lo = max(l16, c), min(l16, c)
+                for e, (h, l) in ((r, (hi, lo)), (4 + r, (16 + l16, c)), (8 + r, (16 + hi, 16 + lo))):
+                    want = pos(h, l, k)
+                    exists = want is not None and h < 30
+                    assert bool((ok_s >> e) & 1) == exists, (k, lane, e)
+                    if exists:
+                        assert t[e] == want, (k, lane, e)
+                        assert t[e] < 8 * 5 * k * 36             # inside the superblock's own storage
+            for qt in range(2):
+                for h in range(2):
+                    for r in range(4):
+                        e = (qt * 2 + h) * 4 + r
+                        cb, rn = 16 * h + lk + 4 * r, 16 * qt + l16      # B^T: this block's column, the next block's row
+                        want = pos(30 + rn, cb, k)
+                        exists = want is not None and rn < 30 and cb < 30
+                        assert bool((ok_b >> e) & 1) == exists, (k, lane, "B", e)
+                        if exists:
+                            assert t[12 + e] == want
+                        rb, cs = 16 * h + lk + 4 * r, 16 * qt + l16      # A^T: this block's row, the left block's column
+                        want = pos(30 + rb, cs, k)
+                        exists = want is not None and rb < 30 and cs < 30
+                        assert bool((ok_a >> e) & 1) == exists, (k, lane, "A", e)
+                        if exists:
+                            assert t[32 + e] == want
+    # spline order 6: five control points per superblock never leave the band inside a superblock; the coupling to the next one exists
+    # exactly where the next block's control point is not behind this one's (distance 5 + j' - j < 6)
+    assert fn(6, 0, out) == 0 and (out[28] & 0xfff) == 0xfff
