@@ -183,7 +183,8 @@ class CApi:
             g("debug_lm_control_replay", C.c_int32,
               [C.c_int32, C.c_int32, D, I, C.POINTER(SolverOptions), D, I, D])
             g("debug_plan_info", C.c_int32, [P, I, C.c_int32])
-            g("debug_roll_table", C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_uint32)])
+            if hasattr(self.lib, self.prefix + "debug_roll_table"):      # (a library of an older round, loaded for a same-box A/B, has none)
+                g("debug_roll_table", C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_uint32)])
 
     def _get(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)
