@@ -351,3 +351,58 @@ def test_bench_refuses_more_gpus_than_the_box_has():
     n = torch.cuda.device_count() + 1
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "only %d GPU(s) visible" % (n - 1) in r.stderr and r.stdout.strip() == ""
+
+
+_LOAD_ORDER_SCRIPT = r"""
+import sys
+sys.path.insert(0, %r)
+from calico_amd import _capi, synthetic as syn
+assert "torch" not in sys.modules
+
+
+def rccl_images():
+    seen = set()
+    for line in open("/proc/self/maps"):
+        path = line.split()[-1]
+        if "/" in path and path.rsplit("/", 1)[1].startswith("librccl"):
+            seen.add(path)
+    return sorted(seen)
+
+
+hip = _capi.load_hip()
+scene = syn.make_scene(2, 1, True, 2, cam_rate=10.0, imu_rate=50.0, duration=3.0, segment_duration=3.0 / 23.9,
+                       pixel_noise=0.1, gyro_noise=1e-3, accel_noise=1e-2, robust=True, seed=3)
+b = syn.build_problem(hip, scene)
+uid = _capi.comm_unique_id(hip)                  # the first calico_comm_* call: the library loads an RCCL of its own
+b.problem.comm_init_rccl(uid, 0, 1)
+print("IMAGES_BEFORE", len(rccl_images()), flush=True)
+sys.stderr.write("MARK\n"); sys.stderr.flush()
+import torch                                     # ... and only now the application brings its own
+torch.zeros(1, device="cuda")
+import torch.distributed                         # (pulls in torch's librccl where torch links it lazily)
+b2 = syn.build_problem(hip, scene)
+b2.problem.comm_init_rccl(_capi.comm_unique_id(hip), 0, 1)
+print("IMAGES_AFTER", len(rccl_images()), flush=True)
+o = hip.default_options()
+o.minimizer_progress_to_stdout = 0
+o.max_num_iterations = 3
+s = b2.problem.solve(o)
+print("SOLVED", s.num_iterations, flush=True)
+import os
+os._exit(0)                                      # (two RCCL images: the exit handlers are what this order breaks)
+"""
+
+
+def test_rccl_load_order_is_reported():
+    """include/calico_hip.h, LOAD ORDER: a process that makes its first calico_comm_* call BEFORE loading its own RCCL
+    (torch imported afterwards) may end up with two librccl images. The library cannot prevent that; calico_comm_init_rccl
+    must say so on stderr exactly when it is the case, stay silent otherwise, and the handle must still work."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", _LOAD_ORDER_SCRIPT % ROOT], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = dict(line.split()[:2] for line in r.stdout.splitlines() if line.split() and line.split()[0] in ("IMAGES_BEFORE", "IMAGES_AFTER", "SOLVED"))
+    assert int(out["IMAGES_BEFORE"]) == 1 and int(out["SOLVED"]) >= 1
+    before, _, after = r.stderr.partition("MARK\n")
+    assert "two librccl images" not in before
+    assert ("two librccl images" in after) == (int(out["IMAGES_AFTER"]) > 1)
