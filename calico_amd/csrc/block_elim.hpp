@@ -94,10 +94,22 @@ struct PivotChain {
     x0 = e0 * r0; x1 = __builtin_fma(-l10, x0, e1) * r1;
     x2 = __builtin_fma(-l21, x1, __builtin_fma(-l20, x0, e2)) * r2;
     x3a = __builtin_fma(-l32, x2, __builtin_fma(-l31, x1, __builtin_fma(-l30, x0, e3)));
+    w_lo = (__double2loint(x0) & m0) | (__double2loint(x1) & m1) | (__double2loint(x2) & m2);
+    w_hi = (__double2hiint(x0) & m0) | (__double2hiint(x1) & m1) | (__double2hiint(x2) & m2);
+    asm volatile("" : "+v"(w_lo), "+v"(w_hi));      // (formed here, beside the last pivot's rsqrt: two v_and_or are left behind it)
   }
   DEVI double s6() {    // the lane's entry of -L44⁻¹ in the A-operand layout (row l16 < 4, k = lk; zero elsewhere)
-    const double w012 = l16 == 0 ? x0 : (l16 == 1 ? x1 : (l16 == 2 ? x2 : 0.0));
-    return l16 == 3 ? x3a * r3 : w012;
+    const double x3 = x3a * r3;
+    return __hiloint2double((__double2hiint(x3) & m3) | w_hi, (__double2loint(x3) & m3) | w_lo);
+  }
+  // The lane's row is picked with masks (all ones where l16 == i), not with a chain of selects on l16: the compiler turns
+  // that chain into a switch -- three levels of exec-mask branches, twenty-odd instructions, in the middle of every step's
+  // chain (round 6, read off the ISA). The masks are opaque to it on purpose.
+  int m0, m1, m2, m3, w_lo, w_hi;
+  DEVI void set_lane(int l16_) {
+    l16 = l16_;
+    m0 = l16_ == 0 ? -1 : 0; m1 = l16_ == 1 ? -1 : 0; m2 = l16_ == 2 ? -1 : 0; m3 = l16_ == 3 ? -1 : 0;
+    asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3));
   }
 };
 
@@ -138,7 +150,7 @@ DEVI void elim_chief_reg(f64x4 t00, f64x4 t01, f64x4 t11, double* A, int LD, con
   const int l16 = lane & 15, lk = lane >> 4;
   const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
   PivotChain pc;
-  pc.l16 = l16;
+  pc.set_lane(l16);
   pc.e0 = lk == 0 ? -1.0 : 0.0; pc.e1 = lk == 1 ? -1.0 : 0.0; pc.e2 = lk == 2 ? -1.0 : 0.0; pc.e3 = lk == 3 ? -1.0 : 0.0;
   double* const pub = ch.buf + lane;
   f64x4 p0 = zero4, p1 = zero4;       // panel products (register 0: the step's columns of L for rows 0..15 / 16..31)
