@@ -2813,7 +2813,7 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
     //     progress word), so the owner's input for block l+1 is ready a few hundred clocks after block l is;
     //   * wave 4 follows every block with the identity rows (L⁻ᵀ) and the right-hand side, and forms the right-hand side of the
     //     next block's rows itself; wave 5 clears the channels behind the followers and carries the right-hand side of the rows
-    //     further down; wave 6 the one trailing block nobody owns in time (rows of block 3 x columns of block 2, from block 0).
+    //     further down; waves 0 and 7 the one trailing block nobody owns in time (rows of block 3 x columns of block 2, from block 0).
     // Two compact channels by block parity; order by single-writer counters (a wave's LDS instructions execute in order).
     // ================================================================================================================
     constexpr bool CC = true;
@@ -2937,17 +2937,20 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
           if (row0 + lane < mp) gv[p] -= (a4[0] + a4[1]) + (a4[2] + a4[3]);
         }
         ctr_set(K_GV, l + 1);
-        if (l == 0 && nb == 4) { trail_tile(6, 4, 0); ctr_set(K_BG32, 1); }      // (its tile of the unowned block: see below)
       }
     }
-    if (nb == 4 && (uw == 0 || uw >= 6)) {
-      // rows of block 3 x columns of block 2 minus block 0's share (block 1's accumulates in the owner's registers): four tiles, one
-      // each for waves 5, 6, 7 and wave 0 (behind its identity rows) -- all four on wave 6 were 2k clocks of matrix pipe beside the
-      // owner of block-row 2 on its SIMD, just when it is the next chief's follower
-      const int q4 = uw == 0 ? 3 : uw - 5;
+    if (nb == 4 && (uw == 0 || uw == 7)) {
+      // rows of block 3 x columns of block 2 minus block 0's share (block 1's accumulates in the owner's registers): four tiles, 512
+      // clocks of matrix pipe each, while block 1 is eliminated. Three on wave 0 (behind its identity rows: its SIMD only carries the
+      // right-hand side's follower by then), one on wave 7. Not on wave 5 or 6: one tile on wave 5 made step 2 of block 1's chief,
+      // on its SIMD, 1.33k clocks instead of 0.83k (per-step stamps, CALICO_KERNEL_TIMING=1), and wave 6 sits beside the next chief.
       ctr_wait([&](auto c) { return c(K_DONE + 2) >= 1 && c(K_DONE + 3) >= 1; });
-      trail_tile(6 + (q4 >> 1), 4 + (q4 & 1), 0);
-      ctr_set(K_BG32 + q4, 1);
+      if (uw == 7) { trail_tile(7, 4, 0); ctr_set(K_BG32 + 2, 1); }
+      else {
+        trail_tile(6, 4, 0); ctr_set(K_BG32, 1);
+        trail_tile(6, 5, 0); ctr_set(K_BG32 + 1, 1);
+        trail_tile(7, 5, 0); ctr_set(K_BG32 + 3, 1);
+      }
     }
     lds_barrier();
     if (CAL_DEV_TIMING(a.debug == 1 && tid == 0)) {
