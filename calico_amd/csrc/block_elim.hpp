@@ -88,27 +88,36 @@ struct PivotChain {
   }
   DEVI void s4() {
     a33 = -readlane_f64(d, 51 + b);
-    r3 = rsqrt_nr(__builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, a33))));
+    // the last pivot's 1/sqrt is not formed: it has one consumer, the lane's entry of row 3, which takes the estimate and the Newton
+    // factor apart (s6) -- one product less behind the rsqrt, the last thing on the chain
+    const double d3 = __builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, a33)));
+    rs3 = __builtin_amdgcn_rsq(d3);
+    const double h3 = 0.5 * d3;
+    e3n = __builtin_fma(-(h3 * rs3), rs3, 1.5);
+#if CALICO_RSQRT_NEWTON_STEPS > 1
+    { const double r = rs3 * e3n; rs3 = r; e3n = __builtin_fma(-(h3 * r), r, 1.5); }
+#endif
   }
   DEVI void s5() {      // forward substitution L44 x = -e_lk (off the chain up to the last product)
     x0 = e0 * r0; x1 = __builtin_fma(-l10, x0, e1) * r1;
     x2 = __builtin_fma(-l21, x1, __builtin_fma(-l20, x0, e2)) * r2;
     x3a = __builtin_fma(-l32, x2, __builtin_fma(-l31, x1, __builtin_fma(-l30, x0, e3)));
-    w_lo = (__double2loint(x0) & m0) | (__double2loint(x1) & m1) | (__double2loint(x2) & m2);
-    w_hi = (__double2hiint(x0) & m0) | (__double2hiint(x1) & m1) | (__double2hiint(x2) & m2);
-    asm volatile("" : "+v"(w_lo), "+v"(w_hi));      // (formed here, beside the last pivot's rsqrt: two v_and_or are left behind it)
+    // the lane's row, picked by 0 / 1 factors (exact: one term per lane is not zero): rows 0..2 summed here, row 3's share as far as
+    // it goes without the last pivot
+    pre = __builtin_fma(m2, x2, __builtin_fma(m1, x1, m0 * x0));
+    q3 = (m3 * x3a) * rs3;
   }
   DEVI double s6() {    // the lane's entry of -L44⁻¹ in the A-operand layout (row l16 < 4, k = lk; zero elsewhere)
-    const double x3 = x3a * r3;
-    return __hiloint2double((__double2hiint(x3) & m3) | w_hi, (__double2loint(x3) & m3) | w_lo);
+    return __builtin_fma(q3, e3n, pre);
   }
-  // The lane's row is picked with masks (all ones where l16 == i), not with a chain of selects on l16: the compiler turns
-  // that chain into a switch -- three levels of exec-mask branches, twenty-odd instructions, in the middle of every step's
-  // chain (round 6, read off the ISA). The masks are opaque to it on purpose.
-  int m0, m1, m2, m3, w_lo, w_hi;
+  // The lane's row is picked by arithmetic on lane constants, not by a chain of selects on l16: the compiler turns that chain into a
+  // switch -- three levels of exec-mask branches, twenty-odd instructions, in the middle of every step's chain (round 6, read off
+  // the ISA) --, and the chain is issue-bound (~70 instructions at ~5 clocks): five FP64 instructions here against ten integer ones
+  // for masks + and/or. (A failed pivot's NaN / Inf reaches every lane through the zero factors; such a factor is thrown away.)
+  double m0, m1, m2, m3, pre, q3, rs3, e3n;
   DEVI void set_lane(int l16_) {
     l16 = l16_;
-    m0 = l16_ == 0 ? -1 : 0; m1 = l16_ == 1 ? -1 : 0; m2 = l16_ == 2 ? -1 : 0; m3 = l16_ == 3 ? -1 : 0;
+    m0 = l16_ == 0 ? 1.0 : 0.0; m1 = l16_ == 1 ? 1.0 : 0.0; m2 = l16_ == 2 ? 1.0 : 0.0; m3 = l16_ == 3 ? 1.0 : 0.0;
     asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3));
   }
 };
