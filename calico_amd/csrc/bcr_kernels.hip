@@ -2849,6 +2849,13 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
           elim_load_rows(A + (BP * j) * DNL, DNL, 1, lane, x0[0], x1[0]);
           elim_load_rows(A + (BP * j + 16) * DNL, DNL, 1, lane, x0[1], x1[1]);
         }
+        if (j > 1) {
+          // the rows it will follow block 1 with: nobody else touches them, so block 0's share accumulates ON them and the input of
+          // block 1's follow stands in registers when block 0's last step is through (loading them then and adding the share put
+          // the next chief's follower 0.85k clocks behind before its first step)
+          elim_load_rows(A + (BP * j) * DNL + BP, DNL, 1, lane, nx0[0], nx1[0]);
+          elim_load_rows(A + (BP * j + 16) * DNL + BP, DNL, 1, lane, nx0[1], nx1[1]);
+        }
         for (int l = 0; l <= j; ++l) {
           const int c0 = BP * l;
           const ElimChannel chl = elim_channel(chan + (l & 1) * kElimCompactDoubles);
@@ -2879,8 +2886,11 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
               f64x4 b0, b1;
 #pragma unroll
               for (int q = 0; q < 2; ++q) {
-                elim_load_rows(A + (BP * j + 16 * q) * DNL + BP * (l + 1), DNL, 1, lane, b0, b1);
-                x0[q] = b0 + nx0[q]; x1[q] = b1 + nx1[q];
+                if (l == 0) { x0[q] = nx0[q]; x1[q] = nx1[q]; }      // (accumulated on the rows themselves: see the top)
+                else {
+                  elim_load_rows(A + (BP * j + 16 * q) * DNL + BP * (l + 1), DNL, 1, lane, b0, b1);
+                  x0[q] = b0 + nx0[q]; x1[q] = b1 + nx1[q];
+                }
                 nx0[q] = zero4; nx1[q] = zero4;
               }
             }
