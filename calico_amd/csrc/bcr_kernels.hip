@@ -440,6 +440,14 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
 #pragma unroll
     for (int i = 0; i < 4; ++i) tva[i] = tl[8 + i];
   }
+  // This kernel's code asked for as data, so that it stands in the XCD's L2 when the instruction fetch comes for it (see
+  // prefetch_code): behind a kernel boundary the code of a launch is not in the L2 any more -- the evaluation and the gather move
+  // 40 MB through it per iteration --, and a wave that runs into a line nobody has fetched waits ~2k clocks for it.
+  // Not in the rolling form: there the head IS the critical path (table and state -> requests -> first tiles), and these ~300
+  // misses per workgroup in front of them -- by all waves, or by waves 4..6 alone -- made level 0 1.0 / 1.35 us LONGER
+  // (r06_code_prefetch_ab.txt); the barrier form waits for its first block at a barrier anyway: level 1 11.0 -> 10.5 us.
+  int code_pf = 0;
+  if constexpr (!ROLL) code_pf = prefetch_code(threadIdx.x, kLevelThreads, 40 * 1024);
   // `pub` (the last level's launch when the Schur complement rides in it): this level's workgroups are the PRODUCERS of
   // an in-launch fan-in -- what the riders read (Y rows, the root's pending slots, separators updated in place) leaves
   // with write-through stores, and every producing workgroup arrives at `fan_word` once, terminated or not; the riders
@@ -1538,6 +1546,7 @@ __global__ __launch_bounds__(kLevelThreads) void bcr_level_kernel(SolveArgs a, B
     if (uniform(terminated_v)) { if (pub) fanin_arrive(fan_word); return; }
     if (load0) commit(0, pr, m0);
   }
+  asm volatile("" :: "v"(code_pf));      // (prefetch_code: waited for with the first block's loads)
   __syncthreads();
   LTICK(0)
   if (CAL_DEV_TIMING(a.debug >= 4)) t_first = __builtin_readcyclecounter() - t_kernel;
@@ -2620,7 +2629,7 @@ static_assert(kDenseChan >= 64 * DLD, "the panel buffer must fit where the chann
 // COH (the body rides in reduced_fused_kernel behind the blocked steps of the same launch): what those steps wrote -- the
 // system that is left, the factor's panels, the forward-substituted right-hand side -- is read with L1-bypassing loads.
 template <bool COH = false>
-DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const Handoff& ho, int t0 = 0, int outer_back = 0, int elim = 0) {
+DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const Handoff& ho, int t0 = 0, int outer_back = 0, int elim = 0, int code_pf = 0) {
   auto ldc = [](const double* p) { return COH ? load_sc1(p) : *p; };
   const long long t_entry = CAL_DEV_TIMING(a.debug != 0) ? __builtin_readcyclecounter() : 0;
   LmState* st = a.st;
@@ -2748,6 +2757,7 @@ DEVI void dense_block_solve_body(const SolveArgs& a, int nsl, double* lds, const
   const bool dbg = CAL_DEV_TIMING(a.debug == 1 && (tid == 0 || tid == 64 * 5));
   long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk = dbg ? __builtin_readcyclecounter() : 0;
 #define DTICK(i) if (dbg) { const long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; }
+  asm volatile("" :: "v"(code_pf));      // (prefetch_code: the kernel's code, asked for at its first instructions)
   __syncthreads();
   DTICK(0)
   if (dbg) printf("dense_block_solve wave %d: %lld clocks from the kernel's first instruction to the loaded system\n", wave, (long long)(tk - t_entry));
@@ -3234,14 +3244,16 @@ __global__ __launch_bounds__(kDenseThreads) void dense_back_kernel(SolveArgs a, 
   __shared__ double sh[64];
   const Handoff ho = {word, seq};
   const long long t_db = CAL_DEV_TIMING(a.debug == 4) ? __builtin_readcyclecounter() : 0;
+  const int code_pf = 0;
   if (blockIdx.x == 0) {
-    dense_block_solve_body(a, nsl, lds, ho, 0, 0, elim);
+    dense_block_solve_body(a, nsl, lds, ho, 0, 0, elim, code_pf);
     if (CAL_DEV_TIMING(a.debug == 4 && threadIdx.x == 0)) printf("dense_back: the solve's workgroup lived %lld clocks (terminated %d)\n", (long long)(__builtin_readcyclecounter() - t_db), a.st->terminated);
     return;
   }
   bcr_back_body<QM, MODE, true, PRE>(a, b, int(blockIdx.x) - 1, node0, n_nodes, 1, q_max, x, x_cand, blocks, n_blocks, ts, lds, sh, ho,
                                      node0 == 0 ? q_max : 0);      // (the nodes of this launch are level 0's: launch_dense_back)
   if (CAL_DEV_TIMING(a.debug == 4 && threadIdx.x == 0)) printf("dense_back: workgroup %d lived %lld clocks (terminated %d)\n", int(blockIdx.x), (long long)(__builtin_readcyclecounter() - t_db), a.st->terminated);
+  asm volatile("" :: "v"(code_pf));
 }
 size_t dense_block_solve_lds_bytes() { return size_t(128 * DNL + 128 + kDenseChan + 128 * 3 + 32 + 128 + kDenseThreads) * sizeof(double); }
 hipError_t configure_dense_block_solve() {

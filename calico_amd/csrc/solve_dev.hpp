@@ -144,6 +144,20 @@ DEVI void post_eval_body(SolveArgs a, const double* __restrict__ x, const BlockD
 }
 
 
+// This kernel's code, from here on, asked for as data (one word per 128-byte line), so that it stands in the XCD's L2 when the
+// instruction fetch comes for it. Behind a kernel boundary a launch's code is not in the L2 any more (the evaluation and the gather
+// move ~40 MB through the eight L2s per iteration), the sequencer's prefetch runs a line or two ahead, and straight-line code that
+// runs once -- a single-block chief pass, a head -- then waits ~2k clocks per line nobody has fetched (round 6: per-step stamps of
+// level 1's chief: one step of 2.4k clocks among steps of 0.55-0.8k, 2.2k in front of its first step). The caller keeps the returned
+// value alive up to a point where it waits for its loads anyway (the loads of a wave return in order: asked for in front of loads
+// that somebody waits for, they delay those). Reads past the kernel's end stay inside the code object's text segment.
+DEVI int prefetch_code(int tid, int nthreads, int bytes) {
+  const char* pc = reinterpret_cast<const char*>(__builtin_amdgcn_s_getpc());
+  int acc = 0;
+  for (int q = tid * 128; q < bytes; q += nthreads * 128) acc += *reinterpret_cast<const int*>(pc + q);
+  return acc;
+}
+
 DEVI double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
