@@ -23,6 +23,14 @@
 
 namespace cal {
 
+// a value every lane holds alike, handed to the compiler as such (scalar registers instead of a vector pair)
+__device__ __forceinline__ double wave_uniform(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+
 // Wave-uniform context of a work item.
 struct ItemCtx {
   const SensorDev* s;
@@ -694,7 +702,7 @@ DEV void eval_items_body(const EvalArgs& a, const int item_id, double* lds, Item
   const LayoutDev& L = ip->L;       // (copies inside the item record: one hop instead of item -> layout -> sensor)
   const SensorDev& S = ip->S;
   ItemCtx c;
-  c.s = &S; c.L = &L; c.k = a.order; c.x = a.x; c.info = a.project ? -1.0 : S.info;
+  c.s = &S; c.L = &L; c.k = a.order; c.x = a.x; c.info = wave_uniform(a.project ? -1.0 : S.info);      // (in SGPRs: as a VGPR pair it was the one value the work items spilled to scratch, reloaded sixteen times)
   const int ki = it.seg + a.order - 1;
   c.knot0 = a.knots[ki]; c.knot1 = a.knots[ki + 1];
   c.M = a.basis + size_t(it.seg) * a.order * a.order;
@@ -1110,8 +1118,11 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds, FrameP
   const bool jok = j < P1e;          // (P1e <= 31)
   int s0 = 0, s1 = 0, s2 = 0;
   double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-  if (j < 3) { s0 = 0; s1 = 1; s2 = 2; c0 = Jl.m[0][j]; c1 = Jl.m[1][j]; c2 = Jl.m[2][j]; }          // rotation: Y·J_l
-  else if (j < 6) { s0 = 3; s1 = 4; s2 = 5; c0 = -R_rw.m[0][j - 3]; c1 = -R_rw.m[1][j - 3]; c2 = -R_rw.m[2][j - 3]; }   // position: -T·R_rw
+  // (column `jc` of a 3x3 matrix by selects: a run-time index into the matrix put both matrices into scratch -- the kernel's only
+  //  scratch use, 152 bytes per lane and nine dependent scratch loads per frame)
+  auto mcol = [](const M3& A, int r, int jc) { return jc == 0 ? A.m[r][0] : (jc == 1 ? A.m[r][1] : A.m[r][2]); };
+  if (j < 3) { s0 = 0; s1 = 1; s2 = 2; c0 = mcol(Jl, 0, j); c1 = mcol(Jl, 1, j); c2 = mcol(Jl, 2, j); }          // rotation: Y·J_l
+  else if (j < 6) { s0 = 3; s1 = 4; s2 = 5; c0 = -mcol(R_rw, 0, j - 3); c1 = -mcol(R_rw, 1, j - 3); c2 = -mcol(R_rw, 2, j - 3); }   // position: -T·R_rw
   else if (pm.intr >= 0 && j >= pm.intr && j < pm.intr + Kin) { s0 = sm.k + (j - pm.intr); c0 = 1.0; }
   else if (pm.q >= 0 && j >= pm.q && j < pm.q + 3) {                    // camera q: 2Y - 2T[t_rc]×
     const int c = j - pm.q, ka = (c + 1) % 3, kb = (c + 2) % 3;
@@ -1119,7 +1130,7 @@ DEV void eval_frames_body(const EvalArgs& a, const int fidx, double* lds, FrameP
   }
   else if (pm.t >= 0 && j >= pm.t && j < pm.t + 3) { s0 = 3 + (j - pm.t); c0 = -1.0; }                 // camera t: -T
   else if (pm.bq >= 0 && j >= pm.bq && j < pm.bq + 3) { s0 = sm.z + (j - pm.bq); c0 = -2.0; }         // body q: -2Z
-  else if (pm.bt >= 0 && j >= pm.bt && j < pm.bt + 3) { const int c = j - pm.bt; s0 = 3; s1 = 4; s2 = 5; c0 = R_rw.m[0][c]; c1 = R_rw.m[1][c]; c2 = R_rw.m[2][c]; }
+  else if (pm.bt >= 0 && j >= pm.bt && j < pm.bt + 3) { const int c = j - pm.bt; s0 = 3; s1 = 4; s2 = 5; c0 = mcol(R_rw, 0, c); c1 = mcol(R_rw, 1, c); c2 = mcol(R_rw, 2, c); }
   else { s0 = sm.r; c0 = 1.0; }
   FTICK(7)
   wave_lds_sync();
