@@ -220,8 +220,9 @@ _ROUTE_SCENES = {
 }
 
 
-def _route_scene(name, robust=True, seed=13, camera_model=1, imu_model=3):
-    cam_rate, imu_rate, _ = _ROUTE_SCENES[name]
+def _route_scene(name, robust=True, seed=13, camera_model=1, imu_model=3, imu_rate=None):
+    cam_rate, imu_rate_default, _ = _ROUTE_SCENES[name]
+    imu_rate = imu_rate_default if imu_rate is None else imu_rate
     # knots at 10 Hz (make_scene's default) over 3 s: 0.1 s segments
     return syn.make_scene(2, camera_model, True, imu_model, cam_rate=cam_rate, imu_rate=imu_rate, duration=3.0,
                           segment_duration=3.0 / 23.9, pixel_noise=0.1, gyro_noise=1e-3, accel_noise=1e-2, robust=robust,
@@ -272,7 +273,13 @@ def test_unfused_route_other_models(camera_model, imu_model, hip, oracle):
 def test_unfused_route_converged_solve_matches_oracle(name, hip, oracle):
     """Both sides to convergence with the default options: termination, iteration count, accept / reject sequence, cost per
     iteration, every estimate (1e-6) and the tau = 3 inlier masks (bit-exact)."""
-    scene = _route_scene(name, seed=19)
+    # (three_frames_per_cell: the IMU at 100 Hz here. At the shape's 50 Hz -- 150 samples per IMU for the twelve-parameter model --
+    #  this draw leaves a nearly flat valley: with function / parameter tolerances of 1e-9 / 1e-10 the two sides end at the same
+    #  cost with intrinsics 4e-4 apart, and with the default tolerances the estimates of three builds of this library sat at 0.6,
+    #  0.8 and 1.1 of the 1e-6 bound, moved by last-bit changes of the linear solve -- such a minimum does not determine its
+    #  estimates to 1e-6, whoever computes them. At 100 Hz (still one work item per IMU cell, three or four frames per camera
+    #  cell) the same builds are at <= 0.12 of the bound: profiles/dev/route_diff2.py.)
+    scene = _route_scene(name, seed=19, imu_rate=100.0 if name == "three_frames_per_cell" else None)
     gpu, ref, sg, sr = solve_both(scene, hip, oracle, max_iter=50)
     _assert_route(gpu, name)
     assert sg.termination_type == sr.termination_type == _capi.CONVERGENCE
